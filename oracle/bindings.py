@@ -1,0 +1,383 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes bindings for
+
+  * liboracle.so          -- the CPU restatement (oracle/viso_oracle.c)
+  * _ref/libvisoref.so    -- the real reference compiled in place (oracle/Makefile `make ref`)
+
+Both expose the same Python surface (class CpuMatcher) so that tests can run one
+body against either.  Nothing in the product imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libvisoref.so")
+
+MATCH_DTYPE = np.dtype(
+    [("u1p", "<f4"), ("v1p", "<f4"), ("i1p", "<i4"), ("u2p", "<f4"), ("v2p", "<f4"), ("i2p", "<i4"),
+     ("u1c", "<f4"), ("v1c", "<f4"), ("i1c", "<i4"), ("u2c", "<f4"), ("v2c", "<f4"), ("i2c", "<i4")])
+assert MATCH_DTYPE.itemsize == 48
+
+PARAM_NAMES = ["nms_n", "nms_tau", "match_binsize", "match_radius", "match_disp_tolerance",
+               "outlier_disp_tolerance", "outlier_flow_tolerance", "multi_stage", "half_resolution", "refinement"]
+DEFAULT_PARAMS = dict(nms_n=3, nms_tau=50, match_binsize=50, match_radius=200, match_disp_tolerance=2,
+                      outlier_disp_tolerance=5, outlier_flow_tolerance=5, multi_stage=1, half_resolution=1,
+                      refinement=1, f=1.0, cu=0.0, cv=0.0, base=1.0)
+FEATURE_SETS = {"1p1": 0, "2p1": 1, "1c1": 2, "2c1": 3, "1p2": 4, "2p2": 5, "1c2": 6, "2c2": 7}
+
+
+class VoParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in PARAM_NAMES] + [(n, C.c_double) for n in ("f", "cu", "cv", "base")]
+
+
+def make_params(**kw):
+    d = dict(DEFAULT_PARAMS)
+    d.update(kw)
+    return d
+
+
+def bpl16(w):
+    return w + 15 - (w - 1) % 16
+
+
+def pad_image(img):
+    """(H,W) uint8 -> (H,bpl16(W)) uint8 with zero padding."""
+    h, w = img.shape
+    out = np.zeros((h, bpl16(w)), dtype=np.uint8)
+    out[:, :w] = img
+    return out
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+
+
+def build_ref():
+    subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+_p_u8 = C.POINTER(C.c_uint8)
+_p_i16 = C.POINTER(C.c_int16)
+_p_i32 = C.POINTER(C.c_int32)
+_p_f32 = C.POINTER(C.c_float)
+_p_f64 = C.POINTER(C.c_double)
+
+
+def _u8(a):
+    return a.ctypes.data_as(_p_u8)
+
+
+def _i16(a):
+    return a.ctypes.data_as(_p_i16)
+
+
+def _i32(a):
+    return a.ctypes.data_as(_p_i32)
+
+
+_oracle = None
+_ref = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        L = C.CDLL(ORACLE_SO)
+        L.vo_create.restype = C.c_void_p
+        L.vo_create.argtypes = [C.POINTER(VoParams)]
+        L.vo_destroy.argtypes = [C.c_void_p]
+        L.vo_set_intrinsics.argtypes = [C.c_void_p] + [C.c_double] * 4
+        L.vo_push_back.argtypes = [C.c_void_p, _p_u8, _p_u8, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.vo_match_features.argtypes = [C.c_void_p, C.c_int32, _p_f64]
+        L.vo_num_matches.argtypes = [C.c_void_p]
+        L.vo_get_matches.argtypes = [C.c_void_p, C.c_void_p]
+        L.vo_bucket_features.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float]
+        L.vo_get_gain.argtypes = [C.c_void_p, _p_i32, C.c_int32]
+        L.vo_get_gain.restype = C.c_float
+        L.vo_stage_size.argtypes = [C.c_void_p, C.c_int32]
+        L.vo_stage_get.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.vo_num_ranges.argtypes = [C.c_void_p]
+        L.vo_get_ranges.argtypes = [C.c_void_p, C.c_void_p]
+        L.vo_num_features.argtypes = [C.c_void_p, C.c_int32]
+        L.vo_get_features.argtypes = [C.c_void_p, C.c_int32, _p_i32]
+        L.vo_get_gradients.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _p_u8, _p_u8]
+        L.vo_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.vo_half_image.argtypes = [_p_u8, C.c_int32, C.c_int32, C.c_int32, _p_u8]
+        L.vo_sobel5x5.argtypes = [_p_u8, _p_u8, _p_u8, C.c_int32, C.c_int32]
+        L.vo_blob5x5.argtypes = [_p_u8, _p_i16, C.c_int32, C.c_int32]
+        L.vo_checkerboard5x5.argtypes = [_p_u8, _p_i16, C.c_int32, C.c_int32]
+        L.vo_nms.argtypes = [_p_i16, _p_i16] + [C.c_int32] * 5 + [_p_i32, C.c_int32]
+        L.vo_delaunay.argtypes = [_p_f32, C.c_int32, _p_i32, C.c_int32]
+        L.vo_remove_outliers.argtypes = [C.POINTER(VoParams), C.c_void_p, C.c_int32, C.c_int32]
+        _oracle = L
+    return _oracle
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(REF_SO)
+        L.ref_matcher_create.restype = C.c_void_p
+        L.ref_matcher_create.argtypes = [_p_i32, _p_f64]
+        L.ref_matcher_destroy.argtypes = [C.c_void_p]
+        L.ref_matcher_set_intrinsics.argtypes = [C.c_void_p] + [C.c_double] * 4
+        L.ref_matcher_push.argtypes = [C.c_void_p, _p_u8, _p_u8, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.ref_matcher_match.argtypes = [C.c_void_p, C.c_int32, _p_f64]
+        L.ref_matcher_match_staged.argtypes = [C.c_void_p, C.c_int32, _p_f64]
+        L.ref_matcher_stage_size.argtypes = [C.c_void_p, C.c_int32]
+        L.ref_matcher_stage_get.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.ref_matcher_num_ranges.argtypes = [C.c_void_p]
+        L.ref_matcher_get_ranges.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_matcher_num_matches.argtypes = [C.c_void_p]
+        L.ref_matcher_get_matches.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_matcher_bucket.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float]
+        L.ref_matcher_gain.argtypes = [C.c_void_p, _p_i32, C.c_int32]
+        L.ref_matcher_gain.restype = C.c_float
+        L.ref_matcher_num_features.argtypes = [C.c_void_p, C.c_int32]
+        L.ref_matcher_get_features.argtypes = [C.c_void_p, C.c_int32, _p_i32]
+        L.ref_matcher_get_gradients.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _p_u8, _p_u8]
+        L.ref_sobel5x5.argtypes = [_p_u8, _p_u8, _p_u8, C.c_int32, C.c_int32]
+        L.ref_blob5x5.argtypes = [_p_u8, _p_i16, C.c_int32, C.c_int32]
+        L.ref_checkerboard5x5.argtypes = [_p_u8, _p_i16, C.c_int32, C.c_int32]
+        L.ref_half_image.argtypes = [_p_u8, C.c_int32, C.c_int32, C.c_int32, _p_u8]
+        L.ref_nms.argtypes = [_p_i16, _p_i16] + [C.c_int32] * 5 + [_p_i32, C.c_int32]
+        L.ref_triangulate.argtypes = [_p_f32, C.c_int32, _p_i32, C.c_int32]
+        L.ref_remove_outliers.argtypes = [_p_i32, _p_f64, C.c_void_p, C.c_int32, C.c_int32]
+        L.ref_vo_stereo_create.restype = C.c_void_p
+        L.ref_vo_stereo_create.argtypes = [_p_i32] + [C.c_double] * 4 + [C.c_int32, C.c_double, C.c_double]
+        L.ref_vo_stereo_destroy.argtypes = [C.c_void_p]
+        L.ref_vo_stereo_process.argtypes = [C.c_void_p, _p_u8, _p_u8, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                            _p_f64, _p_f64]
+        L.ref_vo_num_matches.argtypes = [C.c_void_p]
+        L.ref_vo_get_matches.argtypes = [C.c_void_p, C.c_void_p]
+        _ref = L
+    return _ref
+
+
+def _ip_dp(p):
+    ip = np.array([p[n] for n in PARAM_NAMES], dtype=np.int32)
+    dp = np.array([p["f"], p["cu"], p["cv"], p["base"]], dtype=np.float64)
+    return ip, dp
+
+
+def _vo_params(p):
+    s = VoParams()
+    for n in PARAM_NAMES:
+        setattr(s, n, int(p[n]))
+    for n in ("f", "cu", "cv", "base"):
+        setattr(s, n, float(p[n]))
+    return s
+
+
+def _tr_ptr(Tr):
+    if Tr is None:
+        return None, None
+    t = np.ascontiguousarray(np.asarray(Tr, dtype=np.float64).reshape(-1)[:12])
+    return t, t.ctypes.data_as(_p_f64)
+
+
+class CpuMatcher:
+    """Common face over the oracle ("oracle") and the real reference ("ref")."""
+
+    def __init__(self, kind="oracle", **params):
+        self.kind = kind
+        self.p = make_params(**params)
+        if kind == "oracle":
+            self.L = oracle_lib()
+            sp = _vo_params(self.p)
+            self.h = C.c_void_p(self.L.vo_create(C.byref(sp)))
+        else:
+            self.L = ref_lib()
+            ip, dp = _ip_dp(self.p)
+            self.h = C.c_void_p(self.L.ref_matcher_create(_i32(ip), dp.ctypes.data_as(_p_f64)))
+
+    def close(self):
+        if self.h:
+            (self.L.vo_destroy if self.kind == "oracle" else self.L.ref_matcher_destroy)(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_intrinsics(self, f, cu, cv, base):
+        (self.L.vo_set_intrinsics if self.kind == "oracle" else self.L.ref_matcher_set_intrinsics)(self.h, f, cu, cv, base)
+
+    def push_back(self, I1, I2=None, replace=False):
+        I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+        h, w = I1.shape
+        p2 = None
+        if I2 is not None:
+            I2 = np.ascontiguousarray(I2, dtype=np.uint8)
+            assert I2.shape == I1.shape
+            p2 = _u8(I2)
+        fn = self.L.vo_push_back if self.kind == "oracle" else self.L.ref_matcher_push
+        return fn(self.h, _u8(I1), p2, w, h, w, int(replace))
+
+    def match(self, method, Tr=None):
+        """runs matchFeatures with stage capture; returns True if matching ran."""
+        t, tp = _tr_ptr(Tr)
+        if self.kind == "oracle":
+            return self.L.vo_match_features(self.h, method, tp) == 1
+        return self.L.ref_matcher_match_staged(self.h, method, tp) == 1
+
+    def matches(self):
+        n = (self.L.vo_num_matches if self.kind == "oracle" else self.L.ref_matcher_num_matches)(self.h)
+        out = np.zeros(n, dtype=MATCH_DTYPE)
+        if n:
+            (self.L.vo_get_matches if self.kind == "oracle" else self.L.ref_matcher_get_matches)(self.h, out.ctypes.data)
+        return out
+
+    def stage(self, s):
+        n = (self.L.vo_stage_size if self.kind == "oracle" else self.L.ref_matcher_stage_size)(self.h, s)
+        out = np.zeros(n, dtype=MATCH_DTYPE)
+        if n:
+            (self.L.vo_stage_get if self.kind == "oracle" else self.L.ref_matcher_stage_get)(self.h, s, out.ctypes.data)
+        return out
+
+    def ranges(self):
+        n = (self.L.vo_num_ranges if self.kind == "oracle" else self.L.ref_matcher_num_ranges)(self.h)
+        out = np.zeros((n, 4, 4), dtype=np.float32)  # [bin][u_min,u_max,v_min,v_max][stage]
+        if n:
+            (self.L.vo_get_ranges if self.kind == "oracle" else self.L.ref_matcher_get_ranges)(self.h, out.ctypes.data)
+        return out
+
+    def features(self, which):
+        w = FEATURE_SETS[which] if isinstance(which, str) else which
+        n = (self.L.vo_num_features if self.kind == "oracle" else self.L.ref_matcher_num_features)(self.h, w)
+        out = np.zeros((n, 12), dtype=np.int32)
+        if n:
+            (self.L.vo_get_features if self.kind == "oracle" else self.L.ref_matcher_get_features)(self.h, w, _i32(out))
+        return out
+
+    def gradients(self, which, full, shape):
+        du = np.zeros(shape, dtype=np.uint8)
+        dv = np.zeros(shape, dtype=np.uint8)
+        fn = self.L.vo_get_gradients if self.kind == "oracle" else self.L.ref_matcher_get_gradients
+        n = fn(self.h, which, int(full), _u8(du), _u8(dv))
+        assert n == 0 or n == du.size, (n, du.size)
+        return (du, dv) if n else (None, None)
+
+    def bucket(self, max_features, bw, bh):
+        (self.L.vo_bucket_features if self.kind == "oracle" else self.L.ref_matcher_bucket)(self.h, max_features, bw, bh)
+
+    def gain(self, inliers):
+        a = np.ascontiguousarray(inliers, dtype=np.int32)
+        return float((self.L.vo_get_gain if self.kind == "oracle" else self.L.ref_matcher_gain)(self.h, _i32(a), len(a)))
+
+    def counters(self):
+        assert self.kind == "oracle"
+        c = (C.c_int64 * 5)()
+        self.L.vo_get_counters(self.h, c)
+        return dict(zip(("Q", "C", "S", "M", "M_out"), list(c)))
+
+
+# ---- free-standing stages -------------------------------------------------
+
+def half_image(kind, img_padded, w):
+    h, bpl = img_padded.shape
+    out = np.zeros((h // 2, bpl16(w // 2)), dtype=np.uint8)
+    fn = oracle_lib().vo_half_image if kind == "oracle" else ref_lib().ref_half_image
+    fn(_u8(np.ascontiguousarray(img_padded)), w, h, bpl, _u8(out))
+    return out
+
+
+def sobel5x5(kind, img_padded):
+    h, bpl = img_padded.shape
+    du = np.zeros((h, bpl), dtype=np.uint8)
+    dv = np.zeros((h, bpl), dtype=np.uint8)
+    fn = oracle_lib().vo_sobel5x5 if kind == "oracle" else ref_lib().ref_sobel5x5
+    fn(_u8(np.ascontiguousarray(img_padded)), _u8(du), _u8(dv), bpl, h)
+    return du, dv
+
+
+def blob5x5(kind, img_padded):
+    h, bpl = img_padded.shape
+    out = np.zeros((h, bpl), dtype=np.int16)
+    fn = oracle_lib().vo_blob5x5 if kind == "oracle" else ref_lib().ref_blob5x5
+    fn(_u8(np.ascontiguousarray(img_padded)), _i16(out), bpl, h)
+    return out
+
+
+def checkerboard5x5(kind, img_padded):
+    h, bpl = img_padded.shape
+    out = np.zeros((h, bpl), dtype=np.int16)
+    fn = oracle_lib().vo_checkerboard5x5 if kind == "oracle" else ref_lib().ref_checkerboard5x5
+    fn(_u8(np.ascontiguousarray(img_padded)), _i16(out), bpl, h)
+    return out
+
+
+def nms(kind, f1, f2, w, n, tau):
+    h, bpl = f1.shape
+    cap = 4 * (w // (n + 1) + 1) * (h // (n + 1) + 1) + 16
+    out = np.zeros((cap, 4), dtype=np.int32)
+    fn = oracle_lib().vo_nms if kind == "oracle" else ref_lib().ref_nms
+    k = fn(_i16(np.ascontiguousarray(f1)), _i16(np.ascontiguousarray(f2)), w, h, bpl, n, tau, _i32(out), cap)
+    assert k <= cap
+    return out[:k]
+
+
+def delaunay(kind, pts):
+    pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
+    n = len(pts)
+    cap = 2 * n + 16
+    tris = np.zeros((cap, 3), dtype=np.int32)
+    fn = oracle_lib().vo_delaunay if kind == "oracle" else ref_lib().ref_triangulate
+    k = fn(pts.ctypes.data_as(_p_f32), n, _i32(tris), cap)
+    assert k <= cap
+    return tris[:k]
+
+
+def remove_outliers(kind, matches, method, **params):
+    p = make_params(**params)
+    m = np.ascontiguousarray(matches.copy())
+    if kind == "oracle":
+        sp = _vo_params(p)
+        k = oracle_lib().vo_remove_outliers(C.byref(sp), m.ctypes.data, len(m), method)
+    else:
+        ip, dp = _ip_dp(p)
+        k = ref_lib().ref_remove_outliers(_i32(ip), dp.ctypes.data_as(_p_f64), m.ctypes.data, len(m), method)
+    return m[:k]
+
+
+class RefStereoVO:
+    """VisualOdometryStereo of the reference (Tr_delta fixtures)."""
+
+    def __init__(self, f, cu, cv, base, bucket=(2, 50.0, 50.0), **params):
+        self.L = ref_lib()
+        p = make_params(**params)
+        ip, _ = _ip_dp(p)
+        self.h = C.c_void_p(self.L.ref_vo_stereo_create(_i32(ip), f, cu, cv, base, bucket[0], bucket[1], bucket[2]))
+
+    def process(self, I1, I2, replace=False):
+        I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+        I2 = np.ascontiguousarray(I2, dtype=np.uint8)
+        h, w = I1.shape
+        tin = np.zeros(16)
+        tout = np.zeros(16)
+        rc = self.L.ref_vo_stereo_process(self.h, _u8(I1), _u8(I2), w, h, w, int(replace),
+                                          tin.ctypes.data_as(_p_f64), tout.ctypes.data_as(_p_f64))
+        return bool(rc & 1), bool(rc & 2), tin.reshape(4, 4), tout.reshape(4, 4)
+
+    def matches(self):
+        n = self.L.ref_vo_num_matches(self.h)
+        out = np.zeros(n, dtype=MATCH_DTYPE)
+        if n:
+            self.L.ref_vo_get_matches(self.h, out.ctypes.data)
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.ref_vo_stereo_destroy(self.h)
+            self.h = None

@@ -1,0 +1,95 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of libviso2's matcher
+ * hot path as vendored in dphoyes/OpenCL-Structure-from-Motion (viso/matcher.cpp,
+ * viso/filter.cpp, the Delaunay part of viso/triangle.cpp).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * this library; the product (libvisomatch.so) never links or calls it.
+ *
+ * Parity status: PINNED -- every stage is checked against the real reference
+ * compiled in place (oracle/_ref, see oracle/Makefile) by tests/test_oracle_vs_ref.py
+ * and against the committed golden vectors in tests/golden/ generated from it.
+ */
+#ifndef VISO_ORACLE_H
+#define VISO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Matcher::parameters, viso/matcher.h:42-69 */
+typedef struct {
+  int32_t nms_n, nms_tau, match_binsize, match_radius, match_disp_tolerance;
+  int32_t outlier_disp_tolerance, outlier_flow_tolerance, multi_stage, half_resolution, refinement;
+  double f, cu, cv, base;
+} vo_params;
+
+/* Matcher::p_match, viso/matcher.h:86-100 (48 bytes) */
+typedef struct {
+  float u1p, v1p;
+  int32_t i1p;
+  float u2p, v2p;
+  int32_t i2p;
+  float u1c, v1c;
+  int32_t i1c;
+  float u2c, v2c;
+  int32_t i2c;
+} vo_match;
+
+/* Matcher::range, viso/matcher.h:152-157 (64 bytes) */
+typedef struct {
+  float u_min[4], u_max[4], v_min[4], v_max[4];
+} vo_range;
+
+typedef struct vo_matcher vo_matcher;
+
+void vo_default_params(vo_params *p);
+
+/* ---- free-standing stages (all images are bpl x h, bpl % 16 == 0) ---- */
+int32_t vo_bpl16(int32_t w); /* w + 15 - (w-1)%16, viso/matcher.cpp:160 */
+void vo_half_image(const uint8_t *in, int32_t w, int32_t h, int32_t bpl, uint8_t *out);
+void vo_sobel5x5(const uint8_t *in, uint8_t *du, uint8_t *dv, int32_t bpl, int32_t h);
+void vo_blob5x5(const uint8_t *in, int16_t *out, int32_t bpl, int32_t h);
+void vo_checkerboard5x5(const uint8_t *in, int16_t *out, int32_t bpl, int32_t h);
+int32_t vo_nms(const int16_t *f1, const int16_t *f2, int32_t w, int32_t h, int32_t bpl, int32_t n, int32_t tau,
+               int32_t *out4, int32_t cap);
+void vo_descriptor(const uint8_t *du, const uint8_t *dv, int32_t bpl, int32_t u, int32_t v, uint8_t *desc32);
+/* Delaunay triangulation identical to Triangle 1.6 "zQB" on integer-valued points */
+int32_t vo_delaunay(const float *pts_xy, int32_t n, int32_t *tris, int32_t cap);
+int32_t vo_remove_outliers(const vo_params *p, vo_match *m, int32_t n, int32_t method);
+
+/* ---- the matcher object (mirrors class Matcher, viso/matcher.h:37-136) ---- */
+vo_matcher *vo_create(const vo_params *p);
+void vo_destroy(vo_matcher *m);
+void vo_set_intrinsics(vo_matcher *m, double f, double cu, double cv, double base);
+/* returns 0 on success, -1 for the reference's "Image dimension mismatch" */
+int32_t vo_push_back(vo_matcher *m, const uint8_t *I1, const uint8_t *I2, int32_t w, int32_t h, int32_t bpl,
+                     int32_t replace);
+/* returns 1 if matching ran, 0 if the reference's sanity checks return early, -2 unsupported */
+int32_t vo_match_features(vo_matcher *m, int32_t method, const double *Tr_delta_rowmajor_3x4_or_4x4);
+int32_t vo_num_matches(const vo_matcher *m);
+void vo_get_matches(const vo_matcher *m, vo_match *out);
+void vo_bucket_features(vo_matcher *m, int32_t max_features, float bucket_width, float bucket_height);
+float vo_get_gain(const vo_matcher *m, const int32_t *inliers, int32_t n);
+
+/* stage captures of the last vo_match_features():
+ * 0 pass-1 matching, 1 pass-1 outlier removal, 2 pass-2 matching, 3 refinement, 4 final */
+int32_t vo_stage_size(const vo_matcher *m, int32_t stage);
+void vo_stage_get(const vo_matcher *m, int32_t stage, vo_match *out);
+int32_t vo_num_ranges(const vo_matcher *m);
+void vo_get_ranges(const vo_matcher *m, vo_range *out);
+/* which: 0=1p1 1=2p1 2=1c1 3=2c1 4=1p2 5=2p2 6=1c2 7=2c2 ; records are int32[12] */
+int32_t vo_num_features(const vo_matcher *m, int32_t which);
+void vo_get_features(const vo_matcher *m, int32_t which, int32_t *out);
+/* which: 0=1p 1=2p 2=1c 3=2c; returns plane bytes or 0 */
+int32_t vo_get_gradients(const vo_matcher *m, int32_t which, int32_t full, uint8_t *du, uint8_t *dv);
+
+/* work counters of the last vo_match_features() (for the bench's algorithmic-bytes model,
+ * SURVEY.md section 8d): {findMatch calls Q, candidates visited C, SADs S, matches refined M, matches out} */
+void vo_get_counters(const vo_matcher *m, int64_t *out5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
