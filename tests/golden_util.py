@@ -1,0 +1,122 @@
+"""Shared drivers that replay the golden fixtures (tests/golden/*.npz, generated from the real
+reference by tests/golden/make_golden.py) through any matcher exposing the CpuMatcher face
+(push_back / match / stage / features / ranges / matches / set_intrinsics)."""
+import hashlib
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def same(a, b):
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+def params_of(g, pi):
+    keys = [str(k) for k in g["param_keys"]]
+    vals = g[f"p{pi}_params"]
+    out = {}
+    for k, v in zip(keys, vals):
+        out[k] = float(v) if k in ("f", "cu", "cv", "base") else int(v)
+    return out
+
+
+def n_param_sets(g):
+    return len([k for k in g.files if k.endswith("_params")])
+
+
+def replay_small(g, synth, make_matcher, pi, method, check_stages=True):
+    """returns number of compared arrays"""
+    w, h, nf = int(g["w"]), int(g["h"]), int(g["n_frames"])
+    seq = synth.stereo_sequence(int(g["seed"]), w, h, nf, disparity=int(g["disparity"]), ramp=tuple(int(x) for x in g["ramp"]))
+    for f, (l, r) in enumerate(seq):
+        assert sha(l) + sha(r) == str(g["input_sha"][f]), "synthetic generator drifted from the fixture inputs"
+    params = params_of(g, pi)
+    m = make_matcher(**params)
+    tr = g["tr"] if "tr" in g.files else None
+    if "intr" in g.files:
+        m.set_intrinsics(*[float(x) for x in g["intr"]])
+    ns = 4 if method == 2 else 2
+    checked = 0
+    for f, (l, r) in enumerate(seq):
+        m.push_back(l, r if method else None)
+        for s in ("1c1", "1c2", "2c1", "2c2"):
+            key = f"p{pi}_f{f}_feat_{s}"
+            if key in g.files and (method != 0 or s[0] == "1"):
+                got = m.features(s)
+                assert same(got, g[key]), f"features {s} frame {f}: got {got.shape} want {g[key].shape}"
+                checked += 1
+        T = tr if (tr is not None and f >= 2) else None
+        ran = m.match(method, T)
+        key = f"p{pi}_m{method}_f{f}"
+        assert int(ran) == int(g[key + "_ran"]), (key, ran)
+        if ran:
+            if check_stages:
+                for s in range(5):
+                    got = m.stage(s)
+                    want = g[key + f"_stage{s}"]
+                    assert same(got, want), f"{key} stage {s}: got {got.shape} want {want.shape}"
+                    checked += 1
+                if params["multi_stage"]:
+                    assert np.array_equal(m.ranges()[:, :, :ns], g[key + "_ranges"][:, :, :ns]), key + " ranges"
+                    checked += 1
+            assert same(m.matches(), g[key + "_stage4"]), key + " final"
+            checked += 1
+    m.close()
+    return checked
+
+
+def replay_hashed(g, synth, make_matcher, frames=None, check_stages=True):
+    w, h, nf, method = int(g["w"]), int(g["h"]), int(g["n_frames"]), int(g["method"])
+    blur = int(g["blur"])
+    if method == 0:
+        seq = [(x, None) for x in synth.mono_sequence(int(g["seed"]), w, h, nf, blur=blur)]
+    else:
+        seq = synth.stereo_sequence(int(g["seed"]), w, h, nf, blur=blur)
+    m = make_matcher()
+    sets = ("1c1", "1c2") if method == 0 else ("1c1", "1c2", "2c1", "2c2")
+    nf = nf if frames is None else min(nf, frames)
+    for f in range(nf):
+        l, r = seq[f]
+        assert sha(l) + (sha(r) if r is not None else "") == str(g["input_sha"][f])
+        m.push_back(l, r)
+        ran = m.match(method)
+        for k, s in enumerate(sets):
+            got = m.features(s)
+            assert len(got) == int(g["counts"][f][k]), (f, s, len(got), int(g["counts"][f][k]))
+            assert sha(got) == str(g["hashes"][f][k]), (f, s)
+        if ran and check_stages:
+            for s in range(5):
+                got = m.stage(s)
+                assert len(got) == int(g["counts"][f][len(sets) + s]), (f, "stage", s, len(got))
+                assert sha(got) == str(g["hashes"][f][len(sets) + s]), (f, "stage", s)
+        fin = m.matches()
+        assert len(fin) == int(g["counts"][f][-1]) and sha(fin) == str(g["hashes"][f][-1]), (f, "final")
+    m.close()
+
+
+def replay_vo_sequence(g, synth, make_matcher, n_frames=None):
+    """config 2: quad matching with the replayed Tr_delta feedback; final list per frame"""
+    w, h = int(g["w"]), int(g["h"])
+    nf = int(g["n_frames"]) if n_frames is None else n_frames
+    cv = synth.canvas(int(g["seed"]), w, h)
+    m = make_matcher()
+    m.set_intrinsics(*[float(x) for x in g["intr"]])
+    for f in range(nf):
+        l, r = synth.stereo_frame(cv, f, w, h)
+        assert sha(l) + sha(r) == str(g["input_sha"][f])
+        m.push_back(l, r)
+        m.match(2, g["tr_in"][f] if bool(g["tr_valid"][f]) else None)
+        fin = m.matches()
+        assert len(fin) == int(g["counts"][f]), (f, len(fin), int(g["counts"][f]))
+        assert sha(fin) == str(g["hashes"][f]), f
+    m.close()
