@@ -1,0 +1,139 @@
+/* visomatch.h -- C-ABI of libvisomatch.so, the MI355X-native (gfx950, HIP) replacement for
+ * libviso2's per-frame matcher hot path as vendored in dphoyes/OpenCL-Structure-from-Motion.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository).  Plain pointers and sizes only; no C++/torch types cross this line.
+ * The header-only C++ class in include/matcher.h forwards the reference's own
+ * `class Matcher` surface (viso/matcher.h:37-136) to these functions.
+ *
+ * Error convention: functions returning int give 0 (VSM_OK) on success or a negative
+ * VSM_E* code.  The reference's C++ API has no error returns (bad dims print
+ * "ERROR: Image dimension mismatch!" to stderr and leave the state untouched,
+ * viso/matcher.cpp:103-106; matchFeatures with missing buffers returns silently and keeps
+ * the previous matches, :190-216); the C++ wrapper swallows the codes to keep that behaviour.
+ *
+ * Threading: one handle = one HIP device + one stream; a handle is not re-entrant.
+ * Distinct handles are independent (unlike the reference, whose Delaunay code keeps
+ * file-scope state, viso/triangle.cpp:541-550).
+ */
+#ifndef VISOMATCH_H
+#define VISOMATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSM_OK 0
+#define VSM_EDIMS (-1)     /* the reference's "Image dimension mismatch" */
+#define VSM_ENOTREADY (-2) /* matchFeatures' silent early return: ring buffer not filled */
+#define VSM_EHIP (-3)      /* HIP runtime error (message on stderr) */
+#define VSM_EARG (-4)
+
+typedef struct vsm_handle vsm_handle;
+
+/* Matcher::parameters, viso/matcher.h:42-69 (same field order and defaults) */
+typedef struct vsm_params {
+  int32_t nms_n;
+  int32_t nms_tau;
+  int32_t match_binsize;
+  int32_t match_radius;
+  int32_t match_disp_tolerance;
+  int32_t outlier_disp_tolerance;
+  int32_t outlier_flow_tolerance;
+  int32_t multi_stage;
+  int32_t half_resolution;
+  int32_t refinement;
+  double f, cu, cv, base;
+} vsm_params;
+
+/* Matcher::p_match, viso/matcher.h:86-100 -- identical 48-byte layout */
+typedef struct vsm_p_match {
+  float u1p, v1p;
+  int32_t i1p;
+  float u2p, v2p;
+  int32_t i2p;
+  float u1c, v1c;
+  int32_t i1c;
+  float u2c, v2c;
+  int32_t i2c;
+} vsm_p_match;
+
+/* Matcher::parameters::parameters(), viso/matcher.h:57-68 */
+void vsm_default_params(vsm_params *p);
+
+/* Matcher::Matcher(parameters), viso/matcher.cpp:33-61.  Binds the calling thread's current
+ * HIP device.  Returns NULL if no HIP device is usable (never falls back to the CPU). */
+vsm_handle *vsm_create(const vsm_params *p);
+
+/* Matcher::~Matcher(), viso/matcher.cpp:64-93 */
+void vsm_destroy(vsm_handle *h);
+
+/* Matcher::setIntrinsics, viso/matcher.h:78-83 */
+void vsm_set_intrinsics(vsm_handle *h, double f, double cu, double cv, double base);
+
+/* Matcher::pushBack(I1,I2,dims,replace), viso/matcher.cpp:95-181 (I2 == NULL: the mono
+ * overload viso/matcher.h:118).  Host images, row stride bpl.  The input may be reused as
+ * soon as the call returns. */
+int vsm_push_back(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int32_t width, int32_t height, int32_t bpl,
+                  int replace);
+
+/* Same, for images that already live in this device's HBM (the bench's resident-input path). */
+int vsm_push_back_device(vsm_handle *h, const uint8_t *dI1, const uint8_t *dI2, int32_t width, int32_t height,
+                         int32_t bpl, int replace);
+
+/* Matcher::matchFeatures(method, Tr_delta), viso/matcher.cpp:183-241.  method 0 flow, 1 stereo,
+ * 2 quad.  Tr_delta: NULL or 12 doubles = rows 0..2 of the 4x4 matrix, row-major
+ * (what viso/matcher.cpp:989-1002 reads). */
+int vsm_match(vsm_handle *h, int32_t method, const double *Tr_delta);
+
+/* Matcher::getMatches(), viso/matcher.h:131 */
+int32_t vsm_num_matches(vsm_handle *h);
+int32_t vsm_get_matches(vsm_handle *h, vsm_p_match *out, int32_t cap);
+
+/* Matcher::bucketFeatures, viso/matcher.cpp:243-284 (uses the C library rand() like the reference) */
+int vsm_bucket(vsm_handle *h, int32_t max_features, float bucket_width, float bucket_height);
+
+/* Matcher::getGain, viso/matcher.cpp:286-324 */
+float vsm_gain(vsm_handle *h, const int32_t *inliers, int32_t n);
+
+/* ---- stage-level views for parity tests (the reference's private members) ---- */
+
+/* m1p1.. / n1p1.. (viso/matcher.h:232-235).  which: 0=1p1 1=2p1 2=1c1 3=2c1 4=1p2 5=2p2 6=1c2 7=2c2;
+ * records are int32[12] = {u,v,0,class,d1..d8} (viso/matcher.cpp:716-718). */
+int32_t vsm_num_features(vsm_handle *h, int32_t which);
+int32_t vsm_get_features(vsm_handle *h, int32_t which, int32_t *out, int32_t cap_records);
+
+/* match list after each private stage of the last vsm_match():
+ * 0 pass-1 matching(), 1 pass-1 removeOutliers(), 2 pass-2 matching(), 3 refinement(), 4 final */
+void vsm_set_stage_capture(vsm_handle *h, int on); /* stage 2 costs one extra D2H: off by default */
+int32_t vsm_stage_size(vsm_handle *h, int32_t stage);
+int32_t vsm_stage_get(vsm_handle *h, int32_t stage, vsm_p_match *out, int32_t cap);
+
+/* Matcher::ranges (viso/matcher.h:152-157,245): 16 floats per statistics bin */
+int32_t vsm_num_ranges(vsm_handle *h);
+int32_t vsm_get_ranges(vsm_handle *h, float *out, int32_t cap_bins);
+
+/* I?{p,c}_du/_dv[_full] (viso/matcher.h:237-240).  which: 0=1p 1=2p 2=1c 3=2c.  Returns the
+ * plane size in bytes (bpl*h) or 0 when absent; du/dv may be NULL to query the size. */
+int32_t vsm_get_gradients(vsm_handle *h, int32_t which, int32_t full, uint8_t *du, uint8_t *dv);
+
+/* blob / corner filter responses of the current left image (f1,f2 of viso/matcher.cpp:651-678;
+ * transient in the reference).  Returns elements per plane or 0. */
+int32_t vsm_get_filter_responses(vsm_handle *h, int16_t *f1, int16_t *f2);
+
+/* work counters of the last vsm_match(): {findMatch calls, 0, 0, matches refined, matches out}
+ * (slots 1,2 are only counted by the CPU oracle) */
+void vsm_get_counters(vsm_handle *h, int64_t *out5);
+
+/* wall-clock split of the last vsm_match() in microseconds:
+ * {pass-1 GPU+sync, pass-1 host (Delaunay+prior), pass-2 GPU+sync, final host Delaunay, total} */
+void vsm_get_timings(vsm_handle *h, double *out5);
+
+const char *vsm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

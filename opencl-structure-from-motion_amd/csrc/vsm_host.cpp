@@ -1,0 +1,601 @@
+// Host-side stages of the matcher path (see vsm_host.h).  Plain C++17, no HIP.
+#include "vsm_host.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+// =======================================================================================
+// ExactDelaunay: Triangle 1.6 divide-and-conquer with alternating cuts, decision for decision
+// (viso/triangle.cpp: vertexsort :5447, vertexmedian :5513, alternateaxes :5583, mergehulls
+// :5639, divconqrecurse :5963, divconqdelaunay :6161).  Triangle's robust float predicates
+// (:2707, :3335) return the exact sign; on integer coordinates that is the int64 sign used here.
+// The triangle store is index based: nb_[t*3+o] = neighbour handle (t2*4+o2), vx_[t*3+o] = vertex
+// or -1 for the ghost ("NULL") corner of a bounding triangle.
+// =======================================================================================
+uint32_t ExactDelaunay::rnd(uint32_t choices) {  // randomnation, :4046
+  seed_ = (seed_ * 1366u + 150889u) % 714025u;
+  return (uint32_t)(seed_ / (714025u / choices + 1));
+}
+
+ExactDelaunay::OTri ExactDelaunay::make() {
+  int32_t t = ntri_++;
+  nb_[t * 3] = nb_[t * 3 + 1] = nb_[t * 3 + 2] = -1;
+  vx_[t * 3] = vx_[t * 3 + 1] = vx_[t * 3 + 2] = -1;
+  return OTri{t, 0};
+}
+
+void ExactDelaunay::partition(int32_t *a, int32_t n, int axis, int32_t &left, int32_t &right) {
+  const int32_t *k1 = axis ? y_ : x_, *k2 = axis ? x_ : y_;
+  int32_t pv = a[rnd((uint32_t)n)];
+  const int32_t p1 = k1[pv], p2 = k2[pv];
+  left = -1;
+  right = n;
+  while (left < right) {
+    do {
+      left++;
+    } while (left <= right && (k1[a[left]] < p1 || (k1[a[left]] == p1 && k2[a[left]] < p2)));
+    do {
+      right--;
+    } while (left <= right && (k1[a[right]] > p1 || (k1[a[right]] == p1 && k2[a[right]] > p2)));
+    if (left < right) std::swap(a[left], a[right]);
+  }
+}
+
+void ExactDelaunay::sort2(int32_t *a, int axis) {
+  const int32_t *k1 = axis ? y_ : x_, *k2 = axis ? x_ : y_;
+  if (k1[a[0]] > k1[a[1]] || (k1[a[0]] == k1[a[1]] && k2[a[0]] > k2[a[1]])) std::swap(a[0], a[1]);
+}
+
+void ExactDelaunay::vertex_sort(int32_t *a, int32_t n) {
+  if (n == 2) return sort2(a, 0);
+  int32_t l, r;
+  partition(a, n, 0, l, r);
+  if (l > 1) vertex_sort(a, l);
+  if (r < n - 2) vertex_sort(a + r + 1, n - r - 1);
+}
+
+void ExactDelaunay::vertex_median(int32_t *a, int32_t n, int32_t median, int axis) {
+  if (n == 2) return sort2(a, axis);
+  int32_t l, r;
+  partition(a, n, axis, l, r);
+  if (l > median) vertex_median(a, l, median, axis);
+  if (r < median - 1) vertex_median(a + r + 1, n - r - 1, median - r - 1, axis);
+}
+
+void ExactDelaunay::alternate_axes(int32_t *a, int32_t n, int axis) {
+  int32_t divider = n >> 1;
+  if (n <= 3) axis = 0;
+  vertex_median(a, n, divider, axis);
+  if (n - divider >= 2) {
+    if (divider >= 2) alternate_axes(a, divider, 1 - axis);
+    alternate_axes(a + divider, n - divider, 1 - axis);
+  }
+}
+
+void ExactDelaunay::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis) {
+  int32_t ildest = dest(innerleft), ilapex = apex(innerleft);
+  int32_t irorg = org(innerright), irapex = apex(innerright);
+  if (axis == 1) {  // horizontal cut: handles move to the bottom-/top-most hull vertices (:5666)
+    int32_t flpt = org(farleft), flapex = apex(farleft);
+    int32_t frpt = dest(farright), frapex = apex(farright);
+    while (y_[flapex] < y_[flpt]) {
+      farleft = sym(lnext(farleft));
+      flpt = flapex;
+      flapex = apex(farleft);
+    }
+    OTri chk = sym(innerleft);
+    int32_t cv = apex(chk);
+    while (y_[cv] > y_[ildest]) {
+      innerleft = lnext(chk);
+      ilapex = ildest;
+      ildest = cv;
+      chk = sym(innerleft);
+      cv = apex(chk);
+    }
+    while (y_[irapex] < y_[irorg]) {
+      innerright = sym(lnext(innerright));
+      irorg = irapex;
+      irapex = apex(innerright);
+    }
+    chk = sym(farright);
+    cv = apex(chk);
+    while (y_[cv] > y_[frpt]) {
+      farright = lnext(chk);
+      frapex = frpt;
+      frpt = cv;
+      chk = sym(farright);
+      cv = apex(chk);
+    }
+    (void)frapex;
+  }
+  bool changed;
+  do {  // lower common tangent (:5704)
+    changed = false;
+    if (ccw(ildest, ilapex, irorg) > 0) {
+      innerleft = sym(lprev(innerleft));
+      ildest = ilapex;
+      ilapex = apex(innerleft);
+      changed = true;
+    }
+    if (ccw(irapex, irorg, ildest) > 0) {
+      innerright = sym(lnext(innerright));
+      irorg = irapex;
+      irapex = apex(innerright);
+      changed = true;
+    }
+  } while (changed);
+  OTri leftcand = sym(innerleft), rightcand = sym(innerright);
+  OTri base = make();
+  bond(base, innerleft);
+  base = lnext(base);
+  bond(base, innerright);
+  base = lnext(base);
+  set_org(base, irorg);
+  set_dest(base, ildest);
+  if (ildest == org(farleft)) farleft = lnext(base);
+  if (irorg == dest(farright)) farright = lprev(base);
+  int32_t ll = ildest, lr = irorg;
+  int32_t ul = apex(leftcand), ur = apex(rightcand);
+  for (;;) {
+    const bool lfin = ccw(ul, ll, lr) <= 0, rfin = ccw(ur, ll, lr) <= 0;
+    if (lfin && rfin) {  // close the seam with the top bounding triangle (:5771)
+      OTri top = make();
+      set_org(top, ll);
+      set_dest(top, lr);
+      bond(top, base);
+      top = lnext(top);
+      bond(top, rightcand);
+      top = lnext(top);
+      bond(top, leftcand);
+      if (axis == 1) {  // handles back to the left-/right-most vertices
+        int32_t flpt = org(farleft), frpt = dest(farright), frapex = apex(farright);
+        OTri chk = sym(farleft);
+        int32_t cv = apex(chk);
+        while (x_[cv] < x_[flpt]) {
+          farleft = lprev(chk);
+          flpt = cv;
+          chk = sym(farleft);
+          cv = apex(chk);
+        }
+        while (x_[frapex] > x_[frpt]) {
+          farright = sym(lprev(farright));
+          frpt = frapex;
+          frapex = apex(farright);
+        }
+      }
+      return;
+    }
+    if (!lfin) {  // dissolve non-Delaunay edges on the left (:5814)
+      OTri ne = sym(lprev(leftcand));
+      int32_t na = apex(ne);
+      if (na >= 0) {
+        bool bad = incircle(ll, lr, ul, na) > 0;
+        while (bad) {
+          ne = lnext(ne);
+          OTri topc = sym(ne);
+          ne = lnext(ne);
+          OTri sidec = sym(ne);
+          bond(ne, topc);
+          bond(leftcand, sidec);
+          leftcand = lnext(leftcand);
+          OTri outerc = sym(leftcand);
+          ne = lprev(ne);
+          bond(ne, outerc);
+          set_org(leftcand, ll);
+          set_dest(leftcand, -1);
+          set_apex(leftcand, na);
+          set_org(ne, -1);
+          set_dest(ne, ul);
+          set_apex(ne, na);
+          ul = na;
+          ne = sidec;
+          na = apex(ne);
+          bad = na >= 0 && incircle(ll, lr, ul, na) > 0;
+        }
+      }
+    }
+    if (!rfin) {  // ... and on the right (:5862)
+      OTri ne = sym(lnext(rightcand));
+      int32_t na = apex(ne);
+      if (na >= 0) {
+        bool bad = incircle(ll, lr, ur, na) > 0;
+        while (bad) {
+          ne = lprev(ne);
+          OTri topc = sym(ne);
+          ne = lprev(ne);
+          OTri sidec = sym(ne);
+          bond(ne, topc);
+          bond(rightcand, sidec);
+          rightcand = lprev(rightcand);
+          OTri outerc = sym(rightcand);
+          ne = lnext(ne);
+          bond(ne, outerc);
+          set_org(rightcand, -1);
+          set_dest(rightcand, lr);
+          set_apex(rightcand, na);
+          set_org(ne, ur);
+          set_dest(ne, -1);
+          set_apex(ne, na);
+          ur = na;
+          ne = sidec;
+          na = apex(ne);
+          bad = na >= 0 && incircle(ll, lr, ur, na) > 0;
+        }
+      }
+    }
+    if (lfin || (!rfin && incircle(ul, ll, lr, ur) > 0)) {  // new cross edge ll--ur (:5911)
+      bond(base, rightcand);
+      base = lprev(rightcand);
+      set_dest(base, ll);
+      lr = ur;
+      rightcand = sym(base);
+      ur = apex(rightcand);
+    } else {  // new cross edge ul--lr (:5920)
+      bond(base, leftcand);
+      base = lnext(leftcand);
+      set_org(base, lr);
+      ll = ul;
+      leftcand = sym(base);
+      ul = apex(leftcand);
+    }
+  }
+}
+
+void ExactDelaunay::recurse(int32_t *a, int32_t n, int axis, OTri &farleft, OTri &farright) {
+  if (n == 2) {  // one edge = two ghost triangles (:5978)
+    farleft = make();
+    set_org(farleft, a[0]);
+    set_dest(farleft, a[1]);
+    farright = make();
+    set_org(farright, a[1]);
+    set_dest(farright, a[0]);
+    bond(farleft, farright);
+    farleft = lprev(farleft);
+    farright = lnext(farright);
+    bond(farleft, farright);
+    farleft = lprev(farleft);
+    farright = lnext(farright);
+    bond(farleft, farright);
+    farleft = lprev(farright);
+    return;
+  }
+  if (n == 3) {  // (:6006)
+    OTri mid = make(), t1 = make(), t2 = make(), t3 = make();
+    const int64_t area = ccw(a[0], a[1], a[2]);
+    if (area == 0) {
+      set_org(mid, a[0]);
+      set_dest(mid, a[1]);
+      set_org(t1, a[1]);
+      set_dest(t1, a[0]);
+      set_org(t2, a[2]);
+      set_dest(t2, a[1]);
+      set_org(t3, a[1]);
+      set_dest(t3, a[2]);
+      bond(mid, t1);
+      bond(t2, t3);
+      mid = lnext(mid);
+      t1 = lprev(t1);
+      t2 = lnext(t2);
+      t3 = lprev(t3);
+      bond(mid, t3);
+      bond(t1, t2);
+      mid = lnext(mid);
+      t1 = lprev(t1);
+      t2 = lnext(t2);
+      t3 = lprev(t3);
+      bond(mid, t1);
+      bond(t2, t3);
+      farleft = t1;
+      farright = t2;
+    } else {
+      const int32_t b = area > 0 ? a[1] : a[2], c = area > 0 ? a[2] : a[1];
+      set_org(mid, a[0]);
+      set_dest(t1, a[0]);
+      set_org(t3, a[0]);
+      set_dest(mid, b);
+      set_org(t1, b);
+      set_dest(t2, b);
+      set_apex(mid, c);
+      set_org(t2, c);
+      set_dest(t3, c);
+      bond(mid, t1);
+      mid = lnext(mid);
+      bond(mid, t2);
+      mid = lnext(mid);
+      bond(mid, t3);
+      t1 = lprev(t1);
+      t2 = lnext(t2);
+      bond(t1, t2);
+      t1 = lprev(t1);
+      t3 = lprev(t3);
+      bond(t1, t3);
+      t2 = lnext(t2);
+      t3 = lprev(t3);
+      bond(t2, t3);
+      farleft = t1;
+      farright = area > 0 ? t2 : lnext(farleft);
+    }
+    return;
+  }
+  const int32_t divider = n >> 1;
+  OTri innerleft, innerright;
+  recurse(a, divider, 1 - axis, farleft, innerleft);
+  recurse(a + divider, n - divider, 1 - axis, innerright, farright);
+  merge_hulls(farleft, innerleft, innerright, farright, axis);
+}
+
+void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n) {
+  x_ = x;
+  y_ = y;
+  ntri_ = 0;
+  ntri_out_ = 0;
+  seed_ = 1;  // triangleinit(), :4031
+  if (n < 2) return;
+  const size_t cap = (size_t)4 * n + 16;
+  if (nb_.size() < cap * 3) {
+    nb_.resize(cap * 3);
+    vx_.resize(cap * 3);
+  }
+  order_.resize(n);
+  for (int32_t i = 0; i < n; i++) order_[i] = i;
+  int32_t *a = order_.data();
+  vertex_sort(a, n);
+  int32_t i = 0;  // duplicates: the first one in sorted order survives (:6183)
+  for (int32_t j = 1; j < n; j++)
+    if (!(x[a[i]] == x[a[j]] && y[a[i]] == y[a[j]])) a[++i] = a[j];
+  i++;
+  if (i < 2) return;
+  const int32_t divider = i >> 1;
+  if (i - divider >= 2) {
+    if (divider >= 2) alternate_axes(a, divider, 1);
+    alternate_axes(a + divider, i - divider, 1);
+  }
+  OTri hl, hr;
+  recurse(a, i, 0, hl, hr);
+  tri_out_.resize((size_t)ntri_ * 3);
+  for (int32_t t = 0; t < ntri_; t++) {
+    const int32_t *v = &vx_[t * 3];
+    if ((v[0] | v[1] | v[2]) >= 0) {
+      tri_out_[ntri_out_ * 3 + 0] = v[1];
+      tri_out_[ntri_out_ * 3 + 1] = v[2];
+      tri_out_[ntri_out_ * 3 + 2] = v[0];
+      ntri_out_++;
+    }
+  }
+}
+
+// =======================================================================================
+// O1 removeOutliers, viso/matcher.cpp:1207-1377
+// =======================================================================================
+void vsm_host_remove_outliers(VsmHostWork &w, const vsm_params &p, std::vector<vsm_p_match> &m, int method) {
+  const int32_t n = (int32_t)m.size();
+  if (n <= 3) return;
+  w.x.resize(n);
+  w.y.resize(n);
+  for (int32_t i = 0; i < n; i++) {
+    w.x[i] = (int32_t)m[i].u1c;
+    w.y[i] = (int32_t)m[i].v1c;
+  }
+  w.del.run(w.x.data(), w.y.data(), n);
+  w.support.assign(n, 0);
+  const float ftol = (float)p.outlier_flow_tolerance, dtol = (float)p.outlier_disp_tolerance;
+  const int32_t *tri = w.del.triangles();
+  for (int32_t t = 0; t < w.del.num_triangles(); t++) {
+    const int32_t q[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    float fu[3], fv[3], dp[3];
+    for (int k = 0; k < 3; k++) {
+      const vsm_p_match &a = m[q[k]];
+      fu[k] = a.u1c - a.u1p;
+      fv[k] = a.v1c - a.v1p;
+      dp[k] = method == 1 ? a.u1c - a.u2c : a.u1p - a.u2p;
+    }
+    static const int E[3][2] = {{0, 1}, {1, 2}, {0, 2}};
+    for (int e = 0; e < 3; e++) {
+      const int a = E[e][0], b = E[e][1];
+      const bool flow_ok = fabsf(fu[a] - fu[b]) + fabsf(fv[a] - fv[b]) < ftol;
+      const bool disp_ok = fabsf(dp[a] - dp[b]) < dtol;
+      const bool ok = method == 0 ? flow_ok : (method == 1 ? disp_ok : (disp_ok && flow_ok));
+      if (ok) {
+        w.support[q[a]]++;
+        w.support[q[b]]++;
+      }
+    }
+  }
+  int32_t k = 0;
+  for (int32_t i = 0; i < n; i++)
+    if (w.support[i] >= 4) m[k++] = m[i];
+  m.resize(k);
+}
+
+// =======================================================================================
+// M4 computePriorStatistics, viso/matcher.cpp:734-868
+// =======================================================================================
+void vsm_host_prior_statistics(const vsm_params &p, const int32_t *dims_c, const std::vector<vsm_p_match> &m,
+                               int method, std::vector<float> &ranges) {
+  const float bs = (float)p.match_binsize;
+  const int ub = (int)ceilf((float)dims_c[0] / bs), vb = (int)ceilf((float)dims_c[1] / bs);
+  const int nb = ub * vb, ns = method == 2 ? 4 : 2;
+  std::vector<float> lo((size_t)nb * 8, +1000000.f), hi((size_t)nb * 8, -1000000.f);
+  std::vector<int32_t> cnt(nb, 0);
+  for (const vsm_p_match &it : m) {
+    float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float ur = it.u1c, vr = it.v1c;
+    if (method == 0) {
+      d[0] = it.u1p - it.u1c;
+      d[1] = it.v1p - it.v1c;
+      d[2] = it.u1c - it.u1p;
+      d[3] = it.v1c - it.v1p;
+    } else if (method == 1) {
+      d[0] = it.u2c - it.u1c;
+      d[2] = it.u1c - it.u2c;
+    } else {
+      d[0] = it.u2p - it.u1p;
+      d[2] = it.u2c - it.u2p;
+      d[3] = it.v2c - it.v2p;
+      d[4] = it.u1c - it.u2c;
+      d[6] = it.u1p - it.u1c;
+      d[7] = it.v1p - it.v1c;
+      ur = it.u1p;
+      vr = it.v1p;
+    }
+    const int ubin = (int)floorf(ur / bs), vbin = (int)floorf(vr / bs);
+    const int u0 = std::min(std::max(ubin - 1, 0), ub - 1), u1 = std::min(std::max(ubin + 1, 0), ub - 1);
+    const int v0 = std::min(std::max(vbin - 1, 0), vb - 1), v1 = std::min(std::max(vbin + 1, 0), vb - 1);
+    for (int v = v0; v <= v1; v++)
+      for (int u = u0; u <= u1; u++) {
+        const int b = v * ub + u;
+        cnt[b]++;
+        for (int i = 0; i < ns * 2; i++) {
+          lo[b * 8 + i] = std::min(lo[b * 8 + i], d[i]);
+          hi[b * 8 + i] = std::max(hi[b * 8 + i], d[i]);
+        }
+      }
+  }
+  ranges.assign((size_t)nb * 16, 0.f);
+  for (int b = 0; b < nb; b++) {
+    float *r = &ranges[(size_t)b * 16];
+    for (int i = 0; i < ns; i++) {
+      float l[2], h[2];
+      for (int k = 0; k < 2; k++) {
+        l[k] = cnt[b] ? lo[b * 8 + 2 * i + k] : (float)(-p.match_radius);
+        h[k] = cnt[b] ? hi[b * 8 + 2 * i + k] : (float)(+p.match_radius);
+        const float delta = h[k] - l[k];
+        if (delta < 20) {  // widen to at least 20 px (:845-854)
+          const float g = ceilf((20 - delta) / 2);
+          l[k] -= g;
+          h[k] += g;
+        }
+      }
+      r[i] = l[0];
+      r[4 + i] = h[0];
+      r[8 + i] = l[1];
+      r[12 + i] = h[1];
+    }
+  }
+}
+
+// =======================================================================================
+// parabolicFitting tail, viso/matcher.cpp:1425-1453; Matrix::operator* and Matrix::solve
+// (viso/matrix.cpp) evaluated in the same operation order, in double
+// =======================================================================================
+static const double kA[9][6] = {{1, 1, 1, -1, -1, 1}, {0, 1, 0, 0, -1, 1}, {1, 1, -1, 1, -1, 1},
+                                {1, 0, 0, -1, 0, 1},  {0, 0, 0, 0, 0, 1},  {1, 0, 0, 1, 0, 1},
+                                {1, 1, -1, -1, 1, 1}, {0, 1, 0, 0, 1, 1},  {1, 1, 1, 1, 1, 1}};
+
+static bool gauss_jordan6(double A[6][6], double B[6]) {
+  int ipiv[6] = {0, 0, 0, 0, 0, 0};
+  int icol = 0, irow = 0;
+  for (int i = 0; i < 6; i++) {
+    double big = 0.0;
+    for (int j = 0; j < 6; j++)
+      if (ipiv[j] != 1)
+        for (int k = 0; k < 6; k++)
+          if (ipiv[k] == 0 && fabs(A[j][k]) >= big) {
+            big = fabs(A[j][k]);
+            irow = j;
+            icol = k;
+          }
+    ++ipiv[icol];
+    if (irow != icol) {
+      for (int l = 0; l < 6; l++) std::swap(A[irow][l], A[icol][l]);
+      std::swap(B[irow], B[icol]);
+    }
+    if (fabs(A[icol][icol]) < 1e-20) return false;
+    const double pivinv = 1.0 / A[icol][icol];
+    A[icol][icol] = 1.0;
+    for (int l = 0; l < 6; l++) A[icol][l] *= pivinv;
+    B[icol] *= pivinv;
+    for (int ll = 0; ll < 6; ll++)
+      if (ll != icol) {
+        const double dum = A[ll][icol];
+        A[ll][icol] = 0.0;
+        for (int l = 0; l < 6; l++) A[ll][l] -= A[icol][l] * dum;
+        B[ll] -= B[icol] * dum;
+      }
+  }
+  return true;
+}
+
+bool vsm_host_parabolic_update(const int32_t *c9, int du, int dv, float &u2, float &v2) {
+  double b[6], AtA[6][6];
+  for (int i = 0; i < 6; i++) {
+    double s = 0;
+    for (int k = 0; k < 9; k++) s += kA[k][i] * (double)c9[k];
+    b[i] = s;
+    for (int j = 0; j < 6; j++) {
+      double t = 0;
+      for (int k = 0; k < 9; k++) t += kA[k][i] * kA[k][j];
+      AtA[i][j] = t;
+    }
+  }
+  if (!gauss_jordan6(AtA, b)) return false;
+  const float divisor = (float)(b[2] * b[2] - 4.0 * b[0] * b[1]);
+  if (fabsf(divisor) < 1e-8 || fabs(b[2]) < 1e-8) return false;
+  const float ddv = (float)((2.0 * b[0] * b[4] - b[2] * b[3]) / divisor);
+  const float ddu = (float)(-(b[4] + 2.0 * b[1] * ddv) / b[2]);
+  if (fabsf(ddu) >= 1.0 || fabsf(ddv) >= 1.0) return false;
+  u2 = (float)(u2 + ((float)du - 3.0 + ddu));
+  v2 = (float)(v2 + ((float)dv - 3.0 + ddv));
+  return true;
+}
+
+// =======================================================================================
+// B1 bucketFeatures, viso/matcher.cpp:243-284.  std::random_shuffle (libstdc++ stl_algo.h:
+// for i in 1..n-1: swap(a[i], a[rand() % (i+1)])) driven by the C library rand(), whose state
+// the reference's callers seed with srand(0) (viso/viso.cpp:35).
+// =======================================================================================
+void vsm_host_bucket(std::vector<vsm_p_match> &m, int max_features, float bw, float bh) {
+  float u_max = 0, v_max = 0;
+  for (const vsm_p_match &it : m) {
+    if (it.u1c > u_max) u_max = it.u1c;
+    if (it.v1c > v_max) v_max = it.v1c;
+  }
+  const int cols = (int)floorf(u_max / bw) + 1, rows = (int)floorf(v_max / bh) + 1;
+  std::vector<std::vector<vsm_p_match>> buckets((size_t)cols * rows);
+  for (const vsm_p_match &it : m) buckets[(size_t)((int)floorf(it.v1c / bh)) * cols + (int)floorf(it.u1c / bw)].push_back(it);
+  m.clear();
+  for (auto &bk : buckets) {
+    for (size_t i = 1; i < bk.size(); i++) {
+      size_t j = (size_t)(rand() % (int)(i + 1));
+      if (i != j) std::swap(bk[i], bk[j]);
+    }
+    for (size_t k = 0; k < bk.size() && (int)k < max_features; k++) m.push_back(bk[k]);
+  }
+}
+
+// =======================================================================================
+// getGain, viso/matcher.cpp:286-324 (keeps the reference's dims_p clamp for both windows)
+// =======================================================================================
+static float window_mean(const uint8_t *I, int bpl, int u0, int u1, int v0, int v1) {
+  float mean = 0;
+  for (int v = v0; v <= v1; v++)
+    for (int u = u0; u <= u1; u++) mean += (float)I[v * bpl + u];
+  return mean / (float)((u1 - u0 + 1) * (v1 - v0 + 1));
+}
+
+float vsm_host_gain(const uint8_t *I1p, const uint8_t *I1c, const int32_t *dims_p, const int32_t *dims_c,
+                    const std::vector<vsm_p_match> &m, const int32_t *inliers, int32_t n) {
+  if (!I1p || !I1c || m.empty() || n == 0) return 1;
+  const int ws = 3;
+  float gain = 0;
+  int num = 0;
+  auto clampi = [](int v, int hi) { return std::min(std::max(v, 0), hi); };
+  for (int32_t k = 0; k < n; k++) {
+    const int32_t i = inliers[k];
+    if (i < (int32_t)m.size()) {
+      const vsm_p_match &q = m[i];
+      const float mp = window_mean(I1p, dims_p[2], clampi((int)q.u1p - ws, dims_p[0]), clampi((int)q.u1p + ws, dims_p[0]),
+                                   clampi((int)q.v1p - ws, dims_p[1]), clampi((int)q.v1p + ws, dims_p[1]));
+      const float mc = window_mean(I1c, dims_c[2], clampi((int)q.u1c - ws, dims_p[0]), clampi((int)q.u1c + ws, dims_p[0]),
+                                   clampi((int)q.v1c - ws, dims_p[1]), clampi((int)q.v1c + ws, dims_p[1]));
+      if (mp > 10) {
+        gain += mc / mp;
+        num++;
+      }
+    }
+  }
+  return num > 0 ? gain / (float)num : 1;
+}

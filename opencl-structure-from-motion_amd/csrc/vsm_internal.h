@@ -1,0 +1,73 @@
+// Internal structures shared by the host orchestration (vsm_api.cpp) and the gfx950 kernels
+// (vsm_kernels.hip).  Nothing here is part of the C-ABI (include/visomatch.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "visomatch.h"
+
+#define VSM_MARGIN 6  // Matcher::margin = 5+1, viso/matcher.cpp:56
+
+// One feature set (sparse = pass 1, dense = pass 2) of one image, resident in HBM.
+//   feat      T1 records int32[12] in NMS emission order (what m1c1.. hold in the reference)
+//   s_*       the same features regrouped by (class, u_bin, v_bin) bin for the radius search:
+//             coordinates and 32-byte descriptors are contiguous per bin so a lane group reads
+//             a bin as one coalesced run; inside a bin entries ascend by original index, so
+//             "position in the sorted arrays" is exactly findMatch's traversal order
+//             (viso/matcher.cpp:937-940) for a fixed class.
+struct VsmSet {
+  int32_t *feat;       // [cap][12]
+  int32_t *count;      // device scalar
+  int32_t *cand;       // [ncu*ncv*4] packed NMS survivors: u | v<<14 | valid<<31
+  int32_t *bin_start;  // [4*ub*vb + 1]
+  int32_t *s_idx;      // [cap] sorted position -> original index
+  int2 *s_uv;          // [cap]
+  uint4 *s_desc;       // [cap][2]
+  int32_t *tmp;        // [cap] scratch
+  int32_t cap, nms_n, ncu, ncv;
+};
+
+struct VsmImage {
+  uint8_t *img;      // [h][bpl]  padded copy of the input (pad = 0)
+  uint8_t *imgm;     // matching-resolution image: half image, or == img
+  uint8_t *du, *dv;  // matching-resolution Sobel responses
+  uint8_t *du_full, *dv_full;  // full-resolution Sobel responses (half_resolution only; else == du,dv)
+  VsmSet set[2];     // 0 sparse, 1 dense
+};
+
+struct VsmDims {
+  int32_t w, h, bpl;     // full resolution
+  int32_t mw, mh, mbpl;  // matching resolution
+  int32_t scale;         // 2 if half_resolution else 1
+  int32_t ub, vb;        // match bins over the full-resolution image
+};
+
+struct VsmMatchCfg {
+  int32_t method, use_prior, use_tr, sparse;
+  int32_t binsize, radius, disp_tol;
+  double f, cu, cv, base;
+  double t[12];
+};
+
+// per frame-pair buffers
+struct VsmPair {
+  vsm_p_match *raw;    // [cap_query] per-query result of the match chain
+  int32_t *flag;       // [cap_query]
+  vsm_p_match *list1;  // compacted pass-1 list
+  vsm_p_match *list2;  // compacted pass-2 list (refined in place)
+  int32_t *count;      // [2] list sizes
+  float *ranges;       // [ub*vb][16]
+  int32_t *pf;         // refinement==2 scratch: [cap][3][12] {status,du,dv,c0..c8}
+};
+
+// ---- launchers (vsm_kernels.hip) ----
+void vsm_launch_ingest(hipStream_t s, const uint8_t *src, int32_t src_bpl, uint8_t *dst, const VsmDims &d);
+void vsm_launch_features(hipStream_t s, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d, int16_t *f1,
+                         int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res, int binsize,
+                         const VsmImage *h_imgs);
+void vsm_launch_match(hipStream_t s, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
+                      const VsmDims &d, const VsmMatchCfg &cfg, int n_query, vsm_p_match *list, int32_t *list_count);
+void vsm_launch_refine(hipStream_t s, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
+                       const VsmDims &dp, const VsmDims &dc, int method, int refinement, int n_upper,
+                       const int32_t *d_count);

@@ -1,0 +1,714 @@
+// gfx950 (MI355X, CDNA4) kernels of the matcher hot path.  Wave = 64 lanes.
+//
+// All kernels are integer/byte work bounded by HBM (or, for one 1242x375 pair, by launch and
+// dependent-load latency): no MFMA anywhere.  Every kernel takes a z (or y) grid dimension
+// over images / frame pairs so the same code serves the per-frame API (2 images, 1 pair) and
+// batched sequences (hundreds of images per launch), which is what fills 256 CUs.
+//
+// Semantics are those of the reference (pad bytes pinned to 0, filters on the 1-D byte stream);
+// file:line citations below refer to the reference repository.
+
+#include "vsm_internal.h"
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------------------
+// ingest: caller image (row stride src_bpl) -> padded HBM copy [h][bpl], pad bytes = 0
+// (Matcher::pushBack row copy, viso/matcher.cpp:163-175, with the pad pinned to 0)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ingest(const uint8_t *__restrict__ src, int src_bpl, uint8_t *__restrict__ dst,
+                                                int w, int h, int bpl, int aligned) {
+  int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  int y = blockIdx.y;
+  if (x4 >= bpl || y >= h) return;
+  const uint8_t *row = src + (size_t)y * src_bpl;
+  uint32_t v = 0;
+  if (aligned && x4 + 3 < w) {
+    v = *(const uint32_t *)(row + x4);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (x4 + k < w) v |= (uint32_t)row[x4 + k] << (8 * k);
+  }
+  *(uint32_t *)(dst + (size_t)y * bpl + x4) = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// F0 createHalfResolutionImage, viso/matcher.cpp:636-647: (a+b+c+d)/4 over 2x2, pad = 0
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_halve(const VsmImage *__restrict__ imgs, int first, VsmDims d) {
+  const VsmImage &im = imgs[first + blockIdx.z];
+  int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  int y = blockIdx.y;
+  if (x4 >= d.mbpl) return;
+  const uint8_t *r0 = im.img + (size_t)(2 * y) * d.bpl + 2 * x4;
+  const uint8_t *r1 = r0 + d.bpl;
+  uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+  if (2 * x4 < d.bpl) {
+    a0 = *(const uint32_t *)r0;
+    b0 = *(const uint32_t *)r1;
+  }
+  if (2 * x4 + 4 < d.bpl) {
+    a1 = *(const uint32_t *)(r0 + 4);
+    b1 = *(const uint32_t *)(r1 + 4);
+  }
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t ta = k < 2 ? a0 : a1, tb = k < 2 ? b0 : b1;
+    int sh = (k & 1) * 16;
+    uint32_t s = ((ta >> sh) & 0xff) + ((ta >> (sh + 8)) & 0xff) + ((tb >> sh) & 0xff) + ((tb >> (sh + 8)) & 0xff);
+    if (x4 + k < d.mw) out |= (s >> 2) << (8 * k);
+  }
+  *(uint32_t *)(im.imgm + (size_t)y * d.mbpl + x4) = out;
+}
+
+// ---------------------------------------------------------------------------------------
+// F1-F3 image filters on the byte stream of one image (row wrap = the reference's SSE loops):
+//   du,dv : filter::sobel5x5, viso/filter.cpp:316-324 (+128, >>7, unsigned saturate)
+//   f1    : filter::blob5x5,  viso/filter.cpp:343-365  (-box5 + 2*box3 + 7*centre)
+//   f2    : filter::checkerboard5x5, viso/filter.cpp:331-336 (c (x) c, c = 1,1,0,-1,-1)
+// One thread produces 4 horizontally adjacent pixels from a 5 x 12 byte window held in
+// registers (15 dword loads, neighbours hit L1/L2); outputs are one dword of du, one of dv and,
+// for the matching-resolution image, 8 bytes each of f1 and f2.
+// FULL = true: full-resolution image -> du_full,dv_full only.
+// ---------------------------------------------------------------------------------------
+template <bool FULL>
+__global__ void __launch_bounds__(256)
+    k_filters(const VsmImage *__restrict__ imgs, int first, int bpl, int h, int16_t *__restrict__ f1base,
+              int16_t *__restrict__ f2base, size_t f_stride) {
+  const VsmImage &im = imgs[first + blockIdx.z];
+  const uint8_t *__restrict__ in = FULL ? im.img : im.imgm;
+  const int n = bpl * h;
+  const int f0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (f0 >= n) return;
+  int p[5][12];
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    int base = f0 + (r - 2) * bpl;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      int a = base + (q - 1) * 4;
+      uint32_t v = (a >= 0 && a < n) ? *(const uint32_t *)(in + a) : 0u;
+      p[r][q * 4 + 0] = v & 0xff;
+      p[r][q * 4 + 1] = (v >> 8) & 0xff;
+      p[r][q * 4 + 2] = (v >> 16) & 0xff;
+      p[r][q * 4 + 3] = v >> 24;
+    }
+  }
+  // column pass at stream positions f0-2 .. f0+5 (window index 2..9); zero outside rows [2,h-3]
+  int S[8], D[8];
+  const int lo = 2 * bpl, hi = (h - 2) * bpl;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    int g = f0 + i - 2;
+    bool ok = g >= lo && g < hi;
+    int a = p[0][i + 2], b = p[1][i + 2], c = p[2][i + 2], dd = p[3][i + 2], e = p[4][i + 2];
+    S[i] = ok ? a + 4 * b + 6 * c + 4 * dd + e : 0;
+    D[i] = ok ? a + 2 * b - 2 * dd - e : 0;
+  }
+  uint32_t du = 0, dv = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int hu = S[k] + 2 * S[k + 1] - 2 * S[k + 3] - S[k + 4];
+    int hv = D[k] + 4 * D[k + 1] + 6 * D[k + 2] + 4 * D[k + 3] + D[k + 4];
+    int u8 = min(max((hu >> 7) + 128, 0), 255);
+    int v8 = min(max((hv >> 7) + 128, 0), 255);
+    du |= (uint32_t)u8 << (8 * k);
+    dv |= (uint32_t)v8 << (8 * k);
+  }
+  *(uint32_t *)((FULL ? im.du_full : im.du) + f0) = du;
+  *(uint32_t *)((FULL ? im.dv_full : im.dv) + f0) = dv;
+  if (!FULL) {
+    const int y = f0 / bpl, x0 = f0 - y * bpl;
+    int16_t o1[4], o2[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int i = 4 + k, x = x0 + k;
+      int b5 = 0, b3 = 0, ck = 0;
+#pragma unroll
+      for (int r = 0; r < 5; r++) {
+        int r3 = p[r][i - 1] + p[r][i] + p[r][i + 1];
+        int r5 = r3 + p[r][i - 2] + p[r][i + 2];
+        int rd = p[r][i - 2] + p[r][i - 1] - p[r][i + 1] - p[r][i + 2];
+        b5 += r5;
+        if (r >= 1 && r <= 3) b3 += r3;
+        ck += (r < 2) ? rd : (r > 2 ? -rd : 0);
+      }
+      bool in1 = x >= 3 && x <= bpl - 3 && y >= 3 && y <= h - 3;
+      bool in2 = x >= 2 && x <= bpl - 3 && y >= 2 && y <= h - 3;
+      o1[k] = in1 ? (int16_t)(-b5 + 2 * b3 + 7 * p[2][i]) : (int16_t)0;
+      o2[k] = in2 ? (int16_t)ck : (int16_t)0;
+    }
+    int16_t *f1 = f1base + (size_t)blockIdx.z * f_stride, *f2 = f2base + (size_t)blockIdx.z * f_stride;
+    *(uint2 *)(f1 + f0) = make_uint2((uint16_t)o1[0] | ((uint32_t)(uint16_t)o1[1] << 16),
+                                     (uint16_t)o1[2] | ((uint32_t)(uint16_t)o1[3] << 16));
+    *(uint2 *)(f2 + f0) = make_uint2((uint16_t)o2[0] | ((uint32_t)(uint16_t)o2[1] << 16),
+                                     (uint16_t)o2[2] | ((uint32_t)(uint16_t)o2[3] << 16));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// N1 nonMaximumSuppression, viso/matcher.cpp:330-431 (Neubeck & Van Gool alg. 4).
+// One thread per (cell, filter): first-wins min and max of the (n+1)^2 cell (u outer, v inner,
+// strict compares), then the (2n+1)^2 suppression windows.  blockIdx.y: 0 = f1, 1 = f2;
+// blockIdx.z = image*2 + set.  Survivors go to cand[cell*4 + class].
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool nms_suppressed(const int16_t *__restrict__ f, int bpl, int w, int h, int n, int i,
+                                               int j, int ci, int cj, int val, bool want_min) {
+  const int i_hi = min(ci + n, w - 1 - VSM_MARGIN), j_hi = min(cj + n, h - 1 - VSM_MARGIN);
+  for (int i2 = ci - n; i2 <= i_hi; i2++)
+    for (int j2 = cj - n; j2 <= j_hi; j2++) {
+      int cur = f[j2 * bpl + i2];
+      bool better = want_min ? (cur < val) : (cur > val);
+      if (better && (i2 < i || i2 > i + n || j2 < j || j2 > j + n)) return true;
+    }
+  return false;
+}
+
+__global__ void __launch_bounds__(256) k_nms(const VsmImage *__restrict__ imgs, int first, VsmDims d,
+                                             const int16_t *__restrict__ f1base, const int16_t *__restrict__ f2base,
+                                             size_t f_stride, int tau, int set_lo) {
+  const int zi = blockIdx.z >> 1, si = (blockIdx.z & 1);
+  if (si < set_lo) return;
+  const VsmSet &st = imgs[first + zi].set[si];
+  const int ncells = st.ncu * st.ncv;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ncells) return;
+  const int k = blockIdx.y;
+  const int16_t *__restrict__ f = (k ? f2base : f1base) + (size_t)zi * f_stride;
+  const int n = st.nms_n;
+  const int cj = t / st.ncu, ci = t - cj * st.ncu;  // neighbouring lanes walk along u: coalesced rows
+  const int i = n + VSM_MARGIN + ci * (n + 1), j = n + VSM_MARGIN + cj * (n + 1);
+  int mni = i, mnj = j, mxi = i, mxj = j;
+  int mnv = f[j * d.mbpl + i], mxv = mnv;
+  for (int i2 = i; i2 <= i + n; i2++)
+    for (int j2 = j; j2 <= j + n; j2++) {
+      int cur = f[j2 * d.mbpl + i2];
+      if (cur < mnv) {
+        mni = i2;
+        mnj = j2;
+        mnv = cur;
+      } else if (cur > mxv) {
+        mxi = i2;
+        mxj = j2;
+        mxv = cur;
+      }
+    }
+  bool vmin = (mnv <= -tau) && !nms_suppressed(f, d.mbpl, d.mw, d.mh, n, i, j, mni, mnj, mnv, true);
+  bool vmax = (mxv >= tau) && !nms_suppressed(f, d.mbpl, d.mw, d.mh, n, i, j, mxi, mxj, mxv, false);
+  int32_t *c = st.cand + (size_t)(ci * st.ncv + cj) * 4 + 2 * k;
+  c[0] = vmin ? (int32_t)(0x80000000u | (uint32_t)mni | ((uint32_t)mnj << 14)) : 0;
+  c[1] = vmax ? (int32_t)(0x80000000u | (uint32_t)mxi | ((uint32_t)mxj << 14)) : 0;
+}
+
+// block-wide exclusive scan of one int per thread (blockDim.x == 1024); returns the exclusive
+// prefix and the block total.  Wave shuffles + one LDS hop.
+__device__ __forceinline__ int block_excl_scan_1024(int v, int &total, int *s_w /*[17]*/) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  __syncthreads();  // protects s_w reuse across calls
+  if (lane == 63) s_w[wv] = x;
+  __syncthreads();
+  if (wv == 0) {
+    int w = lane < 16 ? s_w[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      int y = __shfl_up(w, o, 64);
+      if (lane >= o) w += y;
+    }
+    if (lane < 16) s_w[lane] = w;  // inclusive wave totals
+  }
+  __syncthreads();
+  total = s_w[15];
+  int wbase = wv ? s_w[wv - 1] : 0;
+  return wbase + x - v;
+}
+
+// ---------------------------------------------------------------------------------------
+// ordered emission of the T1 feature records (viso/matcher.cpp:707-731) + D1 descriptor gather
+// (computeDescriptor, viso/matcher.cpp:433-477).  Feature index = rank in the reference's
+// emission order: cells u-major / v-minor, classes f1min,f1max,f2min,f2max inside a cell.
+// One 1024-thread block per (image, set): chunked exclusive scan over the cells.
+// ---------------------------------------------------------------------------------------
+__constant__ int8_t c_desc_dv[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
+__constant__ int8_t c_desc_du[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
+
+__global__ void __launch_bounds__(1024) k_emit(const VsmImage *__restrict__ imgs, int first, VsmDims d, int set_lo) {
+  __shared__ int s_w[17];
+  __shared__ int s_run;
+  const VsmImage &im = imgs[first + blockIdx.z];
+  const int si = blockIdx.y;
+  const VsmSet &st = im.set[si];
+  if (si < set_lo) {
+    if (threadIdx.x == 0) *st.count = 0;
+    return;
+  }
+  const int ncells = st.ncu * st.ncv;
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (int base = 0; base < ncells; base += 1024) {
+    const int e = base + threadIdx.x;
+    int4 c4 = make_int4(0, 0, 0, 0);
+    if (e < ncells) c4 = *(const int4 *)(st.cand + (size_t)e * 4);
+    const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
+    int cnt = (c4.x < 0) + (c4.y < 0) + (c4.z < 0) + (c4.w < 0);
+    int total;
+    int pos = s_run + block_excl_scan_1024(cnt, total, s_w);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (cc[k] < 0) {
+        const int u = cc[k] & 0x3fff, v = (cc[k] >> 14) & 0x3fff;
+        uint32_t dsc[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          int a0 = (v + c_desc_dv[2 * m]) * d.mbpl + u + c_desc_du[2 * m];
+          int a1 = (v + c_desc_dv[2 * m + 1]) * d.mbpl + u + c_desc_du[2 * m + 1];
+          dsc[m] = (uint32_t)im.du[a0] | ((uint32_t)im.dv[a0] << 8) | ((uint32_t)im.du[a1] << 16) |
+                   ((uint32_t)im.dv[a1] << 24);
+        }
+        uint4 *r = (uint4 *)(st.feat + (size_t)pos * 12);
+        r[0] = make_uint4((uint32_t)(u * d.scale), (uint32_t)(v * d.scale), 0u, (uint32_t)k);
+        r[1] = make_uint4(dsc[0], dsc[1], dsc[2], dsc[3]);
+        r[2] = make_uint4(dsc[4], dsc[5], dsc[6], dsc[7]);
+        pos++;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_run += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *st.count = s_run;
+}
+
+// ---------------------------------------------------------------------------------------
+// M1 createIndexVector, viso/matcher.cpp:870-890, as a stable counting sort into the
+// bin-contiguous SoA arrays (see VsmSet).  bin = (class*ub + u_bin)*vb + v_bin so that the
+// v-bins a query visits for one u_bin are one contiguous run.  One block per (image, set).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int feat_bin(const int32_t *rec, int binsize, int ub, int vb) {
+  int ubin = min((int)floorf((float)rec[0] / (float)binsize), ub - 1);
+  int vbin = min((int)floorf((float)rec[1] / (float)binsize), vb - 1);
+  return (rec[3] * ub + ubin) * vb + vbin;
+}
+
+__global__ void __launch_bounds__(1024) k_bin(const VsmImage *__restrict__ imgs, int first, VsmDims d, int binsize,
+                                              int set_lo) {
+  extern __shared__ int s_mem[];
+  __shared__ int s_w[17];
+  const VsmSet &st = imgs[first + blockIdx.z].set[blockIdx.y];
+  if ((int)blockIdx.y < set_lo) return;
+  const int nb = 4 * d.ub * d.vb;
+  int *s_start = s_mem, *s_cur = s_mem + nb + 1;
+  const int n = *st.count;
+  for (int b = threadIdx.x; b <= nb; b += 1024) s_start[b] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&s_start[feat_bin(st.feat + (size_t)i * 12, binsize, d.ub, d.vb)], 1);
+  __syncthreads();
+  // exclusive scan of the nb histogram entries: per-thread chunk + block scan
+  const int chunk = (nb + 1023) / 1024;
+  const int b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, nb);
+  int sum = 0;
+  for (int b = b0; b < b1; b++) sum += s_start[b];
+  int total;
+  int run = block_excl_scan_1024(sum, total, s_w);
+  for (int b = b0; b < b1; b++) {
+    int c = s_start[b];
+    s_start[b] = run;
+    s_cur[b] = run;
+    run += c;
+  }
+  if (threadIdx.x == 0) s_start[nb] = total;
+  __syncthreads();
+  for (int b = threadIdx.x; b <= nb; b += 1024) st.bin_start[b] = s_start[b];
+  // unordered scatter of indices into their bins ...
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    int b = feat_bin(st.feat + (size_t)i * 12, binsize, d.ub, d.vb);
+    st.tmp[atomicAdd(&s_cur[b], 1)] = i;
+  }
+  __syncthreads();
+  // ... then each entry finds its stable rank (number of smaller indices in its bin: bins hold
+  // at most one feature per NMS cell and class, i.e. a few dozen entries)
+  for (int p = threadIdx.x; p < n; p += 1024) {
+    const int idx = st.tmp[p];
+    const int32_t *rec = st.feat + (size_t)idx * 12;
+    const int b = feat_bin(rec, binsize, d.ub, d.vb);
+    const int lo = s_start[b], hi = s_start[b + 1];
+    int rank = 0;
+    for (int q = lo; q < hi; q++) rank += st.tmp[q] < idx;
+    const int dst = lo + rank;
+    st.s_idx[dst] = idx;
+    st.s_uv[dst] = make_int2(rec[0], rec[1]);
+    st.s_desc[2 * dst] = *(const uint4 *)(rec + 4);
+    st.s_desc[2 * dst + 1] = *(const uint4 *)(rec + 8);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// M2/M3 findMatch + matching, viso/matcher.cpp:892-963 and :965-1153.
+// A group of G lanes owns one query and walks the whole dependent chain (2 stages for flow /
+// stereo, 4 for quad).  In each stage the lanes stride over the candidates of the visited bins
+// (coalesced 8-byte coordinate reads, 32-byte descriptor reads only for in-window candidates),
+// cost = v_sad_u8 x 8 (+ 4*sqrt(du^2+dv^2) in double when a prediction is active), per-lane
+// first-wins strict '<', then a lexicographic (cost, traversal position) min over the group --
+// exactly the reference's "first minimum in (u_bin, v_bin, index) order" (:937-958).
+// ---------------------------------------------------------------------------------------
+#define VSM_NONE 0xffffffffu
+
+__device__ __forceinline__ uint32_t sad32(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1) {
+  uint32_t s = __builtin_amdgcn_sad_u8(a0.x, b0.x, 0u);
+  s = __builtin_amdgcn_sad_u8(a0.y, b0.y, s);
+  s = __builtin_amdgcn_sad_u8(a0.z, b0.z, s);
+  s = __builtin_amdgcn_sad_u8(a0.w, b0.w, s);
+  s = __builtin_amdgcn_sad_u8(a1.x, b1.x, s);
+  s = __builtin_amdgcn_sad_u8(a1.y, b1.y, s);
+  s = __builtin_amdgcn_sad_u8(a1.z, b1.z, s);
+  s = __builtin_amdgcn_sad_u8(a1.w, b1.w, s);
+  return s;
+}
+
+template <int G>
+__device__ __forceinline__ int find_match(const VsmSet &A, int i1, const VsmSet &B, const VsmDims &d,
+                                          const VsmMatchCfg &cfg, const float *__restrict__ range, int stage, bool flow,
+                                          double u_, double v_, int lane) {
+  const int32_t *rec = A.feat + (size_t)i1 * 12;
+  const int4 hd = *(const int4 *)rec;
+  const int u1 = hd.x, v1 = hd.y, c = hd.w;
+  const uint4 d1a = *(const uint4 *)(rec + 4), d1b = *(const uint4 *)(rec + 8);
+  float u_min, u_max, v_min, v_max;
+  if (range) {
+    u_min = (float)u1 + range[stage];
+    u_max = (float)u1 + range[4 + stage];
+    v_min = (float)v1 + range[8 + stage];
+    v_max = (float)v1 + range[12 + stage];
+  } else {
+    u_min = (float)(u1 - cfg.radius);
+    u_max = (float)(u1 + cfg.radius);
+    v_min = (float)(v1 - cfg.radius);
+    v_max = (float)(v1 + cfg.radius);
+  }
+  if (!flow) {
+    v_min = (float)(v1 - cfg.disp_tol);
+    v_max = (float)(v1 + cfg.disp_tol);
+  }
+  const float bs = (float)cfg.binsize;
+  const int ubmin = min(max((int)floorf(u_min / bs), 0), d.ub - 1);
+  const int ubmax = min(max((int)floorf(u_max / bs), 0), d.ub - 1);
+  const int vbmin = min(max((int)floorf(v_min / bs), 0), d.vb - 1);
+  const int vbmax = min(max((int)floorf(v_max / bs), 0), d.vb - 1);
+  const bool pred = (u_ >= 0 && v_ >= 0);
+  double best = 10000000.0;
+  uint32_t bestq = VSM_NONE;
+  for (int ubin = ubmin; ubin <= ubmax; ubin++) {
+    const int b0 = (c * d.ub + ubin) * d.vb;
+    const int q0 = B.bin_start[b0 + vbmin], q1 = B.bin_start[b0 + vbmax + 1];
+    for (int q = q0 + lane; q < q1; q += G) {
+      const int2 uv = B.s_uv[q];
+      if ((float)uv.x >= u_min && (float)uv.x <= u_max && (float)uv.y >= v_min && (float)uv.y <= v_max) {
+        const uint4 a = B.s_desc[2 * q], b = B.s_desc[2 * q + 1];
+        double cost = (double)sad32(d1a, d1b, a, b);
+        if (pred) {
+          double du = (double)uv.x - u_;
+          double dv = (double)uv.y - v_;
+          double dist = sqrt(du * du + dv * dv);
+          cost += 4 * dist;
+        }
+        if (cost < best) {
+          best = cost;
+          bestq = (uint32_t)q;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) {
+    double oc = __shfl_xor(best, m, G);
+    uint32_t oq = (uint32_t)__shfl_xor((int)bestq, m, G);
+    if (oc < best || (oc == best && oq < bestq)) {
+      best = oc;
+      bestq = oq;
+    }
+  }
+  return bestq == VSM_NONE ? 0 : B.s_idx[bestq];
+}
+
+__device__ __forceinline__ int stat_bin_of(int u, int v, int binsize, int ub, int vb) {
+  int ubin = min((int)floorf((float)u / (float)binsize), ub - 1);
+  int vbin = min((int)floorf((float)v / (float)binsize), vb - 1);
+  return vbin * ub + ubin;
+}
+
+template <int G>
+__global__ void __launch_bounds__(256)
+    k_match(const VsmImage *__restrict__ imgs, int img_prev, int img_curr, VsmPair pair, VsmDims d, VsmMatchCfg cfg,
+            int n_query) {
+  const int lane = threadIdx.x & (G - 1);
+  const int qi = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  if (qi >= n_query) return;
+  const int si = cfg.sparse ? 0 : 1;
+  const VsmSet &s1p = imgs[img_prev].set[si], &s2p = imgs[img_prev + 1].set[si];
+  const VsmSet &s1c = imgs[img_curr].set[si], &s2c = imgs[img_curr + 1].set[si];
+  vsm_p_match m;
+  bool ok = false;
+  if (cfg.method == 0) {  // flow, :1006-1041
+    const int4 q = *(const int4 *)(s1c.feat + (size_t)qi * 12);
+    const float *rg = cfg.use_prior ? pair.ranges + 16 * stat_bin_of(q.x, q.y, cfg.binsize, d.ub, d.vb) : nullptr;
+    int i1p = find_match<G>(s1c, qi, s1p, d, cfg, rg, 0, true, -1, -1, lane);
+    int i1c2 = find_match<G>(s1p, i1p, s1c, d, cfg, rg, 1, true, -1, -1, lane);
+    ok = (i1c2 == qi);
+    const int4 p = *(const int4 *)(s1p.feat + (size_t)i1p * 12);
+    m = {(float)p.x, (float)p.y, i1p, -1.f, -1.f, -1, (float)q.x, (float)q.y, qi, -1.f, -1.f, -1};
+  } else if (cfg.method == 1) {  // stereo, :1045-1084
+    const int4 q = *(const int4 *)(s1c.feat + (size_t)qi * 12);
+    const float *rg = cfg.use_prior ? pair.ranges + 16 * stat_bin_of(q.x, q.y, cfg.binsize, d.ub, d.vb) : nullptr;
+    int i2c = find_match<G>(s1c, qi, s2c, d, cfg, rg, 0, false, -1, -1, lane);
+    int i1c2 = find_match<G>(s2c, i2c, s1c, d, cfg, rg, 1, false, -1, -1, lane);
+    const int4 p = *(const int4 *)(s2c.feat + (size_t)i2c * 12);
+    ok = (i1c2 == qi) && (q.x >= p.x);
+    m = {-1.f, -1.f, -1, -1.f, -1.f, -1, (float)q.x, (float)q.y, qi, (float)p.x, (float)p.y, i2c};
+  } else {  // quad, :1088-1153
+    const int4 q = *(const int4 *)(s1p.feat + (size_t)qi * 12);
+    const int u1p = q.x, v1p = q.y;
+    const float *rg = cfg.use_prior ? pair.ranges + 16 * stat_bin_of(u1p, v1p, cfg.binsize, d.ub, d.vb) : nullptr;
+    int i2p = find_match<G>(s1p, qi, s2p, d, cfg, rg, 0, false, -1, -1, lane);
+    const int4 p2 = *(const int4 *)(s2p.feat + (size_t)i2p * 12);
+    const int u2p = p2.x, v2p = p2.y;
+    double u2c_ = -1, v2c_ = -1, u1p_ = -1, v1p_ = -1;
+    if (cfg.use_tr) {  // :1114-1126, contraction-free double arithmetic
+      double dd = (double)u1p - (double)u2p;
+      if (!(dd > 1.0)) dd = 1.0;
+      double x1p = ((double)u1p - cfg.cu) * cfg.base / dd;
+      double y1p = ((double)v1p - cfg.cv) * cfg.base / dd;
+      double z1p = cfg.f * cfg.base / dd;
+      double x2c = cfg.t[0] * x1p + cfg.t[1] * y1p + cfg.t[2] * z1p + cfg.t[3] - cfg.base;
+      double y2c = cfg.t[4] * x1p + cfg.t[5] * y1p + cfg.t[6] * z1p + cfg.t[7];
+      double z2c = cfg.t[8] * x1p + cfg.t[9] * y1p + cfg.t[10] * z1p + cfg.t[11];
+      u2c_ = cfg.f * x2c / z2c + cfg.cu;
+      v2c_ = cfg.f * y2c / z2c + cfg.cv;
+      u1p_ = (double)u1p;
+      v1p_ = (double)v1p;
+    }
+    int i2c = find_match<G>(s2p, i2p, s2c, d, cfg, rg, 1, true, u2c_, v2c_, lane);
+    int i1c = find_match<G>(s2c, i2c, s1c, d, cfg, rg, 2, false, -1, -1, lane);
+    int i1p2 = find_match<G>(s1c, i1c, s1p, d, cfg, rg, 3, true, u1p_, v1p_, lane);
+    const int4 c2 = *(const int4 *)(s2c.feat + (size_t)i2c * 12);
+    const int4 c1 = *(const int4 *)(s1c.feat + (size_t)i1c * 12);
+    ok = (i1p2 == qi) && (u1p >= u2p) && (c1.x >= c2.x);
+    m = {(float)u1p, (float)v1p, qi, (float)u2p, (float)v2p, i2p, (float)c1.x, (float)c1.y, i1c, (float)c2.x,
+         (float)c2.y, i2c};
+  }
+  if (lane == 0) {
+    pair.flag[qi] = ok ? 1 : 0;
+    if (ok) pair.raw[qi] = m;
+  }
+}
+
+// ordered compaction of the accepted queries (push_back order = ascending query index) with the
+// first-come pixel de-dup of flow / stereo (M[] in viso/matcher.cpp:1036-1039, :1078-1081):
+// features sharing a pixel come from one NMS cell, hence are at most 3 indices apart.
+__global__ void __launch_bounds__(1024)
+    k_compact_matches(VsmPair pair, int method, int n_query, vsm_p_match *__restrict__ list, int32_t *list_count) {
+  __shared__ int s_w[17];
+  __shared__ int s_run;
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (int base = 0; base < n_query; base += 1024) {
+    const int i = base + threadIdx.x;
+    int keep = 0;
+    vsm_p_match m;
+    if (i < n_query && pair.flag[i]) {
+      m = pair.raw[i];
+      keep = 1;
+      if (method < 2) {
+        for (int j = max(i - 3, 0); j < i; j++)
+          if (pair.flag[j] && pair.raw[j].u1c == m.u1c && pair.raw[j].v1c == m.v1c) keep = 0;
+      }
+    }
+    int total;
+    int pos = s_run + block_excl_scan_1024(keep, total, s_w);
+    if (keep) list[pos] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) s_run += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *list_count = s_run;
+}
+
+// ---------------------------------------------------------------------------------------
+// R1 refinement, viso/matcher.cpp:1498-1585.  32 lanes per (match, relocation step); lane
+// (dv*5+du) evaluates one of the 25 candidate positions with the 16-byte ELAS descriptor
+// (computeSmallDescriptor, :479-506) read from the full-resolution Sobel planes; first-wins
+// argmin = min over (cost, lane).  Steps: 0 -> (u1p,v1p) [flow, quad], 1 -> (u2c,v2c) [stereo,
+// quad], 2 -> (u2p,v2p) [quad]; each uses the unrefined (u1c,v1c) as its reference (:1544-1577).
+// refinement==2 (parabolicFitting, :1379-1454): 49 lanes of a wave evaluate the 7x7 costs, the
+// 3x3 neighbourhood around the minimum goes to the host, which solves the 9x6 least squares in
+// double exactly as Matrix::solve does.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 small_desc(const uint8_t *__restrict__ du, const uint8_t *__restrict__ dv, int bpl,
+                                            int u, int v) {
+  const int a2 = v * bpl + u, a1 = a2 - bpl, a0 = a1 - bpl, a3 = a2 + bpl, a4 = a3 + bpl;
+  uint4 r;
+  r.x = du[a0] | (du[a1 - 2] << 8) | (du[a1] << 16) | ((uint32_t)du[a1 + 2] << 24);
+  r.y = du[a2 - 1] | (du[a2] << 8) | (du[a2] << 16) | ((uint32_t)du[a2 + 1] << 24);
+  r.z = du[a3 - 2] | (du[a3] << 8) | (du[a3 + 2] << 16) | ((uint32_t)du[a4] << 24);
+  r.w = dv[a1] | (dv[a2 - 1] << 8) | (dv[a2 + 1] << 16) | ((uint32_t)dv[a3] << 24);
+  return r;
+}
+
+__device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b) {
+  uint32_t s = __builtin_amdgcn_sad_u8(a.x, b.x, 0u);
+  s = __builtin_amdgcn_sad_u8(a.y, b.y, s);
+  s = __builtin_amdgcn_sad_u8(a.z, b.z, s);
+  return __builtin_amdgcn_sad_u8(a.w, b.w, s);
+}
+
+__global__ void __launch_bounds__(256)
+    k_refine(const VsmImage *__restrict__ imgs, int img_prev, int img_curr, VsmPair pair, VsmDims dp, VsmDims dc,
+             int method, const int32_t *__restrict__ d_count) {
+  const int lane = threadIdx.x & 31;
+  const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int mi = g / 3, step = g - mi * 3;
+  if (mi >= *d_count) return;
+  if (step == 0 && !(method == 0 || method == 2)) return;
+  if (step == 1 && !(method == 1 || method == 2)) return;
+  if (step == 2 && method != 2) return;
+  vsm_p_match *m = pair.list2 + mi;
+  const VsmImage &ref = imgs[img_curr];
+  const VsmImage &tgt = step == 0 ? imgs[img_prev] : (step == 1 ? imgs[img_curr + 1] : imgs[img_prev + 1]);
+  const VsmDims &dt = step == 1 ? dc : dp;
+  float *pu = step == 0 ? &m->u1p : (step == 1 ? &m->u2c : &m->u2p);
+  float *pv = pu + 1;
+  const float u2 = *pu, v2 = *pv;
+  if (u2 - 2 < VSM_MARGIN || u2 + 2 > dt.w - 1 - VSM_MARGIN || v2 - 2 < VSM_MARGIN || v2 + 2 > dt.h - 1 - VSM_MARGIN)
+    return;
+  const uint4 r = small_desc(ref.du_full, ref.dv_full, dc.bpl, (int)m->u1c, (int)m->v1c);
+  uint32_t key = 0xffffffffu;
+  if (lane < 25) {
+    const int ddv = lane / 5, ddu = lane - ddv * 5;
+    const uint4 t = small_desc(tgt.du_full, tgt.dv_full, dt.bpl, (int)u2 + ddu - 2, (int)v2 + ddv - 2);
+    key = (sad16(r, t) << 5) | (uint32_t)lane;
+  }
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o, 32));
+  if (lane == 0) {
+    const int ind = key & 31;
+    *pu = (float)((double)u2 + ((double)(float)(ind % 5) - 2.0));
+    *pv = (float)((double)v2 + ((double)(float)(ind / 5) - 2.0));
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_parabolic_costs(const VsmImage *__restrict__ imgs, int img_prev, int img_curr, VsmPair pair, VsmDims dp,
+                      VsmDims dc, int method, const int32_t *__restrict__ d_count) {
+  const int lane = threadIdx.x & 63;
+  const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // one wave per (match, step)
+  const int mi = g / 3, step = g - mi * 3;
+  if (mi >= *d_count) return;
+  int32_t *out = pair.pf + ((size_t)mi * 3 + step) * 12;
+  bool active = !((step == 0 && !(method == 0 || method == 2)) || (step == 1 && !(method == 1 || method == 2)) ||
+                  (step == 2 && method != 2));
+  if (!active) {
+    if (lane == 0) out[0] = 2;  // step not applicable
+    return;
+  }
+  const vsm_p_match *m = pair.list2 + mi;
+  const VsmImage &ref = imgs[img_curr];
+  const VsmImage &tgt = step == 0 ? imgs[img_prev] : (step == 1 ? imgs[img_curr + 1] : imgs[img_prev + 1]);
+  const VsmDims &dt = step == 1 ? dc : dp;
+  const float u2 = step == 0 ? m->u1p : (step == 1 ? m->u2c : m->u2p);
+  const float v2 = step == 0 ? m->v1p : (step == 1 ? m->v2c : m->v2p);
+  if (u2 - 3 < VSM_MARGIN || u2 + 3 > dt.w - 1 - VSM_MARGIN || v2 - 3 < VSM_MARGIN || v2 + 3 > dt.h - 1 - VSM_MARGIN) {
+    if (lane == 0) out[0] = 0;  // infeasible: match dropped (wave-uniform branch)
+    return;
+  }
+  const uint4 r = small_desc(ref.du_full, ref.dv_full, dc.bpl, (int)m->u1c, (int)m->v1c);
+  uint32_t key = 0xffffffffu;
+  int cost = 0;
+  if (lane < 49) {
+    const int ddv = lane / 7, ddu = lane - ddv * 7;
+    const uint4 t = small_desc(tgt.du_full, tgt.dv_full, dt.bpl, (int)u2 + ddu - 3, (int)v2 + ddv - 3);
+    cost = (int)sad16(r, t);
+    key = ((uint32_t)cost << 6) | (uint32_t)lane;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o, 64));
+  // key is now wave-uniform: first minimum in (dv, du) order
+  const int ind = key & 63, du = ind % 7, dv = ind / 7;
+  const bool border = (du == 0 || du == 6 || dv == 0 || dv == 6);
+  int c9[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    int src = border ? 0 : (dv + k / 3 - 1) * 7 + (du + k % 3 - 1);
+    c9[k] = __shfl(cost, src, 64);
+  }
+  if (lane == 0) {
+    if (border) {
+      out[0] = 0;
+    } else {
+      out[0] = 1;
+      out[1] = du;
+      out[2] = dv;
+#pragma unroll
+      for (int k = 0; k < 9; k++) out[3 + k] = c9[k];
+    }
+  }
+}
+
+// =======================================================================================
+// launchers
+// =======================================================================================
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+void vsm_launch_ingest(hipStream_t s, const uint8_t *src, int32_t src_bpl, uint8_t *dst, const VsmDims &d) {
+  int aligned = ((src_bpl & 3) == 0) && ((((uintptr_t)src) & 3) == 0);
+  dim3 grid(cdiv(d.bpl / 4, 256), d.h);
+  hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, src, src_bpl, dst, d.w, d.h, d.bpl, aligned);
+}
+
+void vsm_launch_features(hipStream_t s, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d, int16_t *f1,
+                         int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res, int binsize,
+                         const VsmImage *h_imgs) {
+  if (half_res) {
+    hipLaunchKernelGGL(k_halve, dim3(cdiv(d.mbpl / 4, 256), d.mh, n_img), dim3(256), 0, s, d_imgs, first, d);
+    hipLaunchKernelGGL(k_filters<true>, dim3(cdiv(d.bpl * d.h / 4, 256), 1, n_img), dim3(256), 0, s, d_imgs, first,
+                       d.bpl, d.h, (int16_t *)nullptr, (int16_t *)nullptr, (size_t)0);
+  }
+  hipLaunchKernelGGL(k_filters<false>, dim3(cdiv(d.mbpl * d.mh / 4, 256), 1, n_img), dim3(256), 0, s, d_imgs, first,
+                     d.mbpl, d.mh, f1, f2, f_stride);
+  const int set_lo = multi_stage ? 0 : 1;
+  int max_cells = 0;
+  for (int k = 0; k < 2; k++) max_cells = max(max_cells, h_imgs[first].set[k].ncu * h_imgs[first].set[k].ncv);
+  if (max_cells > 0)
+    hipLaunchKernelGGL(k_nms, dim3(cdiv(max_cells, 256), 2, n_img * 2), dim3(256), 0, s, d_imgs, first, d, f1, f2,
+                       f_stride, nms_tau, set_lo);
+  hipLaunchKernelGGL(k_emit, dim3(1, 2, n_img), dim3(1024), 0, s, d_imgs, first, d, set_lo);
+  const size_t shm = (size_t)(2 * (4 * d.ub * d.vb + 1)) * sizeof(int);
+  hipLaunchKernelGGL(k_bin, dim3(1, 2, n_img), dim3(1024), shm, s, d_imgs, first, d, binsize, set_lo);
+}
+
+void vsm_launch_match(hipStream_t s, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
+                      const VsmDims &d, const VsmMatchCfg &cfg, int n_query, vsm_p_match *list, int32_t *list_count) {
+  constexpr int G = 16;
+  if (n_query > 0)
+    hipLaunchKernelGGL(k_match<G>, dim3(cdiv(n_query * G, 256)), dim3(256), 0, s, d_imgs, img_prev, img_curr, pair, d,
+                       cfg, n_query);
+  hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, pair, cfg.method, n_query, list, list_count);
+}
+
+void vsm_launch_refine(hipStream_t s, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
+                       const VsmDims &dp, const VsmDims &dc, int method, int refinement, int n_upper,
+                       const int32_t *d_count) {
+  // n_upper bounds the list size (it may still be device-only); surplus groups exit at once
+  if (n_upper <= 0) return;
+  if (refinement == 2)
+    hipLaunchKernelGGL(k_parabolic_costs, dim3(cdiv(n_upper * 3 * 64, 256)), dim3(256), 0, s, d_imgs, img_prev,
+                       img_curr, pair, dp, dc, method, d_count);
+  else
+    hipLaunchKernelGGL(k_refine, dim3(cdiv(n_upper * 3 * 32, 256)), dim3(256), 0, s, d_imgs, img_prev, img_curr,
+                       pair, dp, dc, method, d_count);
+}

@@ -1,0 +1,230 @@
+"""ctypes binding of libvisomatch.so (include/visomatch.h) -- the Python mirror of the
+reference's `class Matcher` (viso/matcher.h:37-136): pushBack / matchFeatures / getMatches /
+bucketFeatures / getGain / setIntrinsics, plus the stage-level views the parity tests use.
+
+The library is the HIP build for gfx950; there is no CPU path.  Importing works anywhere (the
+CPU test-suite checks the exported symbols), creating a Matcher needs a GPU and raises otherwise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvisomatch.so")
+
+P_MATCH = np.dtype(
+    [("u1p", "<f4"), ("v1p", "<f4"), ("i1p", "<i4"), ("u2p", "<f4"), ("v2p", "<f4"), ("i2p", "<i4"),
+     ("u1c", "<f4"), ("v1c", "<f4"), ("i1c", "<i4"), ("u2c", "<f4"), ("v2c", "<f4"), ("i2c", "<i4")])
+assert P_MATCH.itemsize == 48
+
+INT_PARAMS = ["nms_n", "nms_tau", "match_binsize", "match_radius", "match_disp_tolerance",
+              "outlier_disp_tolerance", "outlier_flow_tolerance", "multi_stage", "half_resolution", "refinement"]
+FEATURE_SETS = {"1p1": 0, "2p1": 1, "1c1": 2, "2c1": 3, "1p2": 4, "2p2": 5, "1c2": 6, "2c2": 7}
+
+# every symbol include/visomatch.h declares
+EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsics", "vsm_push_back",
+           "vsm_push_back_device", "vsm_match", "vsm_num_matches", "vsm_get_matches", "vsm_bucket", "vsm_gain",
+           "vsm_num_features", "vsm_get_features", "vsm_set_stage_capture", "vsm_stage_size", "vsm_stage_get",
+           "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
+           "vsm_get_timings", "vsm_version"]
+
+
+class VsmParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in INT_PARAMS] + [(n, C.c_double) for n in ("f", "cu", "cv", "base")]
+
+
+class VisoMatchError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VisoMatchError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+        L.vsm_version.restype = C.c_char_p
+        L.vsm_default_params.argtypes = [C.POINTER(VsmParams)]
+        L.vsm_create.restype = vp
+        L.vsm_create.argtypes = [C.POINTER(VsmParams)]
+        L.vsm_destroy.argtypes = [vp]
+        L.vsm_set_intrinsics.argtypes = [vp] + [C.c_double] * 4
+        L.vsm_push_back.argtypes = [vp, vp, vp, i32, i32, i32, C.c_int]
+        L.vsm_push_back_device.argtypes = [vp, vp, vp, i32, i32, i32, C.c_int]
+        L.vsm_match.argtypes = [vp, i32, vp]
+        L.vsm_num_matches.argtypes = [vp]
+        L.vsm_get_matches.argtypes = [vp, vp, i32]
+        L.vsm_bucket.argtypes = [vp, i32, f32, f32]
+        L.vsm_gain.argtypes = [vp, vp, i32]
+        L.vsm_gain.restype = f32
+        L.vsm_num_features.argtypes = [vp, i32]
+        L.vsm_get_features.argtypes = [vp, i32, vp, i32]
+        L.vsm_set_stage_capture.argtypes = [vp, C.c_int]
+        L.vsm_stage_size.argtypes = [vp, i32]
+        L.vsm_stage_get.argtypes = [vp, i32, vp, i32]
+        L.vsm_num_ranges.argtypes = [vp]
+        L.vsm_get_ranges.argtypes = [vp, vp, i32]
+        L.vsm_get_gradients.argtypes = [vp, i32, i32, vp, vp]
+        L.vsm_get_filter_responses.argtypes = [vp, vp, vp]
+        L.vsm_get_counters.argtypes = [vp, vp]
+        L.vsm_get_timings.argtypes = [vp, vp]
+        _lib = L
+    return _lib
+
+
+def default_params():
+    p = VsmParams()
+    lib().vsm_default_params(C.byref(p))
+    return p
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Matcher:
+    """Drop-in mirror of the reference Matcher.  Images: (H,W) uint8 numpy arrays (host path,
+    vsm_push_back) or CUDA/HIP torch tensors (device-resident path, vsm_push_back_device)."""
+
+    OK, EDIMS, ENOTREADY, EHIP, EARG = 0, -1, -2, -3, -4
+
+    def __init__(self, stage_capture=False, **params):
+        L = lib()
+        p = default_params()
+        for k, v in params.items():
+            if not hasattr(p, k):
+                raise TypeError(f"unknown matcher parameter {k}")
+            setattr(p, k, v)
+        self.params = p
+        self.h = L.vsm_create(C.byref(p))
+        if not self.h:
+            raise VisoMatchError("vsm_create failed: no usable HIP device (the matcher has no CPU path)")
+        self.h = C.c_void_p(self.h)
+        if stage_capture:
+            L.vsm_set_stage_capture(self.h, 1)
+
+    # --- reference API -------------------------------------------------------------------
+    def set_intrinsics(self, f, cu, cv, base):
+        lib().vsm_set_intrinsics(self.h, f, cu, cv, base)
+
+    def push_back(self, I1, I2=None, replace=False):
+        L = lib()
+        if _is_torch(I1):
+            assert I1.is_cuda and I1.dtype.__str__() == "torch.uint8" and I1.dim() == 2
+            h, w = I1.shape
+            bpl = I1.stride(0)
+            assert I1.stride(1) == 1
+            p2 = None
+            if I2 is not None:
+                assert I2.is_cuda and I2.shape == I1.shape and I2.stride() == I1.stride()
+                p2 = C.c_void_p(I2.data_ptr())
+            return L.vsm_push_back_device(self.h, C.c_void_p(I1.data_ptr()), p2, w, h, bpl, int(replace))
+        I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+        h, w = I1.shape
+        p2 = None
+        if I2 is not None:
+            I2 = np.ascontiguousarray(I2, dtype=np.uint8)
+            assert I2.shape == I1.shape
+            p2 = I2.ctypes.data_as(C.c_void_p)
+        return L.vsm_push_back(self.h, I1.ctypes.data_as(C.c_void_p), p2, w, h, w, int(replace))
+
+    def match_features(self, method, Tr_delta=None):
+        tp = None
+        if Tr_delta is not None:
+            t = np.ascontiguousarray(np.asarray(Tr_delta, dtype=np.float64).reshape(-1)[:12])
+            tp = t.ctypes.data_as(C.c_void_p)
+        rc = lib().vsm_match(self.h, method, tp)
+        if rc not in (self.OK, self.ENOTREADY):
+            raise VisoMatchError(f"vsm_match failed with {rc}")
+        return rc
+
+    def get_matches(self):
+        n = lib().vsm_num_matches(self.h)
+        out = np.zeros(n, dtype=P_MATCH)
+        if n:
+            lib().vsm_get_matches(self.h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def bucket_features(self, max_features, bucket_width, bucket_height):
+        lib().vsm_bucket(self.h, max_features, bucket_width, bucket_height)
+
+    def get_gain(self, inliers):
+        a = np.ascontiguousarray(inliers, dtype=np.int32)
+        return float(lib().vsm_gain(self.h, a.ctypes.data_as(C.c_void_p), len(a)))
+
+    # --- the face the golden drivers use (same names as oracle.bindings.CpuMatcher) ---------
+    def match(self, method, Tr=None):
+        return self.match_features(method, Tr) == self.OK
+
+    matches = get_matches
+    bucket = bucket_features
+    gain = get_gain
+
+    def stage(self, s):
+        n = lib().vsm_stage_size(self.h, s)
+        out = np.zeros(n, dtype=P_MATCH)
+        if n:
+            lib().vsm_stage_get(self.h, s, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def ranges(self):
+        n = lib().vsm_num_ranges(self.h)
+        out = np.zeros((n, 4, 4), dtype=np.float32)
+        if n:
+            lib().vsm_get_ranges(self.h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def features(self, which):
+        w = FEATURE_SETS[which] if isinstance(which, str) else which
+        n = lib().vsm_num_features(self.h, w)
+        out = np.zeros((n, 12), dtype=np.int32)
+        if n:
+            got = lib().vsm_get_features(self.h, w, out.ctypes.data_as(C.c_void_p), n)
+            assert got == n
+        return out
+
+    def gradients(self, which, full):
+        n = lib().vsm_get_gradients(self.h, which, int(full), None, None)
+        if n == 0:
+            return None, None
+        du = np.zeros(n, dtype=np.uint8)
+        dv = np.zeros(n, dtype=np.uint8)
+        lib().vsm_get_gradients(self.h, which, int(full), du.ctypes.data_as(C.c_void_p), dv.ctypes.data_as(C.c_void_p))
+        return du, dv
+
+    def filter_responses(self):
+        n = lib().vsm_get_filter_responses(self.h, None, None)
+        if n == 0:
+            return None, None
+        f1 = np.zeros(n, dtype=np.int16)
+        f2 = np.zeros(n, dtype=np.int16)
+        lib().vsm_get_filter_responses(self.h, f1.ctypes.data_as(C.c_void_p), f2.ctypes.data_as(C.c_void_p))
+        return f1, f2
+
+    def counters(self):
+        c = np.zeros(5, dtype=np.int64)
+        lib().vsm_get_counters(self.h, c.ctypes.data_as(C.c_void_p))
+        return c
+
+    def timings(self):
+        t = np.zeros(5, dtype=np.float64)
+        lib().vsm_get_timings(self.h, t.ctypes.data_as(C.c_void_p))
+        return dict(zip(("pass1_gpu_us", "pass1_host_us", "pass2_gpu_us", "final_host_us", "total_us"), t.tolist()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().vsm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

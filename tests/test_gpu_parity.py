@@ -1,0 +1,155 @@
+"""GPU parity suite (run with -m gpu on an MI355X): the HIP path, called through the C-ABI
+(libvisomatch.so), must be bit-identical to the CPU oracle on seeded inputs and to the committed
+golden vectors of the real reference, stage by stage."""
+import numpy as np
+import pytest
+
+import golden_util as G
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vm():
+    m = pkg("visomatch")
+    m.lib()  # raises if the HIP library is missing: no silent fallback
+    return m
+
+
+def _gpu(vm):
+    return lambda **p: vm.Matcher(stage_capture=True, **p)
+
+
+def _same(a, b):
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("w,h,half", [(320, 96, 1), (333, 101, 1), (640, 480, 1), (1242, 375, 1), (304, 128, 0), (64, 48, 0)])
+def test_filters_vs_oracle(vm, B, synth, w, h, half):
+    l, r = synth.stereo_sequence(21, w, h, 1)[0]
+    m = vm.Matcher(half_resolution=half)
+    assert m.push_back(l, r) == 0
+    img = B.pad_image(l)
+    mimg = B.half_image("oracle", img, w) if half else img
+    du, dv = B.sobel5x5("oracle", mimg)
+    gdu, gdv = m.gradients(2, False)
+    assert np.array_equal(gdu, du.ravel()) and np.array_equal(gdv, dv.ravel())
+    if half:
+        duf, dvf = B.sobel5x5("oracle", img)
+        gduf, gdvf = m.gradients(2, True)
+        assert np.array_equal(gduf, duf.ravel()) and np.array_equal(gdvf, dvf.ravel())
+    f1, f2 = m.filter_responses()
+    assert np.array_equal(f1, B.blob5x5("oracle", mimg).ravel())
+    assert np.array_equal(f2, B.checkerboard5x5("oracle", mimg).ravel())
+    # right image gradients too
+    rimg = B.pad_image(r)
+    rm = B.half_image("oracle", rimg, w) if half else rimg
+    du2, _ = B.sobel5x5("oracle", rm)
+    assert np.array_equal(m.gradients(3, False)[0], du2.ravel())
+    m.close()
+
+
+@pytest.mark.parametrize("method", [2, 0, 1])
+@pytest.mark.parametrize("pi", range(6))
+def test_golden_small(vm, synth, pi, method):
+    assert G.replay_small(G.load("small_304x128"), synth, _gpu(vm), pi, method) > 5
+
+
+@pytest.mark.parametrize("pi", range(2))
+def test_golden_small_tr_delta(vm, synth, pi):
+    assert G.replay_small(G.load("small_tr_352x160"), synth, _gpu(vm), pi, 2) > 5
+
+
+def test_golden_cfgA(vm, synth):
+    G.replay_hashed(G.load("cfgA_1242x375_quad"), synth, _gpu(vm))
+
+
+def test_golden_cfg3_mono(vm, synth):
+    G.replay_hashed(G.load("cfg3_640x480_mono"), synth, _gpu(vm))
+
+
+def test_golden_cfg5_highres(vm, synth):
+    G.replay_hashed(G.load("cfg5_2048x1024_quad"), synth, _gpu(vm))
+
+
+def test_golden_cfg2_sequence_feedback(vm, synth):
+    G.replay_vo_sequence(G.load("cfg2_seq200_tr"), synth, _gpu(vm), n_frames=40)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_vs_oracle_replace_and_params(vm, B, synth, method):
+    """seeded inputs through oracle and GPU side by side, incl. replace=True and odd sizes"""
+    for params in (dict(), dict(nms_n=5, outlier_flow_tolerance=3), dict(match_binsize=40, match_radius=150)):
+        seq = synth.stereo_sequence(77, 417, 163, 4, disparity=10, ramp=(1, 12))
+        g, c = vm.Matcher(stage_capture=True, **params), B.CpuMatcher("oracle", **params)
+        for f, (l, r) in enumerate(seq):
+            rep = f == 2
+            g.push_back(l, r if method else None, replace=rep)
+            c.push_back(l, r if method else None, replace=rep)
+            for s in ("1p1", "1p2", "1c1", "1c2", "2c2"):
+                assert _same(g.features(s), c.features(s)), (params, f, s)
+            assert g.match(method) == c.match(method)
+            for s in range(5):
+                assert _same(g.stage(s), c.stage(s)), (params, f, s)
+        g.close()
+
+
+def test_device_resident_inputs(vm, B, synth):
+    import torch
+    seq = synth.stereo_sequence(5, 500, 200, 3)
+    g, c = vm.Matcher(), B.CpuMatcher("oracle")
+    for l, r in seq:
+        tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+        assert g.push_back(tl, tr) == 0
+        c.push_back(l, r)
+        g.match(2)
+        c.match(2)
+        assert _same(g.matches(), c.matches())
+    assert len(g.matches()) > 100
+
+
+def test_bucketing_gain_and_errors(vm, B, synth):
+    import ctypes
+    libc = ctypes.CDLL(None)
+    seq = synth.stereo_sequence(9, 416, 160, 3)
+    res = []
+    for make in (lambda: vm.Matcher(), lambda: B.CpuMatcher("oracle")):
+        m = make()
+        libc.srand(0)
+        assert not m.match(2)
+        for l, r in seq:
+            m.push_back(l, r)
+            m.match(2)
+            m.bucket(2, 50.0, 50.0)
+        res.append((m.matches(), m.gain(np.arange(0, len(m.matches()), 2))))
+    assert _same(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    m = vm.Matcher()
+    L = vm.lib()
+    assert L.vsm_push_back(m.h, None, None, 128, 64, 128, 0) == m.EDIMS
+    assert m.match_features(2) == m.ENOTREADY
+    l, r = seq[0]
+    m.push_back(l, r)
+    assert m.match_features(2) == m.ENOTREADY and m.match_features(0) == m.ENOTREADY
+    assert len(m.get_matches()) == 0
+
+
+def test_full_size_properties(vm, synth):
+    """size-independent properties at BASELINE's full size: index validity, ordering, closure"""
+    seq = synth.stereo_sequence(1234, 1242, 375, 3)
+    m = vm.Matcher(stage_capture=True)
+    for l, r in seq:
+        m.push_back(l, r)
+        m.match(2)
+    fin, raw = m.matches(), m.stage(2)
+    n1p, n1c = len(m.features("1p2")), len(m.features("1c2"))
+    assert len(fin) > 5000
+    assert np.all(np.diff(raw["i1p"]) > 0)            # emitted in ascending query order
+    assert np.all(np.diff(fin["i1p"]) > 0)            # outlier removal preserves order
+    assert fin["i1p"].max() < n1p and fin["i1c"].max() < n1c
+    assert np.all(raw["u1p"] >= raw["u2p"]) and np.all(raw["u1c"] >= raw["u2c"])
+    f1p = m.features("1p2")
+    assert np.array_equal(f1p[raw["i1p"], 0], raw["u1p"].astype(np.int32))
+    # idempotence: matching again without a push gives the same list
+    m.match(2)
+    assert _same(m.matches(), fin)
