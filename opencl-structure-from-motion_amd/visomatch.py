@@ -48,6 +48,13 @@ def lib():
             raise VisoMatchError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP
+        # runtimes in one process cannot both own the GPU, so when torch is installed let it load
+        # its runtime first; libvisomatch.so then binds to that copy.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch-less environments use /opt/rocm's runtime
+            pass
         L = C.CDLL(LIB_PATH)
         vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
         L.vsm_version.restype = C.c_char_p
