@@ -131,6 +131,18 @@ void vsm_get_counters(vsm_handle *h, int64_t *out5);
  * {pass-1 GPU+sync, pass-1 host (Delaunay+prior), pass-2 GPU+sync, final host Delaunay, total} */
 void vsm_get_timings(vsm_handle *h, double *out5);
 
+/* per-kernel device time measured with HIP events on the handle's own stream (bench.py's
+ * roofline leg).  vsm_set_profiling(h,1) zeroes the accumulators and starts recording. */
+void vsm_set_profiling(vsm_handle *h, int on);
+int32_t vsm_num_kernels(void);
+const char *vsm_kernel_name(int32_t id);
+void vsm_get_kernel_stats(vsm_handle *h, double *total_ms, int64_t *launches);
+
+/* host-only view of the exact Delaunay used by removeOutliers (triangulate("zQB") of
+ * viso/triangle.cpp:8500 on integer points in [0,16384)^2); needs no GPU.  Returns the number
+ * of triangles; tris gets vertex triples by input index. */
+int32_t vsm_host_delaunay(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap, int32_t threads);
+
 const char *vsm_version(void);
 
 #ifdef __cplusplus

@@ -72,6 +72,8 @@ struct vsm_handle {
   int64_t counters[5] = {0, 0, 0, 0, 0};
   double timings[5] = {0, 0, 0, 0, 0};
   std::vector<uint8_t> gainI[2];
+  VsmProf prof;
+  VsmPool *pool = nullptr;
 };
 
 extern "C" {
@@ -101,6 +103,14 @@ vsm_handle *vsm_create(const vsm_params *p) {
   vsm_handle *h = new vsm_handle();
   h->param = *p;
   if (p->half_resolution) h->param.match_radius /= 2;
+  {
+    int nt = 8;  // host threads for the Delaunay sub-problems (the caller's thread included)
+    if (const char *e = getenv("VSM_HOST_THREADS")) nt = atoi(e);
+    unsigned hc = std::thread::hardware_concurrency();
+    if (hc && (unsigned)nt > hc) nt = (int)hc;
+    h->pool = new VsmPool(nt);
+    h->work.pool = h->pool;
+  }
   if (hipGetDevice(&h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void **)&h->h_counts, 16 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
     fprintf(stderr, "visomatch: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
@@ -127,6 +137,7 @@ void vsm_destroy(vsm_handle *h) {
   release_device(h);
   if (h->h_counts) (void)hipHostFree(h->h_counts);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h->pool;
   delete h;
 }
 
@@ -158,7 +169,7 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
   d.mw = p.half_resolution ? w / 2 : w;
   d.mh = p.half_resolution ? hh / 2 : hh;
   d.mbpl = p.half_resolution ? bpl16(d.mw) : d.bpl;
-  if (d.mw <= 0 || d.mh <= 0 || d.mw >= 16384 || d.mh >= 16384) return VSM_EDIMS;
+  if (d.mw <= 0 || d.mh <= 0 || d.w >= 16384 || d.h >= 16384) return VSM_EDIMS;  // 14-bit coordinates
   d.ub = (int32_t)ceilf((float)w / (float)p.match_binsize);
   d.vb = (int32_t)ceilf((float)hh / (float)p.match_binsize);
   const int nb = 4 * d.ub * d.vb;
@@ -287,11 +298,11 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
   for (int k = 0; k < n_img; k++) {
     uint8_t *dst = h->h_imgs[slot * 2 + k].img;
     if (on_device)
-      vsm_launch_ingest(h->stream, src[k], bpl, dst, h->dims);
+      vsm_launch_ingest(h->stream, h->prof, src[k], bpl, dst, h->dims);
     else  // pageable source: HIP stages the rows; the caller's buffer is free again on return
       HIPCHK(hipMemcpy2DAsync(dst, h->dims.bpl, src[k], bpl, w, hh, hipMemcpyHostToDevice, h->stream));
   }
-  vsm_launch_features(h->stream, h->d_imgs, slot * 2, n_img, h->dims, h->f1, h->f2, h->f_stride, h->param.nms_tau,
+  vsm_launch_features(h->stream, h->prof, h->d_imgs, slot * 2, n_img, h->dims, h->f1, h->f2, h->f_stride, h->param.nms_tau,
                       h->param.multi_stage, h->param.half_resolution, h->param.match_binsize, h->h_imgs);
   for (int k = 0; k < n_img; k++)
     for (int s = 0; s < 2; s++)
@@ -299,6 +310,7 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
                             h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
+  h->prof.resolve();
   h->have[slot] = true;
   h->right[slot] = (I2 != nullptr);
   memset(h->n_feat[slot], 0, sizeof(h->n_feat[slot]));
@@ -378,7 +390,7 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
     cfg.sparse = 1;
     cfg.use_prior = 0;
     const int nq = N(qslot, 0, 0);
-    vsm_launch_match(h->stream, h->d_imgs, img_prev, img_curr, h->pair, h->dims, cfg, nq, h->pair.list1, h->pair.count);
+    vsm_launch_match(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, h->dims, cfg, nq, h->pair.list1, h->pair.count);
     int rc = fetch_list(h, h->pair.list1, h->pair.count, h->stage[0]);
     if (rc != VSM_OK) return rc;
     h->counters[0] += (int64_t)nq * stages;
@@ -393,7 +405,7 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
   cfg.sparse = 0;
   cfg.use_prior = p.multi_stage ? 1 : 0;
   const int nq2 = N(qslot, 0, 1);
-  vsm_launch_match(h->stream, h->d_imgs, img_prev, img_curr, h->pair, h->dims, cfg, nq2, h->pair.list2, h->pair.count + 1);
+  vsm_launch_match(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, h->dims, cfg, nq2, h->pair.list2, h->pair.count + 1);
   h->counters[0] += (int64_t)nq2 * stages;
   const bool fetch2 = h->capture_stage2 || p.refinement != 1;
   if (fetch2) {
@@ -404,7 +416,7 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
     // without stage capture the list size stays on the device: the grid is sized for the worst
     // case (every query matched) and surplus groups exit at once
     const int n_upper = fetch2 ? (int)h->stage[2].size() : nq2;
-    vsm_launch_refine(h->stream, h->d_imgs, img_prev, img_curr, h->pair, dp, dc, method, p.refinement, n_upper,
+    vsm_launch_refine(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, dp, dc, method, p.refinement, n_upper,
                       h->pair.count + 1);
     if (p.refinement == 2) {
       const size_t n = h->stage[2].size();
@@ -431,6 +443,7 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
     h->stage[3] = h->stage[2];
   }
   HIPCHK(hipGetLastError());
+  h->prof.resolve();
   const double t3 = now_us();
   h->counters[3] = (int64_t)h->stage[3].size();
   h->stage[4] = h->stage[3];
@@ -540,6 +553,37 @@ int32_t vsm_get_filter_responses(vsm_handle *h, int16_t *f1, int16_t *f2) {
 }
 
 void vsm_set_stage_capture(vsm_handle *h, int on) { h->capture_stage2 = on ? 1 : 0; }
+
+static const char *kKernelNames[VSM_K_COUNT] = {"k_ingest", "k_halve", "k_filters<true>", "k_filters<false>", "k_nms", "k_emit",
+                                                "k_bin", "k_match<16>:pass1", "k_compact_matches:pass1", "k_match<16>:pass2",
+                                                "k_compact_matches:pass2", "k_refine"};
+
+void vsm_set_profiling(vsm_handle *h, int on) {
+  h->prof.on = on != 0;
+  if (on) {
+    memset(h->prof.total_ms, 0, sizeof(h->prof.total_ms));
+    memset(h->prof.launches, 0, sizeof(h->prof.launches));
+  }
+}
+
+int32_t vsm_num_kernels(void) { return VSM_K_COUNT; }
+
+const char *vsm_kernel_name(int32_t id) { return (id >= 0 && id < VSM_K_COUNT) ? kKernelNames[id] : ""; }
+
+void vsm_get_kernel_stats(vsm_handle *h, double *total_ms, int64_t *launches) {
+  memcpy(total_ms, h->prof.total_ms, sizeof(h->prof.total_ms));
+  memcpy(launches, h->prof.launches, sizeof(h->prof.launches));
+}
+
+int32_t vsm_host_delaunay(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap, int32_t threads) {
+  ExactDelaunay d;
+  VsmPool pool(threads);
+  d.run(x, y, n, threads > 1 ? &pool : nullptr);
+  const int32_t nt = d.num_triangles();
+  for (int32_t i = 0; i < nt && i < cap; i++)
+    for (int k = 0; k < 3; k++) tris[i * 3 + k] = d.triangles()[i * 3 + k];
+  return nt;
+}
 
 void vsm_get_counters(vsm_handle *h, int64_t *out5) { memcpy(out5, h->counters, sizeof(h->counters)); }
 void vsm_get_timings(vsm_handle *h, double *out5) { memcpy(out5, h->timings, sizeof(h->timings)); }

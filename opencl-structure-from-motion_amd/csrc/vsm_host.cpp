@@ -6,81 +6,158 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+
+// =======================================================================================
+// VsmPool
+// =======================================================================================
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
+
+VsmPool::VsmPool(int threads) : nthreads_(threads < 1 ? 1 : threads) {
+  if (const char *e = getenv("VSM_HOST_SPIN_US")) spin_us_ = atoi(e);
+  for (int i = 1; i < nthreads_; i++) threads_.emplace_back([this] { worker(); });
+}
+
+VsmPool::~VsmPool() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = true;
+    gen_.store(0xffffffffffull, std::memory_order_release);
+  }
+  cv_.notify_all();
+  for (auto &t : threads_) t.join();
+}
+
+// Task claiming is a CAS on (generation << 32 | next index): a worker that is late for
+// generation g can never claim an index of generation g+1 with g's (possibly destroyed) closure.
+bool VsmPool::claim(uint64_t g, int n, int &idx) {
+  uint64_t v = next_.load(std::memory_order_acquire);
+  for (;;) {
+    if ((v >> 32) != g || (int)(v & 0xffffffffu) >= n) return false;
+    if (next_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) {
+      idx = (int)(v & 0xffffffffu);
+      return true;
+    }
+  }
+}
+
+void VsmPool::worker() {
+  uint64_t seen = 0;
+  for (;;) {
+    // wait for a new generation: spin first, then block
+    auto t0 = std::chrono::steady_clock::now();
+    while (gen_.load(std::memory_order_acquire) == seen) {
+      cpu_relax();
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us_) {
+        std::unique_lock<std::mutex> lk(mu_);
+        sleepers_.fetch_add(1);
+        cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+        sleepers_.fetch_sub(1);
+        break;
+      }
+    }
+    seen = gen_.load(std::memory_order_acquire);
+    if (stop_) return;
+    const std::function<void(int)> *fn = fn_;
+    const int n = ntasks_;
+    int i;
+    while (claim(seen, n, i)) {
+      (*fn)(i);
+      done_.fetch_add(1, std::memory_order_acq_rel);
+    }
+  }
+}
+
+void VsmPool::run(int ntasks, const std::function<void(int)> &fn) {
+  if (ntasks <= 0) return;
+  if (nthreads_ == 1 || ntasks == 1) {
+    for (int i = 0; i < ntasks; i++) fn(i);
+    return;
+  }
+  uint64_t g;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    g = (gen_.load(std::memory_order_relaxed) + 1) & 0xffffffffu;
+    if (g == 0) g = 1;
+    fn_ = &fn;
+    ntasks_ = ntasks;
+    done_.store(0, std::memory_order_relaxed);
+    next_.store(g << 32, std::memory_order_release);
+    gen_.store(g, std::memory_order_release);
+  }
+  if (sleepers_.load() > 0) cv_.notify_all();
+  int i;
+  while (claim(g, ntasks, i)) {
+    fn(i);
+    done_.fetch_add(1, std::memory_order_acq_rel);
+  }
+  while (done_.load(std::memory_order_acquire) < ntasks) cpu_relax();
+}
 
 // =======================================================================================
 // ExactDelaunay: Triangle 1.6 divide-and-conquer with alternating cuts, decision for decision
 // (viso/triangle.cpp: vertexsort :5447, vertexmedian :5513, alternateaxes :5583, mergehulls
 // :5639, divconqrecurse :5963, divconqdelaunay :6161).  Triangle's robust float predicates
-// (:2707, :3335) return the exact sign; on integer coordinates that is the int64 sign used here.
-// The triangle store is index based: nb_[t*3+o] = neighbour handle (t2*4+o2), vx_[t*3+o] = vertex
-// or -1 for the ghost ("NULL") corner of a bounding triangle.
+// (:2707, :3335) return the exact sign; on integer coordinates that is the integer sign used here.
+//
+// What is kept bit-for-bit: the randomised quicksort (it decides which of two duplicate points
+// stays in the mesh, :6183-6197), the recursion shape (n>>1 splits, alternating axes, leaves of
+// 2/3 vertices sorted by x) and every decision of the merge.  What is free to differ, because the
+// result does not depend on it: vertexmedian's pivots (any exact selection yields the same
+// partition of distinct points -> std::nth_element), triangle numbering (slot = 2*position, so
+// sub-problems never share an allocator and can run on different threads), memory layout.
+// Vertices are renumbered by their final sorted position so every sub-problem touches one
+// contiguous slice of xs_/ys_.  nb_[t*3+o] = neighbour handle t2*4+o2, vx_[t*3+o] = vertex
+// position or -1 for the ghost ("NULL") corner of a bounding triangle.
 // =======================================================================================
+#define KXY(k) ((k) >> 20)
+static inline uint64_t key_yx(uint64_t k) { return (((k >> 20) & 0x3fffu) << 14) | (k >> 34); }
+
 uint32_t ExactDelaunay::rnd(uint32_t choices) {  // randomnation, :4046
   seed_ = (seed_ * 1366u + 150889u) % 714025u;
   return (uint32_t)(seed_ / (714025u / choices + 1));
 }
 
-ExactDelaunay::OTri ExactDelaunay::make() {
-  int32_t t = ntri_++;
-  nb_[t * 3] = nb_[t * 3 + 1] = nb_[t * 3 + 2] = -1;
-  vx_[t * 3] = vx_[t * 3 + 1] = vx_[t * 3 + 2] = -1;
-  return OTri{t, 0};
-}
-
-void ExactDelaunay::partition(int32_t *a, int32_t n, int axis, int32_t &left, int32_t &right) {
-  const int32_t *k1 = axis ? y_ : x_, *k2 = axis ? x_ : y_;
-  int32_t pv = a[rnd((uint32_t)n)];
-  const int32_t p1 = k1[pv], p2 = k2[pv];
-  left = -1;
-  right = n;
+void ExactDelaunay::vertex_sort(uint64_t *a, int32_t n) {  // :5447, on packed (x,y) keys
+  if (n == 2) {
+    if (KXY(a[0]) > KXY(a[1])) std::swap(a[0], a[1]);
+    return;
+  }
+  const uint64_t pv = KXY(a[rnd((uint32_t)n)]);
+  int32_t left = -1, right = n;
   while (left < right) {
     do {
       left++;
-    } while (left <= right && (k1[a[left]] < p1 || (k1[a[left]] == p1 && k2[a[left]] < p2)));
+    } while (left <= right && KXY(a[left]) < pv);
     do {
       right--;
-    } while (left <= right && (k1[a[right]] > p1 || (k1[a[right]] == p1 && k2[a[right]] > p2)));
+    } while (left <= right && KXY(a[right]) > pv);
     if (left < right) std::swap(a[left], a[right]);
   }
+  if (left > 1) vertex_sort(a, left);
+  if (right < n - 2) vertex_sort(a + right + 1, n - right - 1);
 }
 
-void ExactDelaunay::sort2(int32_t *a, int axis) {
-  const int32_t *k1 = axis ? y_ : x_, *k2 = axis ? x_ : y_;
-  if (k1[a[0]] > k1[a[1]] || (k1[a[0]] == k1[a[1]] && k2[a[0]] > k2[a[1]])) std::swap(a[0], a[1]);
+// alternateaxes (:5583) for one node: bring the n>>1 smallest keys (by `axis`) to the front
+static inline void select_half(uint64_t *a, int32_t n, int axis) {
+  if (axis == 0)
+    std::nth_element(a, a + (n >> 1), a + n, [](uint64_t p, uint64_t q) { return KXY(p) < KXY(q); });
+  else
+    std::nth_element(a, a + (n >> 1), a + n, [](uint64_t p, uint64_t q) { return key_yx(p) < key_yx(q); });
 }
 
-void ExactDelaunay::vertex_sort(int32_t *a, int32_t n) {
-  if (n == 2) return sort2(a, 0);
-  int32_t l, r;
-  partition(a, n, 0, l, r);
-  if (l > 1) vertex_sort(a, l);
-  if (r < n - 2) vertex_sort(a + r + 1, n - r - 1);
-}
-
-void ExactDelaunay::vertex_median(int32_t *a, int32_t n, int32_t median, int axis) {
-  if (n == 2) return sort2(a, axis);
-  int32_t l, r;
-  partition(a, n, axis, l, r);
-  if (l > median) vertex_median(a, l, median, axis);
-  if (r < median - 1) vertex_median(a + r + 1, n - r - 1, median - r - 1, axis);
-}
-
-void ExactDelaunay::alternate_axes(int32_t *a, int32_t n, int axis) {
-  int32_t divider = n >> 1;
-  if (n <= 3) axis = 0;
-  vertex_median(a, n, divider, axis);
-  if (n - divider >= 2) {
-    if (divider >= 2) alternate_axes(a, divider, 1 - axis);
-    alternate_axes(a + divider, n - divider, 1 - axis);
-  }
-}
-
-void ExactDelaunay::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis) {
+void ExactDelaunay::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis,
+                                int32_t &tcur) {
+  const int32_t *y_ = ys_.data(), *x_ = xs_.data();
   int32_t ildest = dest(innerleft), ilapex = apex(innerleft);
   int32_t irorg = org(innerright), irapex = apex(innerright);
   if (axis == 1) {  // horizontal cut: handles move to the bottom-/top-most hull vertices (:5666)
     int32_t flpt = org(farleft), flapex = apex(farleft);
-    int32_t frpt = dest(farright), frapex = apex(farright);
+    int32_t frpt = dest(farright);
     while (y_[flapex] < y_[flpt]) {
       farleft = sym(lnext(farleft));
       flpt = flapex;
@@ -104,12 +181,10 @@ void ExactDelaunay::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright
     cv = apex(chk);
     while (y_[cv] > y_[frpt]) {
       farright = lnext(chk);
-      frapex = frpt;
       frpt = cv;
       chk = sym(farright);
       cv = apex(chk);
     }
-    (void)frapex;
   }
   bool changed;
   do {  // lower common tangent (:5704)
@@ -128,7 +203,7 @@ void ExactDelaunay::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright
     }
   } while (changed);
   OTri leftcand = sym(innerleft), rightcand = sym(innerright);
-  OTri base = make();
+  OTri base = make(tcur);
   bond(base, innerleft);
   base = lnext(base);
   bond(base, innerright);
@@ -142,7 +217,7 @@ void ExactDelaunay::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright
   for (;;) {
     const bool lfin = ccw(ul, ll, lr) <= 0, rfin = ccw(ur, ll, lr) <= 0;
     if (lfin && rfin) {  // close the seam with the top bounding triangle (:5771)
-      OTri top = make();
+      OTri top = make(tcur);
       set_org(top, ll);
       set_dest(top, lr);
       bond(top, base);
@@ -244,36 +319,53 @@ void ExactDelaunay::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright
   }
 }
 
-void ExactDelaunay::recurse(int32_t *a, int32_t n, int axis, OTri &farleft, OTri &farright) {
-  if (n == 2) {  // one edge = two ghost triangles (:5978)
-    farleft = make();
-    set_org(farleft, a[0]);
-    set_dest(farleft, a[1]);
-    farright = make();
-    set_org(farright, a[1]);
-    set_dest(farright, a[0]);
-    bond(farleft, farright);
-    farleft = lprev(farleft);
-    farright = lnext(farright);
-    bond(farleft, farright);
-    farleft = lprev(farleft);
-    farright = lnext(farright);
-    bond(farleft, farright);
-    farleft = lprev(farright);
-    return;
-  }
-  if (n == 3) {  // (:6006)
-    OTri mid = make(), t1 = make(), t2 = make(), t3 = make();
-    const int64_t area = ccw(a[0], a[1], a[2]);
+// one sub-problem: positions [off, off+n).  Selection (alternateaxes) and triangulation
+// (divconqrecurse) share one recursion; the caller has already brought the right keys into
+// this slice.  Triangle slots: leaves use 2*off.., the merge at boundary b uses 2b-2, 2b-1.
+void ExactDelaunay::recurse(int32_t off, int32_t n, int axis, int32_t &tcur_unused, OTri &farleft, OTri &farright) {
+  (void)tcur_unused;
+  uint64_t *a = key_.data() + off;
+  if (n <= 3) {  // leaf: always ordered by x (then y), :5596-5600
+    if (KXY(a[0]) > KXY(a[1])) std::swap(a[0], a[1]);
+    if (n == 3) {
+      if (KXY(a[1]) > KXY(a[2])) std::swap(a[1], a[2]);
+      if (KXY(a[0]) > KXY(a[1])) std::swap(a[0], a[1]);
+    }
+    for (int32_t i = 0; i < n; i++) {
+      xs_[off + i] = (int32_t)(a[i] >> 34);
+      ys_[off + i] = (int32_t)((a[i] >> 20) & 0x3fff);
+      id_[off + i] = (int32_t)(a[i] & 0xfffff);
+    }
+    int32_t tcur = 2 * off;
+    const int32_t p0 = off, p1 = off + 1, p2 = off + 2;
+    if (n == 2) {  // one edge = two ghost triangles (:5978)
+      farleft = make(tcur);
+      set_org(farleft, p0);
+      set_dest(farleft, p1);
+      farright = make(tcur);
+      set_org(farright, p1);
+      set_dest(farright, p0);
+      bond(farleft, farright);
+      farleft = lprev(farleft);
+      farright = lnext(farright);
+      bond(farleft, farright);
+      farleft = lprev(farleft);
+      farright = lnext(farright);
+      bond(farleft, farright);
+      farleft = lprev(farright);
+      return;
+    }
+    OTri mid = make(tcur), t1 = make(tcur), t2 = make(tcur), t3 = make(tcur);  // (:6006)
+    const int32_t area = ccw(p0, p1, p2);
     if (area == 0) {
-      set_org(mid, a[0]);
-      set_dest(mid, a[1]);
-      set_org(t1, a[1]);
-      set_dest(t1, a[0]);
-      set_org(t2, a[2]);
-      set_dest(t2, a[1]);
-      set_org(t3, a[1]);
-      set_dest(t3, a[2]);
+      set_org(mid, p0);
+      set_dest(mid, p1);
+      set_org(t1, p1);
+      set_dest(t1, p0);
+      set_org(t2, p2);
+      set_dest(t2, p1);
+      set_org(t3, p1);
+      set_dest(t3, p2);
       bond(mid, t1);
       bond(t2, t3);
       mid = lnext(mid);
@@ -291,10 +383,10 @@ void ExactDelaunay::recurse(int32_t *a, int32_t n, int axis, OTri &farleft, OTri
       farleft = t1;
       farright = t2;
     } else {
-      const int32_t b = area > 0 ? a[1] : a[2], c = area > 0 ? a[2] : a[1];
-      set_org(mid, a[0]);
-      set_dest(t1, a[0]);
-      set_org(t3, a[0]);
+      const int32_t b = area > 0 ? p1 : p2, c = area > 0 ? p2 : p1;
+      set_org(mid, p0);
+      set_dest(t1, p0);
+      set_org(t3, p0);
       set_dest(mid, b);
       set_org(t1, b);
       set_dest(t2, b);
@@ -321,47 +413,115 @@ void ExactDelaunay::recurse(int32_t *a, int32_t n, int axis, OTri &farleft, OTri
     return;
   }
   const int32_t divider = n >> 1;
+  // children are cut along the other axis: order them first (alternateaxes(child, 1-axis))
+  if (divider > 3) select_half(a, divider, 1 - axis);
+  if (n - divider > 3) select_half(a + divider, n - divider, 1 - axis);
   OTri innerleft, innerright;
-  recurse(a, divider, 1 - axis, farleft, innerleft);
-  recurse(a + divider, n - divider, 1 - axis, innerright, farright);
-  merge_hulls(farleft, innerleft, innerright, farright, axis);
+  int32_t dummy = 0;
+  recurse(off, divider, 1 - axis, dummy, farleft, innerleft);
+  recurse(off + divider, n - divider, 1 - axis, dummy, innerright, farright);
+  int32_t tcur = 2 * (off + divider) - 2;
+  merge_hulls(farleft, innerleft, innerright, farright, axis, tcur);
 }
 
-void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n) {
-  x_ = x;
-  y_ = y;
-  ntri_ = 0;
+int32_t ExactDelaunay::build_tree(int32_t off, int32_t n, int axis, int32_t tbase, int depth) {
+  const int32_t me = (int32_t)nodes_.size();
+  nodes_.push_back(Node{off, n, axis, tbase, -1, -1, {0, 0}, {0, 0}});
+  if (depth > 0 && n >= 64) {
+    const int32_t divider = n >> 1;
+    const int32_t l = build_tree(off, divider, 1 - axis, 0, depth - 1);
+    const int32_t r = build_tree(off + divider, n - divider, 1 - axis, 0, depth - 1);
+    nodes_[me].left = l;
+    nodes_[me].right = r;
+  }
+  return me;
+}
+
+void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmPool *pool) {
   ntri_out_ = 0;
   seed_ = 1;  // triangleinit(), :4031
   if (n < 2) return;
-  const size_t cap = (size_t)4 * n + 16;
-  if (nb_.size() < cap * 3) {
-    nb_.resize(cap * 3);
-    vx_.resize(cap * 3);
-  }
-  order_.resize(n);
-  for (int32_t i = 0; i < n; i++) order_[i] = i;
-  int32_t *a = order_.data();
+  key_.resize(n);
+  for (int32_t i = 0; i < n; i++) key_[i] = ((uint64_t)(uint32_t)x[i] << 34) | ((uint64_t)(uint32_t)y[i] << 20) | (uint32_t)i;
+  uint64_t *a = key_.data();
   vertex_sort(a, n);
-  int32_t i = 0;  // duplicates: the first one in sorted order survives (:6183)
+  int32_t m = 0;  // duplicates: the first one in sorted order survives (:6183)
   for (int32_t j = 1; j < n; j++)
-    if (!(x[a[i]] == x[a[j]] && y[a[i]] == y[a[j]])) a[++i] = a[j];
-  i++;
-  if (i < 2) return;
-  const int32_t divider = i >> 1;
-  if (i - divider >= 2) {
-    if (divider >= 2) alternate_axes(a, divider, 1);
-    alternate_axes(a + divider, i - divider, 1);
+    if (KXY(a[m]) != KXY(a[j])) a[++m] = a[j];
+  m++;
+  if (m < 2) return;
+  if ((size_t)m * 6 > nb_.size()) {
+    nb_.resize((size_t)m * 6);
+    vx_.resize((size_t)m * 6);
   }
+  xs_.resize(m);
+  ys_.resize(m);
+  id_.resize(m);
+  for (int k = 0; k < 6; k++) vx_[(size_t)(2 * m - 2) * 3 + k] = -1;  // the two unused slots
   OTri hl, hr;
-  recurse(a, i, 0, hl, hr);
-  tri_out_.resize((size_t)ntri_ * 3);
-  for (int32_t t = 0; t < ntri_; t++) {
-    const int32_t *v = &vx_[t * 3];
+  int32_t dummy = 0;
+  const int nthreads = pool ? pool->size() : 1;
+  int depth = 0;
+  while ((1 << depth) < nthreads) depth++;
+  if (nthreads <= 1 || m < 256) {
+    // root: the x-sorted array is cut in the middle; its halves are ordered by recurse()
+    recurse(0, m, 0, dummy, hl, hr);
+  } else {
+    nodes_.clear();
+    build_tree(0, m, 0, 0, depth);
+    // level order lists of internal nodes and the leaf tasks
+    std::vector<std::vector<int32_t>> levels;
+    std::vector<int32_t> tasks, cur{0};
+    while (!cur.empty()) {
+      std::vector<int32_t> next, internal;
+      for (int32_t q : cur) {
+        if (nodes_[q].left < 0) {
+          tasks.push_back(q);
+        } else {
+          internal.push_back(q);
+          next.push_back(nodes_[q].left);
+          next.push_back(nodes_[q].right);
+        }
+      }
+      if (!internal.empty()) levels.push_back(internal);
+      cur.swap(next);
+    }
+    // top-down: order the children of every internal node (the root's slice is already x-sorted)
+    for (const auto &lv : levels)
+      pool->run((int)lv.size() * 2, [&](int t) {
+        const Node &nd = nodes_[lv[t >> 1]];
+        const Node &ch = nodes_[(t & 1) ? nd.right : nd.left];
+        if (ch.n > 3) select_half(key_.data() + ch.off, ch.n, ch.axis);
+      });
+    // the sub-trees below the task nodes: sequential, one per task.  A task node's own slice has
+    // been ordered by its parent; recurse() orders its children.
+    pool->run((int)tasks.size(), [&](int t) {
+      Node &nd = nodes_[tasks[t]];
+      int32_t d2 = 0;
+      recurse(nd.off, nd.n, nd.axis, d2, nd.fl, nd.fr);
+    });
+    // bottom-up merges
+    for (int li = (int)levels.size() - 1; li >= 0; li--) {
+      const auto &lv = levels[li];
+      pool->run((int)lv.size(), [&](int t) {
+        Node &nd = nodes_[lv[t]];
+        Node &l = nodes_[nd.left], &r = nodes_[nd.right];
+        nd.fl = l.fl;
+        nd.fr = r.fr;
+        OTri il = l.fr, ir = r.fl;
+        int32_t tcur = 2 * (nd.off + (nd.n >> 1)) - 2;
+        merge_hulls(nd.fl, il, ir, nd.fr, nd.axis, tcur);
+      });
+    }
+  }
+  tri_out_.resize((size_t)2 * m * 3);
+  const int32_t *idp = id_.data();
+  for (int32_t t = 0; t < 2 * m; t++) {
+    const int32_t *v = &vx_[(size_t)t * 3];
     if ((v[0] | v[1] | v[2]) >= 0) {
-      tri_out_[ntri_out_ * 3 + 0] = v[1];
-      tri_out_[ntri_out_ * 3 + 1] = v[2];
-      tri_out_[ntri_out_ * 3 + 2] = v[0];
+      tri_out_[ntri_out_ * 3 + 0] = idp[v[1]];
+      tri_out_[ntri_out_ * 3 + 1] = idp[v[2]];
+      tri_out_[ntri_out_ * 3 + 2] = idp[v[0]];
       ntri_out_++;
     }
   }
@@ -379,7 +539,7 @@ void vsm_host_remove_outliers(VsmHostWork &w, const vsm_params &p, std::vector<v
     w.x[i] = (int32_t)m[i].u1c;
     w.y[i] = (int32_t)m[i].v1c;
   }
-  w.del.run(w.x.data(), w.y.data(), n);
+  w.del.run(w.x.data(), w.y.data(), n, w.pool);
   w.support.assign(n, 0);
   const float ftol = (float)p.outlier_flow_tolerance, dtol = (float)p.outlier_disp_tolerance;
   const int32_t *tri = w.del.triangles();

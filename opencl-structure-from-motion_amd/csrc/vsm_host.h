@@ -5,17 +5,50 @@
 
 #include <stdint.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "visomatch.h"
 
+// Small fork-join pool for the host stages (Delaunay sub-problems are independent).  Workers spin
+// for a while after each job before they block, so back-to-back frames do not pay a wake-up.
+class VsmPool {
+ public:
+  explicit VsmPool(int threads);
+  ~VsmPool();
+  int size() const { return nthreads_; }
+  // runs fn(0..ntasks-1) on the pool (the caller takes part); returns when all are done
+  void run(int ntasks, const std::function<void(int)> &fn);
+
+ private:
+  void worker();
+  bool claim(uint64_t g, int n, int &idx);
+  int nthreads_;
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::atomic<uint64_t> gen_{0}, next_{0};
+  std::atomic<int> done_{0}, sleepers_{0};
+  int ntasks_ = 0;
+  const std::function<void(int)> *fn_ = nullptr;
+  std::atomic<bool> stop_{false};
+  int spin_us_ = 2000;
+};
+
 // Exact replica of Triangle 1.6's divide-and-conquer Delaunay ("zQB", as called from
-// Matcher::removeOutliers, viso/matcher.cpp:1255-1256) for integer-valued points, with a
-// reusable workspace (no allocation in steady state) and exact int64 predicates.
+// Matcher::removeOutliers, viso/matcher.cpp:1255-1256) for integer-valued points in [0,16384)^2:
+// same vertex order (incl. the randomised quicksort that decides which of two duplicate points
+// survives), same alternating cuts, same merge decisions, exact integer predicates.  Unlike
+// Triangle it is re-entrant, allocation-free in steady state, works on cache-friendly packed keys
+// and solves the independent sub-problems of the top recursion levels on several host threads.
 class ExactDelaunay {
  public:
   // points are (x[i], y[i]); after run(), triangles() lists vertex triples by input index
-  void run(const int32_t *x, const int32_t *y, int32_t n);
+  void run(const int32_t *x, const int32_t *y, int32_t n, VsmPool *pool = nullptr);
   int32_t num_triangles() const { return ntri_out_; }
   const int32_t *triangles() const { return tri_out_.data(); }
 
@@ -23,21 +56,30 @@ class ExactDelaunay {
   struct OTri {
     int32_t t, o;
   };
-  const int32_t *x_ = nullptr, *y_ = nullptr;
-  std::vector<int32_t> nb_, vx_, order_, tri_out_;
-  int32_t ntri_ = 0, ntri_out_ = 0;
+  struct Node {  // one sub-problem of the divide-and-conquer tree
+    int32_t off, n, axis, tbase, left, right;
+    OTri fl, fr;
+  };
+  std::vector<uint64_t> key_;         // (x << 34) | (y << 20) | input index
+  std::vector<int32_t> xs_, ys_, id_; // by sorted position
+  std::vector<int32_t> nb_, vx_, tri_out_;
+  std::vector<Node> nodes_;
+  int32_t ntri_out_ = 0;
   uint64_t seed_ = 1;
 
   uint32_t rnd(uint32_t choices);
-  void partition(int32_t *a, int32_t n, int axis, int32_t &left, int32_t &right);
-  void sort2(int32_t *a, int axis);
-  void vertex_sort(int32_t *a, int32_t n);
-  void vertex_median(int32_t *a, int32_t n, int32_t median, int axis);
-  void alternate_axes(int32_t *a, int32_t n, int axis);
-  void recurse(int32_t *a, int32_t n, int axis, OTri &farleft, OTri &farright);
-  void merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis);
+  void vertex_sort(uint64_t *a, int32_t n);
+  static void alternate_axes(uint64_t *a, int32_t n, int axis);
+  void recurse(int32_t off, int32_t n, int axis, int32_t &tcur, OTri &farleft, OTri &farright);
+  void merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis, int32_t &tcur);
+  int32_t build_tree(int32_t off, int32_t n, int axis, int32_t tbase, int depth);
 
-  OTri make();
+  inline OTri make(int32_t &tcur) {
+    const int32_t t = tcur++;
+    nb_[t * 3] = nb_[t * 3 + 1] = nb_[t * 3 + 2] = -1;
+    vx_[t * 3] = vx_[t * 3 + 1] = vx_[t * 3 + 2] = -1;
+    return OTri{t, 0};
+  }
   inline OTri sym(OTri a) const {
     int32_t e = nb_[a.t * 3 + a.o];
     return OTri{e >> 2, e & 3};
@@ -54,20 +96,23 @@ class ExactDelaunay {
     nb_[a.t * 3 + a.o] = b.t * 4 + b.o;
     nb_[b.t * 3 + b.o] = a.t * 4 + a.o;
   }
-  inline int64_t ccw(int32_t a, int32_t b, int32_t c) const {
-    return (int64_t)(x_[a] - x_[c]) * (y_[b] - y_[c]) - (int64_t)(y_[a] - y_[c]) * (x_[b] - x_[c]);
+  // coordinates < 2^14: the orientation determinant fits int32, the in-circle one int64
+  inline int32_t ccw(int32_t a, int32_t b, int32_t c) const {
+    return (xs_[a] - xs_[c]) * (ys_[b] - ys_[c]) - (ys_[a] - ys_[c]) * (xs_[b] - xs_[c]);
   }
   inline int64_t incircle(int32_t a, int32_t b, int32_t c, int32_t d) const {
-    int64_t adx = x_[a] - x_[d], ady = y_[a] - y_[d], bdx = x_[b] - x_[d], bdy = y_[b] - y_[d];
-    int64_t cdx = x_[c] - x_[d], cdy = y_[c] - y_[d];
-    return (adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) +
-           (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
+    const int32_t adx = xs_[a] - xs_[d], ady = ys_[a] - ys_[d], bdx = xs_[b] - xs_[d], bdy = ys_[b] - ys_[d];
+    const int32_t cdx = xs_[c] - xs_[d], cdy = ys_[c] - ys_[d];
+    return (int64_t)(adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) +
+           (int64_t)(bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) +
+           (int64_t)(cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
   }
 };
 
 struct VsmHostWork {
   ExactDelaunay del;
   std::vector<int32_t> x, y, support;
+  VsmPool *pool = nullptr;  // optional
 };
 
 // Matcher::removeOutliers, viso/matcher.cpp:1207-1377 (in place; order preserved)

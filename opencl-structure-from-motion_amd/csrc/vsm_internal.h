@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "visomatch.h"
 
 #define VSM_MARGIN 6  // Matcher::margin = 5+1, viso/matcher.cpp:56
@@ -61,13 +63,58 @@ struct VsmPair {
   int32_t *pf;         // refinement==2 scratch: [cap][3][12] {status,du,dv,c0..c8}
 };
 
+// Optional per-kernel timing with HIP events recorded on the handle's own stream (bench.py's
+// roofline leg).  Off by default: events cost a few microseconds per launch.
+enum VsmKernelId {
+  VSM_K_INGEST = 0, VSM_K_HALVE, VSM_K_SOBEL_FULL, VSM_K_FILTERS, VSM_K_NMS, VSM_K_EMIT, VSM_K_BIN,
+  VSM_K_MATCH1, VSM_K_COMPACT1, VSM_K_MATCH2, VSM_K_COMPACT2, VSM_K_REFINE, VSM_K_COUNT
+};
+struct VsmProf {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  struct Span { int id; hipEvent_t a, b; };
+  std::vector<Span> open;
+  double total_ms[VSM_K_COUNT] = {};
+  int64_t launches[VSM_K_COUNT] = {};
+  hipEvent_t get() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+  void begin(int id, hipStream_t s) {
+    if (!on) return;
+    Span sp{id, get(), get()};
+    (void)hipEventRecord(sp.a, s);
+    open.push_back(sp);
+  }
+  void end(hipStream_t s) {
+    if (!on) return;
+    (void)hipEventRecord(open.back().b, s);
+  }
+  void resolve() {  // call after the stream has been synchronised
+    for (const Span &sp : open) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+        total_ms[sp.id] += ms;
+        launches[sp.id]++;
+      }
+    }
+    open.clear();
+    used = 0;
+  }
+};
+
 // ---- launchers (vsm_kernels.hip) ----
-void vsm_launch_ingest(hipStream_t s, const uint8_t *src, int32_t src_bpl, uint8_t *dst, const VsmDims &d);
-void vsm_launch_features(hipStream_t s, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d, int16_t *f1,
+void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const uint8_t *src, int32_t src_bpl, uint8_t *dst, const VsmDims &d);
+void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d, int16_t *f1,
                          int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res, int binsize,
                          const VsmImage *h_imgs);
-void vsm_launch_match(hipStream_t s, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
+void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
                       const VsmDims &d, const VsmMatchCfg &cfg, int n_query, vsm_p_match *list, int32_t *list_count);
-void vsm_launch_refine(hipStream_t s, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
+void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
                        const VsmDims &dp, const VsmDims &dc, int method, int refinement, int n_upper,
                        const int32_t *d_count);

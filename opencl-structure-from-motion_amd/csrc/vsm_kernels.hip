@@ -664,51 +664,74 @@ __global__ void __launch_bounds__(256)
 // =======================================================================================
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-void vsm_launch_ingest(hipStream_t s, const uint8_t *src, int32_t src_bpl, uint8_t *dst, const VsmDims &d) {
+void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const uint8_t *src, int32_t src_bpl, uint8_t *dst, const VsmDims &d) {
   int aligned = ((src_bpl & 3) == 0) && ((((uintptr_t)src) & 3) == 0);
   dim3 grid(cdiv(d.bpl / 4, 256), d.h);
+  pf.begin(VSM_K_INGEST, s);
   hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, src, src_bpl, dst, d.w, d.h, d.bpl, aligned);
+  pf.end(s);
 }
 
-void vsm_launch_features(hipStream_t s, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d, int16_t *f1,
-                         int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res, int binsize,
-                         const VsmImage *h_imgs) {
+void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d,
+                         int16_t *f1, int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res,
+                         int binsize, const VsmImage *h_imgs) {
   if (half_res) {
+    pf.begin(VSM_K_HALVE, s);
     hipLaunchKernelGGL(k_halve, dim3(cdiv(d.mbpl / 4, 256), d.mh, n_img), dim3(256), 0, s, d_imgs, first, d);
+    pf.end(s);
+    pf.begin(VSM_K_SOBEL_FULL, s);
     hipLaunchKernelGGL(k_filters<true>, dim3(cdiv(d.bpl * d.h / 4, 256), 1, n_img), dim3(256), 0, s, d_imgs, first,
                        d.bpl, d.h, (int16_t *)nullptr, (int16_t *)nullptr, (size_t)0);
+    pf.end(s);
   }
+  pf.begin(VSM_K_FILTERS, s);
   hipLaunchKernelGGL(k_filters<false>, dim3(cdiv(d.mbpl * d.mh / 4, 256), 1, n_img), dim3(256), 0, s, d_imgs, first,
                      d.mbpl, d.mh, f1, f2, f_stride);
+  pf.end(s);
   const int set_lo = multi_stage ? 0 : 1;
   int max_cells = 0;
   for (int k = 0; k < 2; k++) max_cells = max(max_cells, h_imgs[first].set[k].ncu * h_imgs[first].set[k].ncv);
-  if (max_cells > 0)
+  if (max_cells > 0) {
+    pf.begin(VSM_K_NMS, s);
     hipLaunchKernelGGL(k_nms, dim3(cdiv(max_cells, 256), 2, n_img * 2), dim3(256), 0, s, d_imgs, first, d, f1, f2,
                        f_stride, nms_tau, set_lo);
+    pf.end(s);
+  }
+  pf.begin(VSM_K_EMIT, s);
   hipLaunchKernelGGL(k_emit, dim3(1, 2, n_img), dim3(1024), 0, s, d_imgs, first, d, set_lo);
+  pf.end(s);
   const size_t shm = (size_t)(2 * (4 * d.ub * d.vb + 1)) * sizeof(int);
+  pf.begin(VSM_K_BIN, s);
   hipLaunchKernelGGL(k_bin, dim3(1, 2, n_img), dim3(1024), shm, s, d_imgs, first, d, binsize, set_lo);
+  pf.end(s);
 }
 
-void vsm_launch_match(hipStream_t s, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
-                      const VsmDims &d, const VsmMatchCfg &cfg, int n_query, vsm_p_match *list, int32_t *list_count) {
+void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int img_prev, int img_curr,
+                      const VsmPair &pair, const VsmDims &d, const VsmMatchCfg &cfg, int n_query, vsm_p_match *list,
+                      int32_t *list_count) {
   constexpr int G = 16;
-  if (n_query > 0)
+  if (n_query > 0) {
+    pf.begin(cfg.sparse ? VSM_K_MATCH1 : VSM_K_MATCH2, s);
     hipLaunchKernelGGL(k_match<G>, dim3(cdiv(n_query * G, 256)), dim3(256), 0, s, d_imgs, img_prev, img_curr, pair, d,
                        cfg, n_query);
+    pf.end(s);
+  }
+  pf.begin(cfg.sparse ? VSM_K_COMPACT1 : VSM_K_COMPACT2, s);
   hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, pair, cfg.method, n_query, list, list_count);
+  pf.end(s);
 }
 
-void vsm_launch_refine(hipStream_t s, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
-                       const VsmDims &dp, const VsmDims &dc, int method, int refinement, int n_upper,
-                       const int32_t *d_count) {
+void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int img_prev, int img_curr,
+                       const VsmPair &pair, const VsmDims &dp, const VsmDims &dc, int method, int refinement,
+                       int n_upper, const int32_t *d_count) {
   // n_upper bounds the list size (it may still be device-only); surplus groups exit at once
   if (n_upper <= 0) return;
+  pf.begin(VSM_K_REFINE, s);
   if (refinement == 2)
     hipLaunchKernelGGL(k_parabolic_costs, dim3(cdiv(n_upper * 3 * 64, 256)), dim3(256), 0, s, d_imgs, img_prev,
                        img_curr, pair, dp, dc, method, d_count);
   else
     hipLaunchKernelGGL(k_refine, dim3(cdiv(n_upper * 3 * 32, 256)), dim3(256), 0, s, d_imgs, img_prev, img_curr,
                        pair, dp, dc, method, d_count);
+  pf.end(s);
 }

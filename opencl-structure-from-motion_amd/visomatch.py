@@ -27,7 +27,8 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_push_back_device", "vsm_match", "vsm_num_matches", "vsm_get_matches", "vsm_bucket", "vsm_gain",
            "vsm_num_features", "vsm_get_features", "vsm_set_stage_capture", "vsm_stage_size", "vsm_stage_get",
            "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
-           "vsm_get_timings", "vsm_version"]
+           "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
+           "vsm_host_delaunay", "vsm_version"]
 
 
 class VsmParams(C.Structure):
@@ -82,8 +83,25 @@ def lib():
         L.vsm_get_filter_responses.argtypes = [vp, vp, vp]
         L.vsm_get_counters.argtypes = [vp, vp]
         L.vsm_get_timings.argtypes = [vp, vp]
+        L.vsm_set_profiling.argtypes = [vp, C.c_int]
+        L.vsm_kernel_name.restype = C.c_char_p
+        L.vsm_kernel_name.argtypes = [i32]
+        L.vsm_get_kernel_stats.argtypes = [vp, vp, vp]
+        L.vsm_host_delaunay.argtypes = [vp, vp, i32, vp, i32, i32]
         _lib = L
     return _lib
+
+
+def host_delaunay(pts, threads=1):
+    """exact Delaunay of integer points (host code of the product; no GPU needed)"""
+    pts = np.asarray(pts).reshape(-1, 2)
+    x = np.ascontiguousarray(pts[:, 0], dtype=np.int32)
+    y = np.ascontiguousarray(pts[:, 1], dtype=np.int32)
+    cap = 2 * len(x) + 16
+    tris = np.zeros((cap, 3), dtype=np.int32)
+    k = lib().vsm_host_delaunay(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), len(x),
+                                tris.ctypes.data_as(C.c_void_p), cap, threads)
+    return tris[:k]
 
 
 def default_params():
@@ -224,6 +242,18 @@ class Matcher:
         t = np.zeros(5, dtype=np.float64)
         lib().vsm_get_timings(self.h, t.ctypes.data_as(C.c_void_p))
         return dict(zip(("pass1_gpu_us", "pass1_host_us", "pass2_gpu_us", "final_host_us", "total_us"), t.tolist()))
+
+    def set_profiling(self, on):
+        lib().vsm_set_profiling(self.h, int(on))
+
+    def kernel_stats(self):
+        """{kernel name: (total device ms, launches)} since set_profiling(True)"""
+        L = lib()
+        n = L.vsm_num_kernels()
+        ms = np.zeros(n, dtype=np.float64)
+        cnt = np.zeros(n, dtype=np.int64)
+        L.vsm_get_kernel_stats(self.h, ms.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+        return {L.vsm_kernel_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
 
     def close(self):
         if getattr(self, "h", None):

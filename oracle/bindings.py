@@ -278,9 +278,9 @@ class CpuMatcher:
 
     def counters(self):
         assert self.kind == "oracle"
-        c = (C.c_int64 * 5)()
+        c = (C.c_int64 * 8)()
         self.L.vo_get_counters(self.h, c)
-        return dict(zip(("Q", "C", "S", "M", "M_out"), list(c)))
+        return dict(zip(("Q", "C", "S", "M", "M_out", "Q1", "C1", "S1"), list(c)))
 
 
 # ---- free-standing stages -------------------------------------------------

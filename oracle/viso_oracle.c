@@ -284,7 +284,7 @@ struct vo_matcher {
   int32_t n_matched;
   vo_range *ranges;
   int32_t n_ranges;
-  int64_t counters[5];
+  int64_t counters[8]; /* Q,C,S,M,M_out + pass-1 share Q1,C1,S1 */
 };
 
 static int32_t *pack_features(const vo_maxvec *mv, const uint8_t *du, const uint8_t *dv, int32_t bpl, int32_t s) {
@@ -1440,6 +1440,9 @@ int32_t vo_match_features(vo_matcher *M, int32_t method, const double *Tr) {
   if (p->multi_stage) {
     matching(M, 1, &pm1, method, 0, Tr);
     stage_store(M, 0, pm1.a, pm1.n);
+    M->counters[5] = M->counters[0];
+    M->counters[6] = M->counters[1];
+    M->counters[7] = M->counters[2];
     pm1.n = remove_outliers(p, pm1.a, pm1.n, method);
     stage_store(M, 1, pm1.a, pm1.n);
     prior_statistics(M, pm1.a, pm1.n, method);
@@ -1473,7 +1476,7 @@ int32_t vo_num_ranges(const vo_matcher *m) { return m->n_ranges; }
 void vo_get_ranges(const vo_matcher *m, vo_range *out) {
   if (m->n_ranges) memcpy(out, m->ranges, (size_t)m->n_ranges * sizeof(vo_range));
 }
-void vo_get_counters(const vo_matcher *m, int64_t *out5) { memcpy(out5, m->counters, sizeof(m->counters)); }
+void vo_get_counters(const vo_matcher *m, int64_t *out8) { memcpy(out8, m->counters, sizeof(m->counters)); }
 
 int32_t vo_num_features(const vo_matcher *m, int32_t which) {
   static const int IMG[8] = {0, 1, 2, 3, 0, 1, 2, 3};

@@ -86,8 +86,9 @@ void vo_get_features(const vo_matcher *m, int32_t which, int32_t *out);
 int32_t vo_get_gradients(const vo_matcher *m, int32_t which, int32_t full, uint8_t *du, uint8_t *dv);
 
 /* work counters of the last vo_match_features() (for the bench's algorithmic-bytes model,
- * SURVEY.md section 8d): {findMatch calls Q, candidates visited C, SADs S, matches refined M, matches out} */
-void vo_get_counters(const vo_matcher *m, int64_t *out5);
+ * SURVEY.md section 8d): {findMatch calls Q, candidates visited C, SADs S, matches refined M, matches out,
+ * and the pass-1 share Q1, C1, S1} */
+void vo_get_counters(const vo_matcher *m, int64_t *out8);
 
 #ifdef __cplusplus
 }

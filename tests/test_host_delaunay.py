@@ -1,0 +1,40 @@
+"""CPU suite: the product's host Delaunay (libvisomatch.so, no GPU needed) against the oracle's and,
+where its build is present, the real Triangle of the reference -- sequential and multi-threaded."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+
+def _tri_set(t):
+    return sorted(tuple(sorted(map(int, r))) for r in t)
+
+
+def _cases(seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for n, span in ((4, 3), (5, 4), (7, 3), (12, 4), (50, 8), (200, 12), (300, 200), (500, 40), (3000, 120), (8000, 600), (20000, 1000)):
+        out.append(np.stack([rng.integers(0, span * 2, n) * 2, rng.integers(0, span, n) * 2], 1))
+    g = np.stack(np.meshgrid(np.arange(0, 60, 2), np.arange(0, 50, 2)), -1).reshape(-1, 2)
+    out += [g, g[rng.permutation(len(g))], np.stack([np.arange(40) * 2, np.full(40, 6)], 1), np.concatenate([g[:300], g[:300]])]
+    out.append(np.stack([np.full(300, 8), np.arange(300) * 2], 1))  # vertical line
+    return out
+
+
+@pytest.mark.parametrize("threads", [1, 2, 4, 8])
+@pytest.mark.parametrize("seed", range(3))
+def test_product_delaunay_equals_oracle(B, seed, threads):
+    vm = pkg("visomatch")
+    for pts in _cases(seed):
+        a = vm.host_delaunay(pts, threads=threads)
+        b = B.delaunay("oracle", pts.astype(np.float32))
+        assert len(a) == len(b)
+        assert _tri_set(a) == _tri_set(b)
+
+
+def test_product_delaunay_equals_reference(B):
+    if not B.have_ref():
+        pytest.skip("oracle/_ref not built")
+    vm = pkg("visomatch")
+    for pts in _cases(11):
+        assert _tri_set(vm.host_delaunay(pts, threads=4)) == _tri_set(B.delaunay("ref", pts.astype(np.float32)))
