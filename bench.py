@@ -67,9 +67,8 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    shard = importlib.import_module(PKG + ".shard")
+    rank, local_rank, world = shard.rank_info()
     if world != args.gpus:
         print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
@@ -82,7 +81,7 @@ def main():
     vm.lib()  # raises if the HIP library is missing
 
     # ---- this rank's sequence, resident in HBM -------------------------------------------
-    seed = 1234 + rank
+    seed = shard.sequence_seed(rank)
     nf = args.frames
     cv = synth.canvas(seed, W, H)
     host = np.stack([np.stack(synth.stereo_frame(cv, f, W, H)) for f in range(nf)])  # [F,2,H,W]
@@ -103,27 +102,20 @@ def main():
             if collect is not None:
                 collect.append(m.get_matches())
 
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    dmod = dist if world > 1 else None
 
     for _ in range(args.warmup):
         run_sequence()
-    sync_all()
+    shard.barrier(dmod, dev)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_sequence()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    shard.barrier(dmod, dev)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    total_pairs = world * nf * args.steps
+    total_pairs, elapsed, _ = shard.aggregate(dmod, torch, nf * args.steps, elapsed, dev)
     value = total_pairs / elapsed
 
     # ---- verification (outside the timed region): final lists vs the reference's hashes -----
@@ -136,11 +128,7 @@ def main():
         run_sequence(lists)
         ok = all(len(lists[f]) == int(g[key + "_counts"][f]) and sha(lists[f]) == str(g[key + "_hashes"][f])
                  for f in range(nf))
-        verified = bool(ok)
-        if world > 1:
-            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            verified = bool(t.item())
+        _, _, verified = shard.aggregate(dmod, torch, 0, 0, dev, all_ok=bool(ok))
 
     if rank != 0:
         if world > 1:

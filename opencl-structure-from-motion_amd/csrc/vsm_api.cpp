@@ -177,6 +177,10 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
     fprintf(stderr, "visomatch: match_binsize %d gives %d bins, more than the LDS histogram holds\n", p.match_binsize, nb);
     return VSM_EARG;
   }
+  if (p.nms_n < 1 || p.nms_n > 31) {
+    fprintf(stderr, "visomatch: nms_n %d outside the supported range 1..31\n", p.nms_n);
+    return VSM_EARG;
+  }
   int32_t ns = p.nms_n * 3;  // viso/matcher.cpp:685-687
   if (ns > 10) ns = p.nms_n > 10 ? p.nms_n : 10;
   const int32_t nn[2] = {ns, p.nms_n};
@@ -196,7 +200,7 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
     return o;
   };
   struct SetOff {
-    size_t feat, count, cand, bin_start, s_idx, s_uv, s_desc, tmp;
+    size_t feat, count, cand, cell_off, bin_start, s_idx, s_uv, s_desc, tmp;
   };
   struct ImgOff {
     size_t img, imgm, du, dv, duf, dvf;
@@ -214,6 +218,7 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
       io[i].set[k].feat = take(cap * 48);
       io[i].set[k].count = take(4);
       io[i].set[k].cand = take((size_t)(ncu[k] * ncv[k] + 1) * 16);
+      io[i].set[k].cell_off = take((size_t)(ncu[k] * ncv[k] + 2) * 4);
       io[i].set[k].bin_start = take((size_t)(nb + 1) * 4);
       io[i].set[k].s_idx = take(cap * 4);
       io[i].set[k].s_uv = take(cap * 8);
@@ -245,6 +250,7 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
       s.feat = (int32_t *)(b + io[i].set[k].feat);
       s.count = (int32_t *)(b + io[i].set[k].count);
       s.cand = (int32_t *)(b + io[i].set[k].cand);
+      s.cell_off = (int32_t *)(b + io[i].set[k].cell_off);
       s.bin_start = (int32_t *)(b + io[i].set[k].bin_start);
       s.s_idx = (int32_t *)(b + io[i].set[k].s_idx);
       s.s_uv = (int2 *)(b + io[i].set[k].s_uv);
@@ -554,7 +560,7 @@ int32_t vsm_get_filter_responses(vsm_handle *h, int16_t *f1, int16_t *f2) {
 
 void vsm_set_stage_capture(vsm_handle *h, int on) { h->capture_stage2 = on ? 1 : 0; }
 
-static const char *kKernelNames[VSM_K_COUNT] = {"k_ingest", "k_halve", "k_filters<true>", "k_filters<false>", "k_nms", "k_emit",
+static const char *kKernelNames[VSM_K_COUNT] = {"k_ingest", "k_halve", "k_filters<true>", "k_filters<false>", "k_nms", "k_scan_cells", "k_emit",
                                                 "k_bin", "k_match<16>:pass1", "k_compact_matches:pass1", "k_match<16>:pass2",
                                                 "k_compact_matches:pass2", "k_refine"};
 

@@ -22,6 +22,7 @@ struct VsmSet {
   int32_t *feat;       // [cap][12]
   int32_t *count;      // device scalar
   int32_t *cand;       // [ncu*ncv*4] packed NMS survivors: u | v<<14 | valid<<31
+  int32_t *cell_off;   // [ncu*ncv+1] exclusive prefix of survivors per cell (emission order)
   int32_t *bin_start;  // [4*ub*vb + 1]
   int32_t *s_idx;      // [cap] sorted position -> original index
   int2 *s_uv;          // [cap]
@@ -66,7 +67,7 @@ struct VsmPair {
 // Optional per-kernel timing with HIP events recorded on the handle's own stream (bench.py's
 // roofline leg).  Off by default: events cost a few microseconds per launch.
 enum VsmKernelId {
-  VSM_K_INGEST = 0, VSM_K_HALVE, VSM_K_SOBEL_FULL, VSM_K_FILTERS, VSM_K_NMS, VSM_K_EMIT, VSM_K_BIN,
+  VSM_K_INGEST = 0, VSM_K_HALVE, VSM_K_SOBEL_FULL, VSM_K_FILTERS, VSM_K_NMS, VSM_K_SCAN, VSM_K_EMIT, VSM_K_BIN,
   VSM_K_MATCH1, VSM_K_COMPACT1, VSM_K_MATCH2, VSM_K_COMPACT2, VSM_K_REFINE, VSM_K_COUNT
 };
 struct VsmProf {

@@ -150,20 +150,34 @@ __global__ void __launch_bounds__(256)
 
 // ---------------------------------------------------------------------------------------
 // N1 nonMaximumSuppression, viso/matcher.cpp:330-431 (Neubeck & Van Gool alg. 4).
-// One thread per (cell, filter): first-wins min and max of the (n+1)^2 cell (u outer, v inner,
-// strict compares), then the (2n+1)^2 suppression windows.  blockIdx.y: 0 = f1, 1 = f2;
-// blockIdx.z = image*2 + set.  Survivors go to cand[cell*4 + class].
+// One wavefront per (cell, filter).  Lanes load the (n+1)^2 cell pixels (u fastest: contiguous
+// int16 rows) and a 64-lane min-reduction over the key (value, scan position) yields the
+// reference's first-wins extremum ("u outer, v inner, strict compare", :356-380): position
+// o = di*(n+1)+dj.  The (2n+1)^2 suppression windows (:383-428) are then tested lane-parallel and
+// folded with a ballot.  blockIdx.y: 0 = f1, 1 = f2; blockIdx.z = image*2 + set.
+// Survivors go to cand[cell*4 + class] as u | v<<14 | 1<<31.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool nms_suppressed(const int16_t *__restrict__ f, int bpl, int w, int h, int n, int i,
-                                               int j, int ci, int cj, int val, bool want_min) {
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ bool nms_suppressed_wave(const int16_t *__restrict__ f, int bpl, int w, int h, int n, int i,
+                                                    int j, int ci, int cj, int val, bool want_min, int lane) {
+  const int W = 2 * n + 1;
   const int i_hi = min(ci + n, w - 1 - VSM_MARGIN), j_hi = min(cj + n, h - 1 - VSM_MARGIN);
-  for (int i2 = ci - n; i2 <= i_hi; i2++)
-    for (int j2 = cj - n; j2 <= j_hi; j2++) {
-      int cur = f[j2 * bpl + i2];
-      bool better = want_min ? (cur < val) : (cur > val);
-      if (better && (i2 < i || i2 > i + n || j2 < j || j2 > j + n)) return true;
+  bool hit = false;
+  for (int e = lane; e < W * W; e += 64) {
+    const int dj = e / W, di = e - dj * W;
+    const int i2 = ci - n + di, j2 = cj - n + dj;
+    if (i2 <= i_hi && j2 <= j_hi) {
+      const int cur = f[j2 * bpl + i2];
+      const bool better = want_min ? (cur < val) : (cur > val);
+      hit |= better && (i2 < i || i2 > i + n || j2 < j || j2 > j + n);
     }
-  return false;
+  }
+  return __ballot(hit) != 0ull;
 }
 
 __global__ void __launch_bounds__(256) k_nms(const VsmImage *__restrict__ imgs, int first, VsmDims d,
@@ -173,33 +187,35 @@ __global__ void __launch_bounds__(256) k_nms(const VsmImage *__restrict__ imgs, 
   if (si < set_lo) return;
   const VsmSet &st = imgs[first + zi].set[si];
   const int ncells = st.ncu * st.ncv;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave-uniform
   if (t >= ncells) return;
   const int k = blockIdx.y;
   const int16_t *__restrict__ f = (k ? f2base : f1base) + (size_t)zi * f_stride;
-  const int n = st.nms_n;
-  const int cj = t / st.ncu, ci = t - cj * st.ncu;  // neighbouring lanes walk along u: coalesced rows
-  const int i = n + VSM_MARGIN + ci * (n + 1), j = n + VSM_MARGIN + cj * (n + 1);
-  int mni = i, mnj = j, mxi = i, mxj = j;
-  int mnv = f[j * d.mbpl + i], mxv = mnv;
-  for (int i2 = i; i2 <= i + n; i2++)
-    for (int j2 = j; j2 <= j + n; j2++) {
-      int cur = f[j2 * d.mbpl + i2];
-      if (cur < mnv) {
-        mni = i2;
-        mnj = j2;
-        mnv = cur;
-      } else if (cur > mxv) {
-        mxi = i2;
-        mxj = j2;
-        mxv = cur;
-      }
-    }
-  bool vmin = (mnv <= -tau) && !nms_suppressed(f, d.mbpl, d.mw, d.mh, n, i, j, mni, mnj, mnv, true);
-  bool vmax = (mxv >= tau) && !nms_suppressed(f, d.mbpl, d.mw, d.mh, n, i, j, mxi, mxj, mxv, false);
-  int32_t *c = st.cand + (size_t)(ci * st.ncv + cj) * 4 + 2 * k;
-  c[0] = vmin ? (int32_t)(0x80000000u | (uint32_t)mni | ((uint32_t)mnj << 14)) : 0;
-  c[1] = vmax ? (int32_t)(0x80000000u | (uint32_t)mxi | ((uint32_t)mxj << 14)) : 0;
+  const int n = st.nms_n, n1 = n + 1;
+  const int cj = t / st.ncu, ci = t - cj * st.ncu;
+  const int i = n + VSM_MARGIN + ci * n1, j = n + VSM_MARGIN + cj * n1;
+  uint32_t kmin = 0xffffffffu, kmax = 0xffffffffu;
+  for (int e = lane; e < n1 * n1; e += 64) {
+    const int dj = e / n1, di = e - dj * n1;
+    const int val = f[(j + dj) * d.mbpl + i + di];
+    const uint32_t o = (uint32_t)(di * n1 + dj);
+    kmin = min(kmin, ((uint32_t)(val + 32768) << 10) | o);
+    kmax = min(kmax, ((uint32_t)(32767 - val) << 10) | o);
+  }
+  kmin = wave_min_u32(kmin);
+  kmax = wave_min_u32(kmax);
+  const int mnv = (int)(kmin >> 10) - 32768, mno = kmin & 1023;
+  const int mxv = 32767 - (int)(kmax >> 10), mxo = kmax & 1023;
+  const int mni = i + mno / n1, mnj = j + mno % n1, mxi = i + mxo / n1, mxj = j + mxo % n1;
+  bool vmin = mnv <= -tau, vmax = mxv >= tau;  // wave-uniform
+  if (vmin) vmin = !nms_suppressed_wave(f, d.mbpl, d.mw, d.mh, n, i, j, mni, mnj, mnv, true, lane);
+  if (vmax) vmax = !nms_suppressed_wave(f, d.mbpl, d.mw, d.mh, n, i, j, mxi, mxj, mxv, false, lane);
+  if (lane == 0) {
+    int32_t *c = st.cand + (size_t)(ci * st.ncv + cj) * 4 + 2 * k;
+    c[0] = vmin ? (int32_t)(0x80000000u | (uint32_t)mni | ((uint32_t)mnj << 14)) : 0;
+    c[1] = vmax ? (int32_t)(0x80000000u | (uint32_t)mxi | ((uint32_t)mxj << 14)) : 0;
+  }
 }
 
 // block-wide exclusive scan of one int per thread (blockDim.x == 1024); returns the exclusive
@@ -231,59 +247,72 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int &total, int *s_w 
 }
 
 // ---------------------------------------------------------------------------------------
-// ordered emission of the T1 feature records (viso/matcher.cpp:707-731) + D1 descriptor gather
-// (computeDescriptor, viso/matcher.cpp:433-477).  Feature index = rank in the reference's
-// emission order: cells u-major / v-minor, classes f1min,f1max,f2min,f2max inside a cell.
-// One 1024-thread block per (image, set): chunked exclusive scan over the cells.
+// Feature index = rank in the reference's emission order (cells u-major / v-minor, classes
+// f1min,f1max,f2min,f2max inside a cell, viso/matcher.cpp:344-430): exclusive prefix sum of the
+// per-cell survivor counts.  One 1024-thread block per (image, set); every thread owns a run of
+// consecutive cells.
 // ---------------------------------------------------------------------------------------
-__constant__ int8_t c_desc_dv[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
-__constant__ int8_t c_desc_du[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
-
-__global__ void __launch_bounds__(1024) k_emit(const VsmImage *__restrict__ imgs, int first, VsmDims d, int set_lo) {
+__global__ void __launch_bounds__(1024) k_scan_cells(const VsmImage *__restrict__ imgs, int first, int set_lo) {
   __shared__ int s_w[17];
-  __shared__ int s_run;
-  const VsmImage &im = imgs[first + blockIdx.z];
-  const int si = blockIdx.y;
-  const VsmSet &st = im.set[si];
-  if (si < set_lo) {
+  const VsmSet &st = imgs[first + blockIdx.z].set[blockIdx.y];
+  if ((int)blockIdx.y < set_lo) {
     if (threadIdx.x == 0) *st.count = 0;
     return;
   }
   const int ncells = st.ncu * st.ncv;
-  if (threadIdx.x == 0) s_run = 0;
-  __syncthreads();
-  for (int base = 0; base < ncells; base += 1024) {
-    const int e = base + threadIdx.x;
-    int4 c4 = make_int4(0, 0, 0, 0);
-    if (e < ncells) c4 = *(const int4 *)(st.cand + (size_t)e * 4);
-    const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
-    int cnt = (c4.x < 0) + (c4.y < 0) + (c4.z < 0) + (c4.w < 0);
-    int total;
-    int pos = s_run + block_excl_scan_1024(cnt, total, s_w);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (cc[k] < 0) {
-        const int u = cc[k] & 0x3fff, v = (cc[k] >> 14) & 0x3fff;
-        uint32_t dsc[8];
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-          int a0 = (v + c_desc_dv[2 * m]) * d.mbpl + u + c_desc_du[2 * m];
-          int a1 = (v + c_desc_dv[2 * m + 1]) * d.mbpl + u + c_desc_du[2 * m + 1];
-          dsc[m] = (uint32_t)im.du[a0] | ((uint32_t)im.dv[a0] << 8) | ((uint32_t)im.du[a1] << 16) |
-                   ((uint32_t)im.dv[a1] << 24);
-        }
-        uint4 *r = (uint4 *)(st.feat + (size_t)pos * 12);
-        r[0] = make_uint4((uint32_t)(u * d.scale), (uint32_t)(v * d.scale), 0u, (uint32_t)k);
-        r[1] = make_uint4(dsc[0], dsc[1], dsc[2], dsc[3]);
-        r[2] = make_uint4(dsc[4], dsc[5], dsc[6], dsc[7]);
-        pos++;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) s_run += total;
-    __syncthreads();
+  const int chunk = (ncells + 1023) / 1024;
+  const int c0 = min((int)threadIdx.x * chunk, ncells), c1 = min(c0 + chunk, ncells);
+  int sum = 0;
+  for (int c = c0; c < c1; c++) {
+    const int4 v = *(const int4 *)(st.cand + (size_t)c * 4);
+    sum += (v.x < 0) + (v.y < 0) + (v.z < 0) + (v.w < 0);
   }
-  if (threadIdx.x == 0) *st.count = s_run;
+  int total;
+  int run = block_excl_scan_1024(sum, total, s_w);
+  for (int c = c0; c < c1; c++) {
+    const int4 v = *(const int4 *)(st.cand + (size_t)c * 4);
+    st.cell_off[c] = run;
+    run += (v.x < 0) + (v.y < 0) + (v.z < 0) + (v.w < 0);
+  }
+  if (threadIdx.x == 0) {
+    st.cell_off[ncells] = total;
+    *st.count = total;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// T1 feature records (viso/matcher.cpp:707-731) + D1 descriptor gather (computeDescriptor,
+// viso/matcher.cpp:433-477).  One wavefront per cell, 16 lanes per class slot: lane j < 12 of a
+// slot produces dword j of the 48-byte record {u*s, v*s, 0, class, d1..d8} -- a descriptor dword
+// is two taps x (du,dv) = 4 byte gathers -- so every record leaves as one coalesced 48-byte run.
+// ---------------------------------------------------------------------------------------
+__constant__ int8_t c_desc_dv[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
+__constant__ int8_t c_desc_du[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
+
+__global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs, int first, VsmDims d, int set_lo) {
+  const VsmImage &im = imgs[first + blockIdx.z];
+  const int si = blockIdx.y;
+  if (si < set_lo) return;
+  const VsmSet &st = im.set[si];
+  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cell >= st.ncu * st.ncv) return;
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const int4 c4 = *(const int4 *)(st.cand + (size_t)cell * 4);
+  const int cc = g == 0 ? c4.x : (g == 1 ? c4.y : (g == 2 ? c4.z : c4.w));
+  if (cc >= 0 || j >= 12) return;
+  const int before = (g > 0 && c4.x < 0) + (g > 1 && c4.y < 0) + (g > 2 && c4.z < 0);
+  const int pos = st.cell_off[cell] + before;
+  const int u = cc & 0x3fff, v = (cc >> 14) & 0x3fff;
+  uint32_t val;
+  if (j < 4) {
+    val = j == 0 ? (uint32_t)(u * d.scale) : (j == 1 ? (uint32_t)(v * d.scale) : (j == 2 ? 0u : (uint32_t)g));
+  } else {
+    const int m = j - 4;
+    const int a0 = (v + c_desc_dv[2 * m]) * d.mbpl + u + c_desc_du[2 * m];
+    const int a1 = (v + c_desc_dv[2 * m + 1]) * d.mbpl + u + c_desc_du[2 * m + 1];
+    val = (uint32_t)im.du[a0] | ((uint32_t)im.dv[a0] << 8) | ((uint32_t)im.du[a1] << 16) | ((uint32_t)im.dv[a1] << 24);
+  }
+  st.feat[(size_t)pos * 12 + j] = (int32_t)val;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -693,13 +722,18 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
   for (int k = 0; k < 2; k++) max_cells = max(max_cells, h_imgs[first].set[k].ncu * h_imgs[first].set[k].ncv);
   if (max_cells > 0) {
     pf.begin(VSM_K_NMS, s);
-    hipLaunchKernelGGL(k_nms, dim3(cdiv(max_cells, 256), 2, n_img * 2), dim3(256), 0, s, d_imgs, first, d, f1, f2,
+    hipLaunchKernelGGL(k_nms, dim3(cdiv(max_cells, 4), 2, n_img * 2), dim3(256), 0, s, d_imgs, first, d, f1, f2,
                        f_stride, nms_tau, set_lo);
     pf.end(s);
   }
-  pf.begin(VSM_K_EMIT, s);
-  hipLaunchKernelGGL(k_emit, dim3(1, 2, n_img), dim3(1024), 0, s, d_imgs, first, d, set_lo);
+  pf.begin(VSM_K_SCAN, s);
+  hipLaunchKernelGGL(k_scan_cells, dim3(1, 2, n_img), dim3(1024), 0, s, d_imgs, first, set_lo);
   pf.end(s);
+  if (max_cells > 0) {
+    pf.begin(VSM_K_EMIT, s);
+    hipLaunchKernelGGL(k_emit, dim3(cdiv(max_cells, 4), 2, n_img), dim3(256), 0, s, d_imgs, first, d, set_lo);
+    pf.end(s);
+  }
   const size_t shm = (size_t)(2 * (4 * d.ub * d.vb + 1)) * sizeof(int);
   pf.begin(VSM_K_BIN, s);
   hipLaunchKernelGGL(k_bin, dim3(1, 2, n_img), dim3(1024), shm, s, d_imgs, first, d, binsize, set_lo);

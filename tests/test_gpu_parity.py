@@ -153,3 +153,33 @@ def test_full_size_properties(vm, synth):
     # idempotence: matching again without a push gives the same list
     m.match(2)
     assert _same(m.matches(), fin)
+
+
+def test_reference_vo_runs_on_dropin_matcher(synth, tmp_path):
+    """tools/dropin/_build/vo_dropin = the reference's unmodified VisualOdometryStereo sources
+    compiled against include/matcher.h + libvisomatch.so (built where /root/reference exists).
+    Its per-frame Tr_delta must equal what the all-reference build produced (golden cfg2)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "dropin", "_build", "vo_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binary not built (needs the reference sources at build time)")
+    g = G.load("cfg2_seq200_tr")
+    w, h, nf = int(g["w"]), int(g["h"]), 30
+    cv = synth.canvas(int(g["seed"]), w, h)
+    raw = tmp_path / "frames.raw"
+    with open(raw, "wb") as f:
+        f.write(np.array([w, h, nf], dtype=np.int32).tobytes())
+        for i in range(nf):
+            l, r = synth.stereo_frame(cv, i, w, h)
+            f.write(l.tobytes())
+            f.write(r.tobytes())
+    out = tmp_path / "out.bin"
+    intr = [repr(float(x)) for x in g["intr"]]
+    subprocess.check_call([exe, str(raw), str(out)] + intr, timeout=300)
+    rec = np.fromfile(out, dtype=np.float64).reshape(nf, 18)
+    for i in range(nf - 1):
+        assert bool(rec[i, 0]) == bool(g["vo_ok"][i])
+        # Tr_delta after frame i is what matchFeatures receives at frame i+1
+        assert np.array_equal(rec[i, 2:].reshape(4, 4), g["tr_in"][i + 1]), i
