@@ -50,9 +50,15 @@ struct vsm_handle {
   VsmPair pair{};
   int32_t cap_set[2] = {0, 0};
 
-  // pinned host staging
-  int32_t *h_counts = nullptr;  // [8] + [2]
+  // pinned host memory.  hm_* is host-mapped: kernels write the feature counts and the
+  // compacted match lists straight into it, so results need a stream sync but no D2H copy.
+  int32_t *h_counts = nullptr;  // scratch [16]
   float *h_ranges = nullptr;
+  uint8_t *hm_block = nullptr;
+  int32_t *hm_counts = nullptr;  // [8] feature counts (image*2+set) + [2] list sizes
+  vsm_p_match *hm_list1 = nullptr, *hm_list2 = nullptr;
+  bool counts_pending = false;   // a push is in flight: sync before reading hm_counts
+  int pending_slot = 0, pending_imgs = 0;
 
   // ring buffer state (Matcher's prev/curr pointers, viso/matcher.cpp:108-155)
   int cur = 0;
@@ -123,8 +129,11 @@ vsm_handle *vsm_create(const vsm_params *p) {
 static void release_device(vsm_handle *h) {
   if (h->arena) (void)hipFree(h->arena);
   if (h->h_ranges) (void)hipHostFree(h->h_ranges);
+  if (h->hm_block) (void)hipHostFree(h->hm_block);
   h->arena = nullptr;
   h->h_ranges = nullptr;
+  h->hm_block = nullptr;
+  h->counts_pending = false;
   h->allocated = false;
   h->have[0] = h->have[1] = h->right[0] = h->right[1] = false;
   h->f_valid = false;
@@ -173,8 +182,8 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
   d.ub = (int32_t)ceilf((float)w / (float)p.match_binsize);
   d.vb = (int32_t)ceilf((float)hh / (float)p.match_binsize);
   const int nb = 4 * d.ub * d.vb;
-  if ((size_t)(2 * (nb + 1)) * sizeof(int) > 60 * 1024) {
-    fprintf(stderr, "visomatch: match_binsize %d gives %d bins, more than the LDS histogram holds\n", p.match_binsize, nb);
+  if (p.match_binsize < 1 || nb > (1 << 22)) {
+    fprintf(stderr, "visomatch: match_binsize %d is not usable (%d bins)\n", p.match_binsize, nb);
     return VSM_EARG;
   }
   if (p.nms_n < 1 || p.nms_n > 31) {
@@ -200,7 +209,7 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
     return o;
   };
   struct SetOff {
-    size_t feat, count, cand, cell_off, bin_start, s_idx, s_uv, s_desc, tmp;
+    size_t feat, count, cand, cell_off, bin_start, bin_cnt, binid, s_idx, s_uv, s_desc, tmp;
   };
   struct ImgOff {
     size_t img, imgm, du, dv, duf, dvf;
@@ -220,6 +229,8 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
       io[i].set[k].cand = take((size_t)(ncu[k] * ncv[k] + 1) * 16);
       io[i].set[k].cell_off = take((size_t)(ncu[k] * ncv[k] + 2) * 4);
       io[i].set[k].bin_start = take((size_t)(nb + 1) * 4);
+      io[i].set[k].bin_cnt = take((size_t)(nb + 1) * 4);
+      io[i].set[k].binid = take(cap * 4);
       io[i].set[k].s_idx = take(cap * 4);
       io[i].set[k].s_uv = take(cap * 8);
       io[i].set[k].s_desc = take(cap * 32);
@@ -230,6 +241,7 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
   const size_t o_f1 = take(h->f_stride * 2 * 2), o_f2 = take(h->f_stride * 2 * 2);
   const size_t qcap = (size_t)(h->cap_set[0] > h->cap_set[1] ? h->cap_set[0] : h->cap_set[1]);
   const size_t o_raw = take(qcap * 48), o_flag = take(qcap * 4), o_l1 = take(qcap * 48), o_l2 = take(qcap * 48);
+  const size_t o_bc = take((qcap / 256 + 2) * 4);
   const size_t o_cnt = take(16), o_rng = take((size_t)d.ub * d.vb * 64);
   const size_t o_pf = p.refinement == 2 ? take(qcap * 3 * 12 * 4) : 0;
   const size_t o_imgs = take(4 * sizeof(VsmImage));
@@ -252,6 +264,8 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
       s.cand = (int32_t *)(b + io[i].set[k].cand);
       s.cell_off = (int32_t *)(b + io[i].set[k].cell_off);
       s.bin_start = (int32_t *)(b + io[i].set[k].bin_start);
+      s.bin_cnt = (int32_t *)(b + io[i].set[k].bin_cnt);
+      s.binid = (int32_t *)(b + io[i].set[k].binid);
       s.s_idx = (int32_t *)(b + io[i].set[k].s_idx);
       s.s_uv = (int2 *)(b + io[i].set[k].s_uv);
       s.s_desc = (uint4 *)(b + io[i].set[k].s_desc);
@@ -266,16 +280,47 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
   h->f2 = (int16_t *)(b + o_f2);
   h->pair.raw = (vsm_p_match *)(b + o_raw);
   h->pair.flag = (int32_t *)(b + o_flag);
+  h->pair.blockcnt = (int32_t *)(b + o_bc);
   h->pair.list1 = (vsm_p_match *)(b + o_l1);
   h->pair.list2 = (vsm_p_match *)(b + o_l2);
   h->pair.count = (int32_t *)(b + o_cnt);
   h->pair.ranges = (float *)(b + o_rng);
   h->pair.pf = p.refinement == 2 ? (int32_t *)(b + o_pf) : nullptr;
   h->d_imgs = (VsmImage *)(b + o_imgs);
+  {  // host-mapped result block: [counts 256 B][list1][list2]
+    const size_t l1 = al256((size_t)h->cap_set[0] * 48), l2 = al256(qcap * 48);
+    HIPCHK(hipHostMalloc((void **)&h->hm_block, 256 + l1 + l2, hipHostMallocMapped));
+    memset(h->hm_block, 0, 256 + l1 + l2);
+    uint8_t *dblock = nullptr;
+    HIPCHK(hipHostGetDevicePointer((void **)&dblock, h->hm_block, 0));
+    h->hm_counts = (int32_t *)h->hm_block;
+    h->hm_list1 = (vsm_p_match *)(h->hm_block + 256);
+    h->hm_list2 = (vsm_p_match *)(h->hm_block + 256 + l1);
+    for (int i = 0; i < 4; i++)
+      for (int k = 0; k < 2; k++) h->h_imgs[i].set[k].count_host = (int32_t *)dblock + (i * 2 + k);
+    h->pair.hcount = (int32_t *)dblock + 8;
+    h->pair.hlist1 = (vsm_p_match *)(dblock + 256);
+    h->pair.hlist2 = (vsm_p_match *)(dblock + 256 + l1);
+  }
   HIPCHK(hipMemcpyAsync(h->d_imgs, h->h_imgs, 4 * sizeof(VsmImage), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipHostMalloc((void **)&h->h_ranges, (size_t)d.ub * d.vb * 64, hipHostMallocDefault));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->allocated = true;
+  return VSM_OK;
+}
+
+// completes an asynchronous push: waits for the stream and takes the feature counts the
+// kernels wrote into host-mapped memory
+static int settle(vsm_handle *h) {
+  if (!h->counts_pending) return VSM_OK;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  h->prof.resolve();
+  const int slot = h->pending_slot;
+  memset(h->n_feat[slot], 0, sizeof(h->n_feat[slot]));
+  for (int k = 0; k < h->pending_imgs; k++)
+    for (int s2 = 0; s2 < 2; s2++) h->n_feat[slot][k][s2] = h->hm_counts[(slot * 2 + k) * 2 + s2];
+  h->counts_pending = false;
   return VSM_OK;
 }
 
@@ -299,33 +344,33 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
   h->dims_c[0] = w;
   h->dims_c[1] = hh;
   h->dims_c[2] = h->dims.bpl;
-  const uint8_t *src[2] = {I1, I2};
   const int n_img = I2 ? 2 : 1;
-  for (int k = 0; k < n_img; k++) {
-    uint8_t *dst = h->h_imgs[slot * 2 + k].img;
-    if (on_device)
-      vsm_launch_ingest(h->stream, h->prof, src[k], bpl, dst, h->dims);
-    else  // pageable source: HIP stages the rows; the caller's buffer is free again on return
-      HIPCHK(hipMemcpy2DAsync(dst, h->dims.bpl, src[k], bpl, w, hh, hipMemcpyHostToDevice, h->stream));
+  if (h->counts_pending) {  // a previous asynchronous push has not been settled yet
+    int rc = settle(h);
+    if (rc != VSM_OK) return rc;
+  }
+  uint8_t *dst0 = h->h_imgs[slot * 2].img, *dst1 = h->h_imgs[slot * 2 + 1].img;
+  if (on_device) {
+    vsm_launch_ingest(h->stream, h->prof, I1, I2, bpl, dst0, dst1, h->dims);
+  } else {  // pageable source: HIP stages the rows
+    HIPCHK(hipMemcpy2DAsync(dst0, h->dims.bpl, I1, bpl, w, hh, hipMemcpyHostToDevice, h->stream));
+    if (I2) HIPCHK(hipMemcpy2DAsync(dst1, h->dims.bpl, I2, bpl, w, hh, hipMemcpyHostToDevice, h->stream));
   }
   vsm_launch_features(h->stream, h->prof, h->d_imgs, slot * 2, n_img, h->dims, h->f1, h->f2, h->f_stride, h->param.nms_tau,
                       h->param.multi_stage, h->param.half_resolution, h->param.match_binsize, h->h_imgs);
-  for (int k = 0; k < n_img; k++)
-    for (int s = 0; s < 2; s++)
-      HIPCHK(hipMemcpyAsync(&h->h_counts[k * 2 + s], h->h_imgs[slot * 2 + k].set[s].count, 4, hipMemcpyDeviceToHost,
-                            h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
-  h->prof.resolve();
   h->have[slot] = true;
   h->right[slot] = (I2 != nullptr);
-  memset(h->n_feat[slot], 0, sizeof(h->n_feat[slot]));
-  for (int k = 0; k < n_img; k++)
-    for (int s = 0; s < 2; s++) h->n_feat[slot][k][s] = h->h_counts[k * 2 + s];
+  h->pending_slot = slot;
+  h->pending_imgs = n_img;
+  h->counts_pending = true;
   h->f_valid = true;
   h->gainI[0].clear();
   h->gainI[1].clear();
-  return VSM_OK;
+  // Host images: the caller may free or overwrite them as soon as we return (matcherMex does),
+  // so the transfer must have completed.  Device-resident images: the push stays asynchronous and
+  // is settled by the next call that needs its results (the source must stay valid until then).
+  return on_device ? VSM_OK : settle(h);
 }
 
 int vsm_push_back(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int32_t w, int32_t hh, int32_t bpl, int replace) {
@@ -337,21 +382,13 @@ int vsm_push_back_device(vsm_handle *h, const uint8_t *dI1, const uint8_t *dI2, 
   return push_common(h, dI1, dI2, w, hh, bpl, replace, true);
 }
 
-static int fetch_list(vsm_handle *h, const vsm_p_match *d_list, const int32_t *d_count, std::vector<vsm_p_match> &out) {
-  HIPCHK(hipMemcpyAsync(&h->h_counts[8], d_count, 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  const int32_t n = h->h_counts[8];
-  out.resize(n);
-  if (n) {
-    HIPCHK(hipMemcpyAsync(out.data(), d_list, (size_t)n * sizeof(vsm_p_match), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-  }
-  return VSM_OK;
-}
-
 int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
   if (!h->allocated) return VSM_ENOTREADY;
   HIPCHK(hipSetDevice(h->device));
+  {
+    int rc = settle(h);
+    if (rc != VSM_OK) return rc;
+  }
   const vsm_params &p = h->param;
   const int sc = h->cur, sp = h->cur ^ 1;
   auto N = [&](int slot, int side, int set) { return h->have[slot] ? h->n_feat[slot][side][set] : 0; };
@@ -396,9 +433,10 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
     cfg.sparse = 1;
     cfg.use_prior = 0;
     const int nq = N(qslot, 0, 0);
-    vsm_launch_match(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, h->dims, cfg, nq, h->pair.list1, h->pair.count);
-    int rc = fetch_list(h, h->pair.list1, h->pair.count, h->stage[0]);
-    if (rc != VSM_OK) return rc;
+    vsm_launch_match(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, h->dims, cfg, nq, 0);
+    vsm_launch_export(h->stream, h->prof, h->pair, 0, nq);
+    HIPCHK(hipStreamSynchronize(h->stream));  // the list was written into host-mapped memory
+    h->stage[0].assign(h->hm_list1, h->hm_list1 + h->hm_counts[8]);
     h->counters[0] += (int64_t)nq * stages;
     t1 = now_us();
     h->stage[1] = h->stage[0];
@@ -411,24 +449,31 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
   cfg.sparse = 0;
   cfg.use_prior = p.multi_stage ? 1 : 0;
   const int nq2 = N(qslot, 0, 1);
-  vsm_launch_match(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, h->dims, cfg, nq2, h->pair.list2, h->pair.count + 1);
+  vsm_launch_match(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, h->dims, cfg, nq2, 1);
   h->counters[0] += (int64_t)nq2 * stages;
-  const bool fetch2 = h->capture_stage2 || p.refinement != 1;
-  if (fetch2) {
-    int rc = fetch_list(h, h->pair.list2, h->pair.count + 1, h->stage[2]);
-    if (rc != VSM_OK) return rc;
-  }
-  if (p.refinement > 0) {
-    // without stage capture the list size stays on the device: the grid is sized for the worst
-    // case (every query matched) and surplus groups exit at once
-    const int n_upper = fetch2 ? (int)h->stage[2].size() : nq2;
-    vsm_launch_refine(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, dp, dc, method, p.refinement, n_upper,
+  // The list size is still on the device: the refinement / export grids are sized for the worst
+  // case (every query matched) and surplus threads exit at once.
+  if (h->capture_stage2 && p.refinement == 1)  // debug view: keep the unrefined list (raw is free again)
+    HIPCHK(hipMemcpyAsync(h->pair.raw, h->pair.list2, (size_t)nq2 * sizeof(vsm_p_match), hipMemcpyDeviceToDevice, h->stream));
+  if (p.refinement > 0)
+    vsm_launch_refine(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, dp, dc, method, p.refinement, nq2,
                       h->pair.count + 1);
+  vsm_launch_export(h->stream, h->prof, h->pair, 1, nq2);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  const int32_t n2 = h->hm_counts[9];
+  if (p.refinement == 1) {
+    h->stage[3].assign(h->hm_list2, h->hm_list2 + n2);
+    if (h->capture_stage2) {
+      h->stage[2].resize(n2);
+      if (n2) HIPCHK(hipMemcpy(h->stage[2].data(), h->pair.raw, (size_t)n2 * sizeof(vsm_p_match), hipMemcpyDeviceToHost));
+    }
+  } else {
+    h->stage[2].assign(h->hm_list2, h->hm_list2 + n2);
     if (p.refinement == 2) {
       const size_t n = h->stage[2].size();
       h->pf.resize(n * 36);
-      if (n) HIPCHK(hipMemcpyAsync(h->pf.data(), h->pair.pf, n * 36 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
+      if (n) HIPCHK(hipMemcpy(h->pf.data(), h->pair.pf, n * 36 * sizeof(int32_t), hipMemcpyDeviceToHost));
       h->stage[3].clear();
       for (size_t i = 0; i < n; i++) {  // viso/matcher.cpp:1541-1581: a failed fit drops the match
         vsm_p_match m = h->stage[2][i];
@@ -442,13 +487,9 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
         if (ok) h->stage[3].push_back(m);
       }
     } else {
-      int rc = fetch_list(h, h->pair.list2, h->pair.count + 1, h->stage[3]);
-      if (rc != VSM_OK) return rc;
+      h->stage[3] = h->stage[2];
     }
-  } else {
-    h->stage[3] = h->stage[2];
   }
-  HIPCHK(hipGetLastError());
   h->prof.resolve();
   const double t3 = now_us();
   h->counters[3] = (int64_t)h->stage[3].size();
@@ -481,7 +522,7 @@ int vsm_bucket(vsm_handle *h, int32_t max_features, float bw, float bh) {
 
 float vsm_gain(vsm_handle *h, const int32_t *inliers, int32_t n) {
   const int sc = h->cur, sp = h->cur ^ 1;
-  if (!h->allocated || !h->have[sp] || !h->have[sc] || h->matched.empty() || n == 0) return 1;
+  if (!h->allocated || !h->have[sp] || !h->have[sc] || h->matched.empty() || n == 0 || settle(h) != VSM_OK) return 1;
   const size_t bytes = (size_t)h->dims.bpl * h->dims.h;
   for (int k = 0; k < 2; k++) {  // left images come back from HBM on first use
     if (h->gainI[k].size() != bytes) {
@@ -496,6 +537,7 @@ float vsm_gain(vsm_handle *h, const int32_t *inliers, int32_t n) {
 // ---- stage-level views ----
 static bool which_set(vsm_handle *h, int32_t which, int &img, int &set, int32_t &n) {
   if (which < 0 || which > 7 || !h->allocated) return false;
+  if (settle(h) != VSM_OK) return false;
   const int prev = (which & 3) < 2, side = which & 1;
   set = which >> 2;
   const int slot = prev ? (h->cur ^ 1) : h->cur;
@@ -539,7 +581,7 @@ int32_t vsm_get_ranges(vsm_handle *h, float *out, int32_t cap_bins) {
 }
 
 int32_t vsm_get_gradients(vsm_handle *h, int32_t which, int32_t full, uint8_t *du, uint8_t *dv) {
-  if (!h->allocated || which < 0 || which > 3) return 0;
+  if (!h->allocated || which < 0 || which > 3 || settle(h) != VSM_OK) return 0;
   const int slot = which < 2 ? (h->cur ^ 1) : h->cur, side = which & 1;
   if (!h->have[slot] || (side && !h->right[slot])) return 0;
   if (full && !h->param.half_resolution) return 0;
@@ -551,7 +593,7 @@ int32_t vsm_get_gradients(vsm_handle *h, int32_t which, int32_t full, uint8_t *d
 }
 
 int32_t vsm_get_filter_responses(vsm_handle *h, int16_t *f1, int16_t *f2) {
-  if (!h->allocated || !h->f_valid) return 0;
+  if (!h->allocated || !h->f_valid || settle(h) != VSM_OK) return 0;
   const int32_t n = h->dims.mbpl * h->dims.mh;
   if (f1 && hipMemcpy(f1, h->f1, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   if (f2 && hipMemcpy(f2, h->f2, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) return 0;
@@ -561,8 +603,8 @@ int32_t vsm_get_filter_responses(vsm_handle *h, int16_t *f1, int16_t *f2) {
 void vsm_set_stage_capture(vsm_handle *h, int on) { h->capture_stage2 = on ? 1 : 0; }
 
 static const char *kKernelNames[VSM_K_COUNT] = {"k_ingest", "k_halve", "k_filters<true>", "k_filters<false>", "k_nms", "k_scan_cells", "k_emit",
-                                                "k_bin", "k_match<16>:pass1", "k_compact_matches:pass1", "k_match<16>:pass2",
-                                                "k_compact_matches:pass2", "k_refine"};
+                                                "k_bin_scan", "k_bin_scatter", "k_bin_rank", "k_match<16>:pass1", "k_compact_matches:pass1", "k_match<16>:pass2",
+                                                "k_compact_matches:pass2", "k_refine", "k_export_list"};
 
 void vsm_set_profiling(vsm_handle *h, int on) {
   h->prof.on = on != 0;

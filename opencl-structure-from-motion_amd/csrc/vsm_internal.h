@@ -21,9 +21,12 @@
 struct VsmSet {
   int32_t *feat;       // [cap][12]
   int32_t *count;      // device scalar
+  int32_t *count_host; // the same number in host-mapped pinned memory (read after a stream sync)
   int32_t *cand;       // [ncu*ncv*4] packed NMS survivors: u | v<<14 | valid<<31
   int32_t *cell_off;   // [ncu*ncv+1] exclusive prefix of survivors per cell (emission order)
   int32_t *bin_start;  // [4*ub*vb + 1]
+  int32_t *bin_cnt;    // [4*ub*vb] histogram, then scatter cursor
+  int32_t *binid;      // [cap] bin of every feature (emission order)
   int32_t *s_idx;      // [cap] sorted position -> original index
   int2 *s_uv;          // [cap]
   uint4 *s_desc;       // [cap][2]
@@ -57,9 +60,12 @@ struct VsmMatchCfg {
 struct VsmPair {
   vsm_p_match *raw;    // [cap_query] per-query result of the match chain
   int32_t *flag;       // [cap_query]
+  int32_t *blockcnt;   // [cap_query/256 + 1] survivors per 256-query block
   vsm_p_match *list1;  // compacted pass-1 list
-  vsm_p_match *list2;  // compacted pass-2 list (refined in place)
+  vsm_p_match *list2;  // compacted pass-2 list (unrefined: refinement writes to hlist2)
   int32_t *count;      // [2] list sizes
+  vsm_p_match *hlist1, *hlist2;  // host-mapped pinned copies the kernels write directly (no D2H copy)
+  int32_t *hcount;               // [2] host-mapped list sizes
   float *ranges;       // [ub*vb][16]
   int32_t *pf;         // refinement==2 scratch: [cap][3][12] {status,du,dv,c0..c8}
 };
@@ -67,8 +73,8 @@ struct VsmPair {
 // Optional per-kernel timing with HIP events recorded on the handle's own stream (bench.py's
 // roofline leg).  Off by default: events cost a few microseconds per launch.
 enum VsmKernelId {
-  VSM_K_INGEST = 0, VSM_K_HALVE, VSM_K_SOBEL_FULL, VSM_K_FILTERS, VSM_K_NMS, VSM_K_SCAN, VSM_K_EMIT, VSM_K_BIN,
-  VSM_K_MATCH1, VSM_K_COMPACT1, VSM_K_MATCH2, VSM_K_COMPACT2, VSM_K_REFINE, VSM_K_COUNT
+  VSM_K_INGEST = 0, VSM_K_HALVE, VSM_K_SOBEL_FULL, VSM_K_FILTERS, VSM_K_NMS, VSM_K_SCAN, VSM_K_EMIT, VSM_K_BINSCAN, VSM_K_BINSCATTER, VSM_K_BINRANK,
+  VSM_K_MATCH1, VSM_K_COMPACT1, VSM_K_MATCH2, VSM_K_COMPACT2, VSM_K_REFINE, VSM_K_EXPORT, VSM_K_COUNT
 };
 struct VsmProf {
   bool on = false;
@@ -110,12 +116,14 @@ struct VsmProf {
 };
 
 // ---- launchers (vsm_kernels.hip) ----
-void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const uint8_t *src, int32_t src_bpl, uint8_t *dst, const VsmDims &d);
+void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const uint8_t *src0, const uint8_t *src1, int32_t src_bpl,
+                       uint8_t *dst0, uint8_t *dst1, const VsmDims &d);
 void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d, int16_t *f1,
                          int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res, int binsize,
                          const VsmImage *h_imgs);
 void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
-                      const VsmDims &d, const VsmMatchCfg &cfg, int n_query, vsm_p_match *list, int32_t *list_count);
+                      const VsmDims &d, const VsmMatchCfg &cfg, int n_query, int which);
+void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair &pair, int which, int n_upper);
 void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
                        const VsmDims &dp, const VsmDims &dc, int method, int refinement, int n_upper,
                        const int32_t *d_count);

@@ -16,8 +16,11 @@
 // ingest: caller image (row stride src_bpl) -> padded HBM copy [h][bpl], pad bytes = 0
 // (Matcher::pushBack row copy, viso/matcher.cpp:163-175, with the pad pinned to 0)
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ingest(const uint8_t *__restrict__ src, int src_bpl, uint8_t *__restrict__ dst,
+__global__ void __launch_bounds__(256) k_ingest(const uint8_t *__restrict__ src0, const uint8_t *__restrict__ src1,
+                                                int src_bpl, uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1,
                                                 int w, int h, int bpl, int aligned) {
+  const uint8_t *__restrict__ src = blockIdx.z ? src1 : src0;
+  uint8_t *__restrict__ dst = blockIdx.z ? dst1 : dst0;
   int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   int y = blockIdx.y;
   if (x4 >= bpl || y >= h) return;
@@ -252,13 +255,17 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int &total, int *s_w 
 // per-cell survivor counts.  One 1024-thread block per (image, set); every thread owns a run of
 // consecutive cells.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_scan_cells(const VsmImage *__restrict__ imgs, int first, int set_lo) {
+__global__ void __launch_bounds__(1024) k_scan_cells(const VsmImage *__restrict__ imgs, int first, int set_lo, int nb) {
   __shared__ int s_w[17];
   const VsmSet &st = imgs[first + blockIdx.z].set[blockIdx.y];
   if ((int)blockIdx.y < set_lo) {
-    if (threadIdx.x == 0) *st.count = 0;
+    if (threadIdx.x == 0) {
+      *st.count = 0;
+      *st.count_host = 0;
+    }
     return;
   }
+  for (int b = threadIdx.x; b < nb; b += 1024) st.bin_cnt[b] = 0;  // histogram filled by k_emit
   const int ncells = st.ncu * st.ncv;
   const int chunk = (ncells + 1023) / 1024;
   const int c0 = min((int)threadIdx.x * chunk, ncells), c1 = min(c0 + chunk, ncells);
@@ -277,6 +284,7 @@ __global__ void __launch_bounds__(1024) k_scan_cells(const VsmImage *__restrict_
   if (threadIdx.x == 0) {
     st.cell_off[ncells] = total;
     *st.count = total;
+    *st.count_host = total;
   }
 }
 
@@ -289,7 +297,14 @@ __global__ void __launch_bounds__(1024) k_scan_cells(const VsmImage *__restrict_
 __constant__ int8_t c_desc_dv[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
 __constant__ int8_t c_desc_du[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
 
-__global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs, int first, VsmDims d, int set_lo) {
+__device__ __forceinline__ int bin_of(int u, int v, int c, int binsize, int ub, int vb) {
+  int ubin = min((int)floorf((float)u / (float)binsize), ub - 1);
+  int vbin = min((int)floorf((float)v / (float)binsize), vb - 1);
+  return (c * ub + ubin) * vb + vbin;
+}
+
+__global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs, int first, VsmDims d, int set_lo,
+                                              int binsize) {
   const VsmImage &im = imgs[first + blockIdx.z];
   const int si = blockIdx.y;
   if (si < set_lo) return;
@@ -303,6 +318,11 @@ __global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs,
   const int before = (g > 0 && c4.x < 0) + (g > 1 && c4.y < 0) + (g > 2 && c4.z < 0);
   const int pos = st.cell_off[cell] + before;
   const int u = cc & 0x3fff, v = (cc >> 14) & 0x3fff;
+  if (j == 0) {  // M1 createIndexVector (viso/matcher.cpp:870-890): histogram of the search bins
+    const int b = bin_of(u * d.scale, v * d.scale, g, binsize, d.ub, d.vb);
+    st.binid[pos] = b;
+    atomicAdd(&st.bin_cnt[b], 1);
+  }
   uint32_t val;
   if (j < 4) {
     val = j == 0 ? (uint32_t)(u * d.scale) : (j == 1 ? (uint32_t)(v * d.scale) : (j == 2 ? 0u : (uint32_t)g));
@@ -318,64 +338,57 @@ __global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs,
 // ---------------------------------------------------------------------------------------
 // M1 createIndexVector, viso/matcher.cpp:870-890, as a stable counting sort into the
 // bin-contiguous SoA arrays (see VsmSet).  bin = (class*ub + u_bin)*vb + v_bin so that the
-// v-bins a query visits for one u_bin are one contiguous run.  One block per (image, set).
+// v-bins a query visits for one u_bin are one contiguous run.  Histogram: k_emit.  Then
+//   k_bin_scan    exclusive scan of the histogram (one block per image/set)
+//   k_bin_scatter every feature takes a slot of its bin (unordered, atomic cursor)
+//   k_bin_rank    every slot finds its stable rank = number of smaller feature indices in its
+//                 bin (a bin holds at most one feature per NMS cell and class: a few dozen) and
+//                 writes the sorted coordinate / descriptor / index arrays
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ int feat_bin(const int32_t *rec, int binsize, int ub, int vb) {
-  int ubin = min((int)floorf((float)rec[0] / (float)binsize), ub - 1);
-  int vbin = min((int)floorf((float)rec[1] / (float)binsize), vb - 1);
-  return (rec[3] * ub + ubin) * vb + vbin;
-}
-
-__global__ void __launch_bounds__(1024) k_bin(const VsmImage *__restrict__ imgs, int first, VsmDims d, int binsize,
-                                              int set_lo) {
-  extern __shared__ int s_mem[];
+__global__ void __launch_bounds__(1024) k_bin_scan(const VsmImage *__restrict__ imgs, int first, int set_lo, int nb) {
   __shared__ int s_w[17];
-  const VsmSet &st = imgs[first + blockIdx.z].set[blockIdx.y];
   if ((int)blockIdx.y < set_lo) return;
-  const int nb = 4 * d.ub * d.vb;
-  int *s_start = s_mem, *s_cur = s_mem + nb + 1;
-  const int n = *st.count;
-  for (int b = threadIdx.x; b <= nb; b += 1024) s_start[b] = 0;
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&s_start[feat_bin(st.feat + (size_t)i * 12, binsize, d.ub, d.vb)], 1);
-  __syncthreads();
-  // exclusive scan of the nb histogram entries: per-thread chunk + block scan
+  const VsmSet &st = imgs[first + blockIdx.z].set[blockIdx.y];
   const int chunk = (nb + 1023) / 1024;
-  const int b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, nb);
+  const int b0 = min((int)threadIdx.x * chunk, nb), b1 = min(b0 + chunk, nb);
   int sum = 0;
-  for (int b = b0; b < b1; b++) sum += s_start[b];
+  for (int b = b0; b < b1; b++) sum += st.bin_cnt[b];
   int total;
   int run = block_excl_scan_1024(sum, total, s_w);
   for (int b = b0; b < b1; b++) {
-    int c = s_start[b];
-    s_start[b] = run;
-    s_cur[b] = run;
+    const int c = st.bin_cnt[b];
+    st.bin_start[b] = run;
+    st.bin_cnt[b] = run;  // becomes the scatter cursor
     run += c;
   }
-  if (threadIdx.x == 0) s_start[nb] = total;
-  __syncthreads();
-  for (int b = threadIdx.x; b <= nb; b += 1024) st.bin_start[b] = s_start[b];
-  // unordered scatter of indices into their bins ...
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    int b = feat_bin(st.feat + (size_t)i * 12, binsize, d.ub, d.vb);
-    st.tmp[atomicAdd(&s_cur[b], 1)] = i;
-  }
-  __syncthreads();
-  // ... then each entry finds its stable rank (number of smaller indices in its bin: bins hold
-  // at most one feature per NMS cell and class, i.e. a few dozen entries)
-  for (int p = threadIdx.x; p < n; p += 1024) {
-    const int idx = st.tmp[p];
-    const int32_t *rec = st.feat + (size_t)idx * 12;
-    const int b = feat_bin(rec, binsize, d.ub, d.vb);
-    const int lo = s_start[b], hi = s_start[b + 1];
-    int rank = 0;
-    for (int q = lo; q < hi; q++) rank += st.tmp[q] < idx;
-    const int dst = lo + rank;
-    st.s_idx[dst] = idx;
-    st.s_uv[dst] = make_int2(rec[0], rec[1]);
-    st.s_desc[2 * dst] = *(const uint4 *)(rec + 4);
-    st.s_desc[2 * dst + 1] = *(const uint4 *)(rec + 8);
-  }
+  if (threadIdx.x == 0) st.bin_start[nb] = total;
+}
+
+__global__ void __launch_bounds__(256) k_bin_scatter(const VsmImage *__restrict__ imgs, int first, int set_lo) {
+  if ((int)blockIdx.y < set_lo) return;
+  const VsmSet &st = imgs[first + blockIdx.z].set[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *st.count) return;
+  st.tmp[atomicAdd(&st.bin_cnt[st.binid[i]], 1)] = i;
+}
+
+__global__ void __launch_bounds__(256) k_bin_rank(const VsmImage *__restrict__ imgs, int first, int set_lo) {
+  if ((int)blockIdx.y < set_lo) return;
+  const VsmSet &st = imgs[first + blockIdx.z].set[blockIdx.y];
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= *st.count) return;
+  const int idx = st.tmp[p];
+  const int b = st.binid[idx];
+  const int lo = st.bin_start[b], hi = st.bin_start[b + 1];
+  int rank = 0;
+  for (int q = lo; q < hi; q++) rank += st.tmp[q] < idx;
+  const int dst = lo + rank;
+  const int32_t *rec = st.feat + (size_t)idx * 12;
+  const int4 hd = *(const int4 *)rec;
+  st.s_idx[dst] = idx;
+  st.s_uv[dst] = make_int2(hd.x, hd.y);
+  st.s_desc[2 * dst] = *(const uint4 *)(rec + 4);
+  st.s_desc[2 * dst + 1] = *(const uint4 *)(rec + 8);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -540,32 +553,67 @@ __global__ void __launch_bounds__(256)
 // ordered compaction of the accepted queries (push_back order = ascending query index) with the
 // first-come pixel de-dup of flow / stereo (M[] in viso/matcher.cpp:1036-1039, :1078-1081):
 // features sharing a pixel come from one NMS cell, hence are at most 3 indices apart.
-__global__ void __launch_bounds__(1024)
-    k_compact_matches(VsmPair pair, int method, int n_query, vsm_p_match *__restrict__ list, int32_t *list_count) {
-  __shared__ int s_w[17];
-  __shared__ int s_run;
-  if (threadIdx.x == 0) s_run = 0;
-  __syncthreads();
-  for (int base = 0; base < n_query; base += 1024) {
-    const int i = base + threadIdx.x;
-    int keep = 0;
-    vsm_p_match m;
-    if (i < n_query && pair.flag[i]) {
-      m = pair.raw[i];
-      keep = 1;
-      if (method < 2) {
-        for (int j = max(i - 3, 0); j < i; j++)
-          if (pair.flag[j] && pair.raw[j].u1c == m.u1c && pair.raw[j].v1c == m.v1c) keep = 0;
-      }
-    }
-    int total;
-    int pos = s_run + block_excl_scan_1024(keep, total, s_w);
-    if (keep) list[pos] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) s_run += total;
-    __syncthreads();
+// Two small kernels, 256 queries per block: k_compact_count leaves one survivor count per
+// block, k_compact_write sums the counts of the blocks before it (a few hundred at most) and
+// writes its survivors; nothing is serialised through one block.
+__device__ __forceinline__ bool match_kept(const VsmPair &pair, int method, int i) {
+  if (!pair.flag[i]) return false;
+  if (method < 2) {
+    const float u = pair.raw[i].u1c, v = pair.raw[i].v1c;
+    for (int j = max(i - 3, 0); j < i; j++)
+      if (pair.flag[j] && pair.raw[j].u1c == u && pair.raw[j].v1c == v) return false;
   }
-  if (threadIdx.x == 0) *list_count = s_run;
+  return true;
+}
+
+__global__ void __launch_bounds__(256) k_compact_count(VsmPair pair, int method, int n_query) {
+  __shared__ int s_cnt[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool keep = i < n_query && match_kept(pair, method, i);
+  const unsigned long long b = __ballot(keep);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) pair.blockcnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ void __launch_bounds__(256)
+    k_compact_write(VsmPair pair, int method, int n_query, vsm_p_match *__restrict__ list, int32_t *list_count,
+                    int32_t *hcount) {
+  __shared__ int s_red[4];
+  __shared__ int s_cnt[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // base = survivors of all earlier blocks
+  int part = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += pair.blockcnt[b];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool keep = i < n_query && match_kept(pair, method, i);
+  const unsigned long long bal = __ballot(keep);
+  if (lane == 0) {
+    s_red[wv] = part;
+    s_cnt[wv] = __popcll(bal);
+  }
+  __syncthreads();
+  int pos = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  for (int w = 0; w < wv; w++) pos += s_cnt[w];
+  pos += __popcll(bal & ((1ull << lane) - 1ull));
+  if (keep) list[pos] = pair.raw[i];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+    const int total = pos + (keep ? 1 : 0);
+    *list_count = total;
+    *hcount = total;
+  }
+}
+
+// wide copy of a finished list into host-mapped pinned memory (16 bytes per lane over PCIe):
+// the host reads it after the stream sync, no D2H copy call and no second round trip
+__global__ void __launch_bounds__(256)
+    k_export_list(const vsm_p_match *__restrict__ list, const int32_t *__restrict__ count, vsm_p_match *__restrict__ hlist) {
+  const int n16 = *count * 3;
+  const uint4 *src = (const uint4 *)list;
+  uint4 *dst = (uint4 *)hlist;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -606,7 +654,7 @@ __global__ void __launch_bounds__(256)
   if (step == 0 && !(method == 0 || method == 2)) return;
   if (step == 1 && !(method == 1 || method == 2)) return;
   if (step == 2 && method != 2) return;
-  vsm_p_match *m = pair.list2 + mi;
+  vsm_p_match *m = pair.list2 + mi;  // refined in place (each step owns its two fields)
   const VsmImage &ref = imgs[img_curr];
   const VsmImage &tgt = step == 0 ? imgs[img_prev] : (step == 1 ? imgs[img_curr + 1] : imgs[img_prev + 1]);
   const VsmDims &dt = step == 1 ? dc : dp;
@@ -693,11 +741,12 @@ __global__ void __launch_bounds__(256)
 // =======================================================================================
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const uint8_t *src, int32_t src_bpl, uint8_t *dst, const VsmDims &d) {
-  int aligned = ((src_bpl & 3) == 0) && ((((uintptr_t)src) & 3) == 0);
-  dim3 grid(cdiv(d.bpl / 4, 256), d.h);
+void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const uint8_t *src0, const uint8_t *src1, int32_t src_bpl,
+                       uint8_t *dst0, uint8_t *dst1, const VsmDims &d) {
+  int aligned = ((src_bpl & 3) == 0) && ((((uintptr_t)src0) & 3) == 0) && ((((uintptr_t)src1) & 3) == 0);
+  dim3 grid(cdiv(d.bpl / 4, 256), d.h, src1 ? 2 : 1);
   pf.begin(VSM_K_INGEST, s);
-  hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, src, src_bpl, dst, d.w, d.h, d.bpl, aligned);
+  hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, src0, src1, src_bpl, dst0, dst1, d.w, d.h, d.bpl, aligned);
   pf.end(s);
 }
 
@@ -718,8 +767,12 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
                      d.mbpl, d.mh, f1, f2, f_stride);
   pf.end(s);
   const int set_lo = multi_stage ? 0 : 1;
-  int max_cells = 0;
-  for (int k = 0; k < 2; k++) max_cells = max(max_cells, h_imgs[first].set[k].ncu * h_imgs[first].set[k].ncv);
+  const int nb = 4 * d.ub * d.vb;
+  int max_cells = 0, max_cap = 0;
+  for (int k = 0; k < 2; k++) {
+    max_cells = max(max_cells, h_imgs[first].set[k].ncu * h_imgs[first].set[k].ncv);
+    max_cap = max(max_cap, h_imgs[first].set[k].cap);
+  }
   if (max_cells > 0) {
     pf.begin(VSM_K_NMS, s);
     hipLaunchKernelGGL(k_nms, dim3(cdiv(max_cells, 4), 2, n_img * 2), dim3(256), 0, s, d_imgs, first, d, f1, f2,
@@ -727,22 +780,27 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
     pf.end(s);
   }
   pf.begin(VSM_K_SCAN, s);
-  hipLaunchKernelGGL(k_scan_cells, dim3(1, 2, n_img), dim3(1024), 0, s, d_imgs, first, set_lo);
+  hipLaunchKernelGGL(k_scan_cells, dim3(1, 2, n_img), dim3(1024), 0, s, d_imgs, first, set_lo, nb);
   pf.end(s);
   if (max_cells > 0) {
     pf.begin(VSM_K_EMIT, s);
-    hipLaunchKernelGGL(k_emit, dim3(cdiv(max_cells, 4), 2, n_img), dim3(256), 0, s, d_imgs, first, d, set_lo);
+    hipLaunchKernelGGL(k_emit, dim3(cdiv(max_cells, 4), 2, n_img), dim3(256), 0, s, d_imgs, first, d, set_lo, binsize);
     pf.end(s);
   }
-  const size_t shm = (size_t)(2 * (4 * d.ub * d.vb + 1)) * sizeof(int);
-  pf.begin(VSM_K_BIN, s);
-  hipLaunchKernelGGL(k_bin, dim3(1, 2, n_img), dim3(1024), shm, s, d_imgs, first, d, binsize, set_lo);
+  pf.begin(VSM_K_BINSCAN, s);
+  hipLaunchKernelGGL(k_bin_scan, dim3(1, 2, n_img), dim3(1024), 0, s, d_imgs, first, set_lo, nb);
+  pf.end(s);
+  pf.begin(VSM_K_BINSCATTER, s);
+  hipLaunchKernelGGL(k_bin_scatter, dim3(cdiv(max_cap, 256), 2, n_img), dim3(256), 0, s, d_imgs, first, set_lo);
+  pf.end(s);
+  pf.begin(VSM_K_BINRANK, s);
+  hipLaunchKernelGGL(k_bin_rank, dim3(cdiv(max_cap, 256), 2, n_img), dim3(256), 0, s, d_imgs, first, set_lo);
   pf.end(s);
 }
 
+// which: 0 = pass-1 lists (list1/hlist1/count[0]), 1 = pass-2 lists
 void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int img_prev, int img_curr,
-                      const VsmPair &pair, const VsmDims &d, const VsmMatchCfg &cfg, int n_query, vsm_p_match *list,
-                      int32_t *list_count) {
+                      const VsmPair &pair, const VsmDims &d, const VsmMatchCfg &cfg, int n_query, int which) {
   constexpr int G = 16;
   if (n_query > 0) {
     pf.begin(cfg.sparse ? VSM_K_MATCH1 : VSM_K_MATCH2, s);
@@ -750,8 +808,18 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int im
                        cfg, n_query);
     pf.end(s);
   }
+  const int nblk = max(cdiv(n_query, 256), 1);
   pf.begin(cfg.sparse ? VSM_K_COMPACT1 : VSM_K_COMPACT2, s);
-  hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, pair, cfg.method, n_query, list, list_count);
+  hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, s, pair, cfg.method, n_query);
+  hipLaunchKernelGGL(k_compact_write, dim3(nblk), dim3(256), 0, s, pair, cfg.method, n_query,
+                     which ? pair.list2 : pair.list1, pair.count + which, pair.hcount + which);
+  pf.end(s);
+}
+
+void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair &pair, int which, int n_upper) {
+  pf.begin(VSM_K_EXPORT, s);
+  hipLaunchKernelGGL(k_export_list, dim3(max(min(cdiv(n_upper * 3, 256), 256), 1)), dim3(256), 0, s,
+                     which ? pair.list2 : pair.list1, pair.count + which, which ? pair.hlist2 : pair.hlist1);
   pf.end(s);
 }
 
