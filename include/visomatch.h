@@ -98,6 +98,25 @@ int vsm_bucket(vsm_handle *h, int32_t max_features, float bucket_width, float bu
 /* Matcher::getGain, viso/matcher.cpp:286-324 */
 float vsm_gain(vsm_handle *h, const int32_t *inliers, int32_t n);
 
+/* ---- look-ahead API: a whole sequence at once ----
+ * Semantically identical to
+ *     for f in 0..n_frames-1:  pushBack(left[f], right[f], dims, false);  matchFeatures(method, Tr[f])
+ * on a fresh Matcher (viso/matcher.cpp:95, :183), but the frames of a chunk (VSM_SEQ_CHUNK, default
+ * 50) go through every kernel in one launch and the host stages of the chunk's frame pairs run in
+ * parallel.  left/right: n_frames images frame_stride bytes apart (host or, with on_device != 0,
+ * HBM); right == NULL (mono) and refinement == 2 fall back to the frame-by-frame path.
+ * Tr_delta: NULL or n_frames x 12 doubles, Tr_valid: NULL (all valid) or n_frames flags.
+ * The streaming ring buffer (vsm_push_back / vsm_match) is not touched except by the fallback. */
+int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, int64_t frame_stride, int on_device,
+                     int32_t n_frames, int32_t width, int32_t height, int32_t bpl, int32_t method,
+                     const double *Tr_delta, const uint8_t *Tr_valid);
+/* getMatches() as it would read after frame `frame` */
+int32_t vsm_sequence_num_matches(vsm_handle *h, int32_t frame);
+int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out, int32_t cap);
+/* wall-clock split of the last vsm_sequence_run() in microseconds: {GPU phases incl. syncs, host
+ * phases, total, chunk size} */
+void vsm_sequence_get_timings(vsm_handle *h, double *out4);
+
 /* ---- stage-level views for parity tests (the reference's private members) ---- */
 
 /* m1p1.. / n1p1.. (viso/matcher.h:232-235).  which: 0=1p1 1=2p1 2=1c1 3=2c1 4=1p2 5=2p2 6=1c2 7=2c2;

@@ -2,9 +2,14 @@
 //
 //   vsm_push_back : H2D (or D2D) ingest -> [halve] -> Sobel full / Sobel+blob+corner -> NMS ->
 //                   ordered feature emission + descriptors -> bin sort            (all on the GPU)
-//   vsm_match     : pass-1 match chain -> D2H -> host Delaunay support + prior boxes -> H2D ->
-//                   pass-2 match chain -> refinement -> D2H -> host Delaunay support
+//   vsm_match     : pass-1 match chain -> export -> host Delaunay support + prior boxes -> H2D ->
+//                   pass-2 match chain -> refinement -> export -> host Delaunay support
+//   vsm_sequence_run : the same work for a whole sequence with look-ahead: the frames of a chunk
+//                   go through every kernel in ONE launch each (grid z/y = image / frame pair) and
+//                   the host stages of the chunk's pairs run in parallel on the pool.
 //
+// A VsmCtx is the device-resident working set for F frame slots and P frame pairs; the streaming
+// ring buffer is the (F=2, P=1) instance, sequences use (F=2C, P=C).
 // There is no CPU fallback: without a usable HIP device vsm_create() returns NULL.
 #include <math.h>
 #include <stdio.h>
@@ -12,6 +17,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <memory>
 #include <vector>
 
 #include "vsm_host.h"
@@ -33,128 +39,41 @@ static inline double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-struct vsm_handle {
-  vsm_params param;  // match_radius already halved for half_resolution (viso/matcher.cpp:59-60)
-  int device = 0;
-  hipStream_t stream = nullptr;
-
-  // device state
-  bool allocated = false;
+// ---------------------------------------------------------------------------------------
+// device working set
+// ---------------------------------------------------------------------------------------
+struct VsmCtx {
+  bool ready = false;
   VsmDims dims{};
+  int nframes = 0, npairs = 0;
   uint8_t *arena = nullptr;
   size_t arena_bytes = 0;
-  VsmImage h_imgs[4];  // image id = frame_slot*2 + side
+  std::vector<VsmImage> h_imgs;  // image id = frame_slot*2 + side
   VsmImage *d_imgs = nullptr;
-  int16_t *f1 = nullptr, *f2 = nullptr;
+  std::vector<VsmPair> h_pairs;
+  VsmPair *d_pairs = nullptr;
+  VsmJob *d_jobs = nullptr;
+  int16_t *f1 = nullptr, *f2 = nullptr;  // transient filter responses of one feature launch
   size_t f_stride = 0;
-  VsmPair pair{};
   int32_t cap_set[2] = {0, 0};
-
-  // pinned host memory.  hm_* is host-mapped: kernels write the feature counts and the
-  // compacted match lists straight into it, so results need a stream sync but no D2H copy.
-  int32_t *h_counts = nullptr;  // scratch [16]
-  float *h_ranges = nullptr;
+  size_t ranges_stride = 0;  // floats per pair
+  float *d_ranges = nullptr;
+  // pinned host memory.  hm_* is host-mapped: kernels write feature counts and exported match
+  // lists straight into it, so results need a stream sync but no D2H copy.
   uint8_t *hm_block = nullptr;
-  int32_t *hm_counts = nullptr;  // [8] feature counts (image*2+set) + [2] list sizes
-  vsm_p_match *hm_list1 = nullptr, *hm_list2 = nullptr;
-  bool counts_pending = false;   // a push is in flight: sync before reading hm_counts
-  int pending_slot = 0, pending_imgs = 0;
-
-  // ring buffer state (Matcher's prev/curr pointers, viso/matcher.cpp:108-155)
-  int cur = 0;
-  bool have[2] = {false, false};   // frame slot holds a left image
-  bool right[2] = {false, false};  // ... and a right image
-  int32_t n_feat[2][2][2] = {};    // [slot][side][set]
-  int32_t dims_p[3] = {0, 0, 0}, dims_c[3] = {0, 0, 0};
-  bool f_valid = false;  // f1/f2 hold the responses of the current left image
-
-  // results
-  std::vector<vsm_p_match> stage[5];
-  std::vector<vsm_p_match> matched;
-  std::vector<float> ranges;
-  std::vector<int32_t> pf;
-  int capture_stage2 = 0;
-  VsmHostWork work;
-  int64_t counters[5] = {0, 0, 0, 0, 0};
-  double timings[5] = {0, 0, 0, 0, 0};
-  std::vector<uint8_t> gainI[2];
-  VsmProf prof;
-  VsmPool *pool = nullptr;
+  int32_t *hm_counts = nullptr;  // [nframes*2 images][2 sets]
+  int32_t *hm_lcount = nullptr;  // [npairs][2]
+  std::vector<vsm_p_match *> hm_list1, hm_list2;  // host views, per pair
+  float *h_ranges = nullptr;     // pinned [npairs][ranges_stride]
+  VsmJob *h_jobs = nullptr;      // pinned [npairs]
 };
 
-extern "C" {
-
-const char *vsm_version(void) { return "visomatch 0.1 (gfx950)"; }
-
-void vsm_default_params(vsm_params *p) {
-  memset(p, 0, sizeof(*p));
-  p->nms_n = 3;
-  p->nms_tau = 50;
-  p->match_binsize = 50;
-  p->match_radius = 200;
-  p->match_disp_tolerance = 2;
-  p->outlier_disp_tolerance = 5;
-  p->outlier_flow_tolerance = 5;
-  p->multi_stage = 1;
-  p->half_resolution = 1;
-  p->refinement = 1;
-}
-
-vsm_handle *vsm_create(const vsm_params *p) {
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-    fprintf(stderr, "visomatch: no HIP device available (this library has no CPU path)\n");
-    return nullptr;
-  }
-  vsm_handle *h = new vsm_handle();
-  h->param = *p;
-  if (p->half_resolution) h->param.match_radius /= 2;
-  {
-    int nt = 8;  // host threads for the Delaunay sub-problems (the caller's thread included)
-    if (const char *e = getenv("VSM_HOST_THREADS")) nt = atoi(e);
-    unsigned hc = std::thread::hardware_concurrency();
-    if (hc && (unsigned)nt > hc) nt = (int)hc;
-    h->pool = new VsmPool(nt);
-    h->work.pool = h->pool;
-  }
-  if (hipGetDevice(&h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipHostMalloc((void **)&h->h_counts, 16 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
-    fprintf(stderr, "visomatch: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
-    delete h;
-    return nullptr;
-  }
-  return h;
-}
-
-static void release_device(vsm_handle *h) {
-  if (h->arena) (void)hipFree(h->arena);
-  if (h->h_ranges) (void)hipHostFree(h->h_ranges);
-  if (h->hm_block) (void)hipHostFree(h->hm_block);
-  h->arena = nullptr;
-  h->h_ranges = nullptr;
-  h->hm_block = nullptr;
-  h->counts_pending = false;
-  h->allocated = false;
-  h->have[0] = h->have[1] = h->right[0] = h->right[1] = false;
-  h->f_valid = false;
-  memset(h->n_feat, 0, sizeof(h->n_feat));
-}
-
-void vsm_destroy(vsm_handle *h) {
-  if (!h) return;
-  (void)hipStreamSynchronize(h->stream);
-  release_device(h);
-  if (h->h_counts) (void)hipHostFree(h->h_counts);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
-  delete h->pool;
-  delete h;
-}
-
-void vsm_set_intrinsics(vsm_handle *h, double f, double cu, double cv, double base) {
-  h->param.f = f;
-  h->param.cu = cu;
-  h->param.cv = cv;
-  h->param.base = base;
+static void ctx_destroy(VsmCtx &c) {
+  if (c.arena) (void)hipFree(c.arena);
+  if (c.hm_block) (void)hipHostFree(c.hm_block);
+  if (c.h_ranges) (void)hipHostFree(c.h_ranges);
+  if (c.h_jobs) (void)hipHostFree(c.h_jobs);
+  c = VsmCtx();
 }
 
 static int nms_cells(int32_t len, int32_t n) {  // loop count of "for (i=n+margin; i<len-n-margin; i+=n+1)"
@@ -162,15 +81,10 @@ static int nms_cells(int32_t len, int32_t n) {  // loop count of "for (i=n+margi
   return span > 0 ? (span + n) / (n + 1) : 0;
 }
 
-// One arena per handle: 4 image slots (prev/curr x left/right), the transient filter responses
-// of one push and the buffers of one frame pair.  Zero-filled once, so row padding stays 0.
-static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
-  if (h->allocated) {
-    (void)hipStreamSynchronize(h->stream);
-    release_device(h);
-  }
-  const vsm_params &p = h->param;
-  VsmDims &d = h->dims;
+// One arena per context, zero-filled once, so row padding stays 0.
+static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int nframes, int npairs, hipStream_t stream) {
+  ctx_destroy(c);
+  VsmDims &d = c.dims;
   d.w = w;
   d.h = hh;
   d.bpl = bpl16(w);
@@ -197,11 +111,13 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
   for (int k = 0; k < 2; k++) {
     ncu[k] = nms_cells(d.mw, nn[k]);
     ncv[k] = nms_cells(d.mh, nn[k]);
-    h->cap_set[k] = 4 * ncu[k] * ncv[k];
-    if (h->cap_set[k] < 4) h->cap_set[k] = 4;
+    c.cap_set[k] = 4 * ncu[k] * ncv[k];
+    if (c.cap_set[k] < 4) c.cap_set[k] = 4;
   }
+  c.nframes = nframes;
+  c.npairs = npairs;
+  const int nimg = nframes * 2;
   const size_t full = al256((size_t)d.bpl * d.h + 64), mres = al256((size_t)d.mbpl * d.mh + 64);
-  // pass 1: size
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -214,8 +130,9 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
   struct ImgOff {
     size_t img, imgm, du, dv, duf, dvf;
     SetOff set[2];
-  } io[4];
-  for (int i = 0; i < 4; i++) {
+  };
+  std::vector<ImgOff> io(nimg);
+  for (int i = 0; i < nimg; i++) {
     io[i].img = take(full);
     io[i].imgm = p.half_resolution ? take(mres) : io[i].img;
     io[i].du = take(mres);
@@ -223,7 +140,7 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
     io[i].duf = p.half_resolution ? take(full) : io[i].du;
     io[i].dvf = p.half_resolution ? take(full) : io[i].dv;
     for (int k = 0; k < 2; k++) {
-      const size_t cap = h->cap_set[k];
+      const size_t cap = c.cap_set[k];
       io[i].set[k].feat = take(cap * 48);
       io[i].set[k].count = take(4);
       io[i].set[k].cand = take((size_t)(ncu[k] * ncv[k] + 1) * 16);
@@ -237,20 +154,46 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
       io[i].set[k].tmp = take(cap * 4);
     }
   }
-  h->f_stride = mres / 2 * 2;  // elements per image plane (int16), keeps 256-byte alignment
-  const size_t o_f1 = take(h->f_stride * 2 * 2), o_f2 = take(h->f_stride * 2 * 2);
-  const size_t qcap = (size_t)(h->cap_set[0] > h->cap_set[1] ? h->cap_set[0] : h->cap_set[1]);
-  const size_t o_raw = take(qcap * 48), o_flag = take(qcap * 4), o_l1 = take(qcap * 48), o_l2 = take(qcap * 48);
-  const size_t o_bc = take((qcap / 256 + 2) * 4);
-  const size_t o_cnt = take(16), o_rng = take((size_t)d.ub * d.vb * 64);
-  const size_t o_pf = p.refinement == 2 ? take(qcap * 3 * 12 * 4) : 0;
-  const size_t o_imgs = take(4 * sizeof(VsmImage));
-  h->arena_bytes = off;
-  HIPCHK(hipMalloc((void **)&h->arena, h->arena_bytes));
-  HIPCHK(hipMemsetAsync(h->arena, 0, h->arena_bytes, h->stream));
-  uint8_t *b = h->arena;
-  for (int i = 0; i < 4; i++) {
-    VsmImage &im = h->h_imgs[i];
+  c.f_stride = mres;  // int16 elements per image plane
+  const size_t o_f1 = take(c.f_stride * 2 * nimg), o_f2 = take(c.f_stride * 2 * nimg);
+  const size_t qcap = (size_t)(c.cap_set[0] > c.cap_set[1] ? c.cap_set[0] : c.cap_set[1]);
+  c.ranges_stride = (size_t)d.ub * d.vb * 16;
+  struct PairOff {
+    size_t raw, flag, bc, l1, l2, cnt, pf;
+  };
+  std::vector<PairOff> po(npairs);
+  for (int j = 0; j < npairs; j++) {
+    po[j].raw = take(qcap * 48);
+    po[j].flag = take(qcap * 4);
+    po[j].bc = take((qcap / 256 + 2) * 4);
+    po[j].l1 = take((size_t)c.cap_set[0] * 48);
+    po[j].l2 = take(qcap * 48);
+    po[j].cnt = take(16);
+    po[j].pf = (p.refinement == 2 && npairs == 1) ? take(qcap * 3 * 12 * 4) : 0;
+  }
+  const size_t o_rng = take(c.ranges_stride * 4 * npairs);
+  const size_t o_imgs = take((size_t)nimg * sizeof(VsmImage));
+  const size_t o_pairs = take((size_t)npairs * sizeof(VsmPair));
+  const size_t o_jobs = take((size_t)npairs * sizeof(VsmJob));
+  c.arena_bytes = off;
+  HIPCHK(hipMalloc((void **)&c.arena, c.arena_bytes));
+  HIPCHK(hipMemsetAsync(c.arena, 0, c.arena_bytes, stream));
+  // host-mapped result block: [image counts][list counts][list1, list2 per pair]
+  const size_t l1 = al256((size_t)c.cap_set[0] * 48), l2 = al256(qcap * 48);
+  const size_t hc = al256((size_t)nimg * 2 * 4), hl = al256((size_t)npairs * 2 * 4);
+  const size_t hm_bytes = hc + hl + (l1 + l2) * npairs;
+  HIPCHK(hipHostMalloc((void **)&c.hm_block, hm_bytes, hipHostMallocMapped));
+  memset(c.hm_block, 0, hc + hl);
+  uint8_t *dblock = nullptr;
+  HIPCHK(hipHostGetDevicePointer((void **)&dblock, c.hm_block, 0));
+  c.hm_counts = (int32_t *)c.hm_block;
+  c.hm_lcount = (int32_t *)(c.hm_block + hc);
+  HIPCHK(hipHostMalloc((void **)&c.h_ranges, c.ranges_stride * 4 * npairs, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&c.h_jobs, sizeof(VsmJob) * npairs, hipHostMallocDefault));
+  uint8_t *b = c.arena;
+  c.h_imgs.resize(nimg);
+  for (int i = 0; i < nimg; i++) {
+    VsmImage &im = c.h_imgs[i];
     im.img = b + io[i].img;
     im.imgm = b + io[i].imgm;
     im.du = b + io[i].du;
@@ -261,6 +204,7 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
       VsmSet &s = im.set[k];
       s.feat = (int32_t *)(b + io[i].set[k].feat);
       s.count = (int32_t *)(b + io[i].set[k].count);
+      s.count_host = (int32_t *)dblock + (i * 2 + k);
       s.cand = (int32_t *)(b + io[i].set[k].cand);
       s.cell_off = (int32_t *)(b + io[i].set[k].cell_off);
       s.bin_start = (int32_t *)(b + io[i].set[k].bin_start);
@@ -270,43 +214,154 @@ static int allocate(vsm_handle *h, int32_t w, int32_t hh) {
       s.s_uv = (int2 *)(b + io[i].set[k].s_uv);
       s.s_desc = (uint4 *)(b + io[i].set[k].s_desc);
       s.tmp = (int32_t *)(b + io[i].set[k].tmp);
-      s.cap = h->cap_set[k];
+      s.cap = c.cap_set[k];
       s.nms_n = nn[k];
       s.ncu = ncu[k];
       s.ncv = ncv[k];
     }
   }
-  h->f1 = (int16_t *)(b + o_f1);
-  h->f2 = (int16_t *)(b + o_f2);
-  h->pair.raw = (vsm_p_match *)(b + o_raw);
-  h->pair.flag = (int32_t *)(b + o_flag);
-  h->pair.blockcnt = (int32_t *)(b + o_bc);
-  h->pair.list1 = (vsm_p_match *)(b + o_l1);
-  h->pair.list2 = (vsm_p_match *)(b + o_l2);
-  h->pair.count = (int32_t *)(b + o_cnt);
-  h->pair.ranges = (float *)(b + o_rng);
-  h->pair.pf = p.refinement == 2 ? (int32_t *)(b + o_pf) : nullptr;
-  h->d_imgs = (VsmImage *)(b + o_imgs);
-  {  // host-mapped result block: [counts 256 B][list1][list2]
-    const size_t l1 = al256((size_t)h->cap_set[0] * 48), l2 = al256(qcap * 48);
-    HIPCHK(hipHostMalloc((void **)&h->hm_block, 256 + l1 + l2, hipHostMallocMapped));
-    memset(h->hm_block, 0, 256 + l1 + l2);
-    uint8_t *dblock = nullptr;
-    HIPCHK(hipHostGetDevicePointer((void **)&dblock, h->hm_block, 0));
-    h->hm_counts = (int32_t *)h->hm_block;
-    h->hm_list1 = (vsm_p_match *)(h->hm_block + 256);
-    h->hm_list2 = (vsm_p_match *)(h->hm_block + 256 + l1);
-    for (int i = 0; i < 4; i++)
-      for (int k = 0; k < 2; k++) h->h_imgs[i].set[k].count_host = (int32_t *)dblock + (i * 2 + k);
-    h->pair.hcount = (int32_t *)dblock + 8;
-    h->pair.hlist1 = (vsm_p_match *)(dblock + 256);
-    h->pair.hlist2 = (vsm_p_match *)(dblock + 256 + l1);
+  c.f1 = (int16_t *)(b + o_f1);
+  c.f2 = (int16_t *)(b + o_f2);
+  c.d_ranges = (float *)(b + o_rng);
+  c.h_pairs.resize(npairs);
+  c.hm_list1.resize(npairs);
+  c.hm_list2.resize(npairs);
+  for (int j = 0; j < npairs; j++) {
+    VsmPair &pr = c.h_pairs[j];
+    pr.raw = (vsm_p_match *)(b + po[j].raw);
+    pr.flag = (int32_t *)(b + po[j].flag);
+    pr.blockcnt = (int32_t *)(b + po[j].bc);
+    pr.list1 = (vsm_p_match *)(b + po[j].l1);
+    pr.list2 = (vsm_p_match *)(b + po[j].l2);
+    pr.count = (int32_t *)(b + po[j].cnt);
+    pr.ranges = c.d_ranges + (size_t)j * c.ranges_stride;
+    pr.pf = po[j].pf ? (int32_t *)(b + po[j].pf) : nullptr;
+    const size_t lo = hc + hl + (l1 + l2) * j;
+    c.hm_list1[j] = (vsm_p_match *)(c.hm_block + lo);
+    c.hm_list2[j] = (vsm_p_match *)(c.hm_block + lo + l1);
+    pr.hlist1 = (vsm_p_match *)(dblock + lo);
+    pr.hlist2 = (vsm_p_match *)(dblock + lo + l1);
+    pr.hcount = (int32_t *)(dblock + hc) + 2 * j;
   }
-  HIPCHK(hipMemcpyAsync(h->d_imgs, h->h_imgs, 4 * sizeof(VsmImage), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipHostMalloc((void **)&h->h_ranges, (size_t)d.ub * d.vb * 64, hipHostMallocDefault));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->allocated = true;
+  c.d_imgs = (VsmImage *)(b + o_imgs);
+  c.d_pairs = (VsmPair *)(b + o_pairs);
+  c.d_jobs = (VsmJob *)(b + o_jobs);
+  HIPCHK(hipMemcpyAsync(c.d_imgs, c.h_imgs.data(), (size_t)nimg * sizeof(VsmImage), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(c.d_pairs, c.h_pairs.data(), (size_t)npairs * sizeof(VsmPair), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  c.ready = true;
   return VSM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+struct vsm_handle {
+  vsm_params param;  // match_radius already halved for half_resolution (viso/matcher.cpp:59-60)
+  int device = 0;
+  hipStream_t stream = nullptr;
+  VsmCtx ring;  // streaming ring buffer: 2 frame slots, 1 pair
+  VsmCtx seq;   // look-ahead sequences: 2 banks of C frame slots, C pairs
+  int seq_chunk = 0;
+
+  // ring buffer state (Matcher's prev/curr pointers, viso/matcher.cpp:108-155)
+  int cur = 0;
+  bool have[2] = {false, false};   // frame slot holds a left image
+  bool right[2] = {false, false};  // ... and a right image
+  int32_t n_feat[2][2][2] = {};    // [slot][side][set]
+  int32_t dims_p[3] = {0, 0, 0}, dims_c[3] = {0, 0, 0};
+  bool f_valid = false;            // f1/f2 hold the responses of the current left image
+  bool counts_pending = false;     // an asynchronous push is in flight
+  int pending_slot = 0, pending_imgs = 0;
+
+  // results of the streaming API
+  std::vector<vsm_p_match> stage[5];
+  std::vector<vsm_p_match> matched;
+  std::vector<float> ranges;
+  std::vector<int32_t> pf;
+  int capture_stage2 = 0;
+  VsmHostWork work;
+  int64_t counters[5] = {0, 0, 0, 0, 0};
+  double timings[5] = {0, 0, 0, 0, 0};
+  std::vector<uint8_t> gainI[2];
+  // results of the sequence API
+  std::vector<std::vector<vsm_p_match>> seq_matches;
+  double seq_timings[4] = {0, 0, 0, 0};
+
+  VsmProf prof;
+  VsmPool *pool = nullptr;
+  VsmForkJoin *fj = nullptr;
+};
+
+extern "C" {
+
+const char *vsm_version(void) { return "visomatch 0.2 (gfx950)"; }
+
+void vsm_default_params(vsm_params *p) {
+  memset(p, 0, sizeof(*p));
+  p->nms_n = 3;
+  p->nms_tau = 50;
+  p->match_binsize = 50;
+  p->match_radius = 200;
+  p->match_disp_tolerance = 2;
+  p->outlier_disp_tolerance = 5;
+  p->outlier_flow_tolerance = 5;
+  p->multi_stage = 1;
+  p->half_resolution = 1;
+  p->refinement = 1;
+}
+
+vsm_handle *vsm_create(const vsm_params *p) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fprintf(stderr, "visomatch: no HIP device available (this library has no CPU path)\n");
+    return nullptr;
+  }
+  vsm_handle *h = new vsm_handle();
+  h->param = *p;
+  if (p->half_resolution) h->param.match_radius /= 2;
+  {
+    // host threads (the caller's thread included): VSM_HOST_THREADS frame-parallel workers for
+    // the look-ahead API, at most 8 of them for the sub-problems of one triangulation (streaming)
+    int nt = 16;
+    if (const char *e = getenv("VSM_HOST_THREADS")) nt = atoi(e);
+    unsigned hc = std::thread::hardware_concurrency();
+    if (hc && (unsigned)nt > hc) nt = (int)hc;
+    h->pool = new VsmPool(nt);
+    h->fj = new VsmForkJoin(nt < 8 ? nt : 8);
+    h->work.pool = h->fj;
+  }
+  if (hipGetDevice(&h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    fprintf(stderr, "visomatch: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
+    delete h->pool;
+    delete h->fj;
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+static void reset_ring_state(vsm_handle *h) {
+  h->have[0] = h->have[1] = h->right[0] = h->right[1] = false;
+  h->f_valid = false;
+  h->counts_pending = false;
+  memset(h->n_feat, 0, sizeof(h->n_feat));
+}
+
+void vsm_destroy(vsm_handle *h) {
+  if (!h) return;
+  (void)hipStreamSynchronize(h->stream);
+  ctx_destroy(h->ring);
+  ctx_destroy(h->seq);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h->pool;
+  delete h->fj;
+  delete h;
+}
+
+void vsm_set_intrinsics(vsm_handle *h, double f, double cu, double cv, double base) {
+  h->param.f = f;
+  h->param.cu = cu;
+  h->param.cv = cv;
+  h->param.base = base;
 }
 
 // completes an asynchronous push: waits for the stream and takes the feature counts the
@@ -319,7 +374,7 @@ static int settle(vsm_handle *h) {
   const int slot = h->pending_slot;
   memset(h->n_feat[slot], 0, sizeof(h->n_feat[slot]));
   for (int k = 0; k < h->pending_imgs; k++)
-    for (int s2 = 0; s2 < 2; s2++) h->n_feat[slot][k][s2] = h->hm_counts[(slot * 2 + k) * 2 + s2];
+    for (int s2 = 0; s2 < 2; s2++) h->n_feat[slot][k][s2] = h->ring.hm_counts[(slot * 2 + k) * 2 + s2];
   h->counts_pending = false;
   return VSM_OK;
 }
@@ -331,9 +386,16 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
     return VSM_EDIMS;
   }
   HIPCHK(hipSetDevice(h->device));
-  if (!h->allocated || w != h->dims.w || hh != h->dims.h) {
+  VsmCtx &c = h->ring;
+  if (!c.ready || w != c.dims.w || hh != c.dims.h) {
     // a change of image size restarts the ring buffer (the reference would match across sizes)
-    int rc = allocate(h, w, hh);
+    (void)hipStreamSynchronize(h->stream);
+    reset_ring_state(h);
+    int rc = ctx_create(c, h->param, w, hh, 2, 1, h->stream);
+    if (rc != VSM_OK) return rc;
+  }
+  if (h->counts_pending) {  // a previous asynchronous push has not been settled yet
+    int rc = settle(h);
     if (rc != VSM_OK) return rc;
   }
   if (!replace) {  // viso/matcher.cpp:123-155: curr becomes prev
@@ -343,21 +405,17 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
   const int slot = h->cur;
   h->dims_c[0] = w;
   h->dims_c[1] = hh;
-  h->dims_c[2] = h->dims.bpl;
+  h->dims_c[2] = c.dims.bpl;
   const int n_img = I2 ? 2 : 1;
-  if (h->counts_pending) {  // a previous asynchronous push has not been settled yet
-    int rc = settle(h);
-    if (rc != VSM_OK) return rc;
-  }
-  uint8_t *dst0 = h->h_imgs[slot * 2].img, *dst1 = h->h_imgs[slot * 2 + 1].img;
   if (on_device) {
-    vsm_launch_ingest(h->stream, h->prof, I1, I2, bpl, dst0, dst1, h->dims);
+    vsm_launch_ingest(h->stream, h->prof, c.d_imgs, slot * 2, I1, I2, 0, bpl, 1, c.dims);
   } else {  // pageable source: HIP stages the rows
-    HIPCHK(hipMemcpy2DAsync(dst0, h->dims.bpl, I1, bpl, w, hh, hipMemcpyHostToDevice, h->stream));
-    if (I2) HIPCHK(hipMemcpy2DAsync(dst1, h->dims.bpl, I2, bpl, w, hh, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpy2DAsync(c.h_imgs[slot * 2].img, c.dims.bpl, I1, bpl, w, hh, hipMemcpyHostToDevice, h->stream));
+    if (I2)
+      HIPCHK(hipMemcpy2DAsync(c.h_imgs[slot * 2 + 1].img, c.dims.bpl, I2, bpl, w, hh, hipMemcpyHostToDevice, h->stream));
   }
-  vsm_launch_features(h->stream, h->prof, h->d_imgs, slot * 2, n_img, h->dims, h->f1, h->f2, h->f_stride, h->param.nms_tau,
-                      h->param.multi_stage, h->param.half_resolution, h->param.match_binsize, h->h_imgs);
+  vsm_launch_features(h->stream, h->prof, c.d_imgs, slot * 2, n_img, c.dims, c.f1, c.f2, c.f_stride, h->param.nms_tau,
+                      h->param.multi_stage, h->param.half_resolution, h->param.match_binsize, c.h_imgs.data());
   HIPCHK(hipGetLastError());
   h->have[slot] = true;
   h->right[slot] = (I2 != nullptr);
@@ -382,33 +440,23 @@ int vsm_push_back_device(vsm_handle *h, const uint8_t *dI1, const uint8_t *dI2, 
   return push_common(h, dI1, dI2, w, hh, bpl, replace, true);
 }
 
-int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
-  if (!h->allocated) return VSM_ENOTREADY;
-  HIPCHK(hipSetDevice(h->device));
-  {
-    int rc = settle(h);
-    if (rc != VSM_OK) return rc;
-  }
-  const vsm_params &p = h->param;
-  const int sc = h->cur, sp = h->cur ^ 1;
-  auto N = [&](int slot, int side, int set) { return h->have[slot] ? h->n_feat[slot][side][set] : 0; };
-  // sanity checks of viso/matcher.cpp:190-212 (a NULL set and an empty set are both "count 0" here)
+// sanity checks of viso/matcher.cpp:190-212 on feature counts n[image 1p,2p,1c,2c][set]
+// (a NULL set and an empty set are both "count 0" here)
+static bool match_ready(const vsm_params &p, int method, const int32_t n[4][2]) {
   if (method == 0) {
-    if (N(sp, 0, 1) == 0 || N(sc, 0, 1) == 0) return VSM_ENOTREADY;
-    if (p.multi_stage && (N(sp, 0, 0) == 0 || N(sc, 0, 0) == 0)) return VSM_ENOTREADY;
+    if (n[0][1] == 0 || n[2][1] == 0) return false;
+    if (p.multi_stage && (n[0][0] == 0 || n[2][0] == 0)) return false;
   } else if (method == 1) {
-    if (N(sc, 0, 1) == 0 || N(sc, 1, 1) == 0) return VSM_ENOTREADY;
-    if (p.multi_stage && (N(sc, 0, 0) == 0 || N(sc, 1, 0) == 0)) return VSM_ENOTREADY;
+    if (n[2][1] == 0 || n[3][1] == 0) return false;
+    if (p.multi_stage && (n[2][0] == 0 || n[3][0] == 0)) return false;
   } else {
-    if (N(sp, 0, 1) == 0 || N(sp, 1, 1) == 0 || N(sc, 0, 1) == 0 || N(sc, 1, 1) == 0) return VSM_ENOTREADY;
-    if (p.multi_stage && (N(sp, 0, 0) == 0 || N(sp, 1, 0) == 0 || N(sc, 0, 0) == 0 || N(sc, 1, 0) == 0))
-      return VSM_ENOTREADY;
+    if (n[0][1] == 0 || n[1][1] == 0 || n[2][1] == 0 || n[3][1] == 0) return false;
+    if (p.multi_stage && (n[0][0] == 0 || n[1][0] == 0 || n[2][0] == 0 || n[3][0] == 0)) return false;
   }
-  const double t0 = now_us();
-  for (int s = 0; s < 5; s++) h->stage[s].clear();
-  h->matched.clear();
-  memset(h->counters, 0, sizeof(h->counters));
+  return true;
+}
 
+static VsmMatchCfg make_cfg(const vsm_params &p, int method) {
   VsmMatchCfg cfg;
   memset(&cfg, 0, sizeof(cfg));
   cfg.method = method;
@@ -419,63 +467,93 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
   cfg.cu = p.cu;
   cfg.cv = p.cv;
   cfg.base = p.base;
-  cfg.use_tr = Tr ? 1 : 0;
-  if (Tr) memcpy(cfg.t, Tr, 12 * sizeof(double));
-  // stereo matching only needs the current pair: point "prev" at the current slot so that no
-  // pointer is dangling; it is never dereferenced for method 1
-  const int img_prev = (method == 1 ? sc : sp) * 2, img_curr = sc * 2;
+  return cfg;
+}
+
+int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
+  VsmCtx &c = h->ring;
+  if (!c.ready) return VSM_ENOTREADY;
+  HIPCHK(hipSetDevice(h->device));
+  {
+    int rc = settle(h);
+    if (rc != VSM_OK) return rc;
+  }
+  const vsm_params &p = h->param;
+  const int sc = h->cur, sp = h->cur ^ 1;
+  int32_t n[4][2];
+  for (int s = 0; s < 2; s++) {
+    n[0][s] = h->have[sp] ? h->n_feat[sp][0][s] : 0;
+    n[1][s] = h->have[sp] ? h->n_feat[sp][1][s] : 0;
+    n[2][s] = h->have[sc] ? h->n_feat[sc][0][s] : 0;
+    n[3][s] = h->have[sc] ? h->n_feat[sc][1][s] : 0;
+  }
+  if (!match_ready(p, method, n)) return VSM_ENOTREADY;
+  const double t0 = now_us();
+  for (int s = 0; s < 5; s++) h->stage[s].clear();
+  h->matched.clear();
+  memset(h->counters, 0, sizeof(h->counters));
+
+  VsmMatchCfg cfg = make_cfg(p, method);
+  VsmJob job;
+  memset(&job, 0, sizeof(job));
+  // stereo matching only needs the current pair: "prev" then aliases the current slot
+  job.img_prev = (method == 1 ? sc : sp) * 2;
+  job.img_curr = sc * 2;
+  const int qimg = method == 2 ? 0 : 2;  // quad iterates the previous left features, flow/stereo the current
+  job.nq[0] = p.multi_stage ? n[qimg][0] : 0;
+  job.nq[1] = n[qimg][1];
+  job.use_tr = Tr ? 1 : 0;
+  if (Tr) memcpy(job.t, Tr, 12 * sizeof(double));
   const int stages = method == 2 ? 4 : 2;
-  const int qslot = method == 2 ? sp : sc;
-  VsmDims dp = h->dims, dc = h->dims;  // one size per handle
+  const VsmDims dp = c.dims, dc = c.dims;  // one size per handle
 
   double t1 = t0, t2 = t0;
   if (p.multi_stage) {
     cfg.sparse = 1;
     cfg.use_prior = 0;
-    const int nq = N(qslot, 0, 0);
-    vsm_launch_match(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, h->dims, cfg, nq, 0);
-    vsm_launch_export(h->stream, h->prof, h->pair, 0, nq);
+    vsm_launch_match(h->stream, h->prof, c.d_imgs, c.d_pairs, nullptr, job, 1, c.dims, cfg, job.nq[0]);
+    vsm_launch_export(h->stream, h->prof, c.d_pairs, 1, 0, job.nq[0]);
     HIPCHK(hipStreamSynchronize(h->stream));  // the list was written into host-mapped memory
-    h->stage[0].assign(h->hm_list1, h->hm_list1 + h->hm_counts[8]);
-    h->counters[0] += (int64_t)nq * stages;
+    h->stage[0].assign(c.hm_list1[0], c.hm_list1[0] + c.hm_lcount[0]);
+    h->counters[0] += (int64_t)job.nq[0] * stages;
     t1 = now_us();
     h->stage[1] = h->stage[0];
     vsm_host_remove_outliers(h->work, p, h->stage[1], method);
     vsm_host_prior_statistics(p, h->dims_c, h->stage[1], method, h->ranges);
-    memcpy(h->h_ranges, h->ranges.data(), h->ranges.size() * sizeof(float));
-    HIPCHK(hipMemcpyAsync(h->pair.ranges, h->h_ranges, h->ranges.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    memcpy(c.h_ranges, h->ranges.data(), h->ranges.size() * sizeof(float));
+    HIPCHK(hipMemcpyAsync(c.d_ranges, c.h_ranges, h->ranges.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     t2 = now_us();
   }
   cfg.sparse = 0;
   cfg.use_prior = p.multi_stage ? 1 : 0;
-  const int nq2 = N(qslot, 0, 1);
-  vsm_launch_match(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, h->dims, cfg, nq2, 1);
+  const int nq2 = job.nq[1];
+  vsm_launch_match(h->stream, h->prof, c.d_imgs, c.d_pairs, nullptr, job, 1, c.dims, cfg, nq2);
   h->counters[0] += (int64_t)nq2 * stages;
   // The list size is still on the device: the refinement / export grids are sized for the worst
   // case (every query matched) and surplus threads exit at once.
   if (h->capture_stage2 && p.refinement == 1)  // debug view: keep the unrefined list (raw is free again)
-    HIPCHK(hipMemcpyAsync(h->pair.raw, h->pair.list2, (size_t)nq2 * sizeof(vsm_p_match), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(c.h_pairs[0].raw, c.h_pairs[0].list2, (size_t)nq2 * sizeof(vsm_p_match), hipMemcpyDeviceToDevice,
+                          h->stream));
   if (p.refinement > 0)
-    vsm_launch_refine(h->stream, h->prof, h->d_imgs, img_prev, img_curr, h->pair, dp, dc, method, p.refinement, nq2,
-                      h->pair.count + 1);
-  vsm_launch_export(h->stream, h->prof, h->pair, 1, nq2);
+    vsm_launch_refine(h->stream, h->prof, c.d_imgs, c.d_pairs, nullptr, job, 1, dp, dc, method, p.refinement, nq2);
+  vsm_launch_export(h->stream, h->prof, c.d_pairs, 1, 1, nq2);
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
-  const int32_t n2 = h->hm_counts[9];
+  const int32_t n2 = c.hm_lcount[1];
   if (p.refinement == 1) {
-    h->stage[3].assign(h->hm_list2, h->hm_list2 + n2);
+    h->stage[3].assign(c.hm_list2[0], c.hm_list2[0] + n2);
     if (h->capture_stage2) {
       h->stage[2].resize(n2);
-      if (n2) HIPCHK(hipMemcpy(h->stage[2].data(), h->pair.raw, (size_t)n2 * sizeof(vsm_p_match), hipMemcpyDeviceToHost));
+      if (n2) HIPCHK(hipMemcpy(h->stage[2].data(), c.h_pairs[0].raw, (size_t)n2 * sizeof(vsm_p_match), hipMemcpyDeviceToHost));
     }
   } else {
-    h->stage[2].assign(h->hm_list2, h->hm_list2 + n2);
+    h->stage[2].assign(c.hm_list2[0], c.hm_list2[0] + n2);
     if (p.refinement == 2) {
-      const size_t n = h->stage[2].size();
-      h->pf.resize(n * 36);
-      if (n) HIPCHK(hipMemcpy(h->pf.data(), h->pair.pf, n * 36 * sizeof(int32_t), hipMemcpyDeviceToHost));
+      const size_t nn2 = h->stage[2].size();
+      h->pf.resize(nn2 * 36);
+      if (nn2) HIPCHK(hipMemcpy(h->pf.data(), c.h_pairs[0].pf, nn2 * 36 * sizeof(int32_t), hipMemcpyDeviceToHost));
       h->stage[3].clear();
-      for (size_t i = 0; i < n; i++) {  // viso/matcher.cpp:1541-1581: a failed fit drops the match
+      for (size_t i = 0; i < nn2; i++) {  // viso/matcher.cpp:1541-1581: a failed fit drops the match
         vsm_p_match m = h->stage[2][i];
         bool ok = true;
         float *tu[3] = {&m.u1p, &m.u2c, &m.u2p}, *tv[3] = {&m.v1p, &m.v2c, &m.v2p};
@@ -522,21 +600,229 @@ int vsm_bucket(vsm_handle *h, int32_t max_features, float bw, float bh) {
 
 float vsm_gain(vsm_handle *h, const int32_t *inliers, int32_t n) {
   const int sc = h->cur, sp = h->cur ^ 1;
-  if (!h->allocated || !h->have[sp] || !h->have[sc] || h->matched.empty() || n == 0 || settle(h) != VSM_OK) return 1;
-  const size_t bytes = (size_t)h->dims.bpl * h->dims.h;
+  VsmCtx &c = h->ring;
+  if (!c.ready || !h->have[sp] || !h->have[sc] || h->matched.empty() || n == 0 || settle(h) != VSM_OK) return 1;
+  const size_t bytes = (size_t)c.dims.bpl * c.dims.h;
   for (int k = 0; k < 2; k++) {  // left images come back from HBM on first use
     if (h->gainI[k].size() != bytes) {
       h->gainI[k].resize(bytes);
-      if (hipMemcpy(h->gainI[k].data(), h->h_imgs[(k == 0 ? sp : sc) * 2].img, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+      if (hipMemcpy(h->gainI[k].data(), c.h_imgs[(k == 0 ? sp : sc) * 2].img, bytes, hipMemcpyDeviceToHost) != hipSuccess)
         return 1;
     }
   }
   return vsm_host_gain(h->gainI[0].data(), h->gainI[1].data(), h->dims_p, h->dims_c, h->matched, inliers, n);
 }
 
+// ---------------------------------------------------------------------------------------
+// Look-ahead sequence API.  Semantics: exactly pushBack(frame f) + matchFeatures(method, Tr[f])
+// for f = 0..n-1 on a fresh matcher.  Frames are processed in chunks of C: every kernel runs once
+// per chunk over all its images / pairs, and the host stages (exact Delaunay support, prior
+// statistics) of the chunk's pairs run concurrently on the pool, one pair per task.
+// ---------------------------------------------------------------------------------------
+static int sequence_fallback(vsm_handle *h, const uint8_t *left, const uint8_t *right, int64_t frame_stride, int on_device,
+                             int32_t n_frames, int32_t w, int32_t hh, int32_t bpl, int32_t method, const double *Tr,
+                             const uint8_t *Tr_valid) {
+  // rarely used configurations (mono input, refinement==2) go frame by frame on a fresh ring
+  (void)hipStreamSynchronize(h->stream);
+  ctx_destroy(h->ring);
+  reset_ring_state(h);
+  h->matched.clear();
+  for (int32_t f = 0; f < n_frames; f++) {
+    const uint8_t *l = left + (size_t)f * frame_stride, *r = right ? right + (size_t)f * frame_stride : nullptr;
+    int rc = push_common(h, l, r, w, hh, bpl, 0, on_device != 0);
+    if (rc != VSM_OK) return rc;
+    const double *t = (Tr && (!Tr_valid || Tr_valid[f])) ? Tr + (size_t)f * 12 : nullptr;
+    rc = vsm_match(h, method, t);
+    if (rc != VSM_OK && rc != VSM_ENOTREADY) return rc;
+    h->seq_matches[f] = h->matched;
+  }
+  return VSM_OK;
+}
+
+int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, int64_t frame_stride, int on_device,
+                     int32_t n_frames, int32_t w, int32_t hh, int32_t bpl, int32_t method, const double *Tr,
+                     const uint8_t *Tr_valid) {
+  if (w <= 0 || hh <= 0 || bpl < w || left == nullptr || n_frames <= 0) {
+    fprintf(stderr, "ERROR: Image dimension mismatch!\n");
+    return VSM_EDIMS;
+  }
+  HIPCHK(hipSetDevice(h->device));
+  const vsm_params &p = h->param;
+  h->seq_matches.assign(n_frames, std::vector<vsm_p_match>());
+  if (!right || p.refinement == 2)
+    return sequence_fallback(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
+
+  int C = 50;
+  if (const char *e = getenv("VSM_SEQ_CHUNK")) C = atoi(e);
+  if (C < 1) C = 1;
+  if (C > n_frames) C = n_frames;
+  VsmCtx &c = h->seq;
+  if (!c.ready || c.dims.w != w || c.dims.h != hh || h->seq_chunk != C) {
+    (void)hipStreamSynchronize(h->stream);
+    int rc = ctx_create(c, p, w, hh, 2 * C, 2 * C, h->stream);  // two banks of frames and of pairs
+    if (rc != VSM_OK) return rc;
+    h->seq_chunk = C;
+  }
+  // Software pipeline over chunks: while the pool works on the final host stage of chunk k (it
+  // reads pair bank k&1 in host-mapped memory), the GPU already runs chunk k+1 on the other bank.
+  std::vector<VsmPool::Ticket> tickets;
+  const int32_t dims_c[3] = {w, hh, c.dims.bpl};
+  int32_t nprev[2][2] = {{0, 0}, {0, 0}};  // feature counts [side][set] of the previous chunk's last frame
+  double tg = 0, thost = 0;
+  const double tstart = now_us();
+  for (int32_t f0 = 0, k = 0; f0 < n_frames; f0 += C, k++) {
+    const int n = std::min<int32_t>(C, n_frames - f0);
+    const int bank = k & 1, first_img = 2 * bank * C, first_pair = bank * C;
+    const VsmPair *d_pairs = c.d_pairs + first_pair;
+    double ta = now_us();
+    // ---- features of the chunk's frames: one launch per kernel ----
+    if (on_device) {
+      vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first_img, left + (size_t)f0 * frame_stride,
+                        right + (size_t)f0 * frame_stride, (size_t)frame_stride, bpl, n, c.dims);
+    } else {
+      for (int i = 0; i < n; i++) {
+        HIPCHK(hipMemcpy2DAsync(c.h_imgs[first_img + 2 * i].img, c.dims.bpl, left + (size_t)(f0 + i) * frame_stride, bpl, w,
+                                hh, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpy2DAsync(c.h_imgs[first_img + 2 * i + 1].img, c.dims.bpl, right + (size_t)(f0 + i) * frame_stride, bpl,
+                                w, hh, hipMemcpyHostToDevice, h->stream));
+      }
+    }
+    vsm_launch_features(h->stream, h->prof, c.d_imgs, first_img, 2 * n, c.dims, c.f1, c.f2, c.f_stride, p.nms_tau,
+                        p.multi_stage, p.half_resolution, p.match_binsize, c.h_imgs.data());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    // ---- one job per frame of the chunk ----
+    int max_nq[2] = {0, 0};
+    std::shared_ptr<std::vector<char>> validp = std::make_shared<std::vector<char>>(n, 0);
+    std::vector<char> &valid = *validp;
+    for (int i = 0; i < n; i++) {
+      const int32_t f = f0 + i;
+      VsmJob &jb = c.h_jobs[i];
+      memset(&jb, 0, sizeof(jb));
+      const int img_c = first_img + 2 * i;
+      int img_p;
+      int32_t cnt[4][2];
+      for (int s = 0; s < 2; s++) {
+        cnt[2][s] = c.hm_counts[img_c * 2 + s];
+        cnt[3][s] = c.hm_counts[(img_c + 1) * 2 + s];
+      }
+      if (method == 1) {
+        img_p = img_c;
+        for (int s = 0; s < 2; s++) cnt[0][s] = cnt[1][s] = 0;
+      } else if (i > 0) {
+        img_p = img_c - 2;
+        for (int s = 0; s < 2; s++) {
+          cnt[0][s] = c.hm_counts[img_p * 2 + s];
+          cnt[1][s] = c.hm_counts[(img_p + 1) * 2 + s];
+        }
+      } else {  // the previous frame is the last one of the other bank
+        img_p = 2 * (1 - bank) * C + 2 * (C - 1);
+        for (int s = 0; s < 2; s++) {
+          cnt[0][s] = f > 0 ? nprev[0][s] : 0;
+          cnt[1][s] = f > 0 ? nprev[1][s] : 0;
+        }
+      }
+      jb.img_prev = img_p;
+      jb.img_curr = img_c;
+      if (match_ready(p, method, cnt)) {
+        valid[i] = 1;
+        const int qimg = method == 2 ? 0 : 2;
+        jb.nq[0] = p.multi_stage ? cnt[qimg][0] : 0;
+        jb.nq[1] = cnt[qimg][1];
+        if (Tr && (!Tr_valid || Tr_valid[f])) {
+          jb.use_tr = 1;
+          memcpy(jb.t, Tr + (size_t)f * 12, 12 * sizeof(double));
+        }
+      }
+      max_nq[0] = std::max(max_nq[0], jb.nq[0]);
+      max_nq[1] = std::max(max_nq[1], jb.nq[1]);
+    }
+    for (int s = 0; s < 2; s++) {  // remember the last frame's counts for the next chunk
+      nprev[0][s] = c.hm_counts[(first_img + 2 * (n - 1)) * 2 + s];
+      nprev[1][s] = c.hm_counts[(first_img + 2 * (n - 1) + 1) * 2 + s];
+    }
+    HIPCHK(hipMemcpyAsync(c.d_jobs, c.h_jobs, sizeof(VsmJob) * n, hipMemcpyHostToDevice, h->stream));
+    VsmMatchCfg cfg = make_cfg(p, method);
+    VsmJob dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    if (p.multi_stage) {
+      cfg.sparse = 1;
+      cfg.use_prior = 0;
+      vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, cfg, max_nq[0]);
+      vsm_launch_export(h->stream, h->prof, d_pairs, n, 0, max_nq[0]);
+      HIPCHK(hipStreamSynchronize(h->stream));
+      double tb = now_us();
+      tg += tb - ta;
+      h->pool->run(n, [&](int i) {  // queued behind the previous chunk's final stage (FIFO)
+        static thread_local VsmHostWork tw;
+        static thread_local std::vector<float> rg;
+        static thread_local std::vector<vsm_p_match> m1;
+        const int pj = first_pair + i;
+        m1.clear();
+        if (valid[i]) m1.assign(c.hm_list1[pj], c.hm_list1[pj] + c.hm_lcount[2 * pj]);
+        vsm_host_remove_outliers(tw, p, m1, method);
+        vsm_host_prior_statistics(p, dims_c, m1, method, rg);
+        memcpy(c.h_ranges + (size_t)pj * c.ranges_stride, rg.data(), rg.size() * sizeof(float));
+      });
+      ta = now_us();
+      thost += ta - tb;
+      HIPCHK(hipMemcpyAsync(c.d_ranges + (size_t)first_pair * c.ranges_stride, c.h_ranges + (size_t)first_pair * c.ranges_stride,
+                            c.ranges_stride * 4 * n, hipMemcpyHostToDevice, h->stream));
+    }
+    // the export below overwrites this pair bank's host lists: chunk k-2 must be done with them
+    if (k >= 2) h->pool->wait(tickets[k - 2]);
+    cfg.sparse = 0;
+    cfg.use_prior = p.multi_stage ? 1 : 0;
+    vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, cfg, max_nq[1]);
+    if (p.refinement > 0)
+      vsm_launch_refine(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, c.dims, method, p.refinement,
+                        max_nq[1]);
+    vsm_launch_export(h->stream, h->prof, d_pairs, n, 1, max_nq[1]);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    h->prof.resolve();
+    tg += now_us() - ta;
+    // final host stage of this chunk: asynchronous, overlapped with the next chunk's GPU work
+    VsmCtx *cp = &c;
+    const vsm_params pcopy = p;
+    tickets.push_back(h->pool->submit(n, [h, cp, pcopy, validp, f0, first_pair, method](int i) {
+      if (!(*validp)[i]) return;
+      static thread_local VsmHostWork tw;
+      const int pj = first_pair + i;
+      std::vector<vsm_p_match> &out = h->seq_matches[f0 + i];
+      out.assign(cp->hm_list2[pj], cp->hm_list2[pj] + cp->hm_lcount[2 * pj + 1]);
+      vsm_host_remove_outliers(tw, pcopy, out, method);
+    }));
+  }
+  {
+    const double tb = now_us();
+    for (auto &t : tickets) h->pool->wait(t);
+    thost += now_us() - tb;
+  }
+  h->seq_timings[0] = tg;
+  h->seq_timings[1] = thost;
+  h->seq_timings[2] = now_us() - tstart;
+  h->seq_timings[3] = (double)C;
+  return VSM_OK;
+}
+
+int32_t vsm_sequence_num_matches(vsm_handle *h, int32_t frame) {
+  return (frame >= 0 && frame < (int32_t)h->seq_matches.size()) ? (int32_t)h->seq_matches[frame].size() : 0;
+}
+
+int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out, int32_t cap) {
+  if (frame < 0 || frame >= (int32_t)h->seq_matches.size()) return 0;
+  int32_t n = (int32_t)h->seq_matches[frame].size();
+  if (n > cap) n = cap;
+  if (n > 0) memcpy(out, h->seq_matches[frame].data(), (size_t)n * sizeof(vsm_p_match));
+  return n;
+}
+
+void vsm_sequence_get_timings(vsm_handle *h, double *out4) { memcpy(out4, h->seq_timings, sizeof(h->seq_timings)); }
+
 // ---- stage-level views ----
 static bool which_set(vsm_handle *h, int32_t which, int &img, int &set, int32_t &n) {
-  if (which < 0 || which > 7 || !h->allocated) return false;
+  if (which < 0 || which > 7 || !h->ring.ready) return false;
   if (settle(h) != VSM_OK) return false;
   const int prev = (which & 3) < 2, side = which & 1;
   set = which >> 2;
@@ -557,9 +843,11 @@ int32_t vsm_get_features(vsm_handle *h, int32_t which, int32_t *out, int32_t cap
   int32_t n;
   if (!which_set(h, which, img, set, n)) return 0;
   if (n > cap) n = cap;
-  if (n > 0 && hipMemcpy(out, h->h_imgs[img].set[set].feat, (size_t)n * 48, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (n > 0 && hipMemcpy(out, h->ring.h_imgs[img].set[set].feat, (size_t)n * 48, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return n;
 }
+
+void vsm_set_stage_capture(vsm_handle *h, int on) { h->capture_stage2 = on ? 1 : 0; }
 
 int32_t vsm_stage_size(vsm_handle *h, int32_t s) { return (s >= 0 && s < 5) ? (int32_t)h->stage[s].size() : 0; }
 
@@ -581,30 +869,31 @@ int32_t vsm_get_ranges(vsm_handle *h, float *out, int32_t cap_bins) {
 }
 
 int32_t vsm_get_gradients(vsm_handle *h, int32_t which, int32_t full, uint8_t *du, uint8_t *dv) {
-  if (!h->allocated || which < 0 || which > 3 || settle(h) != VSM_OK) return 0;
+  VsmCtx &c = h->ring;
+  if (!c.ready || which < 0 || which > 3 || settle(h) != VSM_OK) return 0;
   const int slot = which < 2 ? (h->cur ^ 1) : h->cur, side = which & 1;
   if (!h->have[slot] || (side && !h->right[slot])) return 0;
   if (full && !h->param.half_resolution) return 0;
-  const VsmImage &im = h->h_imgs[slot * 2 + side];
-  const int32_t bytes = full ? h->dims.bpl * h->dims.h : h->dims.mbpl * h->dims.mh;
+  const VsmImage &im = c.h_imgs[slot * 2 + side];
+  const int32_t bytes = full ? c.dims.bpl * c.dims.h : c.dims.mbpl * c.dims.mh;
   if (du && hipMemcpy(du, full ? im.du_full : im.du, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   if (dv && hipMemcpy(dv, full ? im.dv_full : im.dv, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return bytes;
 }
 
 int32_t vsm_get_filter_responses(vsm_handle *h, int16_t *f1, int16_t *f2) {
-  if (!h->allocated || !h->f_valid || settle(h) != VSM_OK) return 0;
-  const int32_t n = h->dims.mbpl * h->dims.mh;
-  if (f1 && hipMemcpy(f1, h->f1, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-  if (f2 && hipMemcpy(f2, h->f2, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  VsmCtx &c = h->ring;
+  if (!c.ready || !h->f_valid || settle(h) != VSM_OK) return 0;
+  const int32_t n = c.dims.mbpl * c.dims.mh;
+  if (f1 && hipMemcpy(f1, c.f1, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (f2 && hipMemcpy(f2, c.f2, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return n;
 }
 
-void vsm_set_stage_capture(vsm_handle *h, int on) { h->capture_stage2 = on ? 1 : 0; }
-
-static const char *kKernelNames[VSM_K_COUNT] = {"k_ingest", "k_halve", "k_filters<true>", "k_filters<false>", "k_nms", "k_scan_cells", "k_emit",
-                                                "k_bin_scan", "k_bin_scatter", "k_bin_rank", "k_match<16>:pass1", "k_compact_matches:pass1", "k_match<16>:pass2",
-                                                "k_compact_matches:pass2", "k_refine", "k_export_list"};
+static const char *kKernelNames[VSM_K_COUNT] = {
+    "k_ingest", "k_halve", "k_filters<true>", "k_filters<false>", "k_nms", "k_scan_cells", "k_emit", "k_bin_scan",
+    "k_bin_scatter", "k_bin_rank", "k_match<16>:pass1", "k_compact_matches:pass1", "k_match<16>:pass2",
+    "k_compact_matches:pass2", "k_refine", "k_export_list"};
 
 void vsm_set_profiling(vsm_handle *h, int on) {
   h->prof.on = on != 0;
@@ -625,7 +914,7 @@ void vsm_get_kernel_stats(vsm_handle *h, double *total_ms, int64_t *launches) {
 
 int32_t vsm_host_delaunay(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap, int32_t threads) {
   ExactDelaunay d;
-  VsmPool pool(threads);
+  VsmForkJoin pool(threads);
   d.run(x, y, n, threads > 1 ? &pool : nullptr);
   const int32_t nt = d.num_triangles();
   for (int32_t i = 0; i < nt && i < cap; i++)

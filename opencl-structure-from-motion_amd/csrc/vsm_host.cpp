@@ -26,6 +26,99 @@ VsmPool::~VsmPool() {
   {
     std::lock_guard<std::mutex> lk(mu_);
     stop_ = true;
+    posted_.fetch_add(1);
+  }
+  cv_.notify_all();
+  for (auto &t : threads_) t.join();
+}
+
+// claims and runs one task of the oldest batch that still has unclaimed tasks
+bool VsmPool::work_one() {
+  Ticket b;
+  int idx = -1;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    while (!queue_.empty() && queue_.front()->next.load(std::memory_order_relaxed) >= queue_.front()->n) queue_.pop_front();
+    if (queue_.empty()) return false;
+    b = queue_.front();
+    idx = b->next.fetch_add(1, std::memory_order_relaxed);
+  }
+  b->fn(idx);
+  b->done.fetch_add(1, std::memory_order_release);
+  return true;
+}
+
+void VsmPool::worker() {
+  for (;;) {
+    if (stop_) return;
+    if (work_one()) continue;
+    // idle: spin on the post counter, then block
+    const uint64_t seen = posted_.load(std::memory_order_acquire);
+    auto t0 = std::chrono::steady_clock::now();
+    while (posted_.load(std::memory_order_acquire) == seen) {
+      cpu_relax();
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us_) {
+        std::unique_lock<std::mutex> lk(mu_);
+        sleepers_.fetch_add(1);
+        cv_.wait(lk, [&] { return posted_.load(std::memory_order_acquire) != seen || stop_; });
+        sleepers_.fetch_sub(1);
+        break;
+      }
+    }
+  }
+}
+
+VsmPool::Ticket VsmPool::submit(int ntasks, std::function<void(int)> fn, bool urgent) {
+  Ticket b = std::make_shared<Batch>();
+  b->fn = std::move(fn);
+  b->n = ntasks < 0 ? 0 : ntasks;
+  if (b->n == 0) return b;
+  if (nthreads_ == 1) {  // no workers: run inline
+    for (int i = 0; i < b->n; i++) b->fn(i);
+    b->next = b->n;
+    b->done = b->n;
+    return b;
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (urgent)
+      queue_.push_front(b);  // a blocking caller is waiting: ahead of background batches
+    else
+      queue_.push_back(b);
+    posted_.fetch_add(1, std::memory_order_release);
+  }
+  if (sleepers_.load() > 0) cv_.notify_all();
+  return b;
+}
+
+void VsmPool::wait(const Ticket &t) {
+  while (t->done.load(std::memory_order_acquire) < t->n) {
+    if (!work_one()) cpu_relax();
+  }
+}
+
+void VsmPool::run(int ntasks, const std::function<void(int)> &fn) {
+  if (ntasks <= 0) return;
+  if (nthreads_ == 1 || ntasks == 1) {
+    for (int i = 0; i < ntasks; i++) fn(i);
+    return;
+  }
+  Ticket t = submit(ntasks, fn, true);
+  wait(t);
+}
+
+// ---------------------------------------------------------------------------------------
+// VsmForkJoin: lock-free fork-join for the fine-grained phases inside one Delaunay
+// ---------------------------------------------------------------------------------------
+VsmForkJoin::VsmForkJoin(int threads) : nthreads_(threads < 1 ? 1 : threads) {
+  if (const char *e = getenv("VSM_HOST_SPIN_US")) spin_us_ = atoi(e);
+  for (int i = 1; i < nthreads_; i++) threads_.emplace_back([this] { worker(); });
+}
+
+VsmForkJoin::~VsmForkJoin() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = true;
     gen_.store(0xffffffffffull, std::memory_order_release);
   }
   cv_.notify_all();
@@ -34,7 +127,7 @@ VsmPool::~VsmPool() {
 
 // Task claiming is a CAS on (generation << 32 | next index): a worker that is late for
 // generation g can never claim an index of generation g+1 with g's (possibly destroyed) closure.
-bool VsmPool::claim(uint64_t g, int n, int &idx) {
+bool VsmForkJoin::claim(uint64_t g, int n, int &idx) {
   uint64_t v = next_.load(std::memory_order_acquire);
   for (;;) {
     if ((v >> 32) != g || (int)(v & 0xffffffffu) >= n) return false;
@@ -45,7 +138,7 @@ bool VsmPool::claim(uint64_t g, int n, int &idx) {
   }
 }
 
-void VsmPool::worker() {
+void VsmForkJoin::worker() {
   uint64_t seen = 0;
   for (;;) {
     // wait for a new generation: spin first, then block
@@ -72,7 +165,7 @@ void VsmPool::worker() {
   }
 }
 
-void VsmPool::run(int ntasks, const std::function<void(int)> &fn) {
+void VsmForkJoin::run(int ntasks, const std::function<void(int)> &fn) {
   if (ntasks <= 0) return;
   if (nthreads_ == 1 || ntasks == 1) {
     for (int i = 0; i < ntasks; i++) fn(i);
@@ -97,6 +190,7 @@ void VsmPool::run(int ntasks, const std::function<void(int)> &fn) {
   }
   while (done_.load(std::memory_order_acquire) < ntasks) cpu_relax();
 }
+
 
 // =======================================================================================
 // ExactDelaunay: Triangle 1.6 divide-and-conquer with alternating cuts, decision for decision
@@ -437,7 +531,7 @@ int32_t ExactDelaunay::build_tree(int32_t off, int32_t n, int axis, int32_t tbas
   return me;
 }
 
-void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmPool *pool) {
+void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool) {
   ntri_out_ = 0;
   seed_ = 1;  // triangleinit(), :4031
   if (n < 2) return;

@@ -7,6 +7,8 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <deque>
+#include <memory>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -14,14 +16,49 @@
 
 #include "visomatch.h"
 
-// Small fork-join pool for the host stages (Delaunay sub-problems are independent).  Workers spin
-// for a while after each job before they block, so back-to-back frames do not pay a wake-up.
+// Small task pool for the host stages (Delaunay sub-problems / frame pairs are independent).
+// Work arrives as batches of n index tasks; batches are served FIFO.  run() is fork-join (the
+// caller takes part); submit()/wait() let the caller keep the GPU busy while a batch is being
+// worked on.  Workers spin for a while when idle before they block, so back-to-back frames do not
+// pay a wake-up.
 class VsmPool {
  public:
+  struct Batch {
+    std::function<void(int)> fn;
+    int n = 0;
+    std::atomic<int> next{0}, done{0};
+  };
+  typedef std::shared_ptr<Batch> Ticket;
+
   explicit VsmPool(int threads);
   ~VsmPool();
   int size() const { return nthreads_; }
-  // runs fn(0..ntasks-1) on the pool (the caller takes part); returns when all are done
+  void run(int ntasks, const std::function<void(int)> &fn);  // blocking
+  Ticket submit(int ntasks, std::function<void(int)> fn, bool urgent = false);  // asynchronous
+  void wait(const Ticket &t);                                // helps until the batch is done
+
+ private:
+  void worker();
+  bool work_one();  // runs one task of the oldest unfinished batch; false if none
+  int nthreads_;
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<Ticket> queue_;
+  std::atomic<uint64_t> posted_{0};
+  std::atomic<int> sleepers_{0};
+  std::atomic<bool> stop_{false};
+  int spin_us_ = 2000;
+};
+
+// Lock-free fork-join pool for the fine-grained phases inside ONE Delaunay (a dozen tasks of
+// 10-100 us each): task claiming is a CAS on (generation << 32 | next index), so a worker that
+// is late for generation g can never run g+1's task with g's closure.
+class VsmForkJoin {
+ public:
+  explicit VsmForkJoin(int threads);
+  ~VsmForkJoin();
+  int size() const { return nthreads_; }
   void run(int ntasks, const std::function<void(int)> &fn);
 
  private:
@@ -48,7 +85,7 @@ class VsmPool {
 class ExactDelaunay {
  public:
   // points are (x[i], y[i]); after run(), triangles() lists vertex triples by input index
-  void run(const int32_t *x, const int32_t *y, int32_t n, VsmPool *pool = nullptr);
+  void run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool = nullptr);
   int32_t num_triangles() const { return ntri_out_; }
   const int32_t *triangles() const { return tri_out_.data(); }
 
@@ -112,7 +149,7 @@ class ExactDelaunay {
 struct VsmHostWork {
   ExactDelaunay del;
   std::vector<int32_t> x, y, support;
-  VsmPool *pool = nullptr;  // optional
+  VsmForkJoin *pool = nullptr;  // optional: threads for the sub-problems of one triangulation
 };
 
 // Matcher::removeOutliers, viso/matcher.cpp:1207-1377 (in place; order preserved)

@@ -49,11 +49,18 @@ struct VsmDims {
   int32_t ub, vb;        // match bins over the full-resolution image
 };
 
-struct VsmMatchCfg {
-  int32_t method, use_prior, use_tr, sparse;
+struct VsmMatchCfg {  // common to all pairs of a launch
+  int32_t method, use_prior, sparse;
   int32_t binsize, radius, disp_tol;
   double f, cu, cv, base;
-  double t[12];
+};
+
+// one frame pair of a (possibly batched) launch
+struct VsmJob {
+  int32_t img_prev, img_curr;  // left image ids; the right images are +1
+  int32_t nq[2];               // queries of the sparse / dense pass
+  int32_t use_tr, pad;
+  double t[12];                // rows 0..2 of Tr_delta (viso/matcher.cpp:989-1002)
 };
 
 // per frame-pair buffers
@@ -116,14 +123,14 @@ struct VsmProf {
 };
 
 // ---- launchers (vsm_kernels.hip) ----
-void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const uint8_t *src0, const uint8_t *src1, int32_t src_bpl,
-                       uint8_t *dst0, uint8_t *dst1, const VsmDims &d);
-void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d, int16_t *f1,
-                         int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res, int binsize,
-                         const VsmImage *h_imgs);
-void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
-                      const VsmDims &d, const VsmMatchCfg &cfg, int n_query, int which);
-void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair &pair, int which, int n_upper);
-void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int img_prev, int img_curr, const VsmPair &pair,
-                       const VsmDims &dp, const VsmDims &dc, int method, int refinement, int n_upper,
-                       const int32_t *d_count);
+void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0,
+                       const uint8_t *src1, size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d);
+void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d,
+                         int16_t *f1, int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res,
+                         int binsize, const VsmImage *h_imgs);
+void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
+                      const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq);
+void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair *d_pairs, int npairs, int pass, int n_upper);
+void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
+                       const VsmJob &job0, int npairs, const VsmDims &dp, const VsmDims &dc, int method, int refinement,
+                       int n_upper);

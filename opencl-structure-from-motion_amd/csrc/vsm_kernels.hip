@@ -16,11 +16,13 @@
 // ingest: caller image (row stride src_bpl) -> padded HBM copy [h][bpl], pad bytes = 0
 // (Matcher::pushBack row copy, viso/matcher.cpp:163-175, with the pad pinned to 0)
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ingest(const uint8_t *__restrict__ src0, const uint8_t *__restrict__ src1,
-                                                int src_bpl, uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1,
-                                                int w, int h, int bpl, int aligned) {
-  const uint8_t *__restrict__ src = blockIdx.z ? src1 : src0;
-  uint8_t *__restrict__ dst = blockIdx.z ? dst1 : dst0;
+__global__ void __launch_bounds__(256) k_ingest(const VsmImage *__restrict__ imgs, int first, const uint8_t *__restrict__ src0,
+                                                const uint8_t *__restrict__ src1, size_t frame_stride, int src_bpl,
+                                                int sides, int w, int h, int bpl, int aligned) {
+  // blockIdx.z = frame*sides + side; image id = first + 2*frame + side
+  const int fr = blockIdx.z / sides, side = blockIdx.z - fr * sides;
+  const uint8_t *__restrict__ src = (side ? src1 : src0) + (size_t)fr * frame_stride;
+  uint8_t *__restrict__ dst = imgs[first + 2 * fr + side].img;
   int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   int y = blockIdx.y;
   if (x4 >= bpl || y >= h) return;
@@ -487,12 +489,16 @@ __device__ __forceinline__ int stat_bin_of(int u, int v, int binsize, int ub, in
 
 template <int G>
 __global__ void __launch_bounds__(256)
-    k_match(const VsmImage *__restrict__ imgs, int img_prev, int img_curr, VsmPair pair, VsmDims d, VsmMatchCfg cfg,
-            int n_query) {
+    k_match(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
+            VsmJob job0, VsmDims d, VsmMatchCfg cfg) {
+  // blockIdx.y = frame pair of a batched launch (jobs == nullptr: the single pair `job0`)
+  const VsmJob &jb = jobs ? jobs[blockIdx.y] : job0;
+  const VsmPair &pair = pairs[blockIdx.y];
   const int lane = threadIdx.x & (G - 1);
   const int qi = (blockIdx.x * blockDim.x + threadIdx.x) / G;
-  if (qi >= n_query) return;
   const int si = cfg.sparse ? 0 : 1;
+  if (qi >= jb.nq[si]) return;
+  const int img_prev = jb.img_prev, img_curr = jb.img_curr;
   const VsmSet &s1p = imgs[img_prev].set[si], &s2p = imgs[img_prev + 1].set[si];
   const VsmSet &s1c = imgs[img_curr].set[si], &s2c = imgs[img_curr + 1].set[si];
   vsm_p_match m;
@@ -521,15 +527,15 @@ __global__ void __launch_bounds__(256)
     const int4 p2 = *(const int4 *)(s2p.feat + (size_t)i2p * 12);
     const int u2p = p2.x, v2p = p2.y;
     double u2c_ = -1, v2c_ = -1, u1p_ = -1, v1p_ = -1;
-    if (cfg.use_tr) {  // :1114-1126, contraction-free double arithmetic
+    if (jb.use_tr) {  // :1114-1126, contraction-free double arithmetic
       double dd = (double)u1p - (double)u2p;
       if (!(dd > 1.0)) dd = 1.0;
       double x1p = ((double)u1p - cfg.cu) * cfg.base / dd;
       double y1p = ((double)v1p - cfg.cv) * cfg.base / dd;
       double z1p = cfg.f * cfg.base / dd;
-      double x2c = cfg.t[0] * x1p + cfg.t[1] * y1p + cfg.t[2] * z1p + cfg.t[3] - cfg.base;
-      double y2c = cfg.t[4] * x1p + cfg.t[5] * y1p + cfg.t[6] * z1p + cfg.t[7];
-      double z2c = cfg.t[8] * x1p + cfg.t[9] * y1p + cfg.t[10] * z1p + cfg.t[11];
+      double x2c = jb.t[0] * x1p + jb.t[1] * y1p + jb.t[2] * z1p + jb.t[3] - cfg.base;
+      double y2c = jb.t[4] * x1p + jb.t[5] * y1p + jb.t[6] * z1p + jb.t[7];
+      double z2c = jb.t[8] * x1p + jb.t[9] * y1p + jb.t[10] * z1p + jb.t[11];
       u2c_ = cfg.f * x2c / z2c + cfg.cu;
       v2c_ = cfg.f * y2c / z2c + cfg.cv;
       u1p_ = (double)u1p;
@@ -566,8 +572,12 @@ __device__ __forceinline__ bool match_kept(const VsmPair &pair, int method, int 
   return true;
 }
 
-__global__ void __launch_bounds__(256) k_compact_count(VsmPair pair, int method, int n_query) {
+__global__ void __launch_bounds__(256)
+    k_compact_count(const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs, VsmJob job0, int method, int pass) {
   __shared__ int s_cnt[4];
+  const VsmPair &pair = pairs[blockIdx.y];
+  const int n_query = (jobs ? jobs[blockIdx.y] : job0).nq[pass];
+  if ((int)blockIdx.x * 256 >= n_query && blockIdx.x > 0) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool keep = i < n_query && match_kept(pair, method, i);
   const unsigned long long b = __ballot(keep);
@@ -577,10 +587,14 @@ __global__ void __launch_bounds__(256) k_compact_count(VsmPair pair, int method,
 }
 
 __global__ void __launch_bounds__(256)
-    k_compact_write(VsmPair pair, int method, int n_query, vsm_p_match *__restrict__ list, int32_t *list_count,
-                    int32_t *hcount) {
+    k_compact_write(const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs, VsmJob job0, int method, int pass) {
   __shared__ int s_red[4];
   __shared__ int s_cnt[4];
+  const VsmPair &pair = pairs[blockIdx.y];
+  const int n_query = (jobs ? jobs[blockIdx.y] : job0).nq[pass];
+  const int nblk = max((n_query + 255) / 256, 1);  // blocks that hold queries of this pair
+  if ((int)blockIdx.x >= nblk) return;
+  vsm_p_match *__restrict__ list = pass ? pair.list2 : pair.list1;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // base = survivors of all earlier blocks
   int part = 0;
@@ -599,20 +613,21 @@ __global__ void __launch_bounds__(256)
   for (int w = 0; w < wv; w++) pos += s_cnt[w];
   pos += __popcll(bal & ((1ull << lane) - 1ull));
   if (keep) list[pos] = pair.raw[i];
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+  if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 255) {
     const int total = pos + (keep ? 1 : 0);
-    *list_count = total;
-    *hcount = total;
+    pair.count[pass] = total;
+    pair.hcount[pass] = total;
   }
 }
 
 // wide copy of a finished list into host-mapped pinned memory (16 bytes per lane over PCIe):
 // the host reads it after the stream sync, no D2H copy call and no second round trip
 __global__ void __launch_bounds__(256)
-    k_export_list(const vsm_p_match *__restrict__ list, const int32_t *__restrict__ count, vsm_p_match *__restrict__ hlist) {
-  const int n16 = *count * 3;
-  const uint4 *src = (const uint4 *)list;
-  uint4 *dst = (uint4 *)hlist;
+    k_export_list(const VsmPair *__restrict__ pairs, int pass) {
+  const VsmPair &pair = pairs[blockIdx.y];
+  const int n16 = pair.count[pass] * 3;
+  const uint4 *src = (const uint4 *)(pass ? pair.list2 : pair.list1);
+  uint4 *dst = (uint4 *)(pass ? pair.hlist2 : pair.hlist1);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
 
@@ -645,12 +660,15 @@ __device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b) {
 }
 
 __global__ void __launch_bounds__(256)
-    k_refine(const VsmImage *__restrict__ imgs, int img_prev, int img_curr, VsmPair pair, VsmDims dp, VsmDims dc,
-             int method, const int32_t *__restrict__ d_count) {
+    k_refine(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
+             VsmJob job0, VsmDims dp, VsmDims dc, int method) {
+  const VsmJob &jb = jobs ? jobs[blockIdx.y] : job0;
+  const VsmPair &pair = pairs[blockIdx.y];
+  const int img_prev = jb.img_prev, img_curr = jb.img_curr;
   const int lane = threadIdx.x & 31;
   const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   const int mi = g / 3, step = g - mi * 3;
-  if (mi >= *d_count) return;
+  if (mi >= pair.count[1]) return;
   if (step == 0 && !(method == 0 || method == 2)) return;
   if (step == 1 && !(method == 1 || method == 2)) return;
   if (step == 2 && method != 2) return;
@@ -680,12 +698,15 @@ __global__ void __launch_bounds__(256)
 }
 
 __global__ void __launch_bounds__(256)
-    k_parabolic_costs(const VsmImage *__restrict__ imgs, int img_prev, int img_curr, VsmPair pair, VsmDims dp,
-                      VsmDims dc, int method, const int32_t *__restrict__ d_count) {
+    k_parabolic_costs(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs,
+                      const VsmJob *__restrict__ jobs, VsmJob job0, VsmDims dp, VsmDims dc, int method) {
+  const VsmJob &jb = jobs ? jobs[blockIdx.y] : job0;
+  const VsmPair &pair = pairs[blockIdx.y];
+  const int img_prev = jb.img_prev, img_curr = jb.img_curr;
   const int lane = threadIdx.x & 63;
   const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // one wave per (match, step)
   const int mi = g / 3, step = g - mi * 3;
-  if (mi >= *d_count) return;
+  if (mi >= pair.count[1]) return;
   int32_t *out = pair.pf + ((size_t)mi * 3 + step) * 12;
   bool active = !((step == 0 && !(method == 0 || method == 2)) || (step == 1 && !(method == 1 || method == 2)) ||
                   (step == 2 && method != 2));
@@ -741,12 +762,15 @@ __global__ void __launch_bounds__(256)
 // =======================================================================================
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const uint8_t *src0, const uint8_t *src1, int32_t src_bpl,
-                       uint8_t *dst0, uint8_t *dst1, const VsmDims &d) {
-  int aligned = ((src_bpl & 3) == 0) && ((((uintptr_t)src0) & 3) == 0) && ((((uintptr_t)src1) & 3) == 0);
-  dim3 grid(cdiv(d.bpl / 4, 256), d.h, src1 ? 2 : 1);
+void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0,
+                       const uint8_t *src1, size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d) {
+  const int sides = src1 ? 2 : 1;
+  int aligned = ((src_bpl & 3) == 0) && ((((uintptr_t)src0) & 3) == 0) && ((((uintptr_t)src1) & 3) == 0) &&
+                ((frame_stride & 3) == 0);
+  dim3 grid(cdiv(d.bpl / 4, 256), d.h, n_frames * sides);
   pf.begin(VSM_K_INGEST, s);
-  hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, src0, src1, src_bpl, dst0, dst1, d.w, d.h, d.bpl, aligned);
+  hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, d_imgs, first, src0, src1, frame_stride, src_bpl, sides, d.w, d.h,
+                     d.bpl, aligned);
   pf.end(s);
 }
 
@@ -798,42 +822,43 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
   pf.end(s);
 }
 
-// which: 0 = pass-1 lists (list1/hlist1/count[0]), 1 = pass-2 lists
-void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int img_prev, int img_curr,
-                      const VsmPair &pair, const VsmDims &d, const VsmMatchCfg &cfg, int n_query, int which) {
+// One launch serves `npairs` frame pairs (blockIdx.y); jobs == nullptr: the single pair job0.
+// pass: 0 = sparse lists (list1/hlist1/count[0]), 1 = dense lists.  max_nq bounds nq[pass].
+void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
+                      const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq) {
   constexpr int G = 16;
-  if (n_query > 0) {
+  const int pass = cfg.sparse ? 0 : 1;
+  if (max_nq > 0) {
     pf.begin(cfg.sparse ? VSM_K_MATCH1 : VSM_K_MATCH2, s);
-    hipLaunchKernelGGL(k_match<G>, dim3(cdiv(n_query * G, 256)), dim3(256), 0, s, d_imgs, img_prev, img_curr, pair, d,
-                       cfg, n_query);
+    hipLaunchKernelGGL(k_match<G>, dim3(cdiv(max_nq * G, 256), npairs), dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0,
+                       d, cfg);
     pf.end(s);
   }
-  const int nblk = max(cdiv(n_query, 256), 1);
+  const int nblk = max(cdiv(max_nq, 256), 1);
   pf.begin(cfg.sparse ? VSM_K_COMPACT1 : VSM_K_COMPACT2, s);
-  hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, s, pair, cfg.method, n_query);
-  hipLaunchKernelGGL(k_compact_write, dim3(nblk), dim3(256), 0, s, pair, cfg.method, n_query,
-                     which ? pair.list2 : pair.list1, pair.count + which, pair.hcount + which);
+  hipLaunchKernelGGL(k_compact_count, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);
+  hipLaunchKernelGGL(k_compact_write, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);
   pf.end(s);
 }
 
-void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair &pair, int which, int n_upper) {
+void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair *d_pairs, int npairs, int pass, int n_upper) {
   pf.begin(VSM_K_EXPORT, s);
-  hipLaunchKernelGGL(k_export_list, dim3(max(min(cdiv(n_upper * 3, 256), 256), 1)), dim3(256), 0, s,
-                     which ? pair.list2 : pair.list1, pair.count + which, which ? pair.hlist2 : pair.hlist1);
+  hipLaunchKernelGGL(k_export_list, dim3(max(min(cdiv(n_upper * 3, 256), 256), 1), npairs), dim3(256), 0, s, d_pairs,
+                     pass);
   pf.end(s);
 }
 
-void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int img_prev, int img_curr,
-                       const VsmPair &pair, const VsmDims &dp, const VsmDims &dc, int method, int refinement,
-                       int n_upper, const int32_t *d_count) {
-  // n_upper bounds the list size (it may still be device-only); surplus groups exit at once
+void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
+                       const VsmJob &job0, int npairs, const VsmDims &dp, const VsmDims &dc, int method, int refinement,
+                       int n_upper) {
+  // n_upper bounds the list sizes (they are still device-only); surplus groups exit at once
   if (n_upper <= 0) return;
   pf.begin(VSM_K_REFINE, s);
   if (refinement == 2)
-    hipLaunchKernelGGL(k_parabolic_costs, dim3(cdiv(n_upper * 3 * 64, 256)), dim3(256), 0, s, d_imgs, img_prev,
-                       img_curr, pair, dp, dc, method, d_count);
+    hipLaunchKernelGGL(k_parabolic_costs, dim3(cdiv(n_upper * 3 * 64, 256), npairs), dim3(256), 0, s, d_imgs, d_pairs,
+                       d_jobs, job0, dp, dc, method);
   else
-    hipLaunchKernelGGL(k_refine, dim3(cdiv(n_upper * 3 * 32, 256)), dim3(256), 0, s, d_imgs, img_prev, img_curr,
-                       pair, dp, dc, method, d_count);
+    hipLaunchKernelGGL(k_refine, dim3(cdiv(n_upper * 3 * 32, 256), npairs), dim3(256), 0, s, d_imgs, d_pairs, d_jobs,
+                       job0, dp, dc, method);
   pf.end(s);
 }

@@ -28,7 +28,8 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_num_features", "vsm_get_features", "vsm_set_stage_capture", "vsm_stage_size", "vsm_stage_get",
            "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
            "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
-           "vsm_host_delaunay", "vsm_version"]
+           "vsm_host_delaunay", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
+           "vsm_sequence_get_timings", "vsm_version"]
 
 
 class VsmParams(C.Structure):
@@ -88,6 +89,10 @@ def lib():
         L.vsm_kernel_name.argtypes = [i32]
         L.vsm_get_kernel_stats.argtypes = [vp, vp, vp]
         L.vsm_host_delaunay.argtypes = [vp, vp, i32, vp, i32, i32]
+        L.vsm_sequence_run.argtypes = [vp, vp, vp, C.c_int64, C.c_int, i32, i32, i32, i32, i32, vp, vp]
+        L.vsm_sequence_num_matches.argtypes = [vp, i32]
+        L.vsm_sequence_get_matches.argtypes = [vp, i32, vp, i32]
+        L.vsm_sequence_get_timings.argtypes = [vp, vp]
         _lib = L
     return _lib
 
@@ -242,6 +247,58 @@ class Matcher:
         t = np.zeros(5, dtype=np.float64)
         lib().vsm_get_timings(self.h, t.ctypes.data_as(C.c_void_p))
         return dict(zip(("pass1_gpu_us", "pass1_host_us", "pass2_gpu_us", "final_host_us", "total_us"), t.tolist()))
+
+    # --- look-ahead API -------------------------------------------------------------------
+    def run_sequence(self, left, right, method, Tr_delta=None, Tr_valid=None, fetch=True):
+        """left/right: [F,H,W] uint8 numpy arrays (host) or CUDA torch tensors (resident in HBM);
+        returns the list of per-frame match arrays (getMatches() after each frame), or, with
+        fetch=False, nothing (the lists stay in the handle: sequence_matches(f))."""
+        L = lib()
+        if _is_torch(left):
+            assert left.is_cuda and left.dim() == 3 and left.stride(2) == 1
+            F, h, w = left.shape
+            bpl, fs = left.stride(1), left.stride(0)
+            pl = C.c_void_p(left.data_ptr())
+            pr = None
+            if right is not None:
+                assert right.is_cuda and right.shape == left.shape and right.stride() == left.stride()
+                pr = C.c_void_p(right.data_ptr())
+            dev = 1
+        else:
+            left = np.ascontiguousarray(left, dtype=np.uint8)
+            F, h, w = left.shape
+            bpl, fs = w, w * h
+            pl = left.ctypes.data_as(C.c_void_p)
+            pr = None
+            if right is not None:
+                right = np.ascontiguousarray(right, dtype=np.uint8)
+                assert right.shape == left.shape
+                pr = right.ctypes.data_as(C.c_void_p)
+            dev = 0
+        tp = vp_ = None
+        if Tr_delta is not None:
+            t = np.ascontiguousarray(np.asarray(Tr_delta, dtype=np.float64).reshape(F, -1)[:, :12])
+            tp = t.ctypes.data_as(C.c_void_p)
+            if Tr_valid is not None:
+                v = np.ascontiguousarray(np.asarray(Tr_valid).astype(np.uint8))
+                vp_ = v.ctypes.data_as(C.c_void_p)
+        rc = L.vsm_sequence_run(self.h, pl, pr, fs, dev, F, w, h, bpl, method, tp, vp_)
+        if rc != self.OK:
+            raise VisoMatchError(f"vsm_sequence_run failed with {rc}")
+        return [self.sequence_matches(f) for f in range(F)] if fetch else None
+
+    def sequence_matches(self, f):
+        L = lib()
+        n = L.vsm_sequence_num_matches(self.h, f)
+        a = np.zeros(n, dtype=P_MATCH)
+        if n:
+            L.vsm_sequence_get_matches(self.h, f, a.ctypes.data_as(C.c_void_p), n)
+        return a
+
+    def sequence_timings(self):
+        t = np.zeros(4, dtype=np.float64)
+        lib().vsm_sequence_get_timings(self.h, t.ctypes.data_as(C.c_void_p))
+        return dict(zip(("gpu_us", "host_us", "total_us", "chunk"), t.tolist()))
 
     def set_profiling(self, on):
         lib().vsm_set_profiling(self.h, int(on))

@@ -183,3 +183,54 @@ def test_reference_vo_runs_on_dropin_matcher(synth, tmp_path):
         assert bool(rec[i, 0]) == bool(g["vo_ok"][i])
         # Tr_delta after frame i is what matchFeatures receives at frame i+1
         assert np.array_equal(rec[i, 2:].reshape(4, 4), g["tr_in"][i + 1]), i
+
+
+@pytest.mark.parametrize("chunk", ["1", "3", "50"])
+@pytest.mark.parametrize("method", [2, 0, 1])
+def test_sequence_api_equals_frame_by_frame(vm, B, synth, monkeypatch, method, chunk):
+    """look-ahead API == pushBack+matchFeatures per frame (oracle), across chunk boundaries"""
+    monkeypatch.setenv("VSM_SEQ_CHUNK", chunk)
+    seq = synth.stereo_sequence(31, 417, 163, 7, disparity=10, ramp=(1, 12))
+    left = np.stack([l for l, _ in seq])
+    right = np.stack([r for _, r in seq])
+    g = vm.Matcher()
+    got = g.run_sequence(left, right, method)
+    c = B.CpuMatcher("oracle")
+    for f, (l, r) in enumerate(seq):
+        c.push_back(l, r)
+        c.match(method)
+        assert _same(got[f], c.matches()), (method, chunk, f, len(got[f]), len(c.matches()))
+    assert len(got[-1]) > 100
+    g.close()
+
+
+def test_sequence_api_golden_feedback_and_device_inputs(vm, synth):
+    """config 2 through the look-ahead API: 60 frames resident in HBM, replayed Tr_delta"""
+    import torch
+    g = G.load("cfg2_seq200_tr")
+    w, h, nf = int(g["w"]), int(g["h"]), 60
+    cv = synth.canvas(int(g["seed"]), w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
+    left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
+    right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
+    m = vm.Matcher()
+    m.set_intrinsics(*[float(x) for x in g["intr"]])
+    got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
+    for f in range(nf):
+        assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), f
+    m.close()
+
+
+def test_sequence_api_fallbacks(vm, B, synth):
+    seq = synth.stereo_sequence(8, 320, 128, 4)
+    left = np.stack([l for l, _ in seq])
+    right = np.stack([r for _, r in seq])
+    for kw, meth, rgt in ((dict(refinement=2), 2, right), (dict(), 0, None)):
+        g = vm.Matcher(**kw)
+        got = g.run_sequence(left, rgt, meth)
+        c = B.CpuMatcher("oracle", **kw)
+        for f, (l, r) in enumerate(seq):
+            c.push_back(l, r if rgt is not None else None)
+            c.match(meth)
+            assert _same(got[f], c.matches()), (kw, f)
+        g.close()
