@@ -79,9 +79,16 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    # host threads for the exact Delaunay stage: this rank's share of the box's cores
+    # host threads for the exact Delaunay stage: this rank's share of the CPUs the job may use
+    # (cgroup quota if there is one -- more spinning threads than that only get throttled)
     ncpu = os.cpu_count() or 16
-    os.environ.setdefault("VSM_HOST_THREADS", str(max(4, min(32, ncpu // max(world, 1)))))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            ncpu = min(ncpu, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    os.environ.setdefault("VSM_HOST_THREADS", str(max(2, min(32, ncpu // max(world, 1)))))
     vm = importlib.import_module(PKG + ".visomatch")
     synth = importlib.import_module(PKG + ".synth")
     vm.lib()  # raises if the HIP library is missing
@@ -126,8 +133,11 @@ def main():
     shard.barrier(dmod, dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         run_sequence()
+        step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
     torch.cuda.synchronize()
     shard.barrier(dmod, dev)
     torch.cuda.synchronize()
@@ -216,6 +226,7 @@ def main():
         "kernel_avg_launch_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in stats.items() if v[1]},
         "sequence_timings_us": m.sequence_timings(),
         "host_threads": int(os.environ["VSM_HOST_THREADS"]),
+        "step_ms_rank0": step_ms,
         "match_timings_us_last_frame": m.timings(),
     }
     print(json.dumps(out))

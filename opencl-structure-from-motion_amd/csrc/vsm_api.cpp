@@ -16,8 +16,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "vsm_host.h"
@@ -35,6 +37,23 @@
 
 static inline int32_t bpl16(int32_t w) { return w + 15 - (w - 1) % 16; }  // viso/matcher.cpp:160
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+// CPUs this process may actually use: the cgroup CPU quota (containers), else the hardware
+// thread count.  Spinning more threads than the quota only gets the whole process throttled.
+static int cpu_budget() {
+  unsigned hc = std::thread::hardware_concurrency();
+  int budget = hc ? (int)hc : 8;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    long period = 0;
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      long quota = atol(q);
+      if (quota > 0) budget = std::min(budget, (int)std::max(1L, quota / period));
+    }
+    fclose(f);
+  }
+  return budget;
+}
+
 static inline double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -323,8 +342,7 @@ vsm_handle *vsm_create(const vsm_params *p) {
     // the look-ahead API, at most 8 of them for the sub-problems of one triangulation (streaming)
     int nt = 16;
     if (const char *e = getenv("VSM_HOST_THREADS")) nt = atoi(e);
-    unsigned hc = std::thread::hardware_concurrency();
-    if (hc && (unsigned)nt > hc) nt = (int)hc;
+    nt = std::max(1, std::min(nt, cpu_budget()));
     h->pool = new VsmPool(nt);
     h->fj = new VsmForkJoin(nt < 8 ? nt : 8);
     h->work.pool = h->fj;
@@ -646,9 +664,11 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     fprintf(stderr, "ERROR: Image dimension mismatch!\n");
     return VSM_EDIMS;
   }
+  const double t_entry = now_us();
   HIPCHK(hipSetDevice(h->device));
   const vsm_params &p = h->param;
-  h->seq_matches.assign(n_frames, std::vector<vsm_p_match>());
+  h->seq_matches.resize(n_frames);  // keeps the capacity of earlier runs: no page-fault storm
+  for (auto &v : h->seq_matches) v.clear();
   if (!right || p.refinement == 2)
     return sequence_fallback(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
 
@@ -689,8 +709,10 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     }
     vsm_launch_features(h->stream, h->prof, c.d_imgs, first_img, 2 * n, c.dims, c.f1, c.f2, c.f_stride, p.nms_tau,
                         p.multi_stage, p.half_resolution, p.match_binsize, c.h_imgs.data());
+    const double tl0 = now_us();
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
+    if (getenv("VSM_DEBUG_TIMING")) fprintf(stderr, "  chunk %d: launch %.0f us, feature sync %.0f us\n", k, tl0 - ta, now_us() - tl0);
     // ---- one job per frame of the chunk ----
     int max_nq[2] = {0, 0};
     std::shared_ptr<std::vector<char>> validp = std::make_shared<std::vector<char>>(n, 0);
@@ -750,8 +772,10 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       cfg.use_prior = 0;
       vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, cfg, max_nq[0]);
       vsm_launch_export(h->stream, h->prof, d_pairs, n, 0, max_nq[0]);
+      const double tl1 = now_us();
       HIPCHK(hipStreamSynchronize(h->stream));
       double tb = now_us();
+      if (getenv("VSM_DEBUG_TIMING")) fprintf(stderr, "  chunk %d: pass1 sync %.0f us\n", k, tb - tl1);
       tg += tb - ta;
       h->pool->run(n, [&](int i) {  // queued behind the previous chunk's final stage (FIFO)
         static thread_local VsmHostWork tw;
@@ -770,7 +794,9 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
                             c.ranges_stride * 4 * n, hipMemcpyHostToDevice, h->stream));
     }
     // the export below overwrites this pair bank's host lists: chunk k-2 must be done with them
+    const double tw0 = now_us();
     if (k >= 2) h->pool->wait(tickets[k - 2]);
+    if (getenv("VSM_DEBUG_TIMING") && now_us() - tw0 > 2000) fprintf(stderr, "  chunk %d: waited %.0f us for chunk %d's final stage\n", k, now_us() - tw0, k - 2);
     cfg.sparse = 0;
     cfg.use_prior = p.multi_stage ? 1 : 0;
     vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, cfg, max_nq[1]);
@@ -778,9 +804,11 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       vsm_launch_refine(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, c.dims, method, p.refinement,
                         max_nq[1]);
     vsm_launch_export(h->stream, h->prof, d_pairs, n, 1, max_nq[1]);
+    const double tl2 = now_us();
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     h->prof.resolve();
+    if (getenv("VSM_DEBUG_TIMING")) fprintf(stderr, "  chunk %d: pass2 launch %.0f us sync %.0f us\n", k, tl2 - ta, now_us() - tl2);
     tg += now_us() - ta;
     // final host stage of this chunk: asynchronous, overlapped with the next chunk's GPU work
     VsmCtx *cp = &c;
@@ -803,6 +831,9 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   h->seq_timings[1] = thost;
   h->seq_timings[2] = now_us() - tstart;
   h->seq_timings[3] = (double)C;
+  if (getenv("VSM_DEBUG_TIMING"))
+    fprintf(stderr, "seq: entry->start %.0f us, gpu %.0f, host %.0f, total %.0f\n", tstart - t_entry, tg, thost,
+            h->seq_timings[2]);
   return VSM_OK;
 }
 

@@ -18,7 +18,8 @@ static inline void cpu_relax() {
 }
 
 VsmPool::VsmPool(int threads) : nthreads_(threads < 1 ? 1 : threads) {
-  if (const char *e = getenv("VSM_HOST_SPIN_US")) spin_us_ = atoi(e);
+  spin_us_ = 100;  // millisecond-sized tasks: a wake-up is cheap next to them, spinning burns quota
+  if (const char *e = getenv("VSM_POOL_SPIN_US")) spin_us_ = atoi(e);
   for (int i = 1; i < nthreads_; i++) threads_.emplace_back([this] { worker(); });
 }
 

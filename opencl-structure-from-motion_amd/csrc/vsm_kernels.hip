@@ -187,9 +187,9 @@ __device__ __forceinline__ bool nms_suppressed_wave(const int16_t *__restrict__ 
 
 __global__ void __launch_bounds__(256) k_nms(const VsmImage *__restrict__ imgs, int first, VsmDims d,
                                              const int16_t *__restrict__ f1base, const int16_t *__restrict__ f2base,
-                                             size_t f_stride, int tau, int set_lo) {
+                                             size_t f_stride, int tau, int set_lo, int set_hi) {
   const int zi = blockIdx.z >> 1, si = (blockIdx.z & 1);
-  if (si < set_lo) return;
+  if (si < set_lo || si > set_hi) return;
   const VsmSet &st = imgs[first + zi].set[si];
   const int ncells = st.ncu * st.ncv;
   const int lane = threadIdx.x & 63;
@@ -221,6 +221,77 @@ __global__ void __launch_bounds__(256) k_nms(const VsmImage *__restrict__ imgs, 
     c[0] = vmin ? (int32_t)(0x80000000u | (uint32_t)mni | ((uint32_t)mnj << 14)) : 0;
     c[1] = vmax ? (int32_t)(0x80000000u | (uint32_t)mxi | ((uint32_t)mxj << 14)) : 0;
   }
+}
+
+// Tile variant for small n (the dense set, n = nms_n <= 4): a 256-thread block stages the f1/f2
+// responses of 16 x 8 cells plus the n-pixel halo in LDS (coalesced row reads, 11 KB at n = 3) and
+// every thread then resolves one (cell, filter) entirely from LDS -- (n+1)^2 + 2 (2n+1)^2 reads --
+// instead of spending a whole wavefront per cell.  Same scan order, same strict compares.
+#define NMS_TCU 16
+#define NMS_TCV 8
+#define NMS_TILE_MAXN 4
+__global__ void __launch_bounds__(256)
+    k_nms_tile(const VsmImage *__restrict__ imgs, int first, VsmDims d, const int16_t *__restrict__ f1base,
+               const int16_t *__restrict__ f2base, size_t f_stride, int tau, int si) {
+  constexpr int MAXW = NMS_TCU * (NMS_TILE_MAXN + 1) + 2 * NMS_TILE_MAXN;  // 88
+  constexpr int MAXH = NMS_TCV * (NMS_TILE_MAXN + 1) + 2 * NMS_TILE_MAXN;  // 48
+  __shared__ int16_t s_f[2][MAXH][MAXW + 2];
+  const VsmSet &st = imgs[first + blockIdx.z].set[si];
+  const int n = st.nms_n, n1 = n + 1;
+  const int tiles_u = (st.ncu + NMS_TCU - 1) / NMS_TCU;
+  const int tu = blockIdx.x % tiles_u, tv = blockIdx.x / tiles_u;
+  const int cu0 = tu * NMS_TCU, cv0 = tv * NMS_TCV;
+  const int u0 = VSM_MARGIN + cu0 * n1, v0 = VSM_MARGIN + cv0 * n1;  // = first cell origin - n
+  const int tw = NMS_TCU * n1 + 2 * n, th = NMS_TCV * n1 + 2 * n;
+  const int16_t *__restrict__ f1 = f1base + (size_t)blockIdx.z * f_stride;
+  const int16_t *__restrict__ f2 = f2base + (size_t)blockIdx.z * f_stride;
+  for (int e = threadIdx.x; e < tw * th; e += 256) {
+    const int y = e / tw, x = e - y * tw;
+    const int u = u0 + x, v = v0 + y;
+    const bool in = u < d.mbpl && v < d.mh;
+    s_f[0][y][x] = in ? f1[v * d.mbpl + u] : (int16_t)0;
+    s_f[1][y][x] = in ? f2[v * d.mbpl + u] : (int16_t)0;
+  }
+  __syncthreads();
+  const int k = threadIdx.x & 1, cl = threadIdx.x >> 1;
+  const int lcu = cl % NMS_TCU, lcv = cl / NMS_TCU;
+  const int ci = cu0 + lcu, cj = cv0 + lcv;
+  if (ci >= st.ncu || cj >= st.ncv) return;
+  const int16_t(*f)[MAXW + 2] = s_f[k];
+  // tile-local coordinates of the cell origin; image coordinates = local + (u0, v0)
+  const int li = n + lcu * n1, lj = n + lcv * n1;
+  int mni = li, mnj = lj, mxi = li, mxj = lj;
+  int mnv = f[lj][li], mxv = mnv;
+  for (int i2 = li; i2 <= li + n; i2++)
+    for (int j2 = lj; j2 <= lj + n; j2++) {
+      const int cur = f[j2][i2];
+      if (cur < mnv) {
+        mni = i2;
+        mnj = j2;
+        mnv = cur;
+      } else if (cur > mxv) {
+        mxi = i2;
+        mxj = j2;
+        mxv = cur;
+      }
+    }
+  // clip limits of the suppression windows (w-1-margin, h-1-margin) in tile-local coordinates
+  const int lim_i = d.mw - 1 - VSM_MARGIN - u0, lim_j = d.mh - 1 - VSM_MARGIN - v0;
+  auto suppressed = [&](int ci2, int cj2, int val, bool want_min) -> bool {
+    const int i_hi = min(ci2 + n, lim_i), j_hi = min(cj2 + n, lim_j);
+    for (int i2 = ci2 - n; i2 <= i_hi; i2++)
+      for (int j2 = cj2 - n; j2 <= j_hi; j2++) {
+        const int cur = f[j2][i2];
+        const bool better = want_min ? (cur < val) : (cur > val);
+        if (better && (i2 < li || i2 > li + n || j2 < lj || j2 > lj + n)) return true;
+      }
+    return false;
+  };
+  const bool vmin = (mnv <= -tau) && !suppressed(mni, mnj, mnv, true);
+  const bool vmax = (mxv >= tau) && !suppressed(mxi, mxj, mxv, false);
+  int32_t *c = st.cand + (size_t)(ci * st.ncv + cj) * 4 + 2 * k;
+  c[0] = vmin ? (int32_t)(0x80000000u | (uint32_t)(mni + u0) | ((uint32_t)(mnj + v0) << 14)) : 0;
+  c[1] = vmax ? (int32_t)(0x80000000u | (uint32_t)(mxi + u0) | ((uint32_t)(mxj + v0) << 14)) : 0;
 }
 
 // block-wide exclusive scan of one int per thread (blockDim.x == 1024); returns the exclusive
@@ -292,9 +363,9 @@ __global__ void __launch_bounds__(1024) k_scan_cells(const VsmImage *__restrict_
 
 // ---------------------------------------------------------------------------------------
 // T1 feature records (viso/matcher.cpp:707-731) + D1 descriptor gather (computeDescriptor,
-// viso/matcher.cpp:433-477).  One wavefront per cell, 16 lanes per class slot: lane j < 12 of a
-// slot produces dword j of the 48-byte record {u*s, v*s, 0, class, d1..d8} -- a descriptor dword
-// is two taps x (du,dv) = 4 byte gathers -- so every record leaves as one coalesced 48-byte run.
+// viso/matcher.cpp:433-477).  16 lanes per cell: lane j < 12 produces dword j of the 48-byte
+// record {u*s, v*s, 0, class, d1..d8} of each survivor of the cell -- a descriptor dword is two
+// taps x (du,dv) = 4 byte gathers -- so every record leaves as one coalesced 48-byte run.
 // ---------------------------------------------------------------------------------------
 __constant__ int8_t c_desc_dv[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
 __constant__ int8_t c_desc_du[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
@@ -311,30 +382,36 @@ __global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs,
   const int si = blockIdx.y;
   if (si < set_lo) return;
   const VsmSet &st = im.set[si];
-  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // 16 lanes per cell (4 cells per wavefront); lane j < 12 writes dword j of each record
+  const int cell = (blockIdx.x * 256 + threadIdx.x) >> 4;
   if (cell >= st.ncu * st.ncv) return;
-  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const int j = threadIdx.x & 15;
   const int4 c4 = *(const int4 *)(st.cand + (size_t)cell * 4);
-  const int cc = g == 0 ? c4.x : (g == 1 ? c4.y : (g == 2 ? c4.z : c4.w));
-  if (cc >= 0 || j >= 12) return;
-  const int before = (g > 0 && c4.x < 0) + (g > 1 && c4.y < 0) + (g > 2 && c4.z < 0);
-  const int pos = st.cell_off[cell] + before;
-  const int u = cc & 0x3fff, v = (cc >> 14) & 0x3fff;
-  if (j == 0) {  // M1 createIndexVector (viso/matcher.cpp:870-890): histogram of the search bins
-    const int b = bin_of(u * d.scale, v * d.scale, g, binsize, d.ub, d.vb);
-    st.binid[pos] = b;
-    atomicAdd(&st.bin_cnt[b], 1);
+  if ((c4.x | c4.y | c4.z | c4.w) >= 0 || j >= 12) return;
+  const int cc4[4] = {c4.x, c4.y, c4.z, c4.w};
+  int pos = st.cell_off[cell];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int cc = cc4[g];
+    if (cc >= 0) continue;
+    const int u = cc & 0x3fff, v = (cc >> 14) & 0x3fff;
+    if (j == 0) {  // M1 createIndexVector (viso/matcher.cpp:870-890): histogram of the search bins
+      const int b = bin_of(u * d.scale, v * d.scale, g, binsize, d.ub, d.vb);
+      st.binid[pos] = b;
+      atomicAdd(&st.bin_cnt[b], 1);
+    }
+    uint32_t val;
+    if (j < 4) {
+      val = j == 0 ? (uint32_t)(u * d.scale) : (j == 1 ? (uint32_t)(v * d.scale) : (j == 2 ? 0u : (uint32_t)g));
+    } else {
+      const int m = j - 4;
+      const int a0 = (v + c_desc_dv[2 * m]) * d.mbpl + u + c_desc_du[2 * m];
+      const int a1 = (v + c_desc_dv[2 * m + 1]) * d.mbpl + u + c_desc_du[2 * m + 1];
+      val = (uint32_t)im.du[a0] | ((uint32_t)im.dv[a0] << 8) | ((uint32_t)im.du[a1] << 16) | ((uint32_t)im.dv[a1] << 24);
+    }
+    st.feat[(size_t)pos * 12 + j] = (int32_t)val;
+    pos++;
   }
-  uint32_t val;
-  if (j < 4) {
-    val = j == 0 ? (uint32_t)(u * d.scale) : (j == 1 ? (uint32_t)(v * d.scale) : (j == 2 ? 0u : (uint32_t)g));
-  } else {
-    const int m = j - 4;
-    const int a0 = (v + c_desc_dv[2 * m]) * d.mbpl + u + c_desc_du[2 * m];
-    const int a1 = (v + c_desc_dv[2 * m + 1]) * d.mbpl + u + c_desc_du[2 * m + 1];
-    val = (uint32_t)im.du[a0] | ((uint32_t)im.dv[a0] << 8) | ((uint32_t)im.du[a1] << 16) | ((uint32_t)im.dv[a1] << 24);
-  }
-  st.feat[(size_t)pos * 12 + j] = (int32_t)val;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -488,7 +565,7 @@ __device__ __forceinline__ int stat_bin_of(int u, int v, int binsize, int ub, in
 }
 
 template <int G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 8)
     k_match(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
             VsmJob job0, VsmDims d, VsmMatchCfg cfg) {
   // blockIdx.y = frame pair of a batched launch (jobs == nullptr: the single pair `job0`)
@@ -662,30 +739,58 @@ __device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b) {
 __global__ void __launch_bounds__(256)
     k_refine(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
              VsmJob job0, VsmDims dp, VsmDims dc, int method) {
+  // the 9 x 9 du/dv neighbourhood of the target (rows v2-4..v2+4, 12 aligned bytes per row that
+  // cover columns u2-4..u2+4) is staged once per (match, step) group: 54 dword loads instead of
+  // 25 x 16 byte gathers
+  __shared__ uint32_t s_win[8][2][9][3];
   const VsmJob &jb = jobs ? jobs[blockIdx.y] : job0;
   const VsmPair &pair = pairs[blockIdx.y];
   const int img_prev = jb.img_prev, img_curr = jb.img_curr;
-  const int lane = threadIdx.x & 31;
+  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   const int mi = g / 3, step = g - mi * 3;
-  if (mi >= pair.count[1]) return;
-  if (step == 0 && !(method == 0 || method == 2)) return;
-  if (step == 1 && !(method == 1 || method == 2)) return;
-  if (step == 2 && method != 2) return;
-  vsm_p_match *m = pair.list2 + mi;  // refined in place (each step owns its two fields)
+  bool active = mi < pair.count[1];
+  if (step == 0 && !(method == 0 || method == 2)) active = false;
+  if (step == 1 && !(method == 1 || method == 2)) active = false;
+  if (step == 2 && method != 2) active = false;
+  vsm_p_match *m = pair.list2 + (active ? mi : 0);  // refined in place (each step owns its two fields)
   const VsmImage &ref = imgs[img_curr];
   const VsmImage &tgt = step == 0 ? imgs[img_prev] : (step == 1 ? imgs[img_curr + 1] : imgs[img_prev + 1]);
   const VsmDims &dt = step == 1 ? dc : dp;
   float *pu = step == 0 ? &m->u1p : (step == 1 ? &m->u2c : &m->u2p);
   float *pv = pu + 1;
-  const float u2 = *pu, v2 = *pv;
-  if (u2 - 2 < VSM_MARGIN || u2 + 2 > dt.w - 1 - VSM_MARGIN || v2 - 2 < VSM_MARGIN || v2 + 2 > dt.h - 1 - VSM_MARGIN)
-    return;
+  float u2 = 0, v2 = 0;
+  if (active) {
+    u2 = *pu;
+    v2 = *pv;
+    if (u2 - 2 < VSM_MARGIN || u2 + 2 > dt.w - 1 - VSM_MARGIN || v2 - 2 < VSM_MARGIN || v2 + 2 > dt.h - 1 - VSM_MARGIN)
+      active = false;
+  }
+  const int iu = (int)u2, iv = (int)v2;
+  const int a0 = (iu - 4) & ~3;  // first staged column (4-byte aligned; rows are 16-byte aligned)
+  if (active) {
+    for (int e = lane; e < 54; e += 32) {
+      const int pl = e / 27, r = (e - pl * 27) / 3, q = e % 3;
+      const uint8_t *base = pl ? tgt.dv_full : tgt.du_full;
+      s_win[grp][pl][r][q] = *(const uint32_t *)(base + (size_t)(iv - 4 + r) * dt.bpl + a0 + 4 * q);
+    }
+  }
+  __syncthreads();
+  if (!active) return;
   const uint4 r = small_desc(ref.du_full, ref.dv_full, dc.bpl, (int)m->u1c, (int)m->v1c);
   uint32_t key = 0xffffffffu;
   if (lane < 25) {
     const int ddv = lane / 5, ddu = lane - ddv * 5;
-    const uint4 t = small_desc(tgt.du_full, tgt.dv_full, dt.bpl, (int)u2 + ddu - 2, (int)v2 + ddv - 2);
+    // candidate centre (cu, cv) in window coordinates: column = u - a0, row = v - (iv-4)
+    const int cx = iu + ddu - 2 - a0, cy = ddv + 2;
+    const uint8_t *wu = (const uint8_t *)&s_win[grp][0][0][0], *wv = (const uint8_t *)&s_win[grp][1][0][0];
+    auto U = [&](int dy, int dx) -> uint32_t { return wu[(cy + dy) * 12 + cx + dx]; };
+    auto V = [&](int dy, int dx) -> uint32_t { return wv[(cy + dy) * 12 + cx + dx]; };
+    uint4 t;
+    t.x = U(-2, 0) | (U(-1, -2) << 8) | (U(-1, 0) << 16) | (U(-1, 2) << 24);
+    t.y = U(0, -1) | (U(0, 0) << 8) | (U(0, 0) << 16) | (U(0, 1) << 24);
+    t.z = U(1, -2) | (U(1, 0) << 8) | (U(1, 2) << 16) | (U(2, 0) << 24);
+    t.w = V(-1, 0) | (V(0, -1) << 8) | (V(0, 1) << 16) | (V(1, 0) << 24);
     key = (sad16(r, t) << 5) | (uint32_t)lane;
   }
 #pragma unroll
@@ -799,8 +904,24 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
   }
   if (max_cells > 0) {
     pf.begin(VSM_K_NMS, s);
-    hipLaunchKernelGGL(k_nms, dim3(cdiv(max_cells, 4), 2, n_img * 2), dim3(256), 0, s, d_imgs, first, d, f1, f2,
-                       f_stride, nms_tau, set_lo);
+    // sets whose n fits the LDS tile kernel go there, the others to the wave-per-cell kernel
+    bool tiled[2] = {false, false};
+    for (int k = set_lo; k < 2; k++) {
+      const VsmSet &st = h_imgs[first].set[k];
+      if (st.nms_n <= NMS_TILE_MAXN && st.ncu * st.ncv > 0) {
+        tiled[k] = true;
+        hipLaunchKernelGGL(k_nms_tile, dim3(cdiv(st.ncu, NMS_TCU) * cdiv(st.ncv, NMS_TCV), 1, n_img), dim3(256), 0, s,
+                           d_imgs, first, d, f1, f2, f_stride, nms_tau, k);
+      }
+    }
+    const int lo = tiled[0] ? 1 : set_lo, hi = tiled[1] ? 0 : 1;  // wave kernel handles sets lo..hi
+    if (lo <= hi) {
+      int mc = 0;
+      for (int k = lo; k <= hi; k++) mc = max(mc, h_imgs[first].set[k].ncu * h_imgs[first].set[k].ncv);
+      if (mc > 0)
+        hipLaunchKernelGGL(k_nms, dim3(cdiv(mc, 4), 2, n_img * 2), dim3(256), 0, s, d_imgs, first, d, f1, f2, f_stride,
+                           nms_tau, lo, hi);
+    }
     pf.end(s);
   }
   pf.begin(VSM_K_SCAN, s);
@@ -808,7 +929,7 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
   pf.end(s);
   if (max_cells > 0) {
     pf.begin(VSM_K_EMIT, s);
-    hipLaunchKernelGGL(k_emit, dim3(cdiv(max_cells, 4), 2, n_img), dim3(256), 0, s, d_imgs, first, d, set_lo, binsize);
+    hipLaunchKernelGGL(k_emit, dim3(cdiv(max_cells, 16), 2, n_img), dim3(256), 0, s, d_imgs, first, d, set_lo, binsize);
     pf.end(s);
   }
   pf.begin(VSM_K_BINSCAN, s);
