@@ -206,7 +206,7 @@ void VsmForkJoin::run(int ntasks, const std::function<void(int)> &fn) {
 // partition of distinct points -> std::nth_element), triangle numbering (slot = 2*position, so
 // sub-problems never share an allocator and can run on different threads), memory layout.
 // Vertices are renumbered by their final sorted position so every sub-problem touches one
-// contiguous slice of xs_/ys_.  nb_[t*3+o] = neighbour handle t2*4+o2, vx_[t*3+o] = vertex
+// contiguous slice of pt_.  tri_[t*8+o] = neighbour handle t2*4+o2, tri_[t*8+4+o] = vertex
 // position or -1 for the ghost ("NULL") corner of a bounding triangle.
 // =======================================================================================
 #define KXY(k) ((k) >> 20)
@@ -217,13 +217,43 @@ uint32_t ExactDelaunay::rnd(uint32_t choices) {  // randomnation, :4046
   return (uint32_t)(seed_ / (714025u / choices + 1));
 }
 
-void ExactDelaunay::vertex_sort(uint64_t *a, int32_t n) {  // :5447, on packed (x,y) keys
+// vertexsort (:5447) on packed (x,y) keys.  The Hoare partition is reproduced exactly, but for
+// large ranges its data-dependent scan loops (a coin-flip branch per element) are replaced by two
+// branch-free passes: the left scan can only stop at the positions L[0] < L[1] < ... holding keys
+// >= pivot, the right scan at R[0] > R[1] > ... holding keys <= pivot, and the reference swaps
+// exactly the pairs (L[t], R[t]) while L[t] < R[t] (the region between two swapped positions is
+// untouched, so later stoppers are the original ones).  After those swaps the scalar loop resumes
+// from (left, right) = (L[K-1], R[K-1]) and finishes the partition, so `left`/`right` and the
+// element order are bit-identical to the reference's.
+void ExactDelaunay::vertex_sort(uint64_t *a, int32_t n) {
   if (n == 2) {
     if (KXY(a[0]) > KXY(a[1])) std::swap(a[0], a[1]);
     return;
   }
   const uint64_t pv = KXY(a[rnd((uint32_t)n)]);
   int32_t left = -1, right = n;
+  if (n >= 64) {
+    uint32_t *L = stop_.data(), *R = stop_.data() + n;
+    int32_t nl = 0, nr = 0;
+    for (int32_t i = 0; i < n; i++) {
+      L[nl] = (uint32_t)i;
+      nl += KXY(a[i]) >= pv;
+    }
+    for (int32_t j = n - 1; j >= 0; j--) {
+      R[nr] = (uint32_t)j;
+      nr += KXY(a[j]) <= pv;
+    }
+    const int32_t lim = nl < nr ? nl : nr;
+    int32_t k = 0;
+    while (k < lim && L[k] < R[k]) {
+      std::swap(a[L[k]], a[R[k]]);
+      k++;
+    }
+    if (k > 0) {
+      left = (int32_t)L[k - 1];
+      right = (int32_t)R[k - 1];
+    }
+  }
   while (left < right) {
     do {
       left++;
@@ -237,44 +267,121 @@ void ExactDelaunay::vertex_sort(uint64_t *a, int32_t n) {  // :5447, on packed (
   if (right < n - 2) vertex_sort(a + right + 1, n - right - 1);
 }
 
-// alternateaxes (:5583) for one node: bring the n>>1 smallest keys (by `axis`) to the front
-static inline void select_half(uint64_t *a, int32_t n, int axis) {
-  if (axis == 0)
-    std::nth_element(a, a + (n >> 1), a + n, [](uint64_t p, uint64_t q) { return KXY(p) < KXY(q); });
-  else
-    std::nth_element(a, a + (n >> 1), a + n, [](uint64_t p, uint64_t q) { return key_yx(p) < key_yx(q); });
+// alternateaxes (:5583) for the whole tree at once.  The reference re-partitions every node with a
+// randomised quick-select; for distinct points the outcome is just "the n>>1 smallest keys along
+// the node's axis go left, leaves (2-3 points) are ordered by x", so it is computed here the way
+// kd-trees are built from presorted lists: every node carries its points once in x order and once
+// in y order; a cut along one axis halves that list in place and stable-partitions the other
+// (one branch-free pass with an L1-resident rank lookup).  O(n) sequential work per level
+// instead of an nth_element per node.  Points are named by their rank in the (x,y)-sorted array.
+void ExactDelaunay::kd_order(int32_t m) {
+  xl_.resize(m);
+  yl_.resize(m);
+  yr_.resize(m);
+  tmp_.resize(m);
+  ord_.resize(m);
+  // y order: LSD radix sort of (y,x) (28 bits) carrying the x-rank
+  {
+    std::vector<uint64_t> &k0 = ybuf0_, &k1 = ybuf1_;
+    k0.resize(m);
+    k1.resize(m);
+    for (int32_t i = 0; i < m; i++) k0[i] = (key_yx(key_[i]) << 32) | (uint32_t)i;
+    uint64_t *src = k0.data(), *dst = k1.data();
+    for (int pass = 0; pass < 3; pass++) {
+      const int sh = 32 + pass * 10;
+      uint32_t cnt[1025] = {0};
+      for (int32_t i = 0; i < m; i++) cnt[((src[i] >> sh) & 1023) + 1]++;
+      for (int b = 0; b < 1024; b++) cnt[b + 1] += cnt[b];
+      for (int32_t i = 0; i < m; i++) dst[cnt[(src[i] >> sh) & 1023]++] = src[i];
+      std::swap(src, dst);
+    }
+    for (int32_t i = 0; i < m; i++) {
+      const uint32_t e = (uint32_t)(src[i] & 0xffffffffu);
+      yl_[i] = e;
+      yr_[e] = (uint32_t)i;
+    }
+  }
+  for (int32_t i = 0; i < m; i++) xl_[i] = (uint32_t)i;
+  // explicit stack of (offset, n, axis); lists of a node occupy [off, off+n) of xl_/yl_
+  struct Nd {
+    int32_t off, n, axis;
+  };
+  std::vector<Nd> st;
+  st.reserve(64);
+  st.push_back(Nd{0, m, 0});
+  const uint32_t *yr = yr_.data();
+  uint32_t *tmp = tmp_.data();
+  while (!st.empty()) {
+    const Nd nd = st.back();
+    st.pop_back();
+    uint32_t *xl = xl_.data() + nd.off, *yl = yl_.data() + nd.off;
+    if (nd.n <= 3) {
+      for (int32_t i = 0; i < nd.n; i++) ord_[nd.off + i] = xl[i];
+      continue;
+    }
+    const int32_t div = nd.n >> 1;
+    int32_t l = 0, r = 0;
+    if (nd.axis == 0) {  // cut in x: xl splits in place, yl is partitioned by x-rank
+      const uint32_t pivot = xl[div];
+      for (int32_t i = 0; i < nd.n; i++) {
+        const uint32_t e = yl[i];
+        const int left = e < pivot;
+        yl[l] = e;
+        tmp[r] = e;
+        l += left;
+        r += 1 - left;
+      }
+      memcpy(yl + l, tmp, (size_t)r * sizeof(uint32_t));
+    } else {  // cut in y
+      const uint32_t pivot = yr[yl[div]];
+      for (int32_t i = 0; i < nd.n; i++) {
+        const uint32_t e = xl[i];
+        const int left = yr[e] < pivot;
+        xl[l] = e;
+        tmp[r] = e;
+        l += left;
+        r += 1 - left;
+      }
+      memcpy(xl + l, tmp, (size_t)r * sizeof(uint32_t));
+    }
+    st.push_back(Nd{nd.off + div, nd.n - div, 1 - nd.axis});
+    st.push_back(Nd{nd.off, div, 1 - nd.axis});
+  }
+  // bring the keys into their final order
+  k2_.resize(m);
+  for (int32_t i = 0; i < m; i++) k2_[i] = key_[ord_[i]];
+  key_.swap(k2_);
 }
 
 void ExactDelaunay::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis,
                                 int32_t &tcur) {
-  const int32_t *y_ = ys_.data(), *x_ = xs_.data();
   int32_t ildest = dest(innerleft), ilapex = apex(innerleft);
   int32_t irorg = org(innerright), irapex = apex(innerright);
   if (axis == 1) {  // horizontal cut: handles move to the bottom-/top-most hull vertices (:5666)
     int32_t flpt = org(farleft), flapex = apex(farleft);
     int32_t frpt = dest(farright);
-    while (y_[flapex] < y_[flpt]) {
+    while (py(flapex) < py(flpt)) {
       farleft = sym(lnext(farleft));
       flpt = flapex;
       flapex = apex(farleft);
     }
     OTri chk = sym(innerleft);
     int32_t cv = apex(chk);
-    while (y_[cv] > y_[ildest]) {
+    while (py(cv) > py(ildest)) {
       innerleft = lnext(chk);
       ilapex = ildest;
       ildest = cv;
       chk = sym(innerleft);
       cv = apex(chk);
     }
-    while (y_[irapex] < y_[irorg]) {
+    while (py(irapex) < py(irorg)) {
       innerright = sym(lnext(innerright));
       irorg = irapex;
       irapex = apex(innerright);
     }
     chk = sym(farright);
     cv = apex(chk);
-    while (y_[cv] > y_[frpt]) {
+    while (py(cv) > py(frpt)) {
       farright = lnext(chk);
       frpt = cv;
       chk = sym(farright);
@@ -324,13 +431,13 @@ void ExactDelaunay::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright
         int32_t flpt = org(farleft), frpt = dest(farright), frapex = apex(farright);
         OTri chk = sym(farleft);
         int32_t cv = apex(chk);
-        while (x_[cv] < x_[flpt]) {
+        while (px(cv) < px(flpt)) {
           farleft = lprev(chk);
           flpt = cv;
           chk = sym(farleft);
           cv = apex(chk);
         }
-        while (x_[frapex] > x_[frpt]) {
+        while (px(frapex) > px(frpt)) {
           farright = sym(lprev(farright));
           frpt = frapex;
           frapex = apex(farright);
@@ -427,8 +534,7 @@ void ExactDelaunay::recurse(int32_t off, int32_t n, int axis, int32_t &tcur_unus
       if (KXY(a[0]) > KXY(a[1])) std::swap(a[0], a[1]);
     }
     for (int32_t i = 0; i < n; i++) {
-      xs_[off + i] = (int32_t)(a[i] >> 34);
-      ys_[off + i] = (int32_t)((a[i] >> 20) & 0x3fff);
+      pt_[off + i] = (uint32_t)(a[i] >> 34) | ((uint32_t)((a[i] >> 20) & 0x3fff) << 16);
       id_[off + i] = (int32_t)(a[i] & 0xfffff);
     }
     int32_t tcur = 2 * off;
@@ -507,10 +613,7 @@ void ExactDelaunay::recurse(int32_t off, int32_t n, int axis, int32_t &tcur_unus
     }
     return;
   }
-  const int32_t divider = n >> 1;
-  // children are cut along the other axis: order them first (alternateaxes(child, 1-axis))
-  if (divider > 3) select_half(a, divider, 1 - axis);
-  if (n - divider > 3) select_half(a + divider, n - divider, 1 - axis);
+  const int32_t divider = n >> 1;  // kd_order() has already arranged both halves
   OTri innerleft, innerright;
   int32_t dummy = 0;
   recurse(off, divider, 1 - axis, dummy, farleft, innerleft);
@@ -537,6 +640,7 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
   seed_ = 1;  // triangleinit(), :4031
   if (n < 2) return;
   key_.resize(n);
+  stop_.resize((size_t)2 * n);
   for (int32_t i = 0; i < n; i++) key_[i] = ((uint64_t)(uint32_t)x[i] << 34) | ((uint64_t)(uint32_t)y[i] << 20) | (uint32_t)i;
   uint64_t *a = key_.data();
   vertex_sort(a, n);
@@ -545,14 +649,14 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
     if (KXY(a[m]) != KXY(a[j])) a[++m] = a[j];
   m++;
   if (m < 2) return;
-  if ((size_t)m * 6 > nb_.size()) {
-    nb_.resize((size_t)m * 6);
-    vx_.resize((size_t)m * 6);
-  }
-  xs_.resize(m);
-  ys_.resize(m);
+  if ((size_t)m * 16 > tri_.size()) tri_.resize((size_t)m * 16);
+  pt_.resize(m);
   id_.resize(m);
-  for (int k = 0; k < 6; k++) vx_[(size_t)(2 * m - 2) * 3 + k] = -1;  // the two unused slots
+  for (int t = 2 * m - 2; t < 2 * m; t++)  // the two unused slots
+    for (int k = 0; k < 3; k++) tri_[(size_t)t * 8 + 4 + k] = -1;
+  key_.resize(m);
+  kd_order(m);
+  a = key_.data();
   OTri hl, hr;
   int32_t dummy = 0;
   const int nthreads = pool ? pool->size() : 1;
@@ -581,15 +685,7 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
       if (!internal.empty()) levels.push_back(internal);
       cur.swap(next);
     }
-    // top-down: order the children of every internal node (the root's slice is already x-sorted)
-    for (const auto &lv : levels)
-      pool->run((int)lv.size() * 2, [&](int t) {
-        const Node &nd = nodes_[lv[t >> 1]];
-        const Node &ch = nodes_[(t & 1) ? nd.right : nd.left];
-        if (ch.n > 3) select_half(key_.data() + ch.off, ch.n, ch.axis);
-      });
-    // the sub-trees below the task nodes: sequential, one per task.  A task node's own slice has
-    // been ordered by its parent; recurse() orders its children.
+    // the sub-trees below the task nodes: sequential, one per task
     pool->run((int)tasks.size(), [&](int t) {
       Node &nd = nodes_[tasks[t]];
       int32_t d2 = 0;
@@ -612,7 +708,7 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
   tri_out_.resize((size_t)2 * m * 3);
   const int32_t *idp = id_.data();
   for (int32_t t = 0; t < 2 * m; t++) {
-    const int32_t *v = &vx_[(size_t)t * 3];
+    const int32_t *v = &tri_[(size_t)t * 8 + 4];
     if ((v[0] | v[1] | v[2]) >= 0) {
       tri_out_[ntri_out_ * 3 + 0] = idp[v[1]];
       tri_out_[ntri_out_ * 3 + 1] = idp[v[2]];

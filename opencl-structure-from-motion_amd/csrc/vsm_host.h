@@ -98,48 +98,63 @@ class ExactDelaunay {
     OTri fl, fr;
   };
   std::vector<uint64_t> key_;         // (x << 34) | (y << 20) | input index
-  std::vector<int32_t> xs_, ys_, id_; // by sorted position
-  std::vector<int32_t> nb_, vx_, tri_out_;
+  std::vector<uint32_t> stop_;        // scratch of the branch-free partition
+  std::vector<uint32_t> xl_, yl_, yr_, tmp_, ord_;  // kd_order(): presorted lists, y-ranks
+  std::vector<uint64_t> ybuf0_, ybuf1_, k2_;
+  std::vector<uint32_t> pt_;          // by sorted position: x | y << 16
+  std::vector<int32_t> id_;           // by sorted position: input index
+  std::vector<int32_t> tri_, tri_out_;
   std::vector<Node> nodes_;
   int32_t ntri_out_ = 0;
   uint64_t seed_ = 1;
 
   uint32_t rnd(uint32_t choices);
   void vertex_sort(uint64_t *a, int32_t n);
-  static void alternate_axes(uint64_t *a, int32_t n, int axis);
+  void kd_order(int32_t m);
   void recurse(int32_t off, int32_t n, int axis, int32_t &tcur, OTri &farleft, OTri &farright);
   void merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis, int32_t &tcur);
   int32_t build_tree(int32_t off, int32_t n, int axis, int32_t tbase, int depth);
 
+  // one 32-byte record per triangle: tri_[t*8 + o] = neighbour handle across edge o,
+  // tri_[t*8 + 4 + o] = vertex o (-1 = ghost corner); pt_[p] = x | y << 16
   inline OTri make(int32_t &tcur) {
     const int32_t t = tcur++;
-    nb_[t * 3] = nb_[t * 3 + 1] = nb_[t * 3 + 2] = -1;
-    vx_[t * 3] = vx_[t * 3 + 1] = vx_[t * 3 + 2] = -1;
+    int32_t *r = &tri_[(size_t)t * 8];
+    r[0] = r[1] = r[2] = -1;
+    r[4] = r[5] = r[6] = -1;
     return OTri{t, 0};
   }
   inline OTri sym(OTri a) const {
-    int32_t e = nb_[a.t * 3 + a.o];
+    int32_t e = tri_[(size_t)a.t * 8 + a.o];
     return OTri{e >> 2, e & 3};
   }
   static inline OTri lnext(OTri a) { return OTri{a.t, a.o == 2 ? 0 : a.o + 1}; }
   static inline OTri lprev(OTri a) { return OTri{a.t, a.o == 0 ? 2 : a.o - 1}; }
-  inline int32_t org(OTri a) const { return vx_[a.t * 3 + (a.o == 2 ? 0 : a.o + 1)]; }
-  inline int32_t dest(OTri a) const { return vx_[a.t * 3 + (a.o == 0 ? 2 : a.o - 1)]; }
-  inline int32_t apex(OTri a) const { return vx_[a.t * 3 + a.o]; }
-  inline void set_org(OTri a, int32_t v) { vx_[a.t * 3 + (a.o == 2 ? 0 : a.o + 1)] = v; }
-  inline void set_dest(OTri a, int32_t v) { vx_[a.t * 3 + (a.o == 0 ? 2 : a.o - 1)] = v; }
-  inline void set_apex(OTri a, int32_t v) { vx_[a.t * 3 + a.o] = v; }
+  inline int32_t org(OTri a) const { return tri_[(size_t)a.t * 8 + 4 + (a.o == 2 ? 0 : a.o + 1)]; }
+  inline int32_t dest(OTri a) const { return tri_[(size_t)a.t * 8 + 4 + (a.o == 0 ? 2 : a.o - 1)]; }
+  inline int32_t apex(OTri a) const { return tri_[(size_t)a.t * 8 + 4 + a.o]; }
+  inline void set_org(OTri a, int32_t v) { tri_[(size_t)a.t * 8 + 4 + (a.o == 2 ? 0 : a.o + 1)] = v; }
+  inline void set_dest(OTri a, int32_t v) { tri_[(size_t)a.t * 8 + 4 + (a.o == 0 ? 2 : a.o - 1)] = v; }
+  inline void set_apex(OTri a, int32_t v) { tri_[(size_t)a.t * 8 + 4 + a.o] = v; }
   inline void bond(OTri a, OTri b) {
-    nb_[a.t * 3 + a.o] = b.t * 4 + b.o;
-    nb_[b.t * 3 + b.o] = a.t * 4 + a.o;
+    tri_[(size_t)a.t * 8 + a.o] = b.t * 4 + b.o;
+    tri_[(size_t)b.t * 8 + b.o] = a.t * 4 + a.o;
   }
+  inline int32_t px(int32_t p) const { return (int32_t)(pt_[p] & 0xffffu); }
+  inline int32_t py(int32_t p) const { return (int32_t)(pt_[p] >> 16); }
   // coordinates < 2^14: the orientation determinant fits int32, the in-circle one int64
   inline int32_t ccw(int32_t a, int32_t b, int32_t c) const {
-    return (xs_[a] - xs_[c]) * (ys_[b] - ys_[c]) - (ys_[a] - ys_[c]) * (xs_[b] - xs_[c]);
+    const uint32_t pa = pt_[a], pb = pt_[b], pc = pt_[c];
+    const int32_t cx = (int32_t)(pc & 0xffffu), cy = (int32_t)(pc >> 16);
+    return ((int32_t)(pa & 0xffffu) - cx) * ((int32_t)(pb >> 16) - cy) -
+           ((int32_t)(pa >> 16) - cy) * ((int32_t)(pb & 0xffffu) - cx);
   }
   inline int64_t incircle(int32_t a, int32_t b, int32_t c, int32_t d) const {
-    const int32_t adx = xs_[a] - xs_[d], ady = ys_[a] - ys_[d], bdx = xs_[b] - xs_[d], bdy = ys_[b] - ys_[d];
-    const int32_t cdx = xs_[c] - xs_[d], cdy = ys_[c] - ys_[d];
+    const uint32_t pa = pt_[a], pb = pt_[b], pc = pt_[c], pd = pt_[d];
+    const int32_t dx = (int32_t)(pd & 0xffffu), dy = (int32_t)(pd >> 16);
+    const int32_t adx = (int32_t)(pa & 0xffffu) - dx, ady = (int32_t)(pa >> 16) - dy;
+    const int32_t bdx = (int32_t)(pb & 0xffffu) - dx, bdy = (int32_t)(pb >> 16) - dy;
+    const int32_t cdx = (int32_t)(pc & 0xffffu) - dx, cdy = (int32_t)(pc >> 16) - dy;
     return (int64_t)(adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) +
            (int64_t)(bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) +
            (int64_t)(cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
