@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--frames", type=int, default=N_FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-per-frame", action="store_true", help="skip the per-frame API leg (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -146,15 +147,17 @@ def main():
     value = total_pairs / elapsed
 
     # ---- the same sequence through the per-frame (drop-in) entry points ---------------------
-    run_frames()
-    shard.barrier(dmod, dev)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    run_frames()
-    torch.cuda.synchronize()
-    pf_elapsed = time.perf_counter() - t1
-    pf_pairs, pf_elapsed, _ = shard.aggregate(dmod, torch, nf, pf_elapsed, dev)
-    per_frame_value = pf_pairs / pf_elapsed
+    per_frame_value = None
+    if not args.no_per_frame:
+        run_frames()
+        shard.barrier(dmod, dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_frames()
+        torch.cuda.synchronize()
+        pf_elapsed = time.perf_counter() - t1
+        pf_pairs, pf_elapsed, _ = shard.aggregate(dmod, torch, nf, pf_elapsed, dev)
+        per_frame_value = pf_pairs / pf_elapsed
 
     # ---- verification (outside the timed region): final lists vs the reference's hashes -----
     verified = None
@@ -164,7 +167,10 @@ def main():
         m.close()
         m = vm.Matcher()           # fresh ring buffer: frame 0 has no predecessor, like the fixture
         m.set_intrinsics(*intr)
-        run_frames(lists_pf)
+        if not args.no_per_frame:
+            run_frames(lists_pf)
+        else:
+            lists_pf = lists
         ok = all(len(l[f]) == int(g[key + "_counts"][f]) and sha(l[f]) == str(g[key + "_hashes"][f])
                  for f in range(nf) for l in (lists, lists_pf))
         _, _, verified = shard.aggregate(dmod, torch, 0, 0, dev, all_ok=bool(ok))
@@ -216,7 +222,7 @@ def main():
                                "default parameters, replayed Tr_delta feedback, look-ahead C-ABI entry point "
                                f"vsm_sequence_run (chunks of {chunk} frames)",
                    "frames_per_step": nf, "sequences": world, "inputs": "resident in HBM"},
-        "per_frame_api": {"value": round(per_frame_value, 3), "unit": "frame-pairs/s",
+        "per_frame_api": {"value": round(per_frame_value, 3) if per_frame_value else None, "unit": "frame-pairs/s",
                           "what": "same sequence through vsm_push_back_device + vsm_match per frame (drop-in "
                                   "Matcher::pushBack/matchFeatures path)"},
         "verified_bit_exact_vs_reference_hashes": verified,

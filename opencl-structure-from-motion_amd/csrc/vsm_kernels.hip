@@ -8,6 +8,8 @@
 // Semantics are those of the reference (pad bytes pinned to 0, filters on the 1-D byte stream);
 // file:line citations below refer to the reference repository.
 
+#include <stdlib.h>
+
 #include "vsm_internal.h"
 
 #define WAVE 64
@@ -294,6 +296,85 @@ __global__ void __launch_bounds__(256)
   c[1] = vmax ? (int32_t)(0x80000000u | (uint32_t)(mxi + u0) | ((uint32_t)(mxj + v0) << 14)) : 0;
 }
 
+// Tile variant for mid-size n (the sparse set, 5 <= n <= 10): 4 x 4 cells + halo in LDS, 8 lanes
+// per (cell, filter): the lanes stride over the cell / window pixels and combine with width-8
+// shuffles (min of (value, scan position) keys, OR of the suppression hits).
+#define NMS8_TC 4
+#define NMS8_MAXN 10
+__global__ void __launch_bounds__(256)
+    k_nms_tile8(const VsmImage *__restrict__ imgs, int first, VsmDims d, const int16_t *__restrict__ f1base,
+                const int16_t *__restrict__ f2base, size_t f_stride, int tau, int si) {
+  constexpr int MAXD = NMS8_TC * (NMS8_MAXN + 1) + 2 * NMS8_MAXN;  // 64
+  __shared__ int16_t s_f[2][MAXD][MAXD + 2];
+  const VsmSet &st = imgs[first + blockIdx.z].set[si];
+  const int n = st.nms_n, n1 = n + 1;
+  const int tiles_u = (st.ncu + NMS8_TC - 1) / NMS8_TC;
+  const int tu = blockIdx.x % tiles_u, tv = blockIdx.x / tiles_u;
+  const int cu0 = tu * NMS8_TC, cv0 = tv * NMS8_TC;
+  const int u0 = VSM_MARGIN + cu0 * n1, v0 = VSM_MARGIN + cv0 * n1;
+  const int tw = NMS8_TC * n1 + 2 * n;
+  const int16_t *__restrict__ f1 = f1base + (size_t)blockIdx.z * f_stride;
+  const int16_t *__restrict__ f2 = f2base + (size_t)blockIdx.z * f_stride;
+  for (int e = threadIdx.x; e < tw * tw; e += 256) {
+    const int y = e / tw, x = e - y * tw;
+    const int u = u0 + x, v = v0 + y;
+    const bool in = u < d.mbpl && v < d.mh;
+    s_f[0][y][x] = in ? f1[v * d.mbpl + u] : (int16_t)0;
+    s_f[1][y][x] = in ? f2[v * d.mbpl + u] : (int16_t)0;
+  }
+  __syncthreads();
+  const int l8 = threadIdx.x & 7, item = threadIdx.x >> 3;  // 32 items: 16 cells x 2 filters
+  const int k = item & 1, cl = item >> 1;
+  const int lcu = cl % NMS8_TC, lcv = cl / NMS8_TC;
+  const int ci = cu0 + lcu, cj = cv0 + lcv;
+  const bool live = ci < st.ncu && cj < st.ncv;  // dead items still take part in the shuffles
+  const int16_t(*f)[MAXD + 2] = s_f[k];
+  const int li = n + lcu * n1, lj = n + lcv * n1;
+  uint32_t kmin = 0xffffffffu, kmax = 0xffffffffu;
+  for (int e = l8; e < n1 * n1; e += 8) {
+    const int dj = e / n1, di = e - dj * n1;
+    const int val = f[lj + dj][li + di];
+    const uint32_t o = (uint32_t)(di * n1 + dj);
+    kmin = min(kmin, ((uint32_t)(val + 32768) << 10) | o);
+    kmax = min(kmax, ((uint32_t)(32767 - val) << 10) | o);
+  }
+#pragma unroll
+  for (int o = 4; o >= 1; o >>= 1) {
+    kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 8));
+    kmax = min(kmax, (uint32_t)__shfl_xor((int)kmax, o, 8));
+  }
+  const int mnv = (int)(kmin >> 10) - 32768, mno = kmin & 1023;
+  const int mxv = 32767 - (int)(kmax >> 10), mxo = kmax & 1023;
+  const int mni = li + mno / n1, mnj = lj + mno % n1, mxi = li + mxo / n1, mxj = lj + mxo % n1;
+  const int lim_i = d.mw - 1 - VSM_MARGIN - u0, lim_j = d.mh - 1 - VSM_MARGIN - v0;
+  const int W = 2 * n + 1;
+  auto suppressed = [&](int ci2, int cj2, int val, bool want_min) -> bool {
+    const int i_hi = min(ci2 + n, lim_i), j_hi = min(cj2 + n, lim_j);
+    int hit = 0;
+    for (int e = l8; e < W * W; e += 8) {
+      const int dj = e / W, di = e - dj * W;
+      const int i2 = ci2 - n + di, j2 = cj2 - n + dj;
+      if (i2 <= i_hi && j2 <= j_hi) {
+        const int cur = f[j2][i2];
+        const bool better = want_min ? (cur < val) : (cur > val);
+        hit |= (better && (i2 < li || i2 > li + n || j2 < lj || j2 > lj + n)) ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) hit |= __shfl_xor(hit, o, 8);
+    return hit != 0;
+  };
+  // both tests run unconditionally so that all 8 lanes of every item reach the shuffles together
+  const bool smin = suppressed(mni, mnj, mnv, true);
+  const bool smax = suppressed(mxi, mxj, mxv, false);
+  if (live && l8 == 0) {
+    const bool vmin = (mnv <= -tau) && !smin, vmax = (mxv >= tau) && !smax;
+    int32_t *c = st.cand + (size_t)(ci * st.ncv + cj) * 4 + 2 * k;
+    c[0] = vmin ? (int32_t)(0x80000000u | (uint32_t)(mni + u0) | ((uint32_t)(mnj + v0) << 14)) : 0;
+    c[1] = vmax ? (int32_t)(0x80000000u | (uint32_t)(mxi + u0) | ((uint32_t)(mxj + v0) << 14)) : 0;
+  }
+}
+
 // block-wide exclusive scan of one int per thread (blockDim.x == 1024); returns the exclusive
 // prefix and the block total.  Wave shuffles + one LDS hop.
 __device__ __forceinline__ int block_excl_scan_1024(int v, int &total, int *s_w /*[17]*/) {
@@ -493,29 +574,49 @@ __device__ __forceinline__ uint32_t sad32(const uint4 &a0, const uint4 &a1, cons
   return s;
 }
 
-template <int G>
-__device__ __forceinline__ int find_match(const VsmSet &A, int i1, const VsmSet &B, const VsmDims &d,
-                                          const VsmMatchCfg &cfg, const float *__restrict__ range, int stage, bool flow,
-                                          double u_, double v_, int lane) {
-  const int32_t *rec = A.feat + (size_t)i1 * 12;
+// the feature a chain stage starts from: position, class and 32-byte descriptor, in registers
+struct VsmQuery {
+  int u, v, c;
+  uint4 da, db;
+};
+
+__device__ __forceinline__ VsmQuery load_query(const VsmSet &A, int i) {
+  const int32_t *rec = A.feat + (size_t)i * 12;
   const int4 hd = *(const int4 *)rec;
-  const int u1 = hd.x, v1 = hd.y, c = hd.w;
-  const uint4 d1a = *(const uint4 *)(rec + 4), d1b = *(const uint4 *)(rec + 8);
+  VsmQuery q;
+  q.u = hd.x;
+  q.v = hd.y;
+  q.c = hd.w;
+  q.da = *(const uint4 *)(rec + 4);
+  q.db = *(const uint4 *)(rec + 8);
+  return q;
+}
+
+// One findMatch (viso/matcher.cpp:892-963) for the query held in `q` against feature set B.
+// Returns the winner's position in B's bin-sorted arrays (VSM_NONE if the window is empty) and
+// REPLACES q by the winner (the lane that found it broadcasts coordinates + descriptor with
+// width-G shuffles), so the next stage of the chain starts without going back to memory; the
+// winner's feature index is only looked up once, at the end of the chain.  An empty window
+// yields feature 0 of B like the reference (min_ind = 0, :898), class included.
+template <int G>
+__device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, const VsmDims &d, const VsmMatchCfg &cfg,
+                                               bool prior, float r_umin, float r_umax, float r_vmin, float r_vmax,
+                                               bool flow, double u_, double v_, int lane) {
   float u_min, u_max, v_min, v_max;
-  if (range) {
-    u_min = (float)u1 + range[stage];
-    u_max = (float)u1 + range[4 + stage];
-    v_min = (float)v1 + range[8 + stage];
-    v_max = (float)v1 + range[12 + stage];
+  if (prior) {
+    u_min = (float)q.u + r_umin;
+    u_max = (float)q.u + r_umax;
+    v_min = (float)q.v + r_vmin;
+    v_max = (float)q.v + r_vmax;
   } else {
-    u_min = (float)(u1 - cfg.radius);
-    u_max = (float)(u1 + cfg.radius);
-    v_min = (float)(v1 - cfg.radius);
-    v_max = (float)(v1 + cfg.radius);
+    u_min = (float)(q.u - cfg.radius);
+    u_max = (float)(q.u + cfg.radius);
+    v_min = (float)(q.v - cfg.radius);
+    v_max = (float)(q.v + cfg.radius);
   }
   if (!flow) {
-    v_min = (float)(v1 - cfg.disp_tol);
-    v_max = (float)(v1 + cfg.disp_tol);
+    v_min = (float)(q.v - cfg.disp_tol);
+    v_max = (float)(q.v + cfg.disp_tol);
   }
   const float bs = (float)cfg.binsize;
   const int ubmin = min(max((int)floorf(u_min / bs), 0), d.ub - 1);
@@ -525,27 +626,46 @@ __device__ __forceinline__ int find_match(const VsmSet &A, int i1, const VsmSet 
   const bool pred = (u_ >= 0 && v_ >= 0);
   double best = 10000000.0;
   uint32_t bestq = VSM_NONE;
+  int2 buv = make_int2(0, 0);
+  uint4 ba = make_uint4(0, 0, 0, 0), bb = make_uint4(0, 0, 0, 0);
   for (int ubin = ubmin; ubin <= ubmax; ubin++) {
-    const int b0 = (c * d.ub + ubin) * d.vb;
+    const int b0 = (q.c * d.ub + ubin) * d.vb;
     const int q0 = B.bin_start[b0 + vbmin], q1 = B.bin_start[b0 + vbmax + 1];
-    for (int q = q0 + lane; q < q1; q += G) {
-      const int2 uv = B.s_uv[q];
-      if ((float)uv.x >= u_min && (float)uv.x <= u_max && (float)uv.y >= v_min && (float)uv.y <= v_max) {
-        const uint4 a = B.s_desc[2 * q], b = B.s_desc[2 * q + 1];
-        double cost = (double)sad32(d1a, d1b, a, b);
-        if (pred) {
-          double du = (double)uv.x - u_;
-          double dv = (double)uv.y - v_;
-          double dist = sqrt(du * du + dv * dv);
-          cost += 4 * dist;
-        }
-        if (cost < best) {
-          best = cost;
-          bestq = (uint32_t)q;
+    // coordinates of the next 4 candidates of this lane are fetched together (most candidates
+    // fail the window test, so these loads are what the chain waits for); descriptors only for
+    // the ones inside the window.  Candidates are still judged in ascending position order.
+    for (int p0 = q0 + lane; p0 < q1; p0 += 4 * G) {
+      int2 uvk[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int p = p0 + k * G;
+        uvk[k] = p < q1 ? B.s_uv[p] : make_int2(-100000, -100000);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int p = p0 + k * G;
+        const int2 uv = uvk[k];
+        if (p < q1 && (float)uv.x >= u_min && (float)uv.x <= u_max && (float)uv.y >= v_min && (float)uv.y <= v_max) {
+          const uint4 a = B.s_desc[2 * p], b = B.s_desc[2 * p + 1];
+          double cost = (double)sad32(q.da, q.db, a, b);
+          if (pred) {
+            double du = (double)uv.x - u_;
+            double dv = (double)uv.y - v_;
+            double dist = sqrt(du * du + dv * dv);
+            cost += 4 * dist;
+          }
+          if (cost < best) {
+            best = cost;
+            bestq = (uint32_t)p;
+            buv = uv;
+            ba = a;
+            bb = b;
+          }
         }
       }
     }
   }
+  const uint32_t myq = bestq;
 #pragma unroll
   for (int m = G / 2; m >= 1; m >>= 1) {
     double oc = __shfl_xor(best, m, G);
@@ -555,7 +675,25 @@ __device__ __forceinline__ int find_match(const VsmSet &A, int i1, const VsmSet 
       bestq = oq;
     }
   }
-  return bestq == VSM_NONE ? 0 : B.s_idx[bestq];
+  if (bestq == VSM_NONE) {  // group-uniform
+    q = load_query(B, 0);
+    return VSM_NONE;
+  }
+  // the winner's lane (unique: positions are distinct) hands its candidate to the whole group
+  int wl = (myq == bestq) ? lane : 0;
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) wl |= __shfl_xor(wl, m, G);
+  q.u = __shfl(buv.x, wl, G);
+  q.v = __shfl(buv.y, wl, G);
+  q.da.x = (uint32_t)__shfl((int)ba.x, wl, G);
+  q.da.y = (uint32_t)__shfl((int)ba.y, wl, G);
+  q.da.z = (uint32_t)__shfl((int)ba.z, wl, G);
+  q.da.w = (uint32_t)__shfl((int)ba.w, wl, G);
+  q.db.x = (uint32_t)__shfl((int)bb.x, wl, G);
+  q.db.y = (uint32_t)__shfl((int)bb.y, wl, G);
+  q.db.z = (uint32_t)__shfl((int)bb.z, wl, G);
+  q.db.w = (uint32_t)__shfl((int)bb.w, wl, G);
+  return bestq;
 }
 
 __device__ __forceinline__ int stat_bin_of(int u, int v, int binsize, int ub, int vb) {
@@ -564,8 +702,10 @@ __device__ __forceinline__ int stat_bin_of(int u, int v, int binsize, int ub, in
   return vbin * ub + ubin;
 }
 
+__device__ __forceinline__ int index_of(const VsmSet &B, uint32_t pos) { return pos == VSM_NONE ? 0 : B.s_idx[pos]; }
+
 template <int G>
-__global__ void __launch_bounds__(256, 8)
+__global__ void __launch_bounds__(256)  // forcing more waves/SIMD only buys spills (measured)
     k_match(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
             VsmJob job0, VsmDims d, VsmMatchCfg cfg) {
   // blockIdx.y = frame pair of a batched launch (jobs == nullptr: the single pair `job0`)
@@ -578,31 +718,39 @@ __global__ void __launch_bounds__(256, 8)
   const int img_prev = jb.img_prev, img_curr = jb.img_curr;
   const VsmSet &s1p = imgs[img_prev].set[si], &s2p = imgs[img_prev + 1].set[si];
   const VsmSet &s1c = imgs[img_curr].set[si], &s2c = imgs[img_curr + 1].set[si];
+  const bool prior = cfg.use_prior != 0;
   vsm_p_match m;
   bool ok = false;
+  // the statistics bin of a chain is that of its start feature (:1020-1022, :1104-1106); its four
+  // per-stage boxes are fetched once
+  VsmQuery q = load_query(cfg.method == 2 ? s1p : s1c, qi);
+  float4 r_umin = make_float4(0, 0, 0, 0), r_umax = r_umin, r_vmin = r_umin, r_vmax = r_umin;
+  if (prior) {
+    const float4 *rg = (const float4 *)(pair.ranges + 16 * stat_bin_of(q.u, q.v, cfg.binsize, d.ub, d.vb));
+    r_umin = rg[0];
+    r_umax = rg[1];
+    r_vmin = rg[2];
+    r_vmax = rg[3];
+  }
+  const int u0 = q.u, v0 = q.v;
   if (cfg.method == 0) {  // flow, :1006-1041
-    const int4 q = *(const int4 *)(s1c.feat + (size_t)qi * 12);
-    const float *rg = cfg.use_prior ? pair.ranges + 16 * stat_bin_of(q.x, q.y, cfg.binsize, d.ub, d.vb) : nullptr;
-    int i1p = find_match<G>(s1c, qi, s1p, d, cfg, rg, 0, true, -1, -1, lane);
-    int i1c2 = find_match<G>(s1p, i1p, s1c, d, cfg, rg, 1, true, -1, -1, lane);
+    const uint32_t p1 = find_match<G>(q, s1p, d, cfg, prior, r_umin.x, r_umax.x, r_vmin.x, r_vmax.x, true, -1, -1, lane);
+    const int u1p = q.u, v1p = q.v;
+    const uint32_t p2 = find_match<G>(q, s1c, d, cfg, prior, r_umin.y, r_umax.y, r_vmin.y, r_vmax.y, true, -1, -1, lane);
+    const int i1p = index_of(s1p, p1), i1c2 = index_of(s1c, p2);
     ok = (i1c2 == qi);
-    const int4 p = *(const int4 *)(s1p.feat + (size_t)i1p * 12);
-    m = {(float)p.x, (float)p.y, i1p, -1.f, -1.f, -1, (float)q.x, (float)q.y, qi, -1.f, -1.f, -1};
+    m = {(float)u1p, (float)v1p, i1p, -1.f, -1.f, -1, (float)u0, (float)v0, qi, -1.f, -1.f, -1};
   } else if (cfg.method == 1) {  // stereo, :1045-1084
-    const int4 q = *(const int4 *)(s1c.feat + (size_t)qi * 12);
-    const float *rg = cfg.use_prior ? pair.ranges + 16 * stat_bin_of(q.x, q.y, cfg.binsize, d.ub, d.vb) : nullptr;
-    int i2c = find_match<G>(s1c, qi, s2c, d, cfg, rg, 0, false, -1, -1, lane);
-    int i1c2 = find_match<G>(s2c, i2c, s1c, d, cfg, rg, 1, false, -1, -1, lane);
-    const int4 p = *(const int4 *)(s2c.feat + (size_t)i2c * 12);
-    ok = (i1c2 == qi) && (q.x >= p.x);
-    m = {-1.f, -1.f, -1, -1.f, -1.f, -1, (float)q.x, (float)q.y, qi, (float)p.x, (float)p.y, i2c};
+    const uint32_t p1 = find_match<G>(q, s2c, d, cfg, prior, r_umin.x, r_umax.x, r_vmin.x, r_vmax.x, false, -1, -1, lane);
+    const int u2c = q.u, v2c = q.v;
+    const uint32_t p2 = find_match<G>(q, s1c, d, cfg, prior, r_umin.y, r_umax.y, r_vmin.y, r_vmax.y, false, -1, -1, lane);
+    const int i2c = index_of(s2c, p1), i1c2 = index_of(s1c, p2);
+    ok = (i1c2 == qi) && (u0 >= u2c);
+    m = {-1.f, -1.f, -1, -1.f, -1.f, -1, (float)u0, (float)v0, qi, (float)u2c, (float)v2c, i2c};
   } else {  // quad, :1088-1153
-    const int4 q = *(const int4 *)(s1p.feat + (size_t)qi * 12);
-    const int u1p = q.x, v1p = q.y;
-    const float *rg = cfg.use_prior ? pair.ranges + 16 * stat_bin_of(u1p, v1p, cfg.binsize, d.ub, d.vb) : nullptr;
-    int i2p = find_match<G>(s1p, qi, s2p, d, cfg, rg, 0, false, -1, -1, lane);
-    const int4 p2 = *(const int4 *)(s2p.feat + (size_t)i2p * 12);
-    const int u2p = p2.x, v2p = p2.y;
+    const int u1p = u0, v1p = v0;
+    const uint32_t p1 = find_match<G>(q, s2p, d, cfg, prior, r_umin.x, r_umax.x, r_vmin.x, r_vmax.x, false, -1, -1, lane);
+    const int u2p = q.u, v2p = q.v;
     double u2c_ = -1, v2c_ = -1, u1p_ = -1, v1p_ = -1;
     if (jb.use_tr) {  // :1114-1126, contraction-free double arithmetic
       double dd = (double)u1p - (double)u2p;
@@ -618,14 +766,16 @@ __global__ void __launch_bounds__(256, 8)
       u1p_ = (double)u1p;
       v1p_ = (double)v1p;
     }
-    int i2c = find_match<G>(s2p, i2p, s2c, d, cfg, rg, 1, true, u2c_, v2c_, lane);
-    int i1c = find_match<G>(s2c, i2c, s1c, d, cfg, rg, 2, false, -1, -1, lane);
-    int i1p2 = find_match<G>(s1c, i1c, s1p, d, cfg, rg, 3, true, u1p_, v1p_, lane);
-    const int4 c2 = *(const int4 *)(s2c.feat + (size_t)i2c * 12);
-    const int4 c1 = *(const int4 *)(s1c.feat + (size_t)i1c * 12);
-    ok = (i1p2 == qi) && (u1p >= u2p) && (c1.x >= c2.x);
-    m = {(float)u1p, (float)v1p, qi, (float)u2p, (float)v2p, i2p, (float)c1.x, (float)c1.y, i1c, (float)c2.x,
-         (float)c2.y, i2c};
+    const uint32_t p2 = find_match<G>(q, s2c, d, cfg, prior, r_umin.y, r_umax.y, r_vmin.y, r_vmax.y, true, u2c_, v2c_, lane);
+    const int u2c = q.u, v2c = q.v;
+    const uint32_t p3 = find_match<G>(q, s1c, d, cfg, prior, r_umin.z, r_umax.z, r_vmin.z, r_vmax.z, false, -1, -1, lane);
+    const int u1c = q.u, v1c = q.v;
+    const uint32_t p4 = find_match<G>(q, s1p, d, cfg, prior, r_umin.w, r_umax.w, r_vmin.w, r_vmax.w, true, u1p_, v1p_, lane);
+    const int i1p2 = index_of(s1p, p4);
+    ok = (i1p2 == qi) && (u1p >= u2p) && (u1c >= u2c);
+    if (ok)
+      m = {(float)u1p, (float)v1p, qi, (float)u2p, (float)v2p, index_of(s2p, p1), (float)u1c, (float)v1c,
+           index_of(s1c, p3), (float)u2c, (float)v2c, index_of(s2c, p2)};
   }
   if (lane == 0) {
     pair.flag[qi] = ok ? 1 : 0;
@@ -709,10 +859,9 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------------------------------
-// R1 refinement, viso/matcher.cpp:1498-1585.  32 lanes per (match, relocation step); lane
-// (dv*5+du) evaluates one of the 25 candidate positions with the 16-byte ELAS descriptor
-// (computeSmallDescriptor, :479-506) read from the full-resolution Sobel planes; first-wins
-// argmin = min over (cost, lane).  Steps: 0 -> (u1p,v1p) [flow, quad], 1 -> (u2c,v2c) [stereo,
+// R1 refinement, viso/matcher.cpp:1498-1585.  One thread per (match, relocation step) evaluates
+// the 25 candidate positions with the 16-byte ELAS descriptor (computeSmallDescriptor, :479-506)
+// from the full-resolution Sobel planes; first-wins argmin in (dv, du) order.  Steps: 0 -> (u1p,v1p) [flow, quad], 1 -> (u2c,v2c) [stereo,
 // quad], 2 -> (u2p,v2p) [quad]; each uses the unrefined (u1c,v1c) as its reference (:1544-1577).
 // refinement==2 (parabolicFitting, :1379-1454): 49 lanes of a wave evaluate the 7x7 costs, the
 // 3x3 neighbourhood around the minimum goes to the host, which solves the 9x6 least squares in
@@ -739,67 +888,73 @@ __device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b) {
 __global__ void __launch_bounds__(256)
     k_refine(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
              VsmJob job0, VsmDims dp, VsmDims dc, int method) {
-  // the 9 x 9 du/dv neighbourhood of the target (rows v2-4..v2+4, 12 aligned bytes per row that
-  // cover columns u2-4..u2+4) is staged once per (match, step) group: 54 dword loads instead of
-  // 25 x 16 byte gathers
-  __shared__ uint32_t s_win[8][2][9][3];
+  // One thread per (match, relocation step).  The 9 x 9 du / 7 x 9 dv neighbourhood of the target
+  // is pulled into registers with 48 independent dword loads (rows are 16-byte aligned, each row is
+  // re-based to column u2-4 with a funnel shift), then the 25 candidate descriptors are pure
+  // register byte-picks + v_sad_u8: no dependent gathers, no cross-lane traffic.
   const VsmJob &jb = jobs ? jobs[blockIdx.y] : job0;
   const VsmPair &pair = pairs[blockIdx.y];
-  const int img_prev = jb.img_prev, img_curr = jb.img_curr;
-  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int mi = g / 3, step = g - mi * 3;
-  bool active = mi < pair.count[1];
-  if (step == 0 && !(method == 0 || method == 2)) active = false;
-  if (step == 1 && !(method == 1 || method == 2)) active = false;
-  if (step == 2 && method != 2) active = false;
-  vsm_p_match *m = pair.list2 + (active ? mi : 0);  // refined in place (each step owns its two fields)
-  const VsmImage &ref = imgs[img_curr];
-  const VsmImage &tgt = step == 0 ? imgs[img_prev] : (step == 1 ? imgs[img_curr + 1] : imgs[img_prev + 1]);
+  if (mi >= pair.count[1]) return;
+  if (step == 0 && !(method == 0 || method == 2)) return;
+  if (step == 1 && !(method == 1 || method == 2)) return;
+  if (step == 2 && method != 2) return;
+  vsm_p_match *m = pair.list2 + mi;  // refined in place (each step owns its two fields)
+  const VsmImage &ref = imgs[jb.img_curr];
+  const VsmImage &tgt = step == 0 ? imgs[jb.img_prev] : (step == 1 ? imgs[jb.img_curr + 1] : imgs[jb.img_prev + 1]);
   const VsmDims &dt = step == 1 ? dc : dp;
   float *pu = step == 0 ? &m->u1p : (step == 1 ? &m->u2c : &m->u2p);
   float *pv = pu + 1;
-  float u2 = 0, v2 = 0;
-  if (active) {
-    u2 = *pu;
-    v2 = *pv;
-    if (u2 - 2 < VSM_MARGIN || u2 + 2 > dt.w - 1 - VSM_MARGIN || v2 - 2 < VSM_MARGIN || v2 + 2 > dt.h - 1 - VSM_MARGIN)
-      active = false;
-  }
+  const float u2 = *pu, v2 = *pv;
+  if (u2 - 2 < VSM_MARGIN || u2 + 2 > dt.w - 1 - VSM_MARGIN || v2 - 2 < VSM_MARGIN || v2 + 2 > dt.h - 1 - VSM_MARGIN)
+    return;
   const int iu = (int)u2, iv = (int)v2;
-  const int a0 = (iu - 4) & ~3;  // first staged column (4-byte aligned; rows are 16-byte aligned)
-  if (active) {
-    for (int e = lane; e < 54; e += 32) {
-      const int pl = e / 27, r = (e - pl * 27) / 3, q = e % 3;
-      const uint8_t *base = pl ? tgt.dv_full : tgt.du_full;
-      s_win[grp][pl][r][q] = *(const uint32_t *)(base + (size_t)(iv - 4 + r) * dt.bpl + a0 + 4 * q);
+  const int a0 = (iu - 4) & ~3, sh = 8 * ((iu - 4) - a0);
+  uint32_t U[9][3], V[9][3];
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const uint32_t *pr = (const uint32_t *)(tgt.du_full + (size_t)(iv - 4 + r) * dt.bpl + a0);
+    const uint32_t d0 = pr[0], d1 = pr[1], d2 = pr[2];
+    U[r][0] = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+    U[r][1] = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
+    U[r][2] = d2 >> sh;
+    if (r >= 1 && r <= 7) {
+      const uint32_t *qr = (const uint32_t *)(tgt.dv_full + (size_t)(iv - 4 + r) * dt.bpl + a0);
+      const uint32_t e0 = qr[0], e1 = qr[1], e2 = qr[2];
+      V[r][0] = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
+      V[r][1] = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
+      V[r][2] = e2 >> sh;
+    } else {
+      V[r][0] = V[r][1] = V[r][2] = 0;
     }
   }
-  __syncthreads();
-  if (!active) return;
-  const uint4 r = small_desc(ref.du_full, ref.dv_full, dc.bpl, (int)m->u1c, (int)m->v1c);
-  uint32_t key = 0xffffffffu;
-  if (lane < 25) {
-    const int ddv = lane / 5, ddu = lane - ddv * 5;
-    // candidate centre (cu, cv) in window coordinates: column = u - a0, row = v - (iv-4)
-    const int cx = iu + ddu - 2 - a0, cy = ddv + 2;
-    const uint8_t *wu = (const uint8_t *)&s_win[grp][0][0][0], *wv = (const uint8_t *)&s_win[grp][1][0][0];
-    auto U = [&](int dy, int dx) -> uint32_t { return wu[(cy + dy) * 12 + cx + dx]; };
-    auto V = [&](int dy, int dx) -> uint32_t { return wv[(cy + dy) * 12 + cx + dx]; };
-    uint4 t;
-    t.x = U(-2, 0) | (U(-1, -2) << 8) | (U(-1, 0) << 16) | (U(-1, 2) << 24);
-    t.y = U(0, -1) | (U(0, 0) << 8) | (U(0, 0) << 16) | (U(0, 1) << 24);
-    t.z = U(1, -2) | (U(1, 0) << 8) | (U(1, 2) << 16) | (U(2, 0) << 24);
-    t.w = V(-1, 0) | (V(0, -1) << 8) | (V(0, 1) << 16) | (V(1, 0) << 24);
-    key = (sad16(r, t) << 5) | (uint32_t)lane;
-  }
+  const uint4 rd = small_desc(ref.du_full, ref.dv_full, dc.bpl, (int)m->u1c, (int)m->v1c);
+#define UB(r, c) ((U[(r)][(c) >> 2] >> (8 * ((c)&3))) & 0xffu)
+#define VB(r, c) ((V[(r)][(c) >> 2] >> (8 * ((c)&3))) & 0xffu)
+  uint32_t best = 0xffffffffu;
+  int ind = 0;
 #pragma unroll
-  for (int o = 16; o >= 1; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o, 32));
-  if (lane == 0) {
-    const int ind = key & 31;
-    *pu = (float)((double)u2 + ((double)(float)(ind % 5) - 2.0));
-    *pv = (float)((double)v2 + ((double)(float)(ind / 5) - 2.0));
+  for (int ddv = 0; ddv < 5; ddv++) {
+#pragma unroll
+    for (int ddu = 0; ddu < 5; ddu++) {
+      const int r = ddv + 2, c = ddu + 2;  // candidate centre in window coordinates
+      uint4 t;
+      t.x = UB(r - 2, c) | (UB(r - 1, c - 2) << 8) | (UB(r - 1, c) << 16) | (UB(r - 1, c + 2) << 24);
+      t.y = UB(r, c - 1) | (UB(r, c) << 8) | (UB(r, c) << 16) | (UB(r, c + 1) << 24);
+      t.z = UB(r + 1, c - 2) | (UB(r + 1, c) << 8) | (UB(r + 1, c + 2) << 16) | (UB(r + 2, c) << 24);
+      t.w = VB(r - 1, c) | (VB(r, c - 1) << 8) | (VB(r, c + 1) << 16) | (VB(r + 1, c) << 24);
+      const uint32_t cost = sad16(rd, t);
+      if (cost < best) {  // first minimum in (dv, du) order, viso/matcher.cpp:1484-1491
+        best = cost;
+        ind = ddv * 5 + ddu;
+      }
+    }
   }
+#undef UB
+#undef VB
+  *pu = (float)((double)u2 + ((double)(float)(ind % 5) - 2.0));
+  *pv = (float)((double)v2 + ((double)(float)(ind / 5) - 2.0));
 }
 
 __global__ void __launch_bounds__(256)
@@ -912,6 +1067,10 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
         tiled[k] = true;
         hipLaunchKernelGGL(k_nms_tile, dim3(cdiv(st.ncu, NMS_TCU) * cdiv(st.ncv, NMS_TCV), 1, n_img), dim3(256), 0, s,
                            d_imgs, first, d, f1, f2, f_stride, nms_tau, k);
+      } else if (st.nms_n <= NMS8_MAXN && st.ncu * st.ncv > 0) {
+        tiled[k] = true;
+        hipLaunchKernelGGL(k_nms_tile8, dim3(cdiv(st.ncu, NMS8_TC) * cdiv(st.ncv, NMS8_TC), 1, n_img), dim3(256), 0, s,
+                           d_imgs, first, d, f1, f2, f_stride, nms_tau, k);
       }
     }
     const int lo = tiled[0] ? 1 : set_lo, hi = tiled[1] ? 0 : 1;  // wave kernel handles sets lo..hi
@@ -947,12 +1106,29 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
 // pass: 0 = sparse lists (list1/hlist1/count[0]), 1 = dense lists.  max_nq bounds nq[pass].
 void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
                       const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq) {
-  constexpr int G = 16;
+  // lanes per query: the chain is latency-bound per wavefront, so big batches want many
+  // queries per wave (G = 2..4) and a lone frame pair wants more lanes per query (G = 8).
+  // VSM_MATCH_G overrides (2, 4, 8, 16) for experiments.
+  static int Genv = -1;
+  if (Genv < 0) {
+    const char *e = getenv("VSM_MATCH_G");
+    Genv = e ? atoi(e) : 0;
+    if (Genv != 0 && Genv != 2 && Genv != 4 && Genv != 8 && Genv != 16) Genv = 0;
+  }
+  const long total_q = (long)npairs * max_nq;
+  const int G = Genv ? Genv : (total_q >= 200000 ? 2 : (total_q >= 30000 ? 4 : 8));
   const int pass = cfg.sparse ? 0 : 1;
   if (max_nq > 0) {
     pf.begin(cfg.sparse ? VSM_K_MATCH1 : VSM_K_MATCH2, s);
-    hipLaunchKernelGGL(k_match<G>, dim3(cdiv(max_nq * G, 256), npairs), dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0,
-                       d, cfg);
+    const dim3 grid(cdiv(max_nq * G, 256), npairs);
+    if (G == 2)
+      hipLaunchKernelGGL(k_match<2>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg);
+    else if (G == 4)
+      hipLaunchKernelGGL(k_match<4>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg);
+    else if (G == 16)
+      hipLaunchKernelGGL(k_match<16>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg);
+    else
+      hipLaunchKernelGGL(k_match<8>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg);
     pf.end(s);
   }
   const int nblk = max(cdiv(max_nq, 256), 1);
@@ -979,7 +1155,7 @@ void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const
     hipLaunchKernelGGL(k_parabolic_costs, dim3(cdiv(n_upper * 3 * 64, 256), npairs), dim3(256), 0, s, d_imgs, d_pairs,
                        d_jobs, job0, dp, dc, method);
   else
-    hipLaunchKernelGGL(k_refine, dim3(cdiv(n_upper * 3 * 32, 256), npairs), dim3(256), 0, s, d_imgs, d_pairs, d_jobs,
-                       job0, dp, dc, method);
+    hipLaunchKernelGGL(k_refine, dim3(cdiv(n_upper * 3, 256), npairs), dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0,
+                       dp, dc, method);
   pf.end(s);
 }
