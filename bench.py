@@ -52,8 +52,10 @@ def algorithmic_bytes(kernel, counts):
         return 48 * counts["Q"] + 8 * counts["C"] + 32 * counts["S"] + 48 * counts["Mraw"]
     if kernel == "k_refine":             # 3 relocations x 26 descriptors x 16 B per match
         return 1248 * counts["M"]
-    if kernel == "k_nms":                # f1,f2 read once per set
-        return counts["imgs"] * 2 * (4 * Ph * Hh)
+    if kernel.startswith("k_nms"):       # f1,f2 read once per set
+        return counts["imgs"] * (4 * Ph * Hh)
+    if kernel == "k_emit":               # 32 B descriptor gather + 48 B record per feature
+        return counts["imgs"] * 80 * counts.get("N", 0)
     return None
 
 
@@ -75,10 +77,19 @@ def main():
     rank, local_rank, world = shard.rank_info()
     if world != args.gpus:
         print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev        # (more ranks than GPUs only happens in rehearsals)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    comm_dev = dev
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if world <= ndev:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI: one rank per GPU
+        else:
+            # rehearsal on a box with fewer GPUs than ranks (RCCL refuses two ranks on one GPU):
+            # the few bytes of aggregation go over gloo instead
+            dist.init_process_group("gloo")
+            comm_dev = torch.device("cpu")
 
     # host threads for the exact Delaunay stage: this rank's share of the CPUs the job may use
     # (cgroup quota if there is one -- more spinning threads than that only get throttled)
@@ -131,7 +142,7 @@ def main():
 
     for _ in range(args.warmup):
         run_sequence()
-    shard.barrier(dmod, dev)
+    shard.barrier(dmod, comm_dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     step_ms = []
@@ -140,23 +151,23 @@ def main():
         run_sequence()
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
     torch.cuda.synchronize()
-    shard.barrier(dmod, dev)
+    shard.barrier(dmod, comm_dev)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    total_pairs, elapsed, _ = shard.aggregate(dmod, torch, nf * args.steps, elapsed, dev)
+    total_pairs, elapsed, _ = shard.aggregate(dmod, torch, nf * args.steps, elapsed, comm_dev)
     value = total_pairs / elapsed
 
     # ---- the same sequence through the per-frame (drop-in) entry points ---------------------
     per_frame_value = None
     if not args.no_per_frame:
         run_frames()
-        shard.barrier(dmod, dev)
+        shard.barrier(dmod, comm_dev)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         run_frames()
         torch.cuda.synchronize()
         pf_elapsed = time.perf_counter() - t1
-        pf_pairs, pf_elapsed, _ = shard.aggregate(dmod, torch, nf, pf_elapsed, dev)
+        pf_pairs, pf_elapsed, _ = shard.aggregate(dmod, torch, nf, pf_elapsed, comm_dev)
         per_frame_value = pf_pairs / pf_elapsed
 
     # ---- verification (outside the timed region): final lists vs the reference's hashes -----
@@ -173,7 +184,7 @@ def main():
             lists_pf = lists
         ok = all(len(l[f]) == int(g[key + "_counts"][f]) and sha(l[f]) == str(g[key + "_hashes"][f])
                  for f in range(nf) for l in (lists, lists_pf))
-        _, _, verified = shard.aggregate(dmod, torch, 0, 0, dev, all_ok=bool(ok))
+        _, _, verified = shard.aggregate(dmod, torch, 0, 0, comm_dev, all_ok=bool(ok))
 
     if rank != 0:
         if world > 1:
@@ -186,7 +197,8 @@ def main():
     torch.cuda.synchronize()
     stats = m.kernel_stats()
     m.set_profiling(False)
-    dom = max(stats, key=lambda k: stats[k][0])
+    # dominant kernel on the HBM side (k_export_list is a PCIe copy into pinned host memory)
+    dom = max((k for k in stats if k != "k_export_list"), key=lambda k: stats[k][0])
     dom_ms, dom_n = stats[dom]
     # per-launch work counters of the dominant kernel from one representative frame pair
     # (features/candidates are stationary over this sequence)
@@ -198,21 +210,27 @@ def main():
     work = None
     if not args.no_cpu_baseline:
         cpu, work = cpu_baseline(host, tr_in, tr_valid, intr)
-    if work is not None:
-        pairs = (nf - 1) / n_launch                  # frame pairs per launch
-        if dom.endswith("pass1"):
-            counts.update(Q=work["Q1"] * pairs, C=work["C1"] * pairs, S=work["S1"] * pairs, Mraw=work["M1"] * pairs)
-        else:
-            counts.update(Q=work["Q2"] * pairs, C=work["C2"] * pairs, S=work["S2"] * pairs, Mraw=work["M"] * pairs)
-        counts["M"] = work["M"] * pairs
-    roof = None
-    ab = algorithmic_bytes(dom, counts) if (work is not None or not dom.startswith(("k_match", "k_refine"))) else None
-    if ab is not None and dom_n > 0:
-        avg_s = dom_ms / dom_n / 1e3
-        achieved = ab / avg_s / 1e9
-        roof = dict(bound="hbm", kernel=dom, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, avg_launch_us=round(dom_ms / dom_n * 1e3, 3),
+    def roofline_of(kname):
+        ms, nl = stats[kname]
+        c2 = dict(counts)
+        if work is not None:
+            pairs = (nf - 1) / n_launch
+            w1 = kname.endswith("pass1")
+            c2.update(Q=work["Q1" if w1 else "Q2"] * pairs, C=work["C1" if w1 else "C2"] * pairs,
+                      S=work["S1" if w1 else "S2"] * pairs, Mraw=work["M1" if w1 else "M"] * pairs, M=work["M"] * pairs,
+                      N=work["N"])
+        elif kname.startswith(("k_match", "k_refine", "k_emit")):
+            return None
+        ab = algorithmic_bytes(kname, c2)
+        if ab is None or nl == 0:
+            return None
+        achieved = ab / (ms / nl / 1e3) / 1e9
+        return dict(bound="hbm", kernel=kname, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, avg_launch_us=round(ms / nl * 1e3, 3),
                     algorithmic_bytes_per_launch=int(ab))
+
+    roof = roofline_of(dom)
+    roof_all = {k: r for k in stats if stats[k][1] for r in [roofline_of(k)] if r}
     out = {
         "metric": "stereo frame-pairs/sec (1242x375) through pushBack+matchFeatures(2), p_matched bit-exact",
         "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -227,6 +245,8 @@ def main():
                                   "Matcher::pushBack/matchFeatures path)"},
         "verified_bit_exact_vs_reference_hashes": verified,
         "roofline": roof,
+        "roofline_by_kernel": {k: {"achieved_GBps": r["achieved"], "frac": r["frac"], "avg_launch_us": r["avg_launch_us"]}
+                               for k, r in roof_all.items()},
         "cpu_baseline": cpu,
         "kernel_ms_per_frame": {k: round(v[0] / nf, 5) for k, v in stats.items() if v[1]},
         "kernel_avg_launch_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in stats.items() if v[1]},
@@ -267,7 +287,7 @@ def cpu_baseline(host, tr_in, tr_valid, intr, budget_s=20.0):
         om.match(2, tr_in[f] if tr_valid[f] else None)
     c = om.counters()
     work = dict(Q1=c["Q1"], C1=c["C1"], S1=c["S1"], Q2=c["Q"] - c["Q1"], C2=c["C"] - c["C1"], S2=c["S"] - c["S1"],
-                M1=len(om.stage(0)), M=int(c["M"]))
+                M1=len(om.stage(0)), M=int(c["M"]), N=len(om.features("1c1")) + len(om.features("1c2")))
     om.close()
     return (dict(value=round(n / dt, 3), unit="frame-pairs/s", cores=1, kind=kind,
                  sample=f"first {n} frames of the same sequence, pushBack+matchFeatures(2), 1 thread"), work)

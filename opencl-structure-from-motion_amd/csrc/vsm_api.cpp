@@ -305,6 +305,8 @@ struct vsm_handle {
   std::vector<std::vector<vsm_p_match>> seq_matches;
   double seq_timings[4] = {0, 0, 0, 0};
 
+  uint8_t *stage_host = nullptr;  // pinned staging for host images
+  size_t stage_bytes = 0;
   VsmProf prof;
   VsmPool *pool = nullptr;
   VsmForkJoin *fj = nullptr;
@@ -369,6 +371,7 @@ void vsm_destroy(vsm_handle *h) {
   (void)hipStreamSynchronize(h->stream);
   ctx_destroy(h->ring);
   ctx_destroy(h->seq);
+  if (h->stage_host) (void)hipHostFree(h->stage_host);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h->pool;
   delete h->fj;
@@ -427,10 +430,24 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
   const int n_img = I2 ? 2 : 1;
   if (on_device) {
     vsm_launch_ingest(h->stream, h->prof, c.d_imgs, slot * 2, I1, I2, 0, bpl, 1, c.dims);
-  } else {  // pageable source: HIP stages the rows
-    HIPCHK(hipMemcpy2DAsync(c.h_imgs[slot * 2].img, c.dims.bpl, I1, bpl, w, hh, hipMemcpyHostToDevice, h->stream));
-    if (I2)
-      HIPCHK(hipMemcpy2DAsync(c.h_imgs[slot * 2 + 1].img, c.dims.bpl, I2, bpl, w, hh, hipMemcpyHostToDevice, h->stream));
+  } else {
+    // Host images: rows go through our own pinned, pre-padded staging buffer (a pageable 2-D copy
+    // is staged row by row by the runtime and costs milliseconds).  The caller's buffer is free as
+    // soon as the memcpy below returns; the staging buffer is reused only after settle().
+    const size_t plane = (size_t)c.dims.bpl * hh;
+    if (h->stage_bytes < 2 * plane) {
+      if (h->stage_host) (void)hipHostFree(h->stage_host);
+      HIPCHK(hipHostMalloc((void **)&h->stage_host, 2 * plane, hipHostMallocDefault));
+      memset(h->stage_host, 0, 2 * plane);  // pad columns stay 0
+      h->stage_bytes = 2 * plane;
+    }
+    const uint8_t *srcs[2] = {I1, I2};
+    for (int k = 0; k < n_img; k++) {
+      uint8_t *st = h->stage_host + k * plane;
+      // only the w image bytes of a row are taken; pad bytes are 0 by definition
+      for (int32_t v = 0; v < hh; v++) memcpy(st + (size_t)v * c.dims.bpl, srcs[k] + (size_t)v * bpl, w);
+      HIPCHK(hipMemcpyAsync(c.h_imgs[slot * 2 + k].img, st, plane, hipMemcpyHostToDevice, h->stream));
+    }
   }
   vsm_launch_features(h->stream, h->prof, c.d_imgs, slot * 2, n_img, c.dims, c.f1, c.f2, c.f_stride, h->param.nms_tau,
                       h->param.multi_stage, h->param.half_resolution, h->param.match_binsize, c.h_imgs.data());
@@ -443,10 +460,10 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
   h->f_valid = true;
   h->gainI[0].clear();
   h->gainI[1].clear();
-  // Host images: the caller may free or overwrite them as soon as we return (matcherMex does),
-  // so the transfer must have completed.  Device-resident images: the push stays asynchronous and
-  // is settled by the next call that needs its results (the source must stay valid until then).
-  return on_device ? VSM_OK : settle(h);
+  // Host images were copied into the staging buffer, so the caller may free or overwrite them as
+  // soon as we return (matcherMex does).  Device-resident images: the source must stay valid until
+  // the next call that needs the push's results settles it.  Either way the push is asynchronous.
+  return VSM_OK;
 }
 
 int vsm_push_back(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int32_t w, int32_t hh, int32_t bpl, int replace) {
@@ -922,7 +939,7 @@ int32_t vsm_get_filter_responses(vsm_handle *h, int16_t *f1, int16_t *f2) {
 }
 
 static const char *kKernelNames[VSM_K_COUNT] = {
-    "k_ingest", "k_halve", "k_filters<true>", "k_filters<false>", "k_nms", "k_scan_cells", "k_emit", "k_bin_scan",
+    "k_ingest", "k_halve", "k_filters<true>", "k_filters<false>", "k_nms:dense", "k_nms:sparse", "k_scan_cells", "k_emit", "k_bin_scan",
     "k_bin_scatter", "k_bin_rank", "k_match<16>:pass1", "k_compact_matches:pass1", "k_match<16>:pass2",
     "k_compact_matches:pass2", "k_refine", "k_export_list"};
 

@@ -80,7 +80,7 @@ struct VsmPair {
 // Optional per-kernel timing with HIP events recorded on the handle's own stream (bench.py's
 // roofline leg).  Off by default: events cost a few microseconds per launch.
 enum VsmKernelId {
-  VSM_K_INGEST = 0, VSM_K_HALVE, VSM_K_SOBEL_FULL, VSM_K_FILTERS, VSM_K_NMS, VSM_K_SCAN, VSM_K_EMIT, VSM_K_BINSCAN, VSM_K_BINSCATTER, VSM_K_BINRANK,
+  VSM_K_INGEST = 0, VSM_K_HALVE, VSM_K_SOBEL_FULL, VSM_K_FILTERS, VSM_K_NMS, VSM_K_NMS_SPARSE, VSM_K_SCAN, VSM_K_EMIT, VSM_K_BINSCAN, VSM_K_BINSCATTER, VSM_K_BINRANK,
   VSM_K_MATCH1, VSM_K_COMPACT1, VSM_K_MATCH2, VSM_K_COMPACT2, VSM_K_REFINE, VSM_K_EXPORT, VSM_K_COUNT
 };
 struct VsmProf {

@@ -75,11 +75,12 @@ __global__ void __launch_bounds__(256) k_halve(const VsmImage *__restrict__ imgs
 //   du,dv : filter::sobel5x5, viso/filter.cpp:316-324 (+128, >>7, unsigned saturate)
 //   f1    : filter::blob5x5,  viso/filter.cpp:343-365  (-box5 + 2*box3 + 7*centre)
 //   f2    : filter::checkerboard5x5, viso/filter.cpp:331-336 (c (x) c, c = 1,1,0,-1,-1)
-// One thread produces 4 horizontally adjacent pixels from a 5 x 12 byte window held in
-// registers (15 dword loads, neighbours hit L1/L2); outputs are one dword of du, one of dv and,
-// for the matching-resolution image, 8 bytes each of f1 and f2.
-// FULL = true: full-resolution image -> du_full,dv_full only.
+// One thread produces a 4 x 4 pixel patch from an 8-row x 12-byte window held packed in 24
+// registers (24 dword loads for 16 pixels; horizontal neighbours share lines in L1); per patch
+// row it stores one dword of du, one of dv and, for the matching-resolution image, 8 bytes each
+// of f1 and f2.  FULL = true: full-resolution image -> du_full,dv_full only.
 // ---------------------------------------------------------------------------------------
+#define FPB(r, i) ((int)((Wn[(r)][(i) >> 2] >> (8 * ((i)&3))) & 0xffu))
 template <bool FULL>
 __global__ void __launch_bounds__(256)
     k_filters(const VsmImage *__restrict__ imgs, int first, int bpl, int h, int16_t *__restrict__ f1base,
@@ -87,73 +88,79 @@ __global__ void __launch_bounds__(256)
   const VsmImage &im = imgs[first + blockIdx.z];
   const uint8_t *__restrict__ in = FULL ? im.img : im.imgm;
   const int n = bpl * h;
-  const int f0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (f0 >= n) return;
-  int p[5][12];
+  const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;  // 64 x 4 threads per block: 256 px x 16 rows
+  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+  if (x4 >= bpl || y0 >= h) return;
+  // window rows y0-2 .. y0+5, stream bytes x4-4 .. x4+7 of each
+  uint32_t Wn[8][3];
 #pragma unroll
-  for (int r = 0; r < 5; r++) {
-    int base = f0 + (r - 2) * bpl;
+  for (int r = 0; r < 8; r++) {
+    const int base = (y0 + r - 2) * bpl + x4;
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-      int a = base + (q - 1) * 4;
-      uint32_t v = (a >= 0 && a < n) ? *(const uint32_t *)(in + a) : 0u;
-      p[r][q * 4 + 0] = v & 0xff;
-      p[r][q * 4 + 1] = (v >> 8) & 0xff;
-      p[r][q * 4 + 2] = (v >> 16) & 0xff;
-      p[r][q * 4 + 3] = v >> 24;
+      const int a = base + (q - 1) * 4;
+      Wn[r][q] = (a >= 0 && a < n) ? *(const uint32_t *)(in + a) : 0u;
     }
   }
-  // column pass at stream positions f0-2 .. f0+5 (window index 2..9); zero outside rows [2,h-3]
-  int S[8], D[8];
   const int lo = 2 * bpl, hi = (h - 2) * bpl;
+  uint8_t *__restrict__ odu = FULL ? im.du_full : im.du;
+  uint8_t *__restrict__ odv = FULL ? im.dv_full : im.dv;
+  int16_t *f1 = FULL ? nullptr : f1base + (size_t)blockIdx.z * f_stride;
+  int16_t *f2 = FULL ? nullptr : f2base + (size_t)blockIdx.z * f_stride;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    int g = f0 + i - 2;
-    bool ok = g >= lo && g < hi;
-    int a = p[0][i + 2], b = p[1][i + 2], c = p[2][i + 2], dd = p[3][i + 2], e = p[4][i + 2];
-    S[i] = ok ? a + 4 * b + 6 * c + 4 * dd + e : 0;
-    D[i] = ok ? a + 2 * b - 2 * dd - e : 0;
-  }
-  uint32_t du = 0, dv = 0;
+  for (int rr = 0; rr < 4; rr++) {
+    const int y = y0 + rr;
+    if (y >= h) break;
+    const int f0 = y * bpl + x4;
+    // column pass at stream positions f0-2 .. f0+5 (window index 2..9); zero outside rows [2,h-3]
+    int S[8], D[8];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    int hu = S[k] + 2 * S[k + 1] - 2 * S[k + 3] - S[k + 4];
-    int hv = D[k] + 4 * D[k + 1] + 6 * D[k + 2] + 4 * D[k + 3] + D[k + 4];
-    int u8 = min(max((hu >> 7) + 128, 0), 255);
-    int v8 = min(max((hv >> 7) + 128, 0), 255);
-    du |= (uint32_t)u8 << (8 * k);
-    dv |= (uint32_t)v8 << (8 * k);
-  }
-  *(uint32_t *)((FULL ? im.du_full : im.du) + f0) = du;
-  *(uint32_t *)((FULL ? im.dv_full : im.dv) + f0) = dv;
-  if (!FULL) {
-    const int y = f0 / bpl, x0 = f0 - y * bpl;
-    int16_t o1[4], o2[4];
+    for (int i = 0; i < 8; i++) {
+      const int g = f0 + i - 2;
+      const bool ok = g >= lo && g < hi;
+      const int a = FPB(rr, i + 2), b = FPB(rr + 1, i + 2), c = FPB(rr + 2, i + 2), dd = FPB(rr + 3, i + 2),
+                e = FPB(rr + 4, i + 2);
+      S[i] = ok ? a + 4 * b + 6 * c + 4 * dd + e : 0;
+      D[i] = ok ? a + 2 * b - 2 * dd - e : 0;
+    }
+    uint32_t du = 0, dv = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      int i = 4 + k, x = x0 + k;
-      int b5 = 0, b3 = 0, ck = 0;
-#pragma unroll
-      for (int r = 0; r < 5; r++) {
-        int r3 = p[r][i - 1] + p[r][i] + p[r][i + 1];
-        int r5 = r3 + p[r][i - 2] + p[r][i + 2];
-        int rd = p[r][i - 2] + p[r][i - 1] - p[r][i + 1] - p[r][i + 2];
-        b5 += r5;
-        if (r >= 1 && r <= 3) b3 += r3;
-        ck += (r < 2) ? rd : (r > 2 ? -rd : 0);
-      }
-      bool in1 = x >= 3 && x <= bpl - 3 && y >= 3 && y <= h - 3;
-      bool in2 = x >= 2 && x <= bpl - 3 && y >= 2 && y <= h - 3;
-      o1[k] = in1 ? (int16_t)(-b5 + 2 * b3 + 7 * p[2][i]) : (int16_t)0;
-      o2[k] = in2 ? (int16_t)ck : (int16_t)0;
+      const int hu = S[k] + 2 * S[k + 1] - 2 * S[k + 3] - S[k + 4];
+      const int hv = D[k] + 4 * D[k + 1] + 6 * D[k + 2] + 4 * D[k + 3] + D[k + 4];
+      du |= (uint32_t)min(max((hu >> 7) + 128, 0), 255) << (8 * k);
+      dv |= (uint32_t)min(max((hv >> 7) + 128, 0), 255) << (8 * k);
     }
-    int16_t *f1 = f1base + (size_t)blockIdx.z * f_stride, *f2 = f2base + (size_t)blockIdx.z * f_stride;
-    *(uint2 *)(f1 + f0) = make_uint2((uint16_t)o1[0] | ((uint32_t)(uint16_t)o1[1] << 16),
-                                     (uint16_t)o1[2] | ((uint32_t)(uint16_t)o1[3] << 16));
-    *(uint2 *)(f2 + f0) = make_uint2((uint16_t)o2[0] | ((uint32_t)(uint16_t)o2[1] << 16),
-                                     (uint16_t)o2[2] | ((uint32_t)(uint16_t)o2[3] << 16));
+    *(uint32_t *)(odu + f0) = du;
+    *(uint32_t *)(odv + f0) = dv;
+    if (!FULL) {
+      int16_t o1[4], o2[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = 4 + k, x = x4 + k;
+        int b5 = 0, b3 = 0, ck = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+          const int r3 = FPB(rr + r, i - 1) + FPB(rr + r, i) + FPB(rr + r, i + 1);
+          const int r5 = r3 + FPB(rr + r, i - 2) + FPB(rr + r, i + 2);
+          const int rd = FPB(rr + r, i - 2) + FPB(rr + r, i - 1) - FPB(rr + r, i + 1) - FPB(rr + r, i + 2);
+          b5 += r5;
+          if (r >= 1 && r <= 3) b3 += r3;
+          ck += (r < 2) ? rd : (r > 2 ? -rd : 0);
+        }
+        const bool in1 = x >= 3 && x <= bpl - 3 && y >= 3 && y <= h - 3;
+        const bool in2 = x >= 2 && x <= bpl - 3 && y >= 2 && y <= h - 3;
+        o1[k] = in1 ? (int16_t)(-b5 + 2 * b3 + 7 * FPB(rr + 2, i)) : (int16_t)0;
+        o2[k] = in2 ? (int16_t)ck : (int16_t)0;
+      }
+      *(uint2 *)(f1 + f0) = make_uint2((uint16_t)o1[0] | ((uint32_t)(uint16_t)o1[1] << 16),
+                                       (uint16_t)o1[2] | ((uint32_t)(uint16_t)o1[3] << 16));
+      *(uint2 *)(f2 + f0) = make_uint2((uint16_t)o2[0] | ((uint32_t)(uint16_t)o2[1] << 16),
+                                       (uint16_t)o2[2] | ((uint32_t)(uint16_t)o2[3] << 16));
+    }
   }
 }
+#undef FPB
 
 // ---------------------------------------------------------------------------------------
 // N1 nonMaximumSuppression, viso/matcher.cpp:330-431 (Neubeck & Van Gool alg. 4).
@@ -1042,12 +1049,12 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
     hipLaunchKernelGGL(k_halve, dim3(cdiv(d.mbpl / 4, 256), d.mh, n_img), dim3(256), 0, s, d_imgs, first, d);
     pf.end(s);
     pf.begin(VSM_K_SOBEL_FULL, s);
-    hipLaunchKernelGGL(k_filters<true>, dim3(cdiv(d.bpl * d.h / 4, 256), 1, n_img), dim3(256), 0, s, d_imgs, first,
+    hipLaunchKernelGGL(k_filters<true>, dim3(cdiv(d.bpl / 4, 64), cdiv(d.h, 16), n_img), dim3(256), 0, s, d_imgs, first,
                        d.bpl, d.h, (int16_t *)nullptr, (int16_t *)nullptr, (size_t)0);
     pf.end(s);
   }
   pf.begin(VSM_K_FILTERS, s);
-  hipLaunchKernelGGL(k_filters<false>, dim3(cdiv(d.mbpl * d.mh / 4, 256), 1, n_img), dim3(256), 0, s, d_imgs, first,
+  hipLaunchKernelGGL(k_filters<false>, dim3(cdiv(d.mbpl / 4, 64), cdiv(d.mh, 16), n_img), dim3(256), 0, s, d_imgs, first,
                      d.mbpl, d.mh, f1, f2, f_stride);
   pf.end(s);
   const int set_lo = multi_stage ? 0 : 1;
@@ -1058,30 +1065,22 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
     max_cap = max(max_cap, h_imgs[first].set[k].cap);
   }
   if (max_cells > 0) {
-    pf.begin(VSM_K_NMS, s);
-    // sets whose n fits the LDS tile kernel go there, the others to the wave-per-cell kernel
-    bool tiled[2] = {false, false};
+    // per set: small n -> LDS tile kernel, mid n -> 8-lane LDS tile kernel, else wave per cell
     for (int k = set_lo; k < 2; k++) {
       const VsmSet &st = h_imgs[first].set[k];
-      if (st.nms_n <= NMS_TILE_MAXN && st.ncu * st.ncv > 0) {
-        tiled[k] = true;
+      if (st.ncu * st.ncv <= 0) continue;
+      pf.begin(k == 1 ? VSM_K_NMS : VSM_K_NMS_SPARSE, s);
+      if (st.nms_n <= NMS_TILE_MAXN)
         hipLaunchKernelGGL(k_nms_tile, dim3(cdiv(st.ncu, NMS_TCU) * cdiv(st.ncv, NMS_TCV), 1, n_img), dim3(256), 0, s,
                            d_imgs, first, d, f1, f2, f_stride, nms_tau, k);
-      } else if (st.nms_n <= NMS8_MAXN && st.ncu * st.ncv > 0) {
-        tiled[k] = true;
+      else if (st.nms_n <= NMS8_MAXN)
         hipLaunchKernelGGL(k_nms_tile8, dim3(cdiv(st.ncu, NMS8_TC) * cdiv(st.ncv, NMS8_TC), 1, n_img), dim3(256), 0, s,
                            d_imgs, first, d, f1, f2, f_stride, nms_tau, k);
-      }
+      else
+        hipLaunchKernelGGL(k_nms, dim3(cdiv(st.ncu * st.ncv, 4), 2, n_img * 2), dim3(256), 0, s, d_imgs, first, d, f1, f2,
+                           f_stride, nms_tau, k, k);
+      pf.end(s);
     }
-    const int lo = tiled[0] ? 1 : set_lo, hi = tiled[1] ? 0 : 1;  // wave kernel handles sets lo..hi
-    if (lo <= hi) {
-      int mc = 0;
-      for (int k = lo; k <= hi; k++) mc = max(mc, h_imgs[first].set[k].ncu * h_imgs[first].set[k].ncv);
-      if (mc > 0)
-        hipLaunchKernelGGL(k_nms, dim3(cdiv(mc, 4), 2, n_img * 2), dim3(256), 0, s, d_imgs, first, d, f1, f2, f_stride,
-                           nms_tau, lo, hi);
-    }
-    pf.end(s);
   }
   pf.begin(VSM_K_SCAN, s);
   hipLaunchKernelGGL(k_scan_cells, dim3(1, 2, n_img), dim3(1024), 0, s, d_imgs, first, set_lo, nb);
