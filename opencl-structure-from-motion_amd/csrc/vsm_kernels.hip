@@ -14,6 +14,15 @@
 
 #define WAVE 64
 
+// XCD-aware block remap (MI355X: 8 XCDs, each with a private 4 MiB L2; hardware deals blocks
+// round-robin over the XCDs).  Batched launches are flattened to 1-D and logical block
+// L = (b % 8) * ceil(n/8) + b / 8, so every XCD walks one contiguous eighth of the (pair-major)
+// work and the eight L2s stop fetching the same image lines.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int b, int nblocks) {
+  const int per = (nblocks + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+
 // ---------------------------------------------------------------------------------------
 // ingest: caller image (row stride src_bpl) -> padded HBM copy [h][bpl], pad bytes = 0
 // (Matcher::pushBack row copy, viso/matcher.cpp:163-175, with the pad pinned to 0)
@@ -241,19 +250,22 @@ __global__ void __launch_bounds__(256) k_nms(const VsmImage *__restrict__ imgs, 
 #define NMS_TILE_MAXN 4
 __global__ void __launch_bounds__(256)
     k_nms_tile(const VsmImage *__restrict__ imgs, int first, VsmDims d, const int16_t *__restrict__ f1base,
-               const int16_t *__restrict__ f2base, size_t f_stride, int tau, int si) {
+               const int16_t *__restrict__ f2base, size_t f_stride, int tau, int si, int nbx, int n_img) {
   constexpr int MAXW = NMS_TCU * (NMS_TILE_MAXN + 1) + 2 * NMS_TILE_MAXN;  // 88
   constexpr int MAXH = NMS_TCV * (NMS_TILE_MAXN + 1) + 2 * NMS_TILE_MAXN;  // 48
   __shared__ int16_t s_f[2][MAXH][MAXW + 2];
-  const VsmSet &st = imgs[first + blockIdx.z].set[si];
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int zi = lb / nbx, bx = lb - zi * nbx;  // (image, tile)
+  if (zi >= n_img) return;
+  const VsmSet &st = imgs[first + zi].set[si];
   const int n = st.nms_n, n1 = n + 1;
   const int tiles_u = (st.ncu + NMS_TCU - 1) / NMS_TCU;
-  const int tu = blockIdx.x % tiles_u, tv = blockIdx.x / tiles_u;
+  const int tu = bx % tiles_u, tv = bx / tiles_u;
   const int cu0 = tu * NMS_TCU, cv0 = tv * NMS_TCV;
   const int u0 = VSM_MARGIN + cu0 * n1, v0 = VSM_MARGIN + cv0 * n1;  // = first cell origin - n
   const int tw = NMS_TCU * n1 + 2 * n, th = NMS_TCV * n1 + 2 * n;
-  const int16_t *__restrict__ f1 = f1base + (size_t)blockIdx.z * f_stride;
-  const int16_t *__restrict__ f2 = f2base + (size_t)blockIdx.z * f_stride;
+  const int16_t *__restrict__ f1 = f1base + (size_t)zi * f_stride;
+  const int16_t *__restrict__ f2 = f2base + (size_t)zi * f_stride;
   for (int e = threadIdx.x; e < tw * th; e += 256) {
     const int y = e / tw, x = e - y * tw;
     const int u = u0 + x, v = v0 + y;
@@ -310,18 +322,21 @@ __global__ void __launch_bounds__(256)
 #define NMS8_MAXN 10
 __global__ void __launch_bounds__(256)
     k_nms_tile8(const VsmImage *__restrict__ imgs, int first, VsmDims d, const int16_t *__restrict__ f1base,
-                const int16_t *__restrict__ f2base, size_t f_stride, int tau, int si) {
+                const int16_t *__restrict__ f2base, size_t f_stride, int tau, int si, int nbx, int n_img) {
   constexpr int MAXD = NMS8_TC * (NMS8_MAXN + 1) + 2 * NMS8_MAXN;  // 64
   __shared__ int16_t s_f[2][MAXD][MAXD + 2];
-  const VsmSet &st = imgs[first + blockIdx.z].set[si];
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int zi = lb / nbx, bx = lb - zi * nbx;  // (image, tile)
+  if (zi >= n_img) return;
+  const VsmSet &st = imgs[first + zi].set[si];
   const int n = st.nms_n, n1 = n + 1;
   const int tiles_u = (st.ncu + NMS8_TC - 1) / NMS8_TC;
-  const int tu = blockIdx.x % tiles_u, tv = blockIdx.x / tiles_u;
+  const int tu = bx % tiles_u, tv = bx / tiles_u;
   const int cu0 = tu * NMS8_TC, cv0 = tv * NMS8_TC;
   const int u0 = VSM_MARGIN + cu0 * n1, v0 = VSM_MARGIN + cv0 * n1;
   const int tw = NMS8_TC * n1 + 2 * n;
-  const int16_t *__restrict__ f1 = f1base + (size_t)blockIdx.z * f_stride;
-  const int16_t *__restrict__ f2 = f2base + (size_t)blockIdx.z * f_stride;
+  const int16_t *__restrict__ f1 = f1base + (size_t)zi * f_stride;
+  const int16_t *__restrict__ f2 = f2base + (size_t)zi * f_stride;
   for (int e = threadIdx.x; e < tw * tw; e += 256) {
     const int y = e / tw, x = e - y * tw;
     const int u = u0 + x, v = v0 + y;
@@ -465,13 +480,17 @@ __device__ __forceinline__ int bin_of(int u, int v, int c, int binsize, int ub, 
 }
 
 __global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs, int first, VsmDims d, int set_lo,
-                                              int binsize) {
-  const VsmImage &im = imgs[first + blockIdx.z];
+                                              int binsize, int nbx, int n_img) {
+  // (plain round-robin placement: the XCD-contiguous remap made this scatter-heavy kernel slower)
+  const int lb = blockIdx.x;
+  const int zi = lb / nbx, bx = lb - zi * nbx;
+  if (zi >= n_img) return;
+  const VsmImage &im = imgs[first + zi];
   const int si = blockIdx.y;
   if (si < set_lo) return;
   const VsmSet &st = im.set[si];
   // 16 lanes per cell (4 cells per wavefront); lane j < 12 writes dword j of each record
-  const int cell = (blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int cell = (bx * 256 + threadIdx.x) >> 4;
   if (cell >= st.ncu * st.ncv) return;
   const int j = threadIdx.x & 15;
   const int4 c4 = *(const int4 *)(st.cand + (size_t)cell * 4);
@@ -714,12 +733,16 @@ __device__ __forceinline__ int index_of(const VsmSet &B, uint32_t pos) { return 
 template <int G>
 __global__ void __launch_bounds__(256)  // forcing more waves/SIMD only buys spills (measured)
     k_match(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
-            VsmJob job0, VsmDims d, VsmMatchCfg cfg) {
-  // blockIdx.y = frame pair of a batched launch (jobs == nullptr: the single pair `job0`)
-  const VsmJob &jb = jobs ? jobs[blockIdx.y] : job0;
-  const VsmPair &pair = pairs[blockIdx.y];
+            VsmJob job0, VsmDims d, VsmMatchCfg cfg, int nbx, int npairs) {
+  // flattened grid: logical block -> (frame pair, block within pair), XCD-contiguous
+  // (jobs == nullptr: the single pair `job0`)
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int pj = lb / nbx, bx = lb - pj * nbx;
+  if (pj >= npairs) return;
+  const VsmJob &jb = jobs ? jobs[pj] : job0;
+  const VsmPair &pair = pairs[pj];
   const int lane = threadIdx.x & (G - 1);
-  const int qi = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int qi = (bx * blockDim.x + threadIdx.x) / G;
   const int si = cfg.sparse ? 0 : 1;
   if (qi >= jb.nq[si]) return;
   const int img_prev = jb.img_prev, img_curr = jb.img_curr;
@@ -894,14 +917,18 @@ __device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b) {
 
 __global__ void __launch_bounds__(256)
     k_refine(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
-             VsmJob job0, VsmDims dp, VsmDims dc, int method) {
+             VsmJob job0, VsmDims dp, VsmDims dc, int method, int nbx, int npairs) {
   // One thread per (match, relocation step).  The 9 x 9 du / 7 x 9 dv neighbourhood of the target
   // is pulled into registers with 48 independent dword loads (rows are 16-byte aligned, each row is
   // re-based to column u2-4 with a funnel shift), then the 25 candidate descriptors are pure
   // register byte-picks + v_sad_u8: no dependent gathers, no cross-lane traffic.
-  const VsmJob &jb = jobs ? jobs[blockIdx.y] : job0;
-  const VsmPair &pair = pairs[blockIdx.y];
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  // flattened grid: logical block -> (pair, block within pair), XCD-contiguous
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int pj = lb / nbx, bx = lb - pj * nbx;
+  if (pj >= npairs) return;
+  const VsmJob &jb = jobs ? jobs[pj] : job0;
+  const VsmPair &pair = pairs[pj];
+  const int g = bx * blockDim.x + threadIdx.x;
   const int mi = g / 3, step = g - mi * 3;
   if (mi >= pair.count[1]) return;
   if (step == 0 && !(method == 0 || method == 2)) return;
@@ -1070,12 +1097,15 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
       const VsmSet &st = h_imgs[first].set[k];
       if (st.ncu * st.ncv <= 0) continue;
       pf.begin(k == 1 ? VSM_K_NMS : VSM_K_NMS_SPARSE, s);
-      if (st.nms_n <= NMS_TILE_MAXN)
-        hipLaunchKernelGGL(k_nms_tile, dim3(cdiv(st.ncu, NMS_TCU) * cdiv(st.ncv, NMS_TCV), 1, n_img), dim3(256), 0, s,
-                           d_imgs, first, d, f1, f2, f_stride, nms_tau, k);
-      else if (st.nms_n <= NMS8_MAXN)
-        hipLaunchKernelGGL(k_nms_tile8, dim3(cdiv(st.ncu, NMS8_TC) * cdiv(st.ncv, NMS8_TC), 1, n_img), dim3(256), 0, s,
-                           d_imgs, first, d, f1, f2, f_stride, nms_tau, k);
+      if (st.nms_n <= NMS_TILE_MAXN) {
+        const int nbx = cdiv(st.ncu, NMS_TCU) * cdiv(st.ncv, NMS_TCV);
+        hipLaunchKernelGGL(k_nms_tile, dim3(((nbx * n_img + 7) / 8) * 8), dim3(256), 0, s, d_imgs, first, d, f1, f2, f_stride,
+                           nms_tau, k, nbx, n_img);
+      } else if (st.nms_n <= NMS8_MAXN) {
+        const int nbx = cdiv(st.ncu, NMS8_TC) * cdiv(st.ncv, NMS8_TC);
+        hipLaunchKernelGGL(k_nms_tile8, dim3(((nbx * n_img + 7) / 8) * 8), dim3(256), 0, s, d_imgs, first, d, f1, f2, f_stride,
+                           nms_tau, k, nbx, n_img);
+      }
       else
         hipLaunchKernelGGL(k_nms, dim3(cdiv(st.ncu * st.ncv, 4), 2, n_img * 2), dim3(256), 0, s, d_imgs, first, d, f1, f2,
                            f_stride, nms_tau, k, k);
@@ -1087,7 +1117,9 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
   pf.end(s);
   if (max_cells > 0) {
     pf.begin(VSM_K_EMIT, s);
-    hipLaunchKernelGGL(k_emit, dim3(cdiv(max_cells, 16), 2, n_img), dim3(256), 0, s, d_imgs, first, d, set_lo, binsize);
+    const int nbx = cdiv(max_cells, 16);
+    hipLaunchKernelGGL(k_emit, dim3(((nbx * n_img + 7) / 8) * 8, 2), dim3(256), 0, s, d_imgs, first, d, set_lo, binsize, nbx,
+                       n_img);
     pf.end(s);
   }
   pf.begin(VSM_K_BINSCAN, s);
@@ -1119,15 +1151,16 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
   const int pass = cfg.sparse ? 0 : 1;
   if (max_nq > 0) {
     pf.begin(cfg.sparse ? VSM_K_MATCH1 : VSM_K_MATCH2, s);
-    const dim3 grid(cdiv(max_nq * G, 256), npairs);
+    const int nbx = cdiv(max_nq * G, 256);
+    const dim3 grid(((nbx * npairs + 7) / 8) * 8);
     if (G == 2)
-      hipLaunchKernelGGL(k_match<2>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg);
+      hipLaunchKernelGGL(k_match<2>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
     else if (G == 4)
-      hipLaunchKernelGGL(k_match<4>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg);
+      hipLaunchKernelGGL(k_match<4>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
     else if (G == 16)
-      hipLaunchKernelGGL(k_match<16>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg);
+      hipLaunchKernelGGL(k_match<16>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
     else
-      hipLaunchKernelGGL(k_match<8>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg);
+      hipLaunchKernelGGL(k_match<8>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
     pf.end(s);
   }
   const int nblk = max(cdiv(max_nq, 256), 1);
@@ -1154,7 +1187,9 @@ void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const
     hipLaunchKernelGGL(k_parabolic_costs, dim3(cdiv(n_upper * 3 * 64, 256), npairs), dim3(256), 0, s, d_imgs, d_pairs,
                        d_jobs, job0, dp, dc, method);
   else
-    hipLaunchKernelGGL(k_refine, dim3(cdiv(n_upper * 3, 256), npairs), dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0,
-                       dp, dc, method);
+  {
+    const int nbx = cdiv(n_upper * 3, 256), tot = ((nbx * npairs + 7) / 8) * 8;
+    hipLaunchKernelGGL(k_refine, dim3(tot), dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, dp, dc, method, nbx, npairs);
+  }
   pf.end(s);
 }
