@@ -210,6 +210,16 @@ def main():
     work = None
     if not args.no_cpu_baseline:
         cpu, work = cpu_baseline(host, tr_in, tr_valid, intr)
+    # HBM traffic per launch from the committed rocprofv3 PMC summary of this same command
+    # (tools/pmc_summary.py; PMC passes cannot run inside the timed process)
+    pmc = {}
+    try:
+        import csv
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_lookahead_pmc_hbm.csv"))):
+            pmc[r["bench_name"]] = int(float(r["traffic_bytes_per_launch"]))
+    except Exception:
+        pass
+
     def roofline_of(kname):
         ms, nl = stats[kname]
         c2 = dict(counts)
@@ -226,7 +236,7 @@ def main():
             return None
         achieved = ab / (ms / nl / 1e3) / 1e9
         return dict(bound="hbm", kernel=kname, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, avg_launch_us=round(ms / nl * 1e3, 3),
+                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=pmc.get(kname), avg_launch_us=round(ms / nl * 1e3, 3),
                     algorithmic_bytes_per_launch=int(ab))
 
     roof = roofline_of(dom)

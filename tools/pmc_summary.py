@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 PMC passes into profiles/<tag>_pmc_hbm.csv.
+
+  python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.csv>
+
+The two inputs come from SEPARATE runs (`rocprofv3 --pmc FETCH_SIZE --kernel-trace ...` and
+`--pmc WRITE_SIZE ...`; FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950) of
+`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-per-frame`.
+traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch: on gfx950 FETCH_SIZE reports half
+of the bytes of wide streaming reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
+`bench_name` is the kernel's name in bench.py's kernel tables.
+"""
+import collections
+import csv
+import sys
+
+NAMES = {"k_match<2>": "k_match<16>:pass2", "k_match<4>": "k_match<16>:pass1", "k_nms_tile": "k_nms:dense",
+         "k_nms_tile8": "k_nms:sparse", "k_compact_write": "k_compact_matches"}
+
+
+def agg(path, counter):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") == counter:
+            d[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in d.items()}
+
+
+f = agg(sys.argv[1], "FETCH_SIZE")
+w = agg(sys.argv[2], "WRITE_SIZE")
+with open(sys.argv[3], "w") as o:
+    o.write("kernel,bench_name,avg_FETCH_SIZE_raw_KB,avg_WRITE_SIZE_raw_KB,dispatches,traffic_bytes_per_launch\n")
+    for k in sorted(set(f) | set(w)):
+        if k.startswith("__amd"):
+            continue
+        a, b = f.get(k, (0, 0)), w.get(k, (0, 0))
+        o.write(f"{k},{NAMES.get(k, k)},{a[0]:.2f},{b[0]:.2f},{a[1]},{(2 * a[0] + b[0]) * 1024:.0f}\n")
+print("wrote", sys.argv[3])
