@@ -234,3 +234,44 @@ def test_sequence_api_fallbacks(vm, B, synth):
             c.match(meth)
             assert _same(got[f], c.matches()), (kw, f)
         g.close()
+
+
+def test_degenerate_inputs(vm, B, synth):
+    """no features / no cells / tiny images: same silent behaviour as the oracle, no faults"""
+    flat = np.full((120, 200), 77, dtype=np.uint8)
+    l, r = synth.stereo_sequence(2, 200, 120, 1)[0]
+    for imgs in ([(flat, flat), (flat, flat)],                      # constant: no feature at all
+                 [(l, r), (flat, flat), (l, r)],                    # features appear / vanish / reappear
+                 [(l[:30, :40].copy(), r[:30, :40].copy())] * 2,    # too small for a single sparse cell
+                 [(l[:14, :14].copy(), r[:14, :14].copy())] * 2):   # smaller than the margins
+        g, c = vm.Matcher(stage_capture=True), B.CpuMatcher("oracle")
+        for a, b in imgs:
+            assert g.push_back(a, b) == 0
+            c.push_back(a, b)
+            for s in ("1c1", "1c2", "2c1", "2c2"):
+                assert _same(g.features(s), c.features(s))
+            for meth in (2, 1, 0):
+                assert g.match(meth) == c.match(meth)
+                assert _same(g.matches(), c.matches())
+        got = vm.Matcher().run_sequence(np.stack([a for a, _ in imgs]), np.stack([b for _, b in imgs]), 2)
+        c2 = B.CpuMatcher("oracle")
+        for f, (a, b) in enumerate(imgs):
+            c2.push_back(a, b)
+            c2.match(2)
+            assert _same(got[f], c2.matches())
+        g.close()
+
+
+def test_mono_then_stereo_and_replace_first(vm, B, synth):
+    """ring-buffer corner cases: replace on an empty matcher, mono pushes between stereo pushes"""
+    seq = synth.stereo_sequence(4, 320, 128, 4)
+    g, c = vm.Matcher(stage_capture=True), B.CpuMatcher("oracle")
+    steps = [(0, True, True), (1, True, False), (2, False, False), (3, True, False)]  # (frame, stereo?, replace?)
+    for f, stereo, rep in steps:
+        l, r = seq[f]
+        g.push_back(l, r if stereo else None, replace=rep)
+        c.push_back(l, r if stereo else None, replace=rep)
+        for meth in (0, 1, 2):
+            assert g.match(meth) == c.match(meth), (f, meth)
+            assert _same(g.matches(), c.matches()), (f, meth)
+    g.close()
