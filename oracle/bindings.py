@@ -118,6 +118,23 @@ def oracle_lib():
         L.vo_nms.argtypes = [_p_i16, _p_i16] + [C.c_int32] * 5 + [_p_i32, C.c_int32]
         L.vo_delaunay.argtypes = [_p_f32, C.c_int32, _p_i32, C.c_int32]
         L.vo_remove_outliers.argtypes = [C.POINTER(VoParams), C.c_void_p, C.c_int32, C.c_int32]
+        L.vo_ego_sampler_seed.argtypes = [C.c_uint32]
+        L.vo_ego_sampler_state.restype = C.c_uint32
+        L.vo_estimate_motion_stereo.argtypes = [C.c_void_p, C.c_int32, C.POINTER(VoEgoParams), _p_f64, _p_i32, _p_i32]
+        L.vo_tr_vector_to_matrix.argtypes = [_p_f64, _p_f64]
+        L.vo_stereo_create.restype = C.c_void_p
+        L.vo_stereo_create.argtypes = [C.POINTER(VoParams), C.c_int32, C.c_double, C.c_double, C.POINTER(VoEgoParams)]
+        L.vo_stereo_destroy.argtypes = [C.c_void_p]
+        L.vo_stereo_process.argtypes = [C.c_void_p, _p_u8, _p_u8, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.vo_stereo_process_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.vo_stereo_get_motion.argtypes = [C.c_void_p, _p_f64]
+        L.vo_stereo_tr_valid.argtypes = [C.c_void_p]
+        L.vo_stereo_num_matches.argtypes = [C.c_void_p]
+        L.vo_stereo_get_matches.argtypes = [C.c_void_p, C.c_void_p]
+        L.vo_stereo_num_inliers.argtypes = [C.c_void_p]
+        L.vo_stereo_get_inliers.argtypes = [C.c_void_p, _p_i32]
+        L.vo_stereo_matcher.restype = C.c_void_p
+        L.vo_stereo_matcher.argtypes = [C.c_void_p]
         _oracle = L
     return _oracle
 
@@ -159,6 +176,12 @@ def ref_lib():
                                             _p_f64, _p_f64]
         L.ref_vo_num_matches.argtypes = [C.c_void_p]
         L.ref_vo_get_matches.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_vo_stereo_set_ransac.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_int32]
+        L.ref_vo_process_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, _p_f64]
+        L.ref_vo_num_bucketed.argtypes = [C.c_void_p]
+        L.ref_vo_get_bucketed.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_vo_num_inliers.argtypes = [C.c_void_p]
+        L.ref_vo_get_inliers.argtypes = [C.c_void_p, _p_i32]
         _ref = L
     return _ref
 
@@ -354,11 +377,33 @@ def remove_outliers(kind, matches, method, **params):
 class RefStereoVO:
     """VisualOdometryStereo of the reference (Tr_delta fixtures)."""
 
-    def __init__(self, f, cu, cv, base, bucket=(2, 50.0, 50.0), **params):
+    def __init__(self, f, cu, cv, base, bucket=(2, 50.0, 50.0), ransac_iters=200, inlier_threshold=2.0,
+                 reweighting=True, **params):
         self.L = ref_lib()
         p = make_params(**params)
         ip, _ = _ip_dp(p)
         self.h = C.c_void_p(self.L.ref_vo_stereo_create(_i32(ip), f, cu, cv, base, bucket[0], bucket[1], bucket[2]))
+        self.L.ref_vo_stereo_set_ransac(self.h, ransac_iters, inlier_threshold, int(reweighting))
+
+    def process_matches(self, m):
+        m = np.ascontiguousarray(m, dtype=MATCH_DTYPE)
+        tout = np.zeros(16)
+        ok = self.L.ref_vo_process_matches(self.h, m.ctypes.data, len(m), tout.ctypes.data_as(_p_f64))
+        return bool(ok), tout.reshape(4, 4)
+
+    def bucketed(self):
+        n = self.L.ref_vo_num_bucketed(self.h)
+        out = np.zeros(n, dtype=MATCH_DTYPE)
+        if n:
+            self.L.ref_vo_get_bucketed(self.h, out.ctypes.data)
+        return out
+
+    def inliers(self):
+        n = self.L.ref_vo_num_inliers(self.h)
+        out = np.zeros(n, dtype=np.int32)
+        if n:
+            self.L.ref_vo_get_inliers(self.h, _i32(out))
+        return out
 
     def process(self, I1, I2, replace=False):
         I1 = np.ascontiguousarray(I1, dtype=np.uint8)
@@ -380,4 +425,81 @@ class RefStereoVO:
     def close(self):
         if self.h:
             self.L.ref_vo_stereo_destroy(self.h)
+            self.h = None
+
+
+class VoEgoParams(C.Structure):
+    _fields_ = [("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double), ("base", C.c_double),
+                ("ransac_iters", C.c_int32), ("inlier_threshold", C.c_double), ("reweighting", C.c_int32)]
+
+
+def ego_params(f, cu, cv, base, ransac_iters=200, inlier_threshold=2.0, reweighting=True):
+    e = VoEgoParams()
+    e.f, e.cu, e.cv, e.base = float(f), float(cu), float(cv), float(base)
+    e.ransac_iters, e.inlier_threshold, e.reweighting = int(ransac_iters), float(inlier_threshold), int(reweighting)
+    return e
+
+
+def oracle_sampler_seed(s=71):
+    oracle_lib().vo_ego_sampler_seed(s)
+
+
+def oracle_estimate_motion(m, ep):
+    """vo_estimate_motion_stereo -> (rc, tr6, inliers)"""
+    L = oracle_lib()
+    m = np.ascontiguousarray(m, dtype=MATCH_DTYPE)
+    tr = np.zeros(6)
+    inl = np.zeros(max(len(m), 1), dtype=np.int32)
+    n = C.c_int32(-1)
+    rc = L.vo_estimate_motion_stereo(m.ctypes.data, len(m), C.byref(ep), tr.ctypes.data_as(_p_f64), _i32(inl),
+                                     C.byref(n))
+    return rc, tr, inl[:max(n.value, 0)].copy()
+
+
+class OracleStereoVO:
+    """The oracle's VisualOdometryStereo; same face as RefStereoVO."""
+
+    def __init__(self, f, cu, cv, base, bucket=(2, 50.0, 50.0), ransac_iters=200, inlier_threshold=2.0,
+                 reweighting=True, **params):
+        self.L = oracle_lib()
+        sp = _vo_params(make_params(**params))
+        ep = ego_params(f, cu, cv, base, ransac_iters, inlier_threshold, reweighting)
+        self.h = C.c_void_p(self.L.vo_stereo_create(C.byref(sp), bucket[0], bucket[1], bucket[2], C.byref(ep)))
+
+    def motion(self):
+        t = np.zeros(16)
+        self.L.vo_stereo_get_motion(self.h, t.ctypes.data_as(_p_f64))
+        return t.reshape(4, 4)
+
+    def process(self, I1, I2, replace=False):
+        I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+        I2 = np.ascontiguousarray(I2, dtype=np.uint8)
+        h, w = I1.shape
+        valid = bool(self.L.vo_stereo_tr_valid(self.h))
+        tin = self.motion()
+        ok = self.L.vo_stereo_process(self.h, _u8(I1), _u8(I2), w, h, w, int(replace))
+        return bool(ok), valid, tin, self.motion()
+
+    def process_matches(self, m):
+        m = np.ascontiguousarray(m, dtype=MATCH_DTYPE)
+        ok = self.L.vo_stereo_process_matches(self.h, m.ctypes.data, len(m))
+        return bool(ok), self.motion()
+
+    def bucketed(self):
+        n = self.L.vo_stereo_num_matches(self.h)
+        out = np.zeros(n, dtype=MATCH_DTYPE)
+        if n:
+            self.L.vo_stereo_get_matches(self.h, out.ctypes.data)
+        return out
+
+    def inliers(self):
+        n = self.L.vo_stereo_num_inliers(self.h)
+        out = np.zeros(n, dtype=np.int32)
+        if n:
+            self.L.vo_stereo_get_inliers(self.h, _i32(out))
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.vo_stereo_destroy(self.h)
             self.h = None

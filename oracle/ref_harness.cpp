@@ -417,4 +417,35 @@ void ref_vo_get_matches(void *h, void *out) {
   if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(Matcher::p_match));
 }
 
+// stereo-specific knobs (viso/viso_stereo.h:33-44); call right after create
+void ref_vo_stereo_set_ransac(void *h, int32_t iters, double inlier_threshold, int32_t reweighting) {
+  VisualOdometryStereo *vo = (VisualOdometryStereo *)h;
+  vo->param.ransac_iters = iters;
+  vo->param.inlier_threshold = inlier_threshold;
+  vo->param.reweighting = reweighting != 0;
+}
+
+// VisualOdometry::process(std::vector<p_match>) (viso/viso.h:74-77): egomotion on a given match list
+int32_t ref_vo_process_matches(void *h, const void *m, int32_t n, double *tr_out) {
+  VisualOdometryStereo *vo = (VisualOdometryStereo *)h;
+  std::vector<Matcher::p_match> v((size_t)n);
+  if (n) memcpy(v.data(), m, (size_t)n * sizeof(Matcher::p_match));
+  bool ok = vo->process(v);
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) tr_out[i * 4 + j] = vo->Tr_delta.val[i][j];
+  return ok ? 1 : 0;
+}
+
+// the bucketed list estimateMotion saw, and its inliers
+int32_t ref_vo_num_bucketed(void *h) { return (int32_t)((VisualOdometryStereo *)h)->p_matched.size(); }
+void ref_vo_get_bucketed(void *h, void *out) {
+  std::vector<Matcher::p_match> &v = ((VisualOdometryStereo *)h)->p_matched;
+  if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(Matcher::p_match));
+}
+int32_t ref_vo_num_inliers(void *h) { return (int32_t)((VisualOdometryStereo *)h)->inliers.size(); }
+void ref_vo_get_inliers(void *h, int32_t *out) {
+  std::vector<int32_t> &v = ((VisualOdometryStereo *)h)->inliers;
+  if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(int32_t));
+}
+
 }  // extern "C"

@@ -90,6 +90,38 @@ int32_t vo_get_gradients(const vo_matcher *m, int32_t which, int32_t full, uint8
  * and the pass-1 share Q1, C1, S1} */
 void vo_get_counters(const vo_matcher *m, int64_t *out8);
 
+/* ---- stereo egomotion, the caller downstream of the matcher (viso_ego_oracle.c) ---- */
+/* VisualOdometry::calibration + VisualOdometryStereo::parameters, viso/viso.h:33-42, viso/viso_stereo.h:33-44 */
+typedef struct {
+  double f, cu, cv, base;
+  int32_t ransac_iters;
+  double inlier_threshold;
+  int32_t reweighting;
+} vo_ego_params;
+void vo_ego_default_params(vo_ego_params *e);
+/* the process-wide sampler of VisualOdometry::getRandomSample (viso/viso.cpp:93), seed 71 */
+void vo_ego_sampler_seed(uint32_t s);
+uint32_t vo_ego_sampler_state(void);
+/* VisualOdometryStereo::estimateMotion; 1 ok (tr6 filled), 0 failed, -1 fewer than 6 matches */
+int32_t vo_estimate_motion_stereo(const vo_match *m, int32_t n, const vo_ego_params *ep, double *tr6, int32_t *inliers,
+                                  int32_t *n_inliers);
+void vo_tr_vector_to_matrix(const double *tr6, double *T16);
+
+typedef struct vo_stereo vo_stereo; /* VisualOdometryStereo, viso/viso_stereo.h:28-88 */
+vo_stereo *vo_stereo_create(const vo_params *mp, int32_t bucket_max, double bucket_w, double bucket_h,
+                            const vo_ego_params *ep);
+void vo_stereo_destroy(vo_stereo *v);
+int32_t vo_stereo_process(vo_stereo *v, const uint8_t *I1, const uint8_t *I2, int32_t w, int32_t h, int32_t bpl,
+                          int32_t replace);
+int32_t vo_stereo_process_matches(vo_stereo *v, const vo_match *m, int32_t n);
+void vo_stereo_get_motion(const vo_stereo *v, double *T16);
+int32_t vo_stereo_tr_valid(const vo_stereo *v);
+int32_t vo_stereo_num_matches(const vo_stereo *v);
+void vo_stereo_get_matches(const vo_stereo *v, vo_match *out);
+int32_t vo_stereo_num_inliers(const vo_stereo *v);
+void vo_stereo_get_inliers(const vo_stereo *v, int32_t *out);
+vo_matcher *vo_stereo_matcher(vo_stereo *v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,3 +120,45 @@ def replay_vo_sequence(g, synth, make_matcher, n_frames=None):
         assert len(fin) == int(g["counts"][f]), (f, len(fin), int(g["counts"][f]))
         assert sha(fin) == str(g["hashes"][f]), f
     m.close()
+
+
+def replay_ego_cases(g, make_vo, reset_sampler):
+    """ego_cases.npz: egomotion on given match lists; `make_vo(**ego)` returns an object with
+    process_matches / inliers / close, `reset_sampler()` puts the RANSAC sampler into the state of
+    a fresh process (the fixture was recorded from one, walking the cases in this order)."""
+    reset_sampler()
+    f, cu, cv, base = [float(x) for x in g["intr"]]
+    for ci in range(int(g["n_cases"])):
+        m = g[f"c{ci}_matches"]
+        it, thr, rw = g[f"c{ci}_ego"]
+        vo = make_vo(f, cu, cv, base, ransac_iters=int(it), inlier_threshold=float(thr), reweighting=bool(rw))
+        ok, T = vo.process_matches(m)
+        assert ok == bool(g[f"c{ci}_ok"][0]), ci
+        assert T.tobytes() == g[f"c{ci}_T"][0].tobytes(), (ci, np.abs(T - g[f"c{ci}_T"][0]).max())
+        assert np.array_equal(vo.inliers(), g[f"c{ci}_inliers"]), ci
+        ok2, T2 = vo.process_matches(m[: max(len(m) // 2, 3)])
+        assert ok2 == bool(g[f"c{ci}_ok"][1]), ci
+        assert T2.tobytes() == g[f"c{ci}_T"][1].tobytes(), ci
+        assert np.array_equal(vo.inliers(), g[f"c{ci}_inliers2"]), ci
+        vo.close()
+
+
+def replay_ego_sequence(g, synth, make_vo, reset_sampler, n_frames=None):
+    """*_ego.npz: the live VisualOdometryStereo::process loop; every frame's result flag, Tr_delta,
+    bucketed list and inlier set must equal the reference's."""
+    reset_sampler()
+    w, h = int(g["w"]), int(g["h"])
+    nf = int(g["n_frames"]) if n_frames is None else n_frames
+    cv = synth.canvas(int(g["seed"]), w, h)
+    vo = make_vo(*[float(x) for x in g["intr"]])
+    for f in range(nf):
+        l, r = synth.stereo_frame(cv, f, w, h)
+        assert sha(l) + sha(r) == str(g["input_sha"][f])
+        res = vo.process(l, r)
+        ok, tout = res[0], res[-1]
+        assert ok == bool(g["ok"][f]), f
+        b, i = vo.bucketed(), vo.inliers()
+        assert len(b) == int(g["n_bucketed"][f]) and sha(b) == str(g["bucketed_sha"][f]), f
+        assert len(i) == int(g["n_inliers"][f]) and sha(i) == str(g["inliers_sha"][f]), f
+        assert tout.tobytes() == g["tr_out"][f].tobytes(), (f, np.abs(tout - g["tr_out"][f]).max())
+    vo.close()
