@@ -170,6 +170,27 @@ def main():
         pf_pairs, pf_elapsed, _ = shard.aggregate(dmod, torch, nf, pf_elapsed, comm_dev)
         per_frame_value = pf_pairs / pf_elapsed
 
+    # ---- the whole VisualOdometryStereo::process loop with LIVE Tr_delta feedback (row f-2) ---
+    vo_value, vo_ok = None, None
+    if not args.no_per_frame:
+        def run_vo(check=None):
+            vm.vo_sampler_seed(71)                      # what a fresh process of the reference starts from
+            vo = vm.VisualOdometryStereo(*intr)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            trail = [vo.process(frames[f, 0], frames[f, 1])[3] for f in range(nf)]
+            dt = time.perf_counter() - t
+            vo.close()
+            return dt, np.array(trail)
+        run_vo()
+        shard.barrier(dmod, comm_dev)
+        vo_dt, trail = run_vo()
+        vo_pairs, vo_dt, _ = shard.aggregate(dmod, torch, nf, vo_dt, comm_dev)
+        vo_value = vo_pairs / vo_dt
+        if seed == 1234 and not args.no_verify:
+            ge = np.load(os.path.join(ROOT, "tests", "golden", "cfg2_seq200_ego.npz"))
+            vo_ok = bool(trail.tobytes() == ge["tr_out"][:nf].tobytes())
+
     # ---- verification (outside the timed region): final lists vs the reference's hashes -----
     verified = None
     if not args.no_verify and key == f"s{seed}":
@@ -253,6 +274,10 @@ def main():
         "per_frame_api": {"value": round(per_frame_value, 3) if per_frame_value else None, "unit": "frame-pairs/s",
                           "what": "same sequence through vsm_push_back_device + vsm_match per frame (drop-in "
                                   "Matcher::pushBack/matchFeatures path)"},
+        "vo_process_api": {"value": round(vo_value, 3) if vo_value else None, "unit": "frames/s",
+                           "tr_delta_trail_bit_exact_vs_reference": vo_ok,
+                           "what": "vsm_vo_stereo_process_device per frame: pushBack + matchFeatures(2, live Tr_delta) + "
+                                   "bucketFeatures + RANSAC/Gauss-Newton egomotion (VisualOdometryStereo::process)"},
         "verified_bit_exact_vs_reference_hashes": verified,
         "roofline": roof,
         "roofline_by_kernel": {k: {"achieved_GBps": r["achieved"], "frac": r["frac"], "avg_launch_us": r["avg_launch_us"]}
@@ -299,8 +324,21 @@ def cpu_baseline(host, tr_in, tr_valid, intr, budget_s=20.0):
     work = dict(Q1=c["Q1"], C1=c["C1"], S1=c["S1"], Q2=c["Q"] - c["Q1"], C2=c["C"] - c["C1"], S2=c["S"] - c["S1"],
                 M1=len(om.stage(0)), M=int(c["M"]), N=len(om.features("1c1")) + len(om.features("1c2")))
     om.close()
+    vo_fps = None
+    if kind == "reference":
+        rv = B.RefStereoVO(*intr)
+        t1 = time.perf_counter()
+        k = 0
+        for f in range(host.shape[0]):
+            rv.process(host[f, 0], host[f, 1])
+            k += 1
+            if time.perf_counter() - t1 > budget_s / 2:
+                break
+        vo_fps = round(k / (time.perf_counter() - t1), 3)
+        rv.close()
     return (dict(value=round(n / dt, 3), unit="frame-pairs/s", cores=1, kind=kind,
-                 sample=f"first {n} frames of the same sequence, pushBack+matchFeatures(2), 1 thread"), work)
+                 sample=f"first {n} frames of the same sequence, pushBack+matchFeatures(2), 1 thread",
+                 vo_process_frames_per_s=vo_fps), work)
 
 
 if __name__ == "__main__":

@@ -162,6 +162,61 @@ void vsm_get_kernel_stats(vsm_handle *h, double *total_ms, int64_t *launches);
  * of triangles; tris gets vertex triples by input index. */
 int32_t vsm_host_delaunay(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap, int32_t threads);
 
+/* ---- stereo visual odometry on top of the matcher ----
+ * class VisualOdometryStereo, viso/viso_stereo.h:28-88 + viso/viso.h:28-131: process() =
+ * pushBack + matchFeatures(2, Tr_delta if valid) + bucketFeatures + getMatches + updateMotion
+ * (viso/viso_stereo.cpp:33-40), with estimateMotion's RANSAC / Gauss-Newton
+ * (viso/viso_stereo.cpp:42-315) spread over the matcher's host pool. */
+typedef struct {
+  vsm_params match;              /* VisualOdometry::parameters::match */
+  int32_t bucket_max_features;   /* VisualOdometry::bucketing, viso/viso.h:45-54 */
+  double bucket_width, bucket_height;
+  double f, cu, cv;              /* VisualOdometry::calibration, viso/viso.h:33-42 */
+  double base;                   /* VisualOdometryStereo::parameters, viso/viso_stereo.h:33-44 */
+  int32_t ransac_iters;
+  double inlier_threshold;
+  int32_t reweighting;
+} vsm_vo_stereo_params;
+typedef struct vsm_vo_stereo vsm_vo_stereo;
+
+void vsm_vo_stereo_default_params(vsm_vo_stereo_params *p);
+/* VisualOdometryStereo::VisualOdometryStereo, viso/viso_stereo.cpp:27-29 (+ srand(0), viso/viso.cpp:35) */
+vsm_vo_stereo *vsm_vo_stereo_create(const vsm_vo_stereo_params *p);
+void vsm_vo_stereo_destroy(vsm_vo_stereo *v);
+/* VisualOdometryStereo::process, viso/viso_stereo.cpp:33-40; returns 1 (true) / 0 (false) */
+int vsm_vo_stereo_process(vsm_vo_stereo *v, const uint8_t *I1, const uint8_t *I2, int32_t width, int32_t height,
+                          int32_t bpl, int replace);
+int vsm_vo_stereo_process_device(vsm_vo_stereo *v, const uint8_t *dI1, const uint8_t *dI2, int32_t width,
+                                 int32_t height, int32_t bpl, int replace);
+/* VisualOdometry::process(std::vector<p_match>), viso/viso.h:74-77 */
+int vsm_vo_stereo_process_matches(vsm_vo_stereo *v, const vsm_p_match *m, int32_t n);
+/* getMotion(): row-major 4x4 Tr_delta, kept from the last success (viso/viso.h:79-87) */
+void vsm_vo_stereo_get_motion(vsm_vo_stereo *v, double *T16);
+int vsm_vo_stereo_motion_valid(vsm_vo_stereo *v);
+/* getNumberOfMatches()/the bucketed p_matched, getNumberOfInliers()/getInlierIndices(), getGain() */
+int32_t vsm_vo_stereo_num_matches(vsm_vo_stereo *v);
+int32_t vsm_vo_stereo_get_matches(vsm_vo_stereo *v, vsm_p_match *out, int32_t cap);
+int32_t vsm_vo_stereo_num_inliers(vsm_vo_stereo *v);
+int32_t vsm_vo_stereo_get_inliers(vsm_vo_stereo *v, int32_t *out, int32_t cap);
+float vsm_vo_stereo_gain(vsm_vo_stereo *v, const int32_t *inliers, int32_t n);
+/* the Matcher inside (VisualOdometry::matcher) */
+vsm_handle *vsm_vo_stereo_matcher(vsm_vo_stereo *v);
+/* wall-clock split of the last process() in microseconds: {matchFeatures, bucketing + copy,
+ * egomotion, total after the push} */
+void vsm_vo_stereo_get_timings(vsm_vo_stereo *v, double *out4);
+/* VisualOdometry::getRandomSample draws from ONE engine per process, seeded 71
+ * (viso/viso.cpp:93); so does this library.  This re-seeds it (parity tests replay fixtures that
+ * were recorded from a fresh process). */
+void vsm_vo_sampler_seed(uint32_t seed);
+
+/* host-only view of the egomotion solver (VisualOdometryStereo::estimateMotion,
+ * viso/viso_stereo.cpp:42-146); needs no GPU.  Returns 1 = success (tr6 = rx,ry,rz,tx,ty,tz),
+ * 0 = failure, -1 = fewer than 6 matches (inliers/n_inliers untouched, like the reference's early
+ * return).  On success T16 (may be NULL) gets transformationVectorToMatrix(tr6), viso/viso.cpp:60-89.
+ * inliers must hold n entries. */
+int32_t vsm_host_estimate_motion_stereo(const vsm_vo_stereo_params *p, const vsm_p_match *m, int32_t n, int32_t threads,
+                                        double *tr6, double *T16, int32_t *inliers, int32_t *n_inliers);
+
 const char *vsm_version(void);
 
 #ifdef __cplusplus

@@ -312,9 +312,13 @@ struct vsm_handle {
   VsmForkJoin *fj = nullptr;
 };
 
+VsmPool *vsm_pool_of(vsm_handle *h) { return h->pool; }
+VsmForkJoin *vsm_forkjoin_of(vsm_handle *h) { return h->fj; }
+double vsm_now_us() { return now_us(); }
+
 extern "C" {
 
-const char *vsm_version(void) { return "visomatch 0.2 (gfx950)"; }
+const char *vsm_version(void) { return "visomatch 0.3 (gfx950)"; }
 
 void vsm_default_params(vsm_params *p) {
   memset(p, 0, sizeof(*p));

@@ -898,6 +898,77 @@ bool vsm_host_parabolic_update(const int32_t *c9, int du, int dv, float &u2, flo
 // for i in 1..n-1: swap(a[i], a[rand() % (i+1)])) driven by the C library rand(), whose state
 // the reference's callers seed with srand(0) (viso/viso.cpp:35).
 // =======================================================================================
+//
+// The shuffles need one rand() per match (about 10k per frame pair) and the C library takes a lock
+// for each; LibcRandStream reads the same stream in bulk instead.  glibc's rand() is random()'s
+// additive-feedback generator r[i] = r[i-31] + r[i-3] (TYPE_3) over a state array that
+// setstate()/initstate() hand out: park the library on a scratch state, step the caller's array
+// directly, then hand it back with the advanced read position encoded the way setstate() decodes
+// it.  A self-test against the library decides once whether that layout holds; if not, every
+// number comes from rand() itself.  Either way the caller's srand()/rand() stream stays coherent.
+namespace {
+class LibcRandStream {
+ public:
+  LibcRandStream() {
+    static const bool usable = self_test();
+    if (!usable) return;
+    old_ = setstate(park_);  // park_ holds a valid state since the self-test
+    int32_t *arr = (int32_t *)old_;
+    if (arr && arr[0] % 5 == 3) {
+      tbl_ = arr + 1;
+      rear_ = arr[0] / 5;
+    }
+  }
+  ~LibcRandStream() {
+    if (!old_) return;
+    if (tbl_) ((int32_t *)old_)[0] = 5 * rear_ + 3;
+    setstate(old_);
+  }
+  inline uint32_t next() {
+    if (!tbl_) return (uint32_t)rand();
+    int front = rear_ + 3;
+    if (front >= 31) front -= 31;
+    const uint32_t v = (uint32_t)tbl_[front] + (uint32_t)tbl_[rear_];
+    tbl_[front] = (int32_t)v;
+    if (++rear_ == 31) rear_ = 0;
+    return v >> 1;
+  }
+
+ private:
+  static bool self_test() {
+    if (getenv("VSM_PLAIN_RAND")) return false;
+    char *probe = park_;
+    char *old = initstate(20240229u, probe, sizeof(park_));
+    if (!old) return false;
+    int32_t copy[32];
+    memcpy(copy, probe, sizeof(copy));
+    bool same = copy[0] % 5 == 3 || copy[0] == 3;
+    int rear = copy[0] / 5;
+    for (int i = 0; i < 200 && same; i++) {
+      int front = rear + 3;
+      if (front >= 31) front -= 31;
+      const uint32_t v = (uint32_t)copy[1 + front] + (uint32_t)copy[1 + rear];
+      copy[1 + front] = (int32_t)v;
+      if (++rear == 31) rear = 0;
+      same = (long)(v >> 1) == random();
+    }
+    // and the encoded position must round-trip through setstate()
+    if (same) {
+      char *mine = setstate(old);
+      same = mine == probe && ((int32_t *)probe)[0] == 5 * rear + 3;
+    } else {
+      setstate(old);
+    }
+    return same;
+  }
+  alignas(8) static char park_[128];  // where the library's generator waits meanwhile
+  char *old_ = nullptr;
+  int32_t *tbl_ = nullptr;
+  int rear_ = 0;
+};
+alignas(8) char LibcRandStream::park_[128];
+}  // namespace
+
 void vsm_host_bucket(std::vector<vsm_p_match> &m, int max_features, float bw, float bh) {
   float u_max = 0, v_max = 0;
   for (const vsm_p_match &it : m) {
@@ -905,16 +976,45 @@ void vsm_host_bucket(std::vector<vsm_p_match> &m, int max_features, float bw, fl
     if (it.v1c > v_max) v_max = it.v1c;
   }
   const int cols = (int)floorf(u_max / bw) + 1, rows = (int)floorf(v_max / bh) + 1;
-  std::vector<std::vector<vsm_p_match>> buckets((size_t)cols * rows);
-  for (const vsm_p_match &it : m) buckets[(size_t)((int)floorf(it.v1c / bh)) * cols + (int)floorf(it.u1c / bw)].push_back(it);
-  m.clear();
-  for (auto &bk : buckets) {
-    for (size_t i = 1; i < bk.size(); i++) {
-      size_t j = (size_t)(rand() % (int)(i + 1));
-      if (i != j) std::swap(bk[i], bk[j]);
-    }
-    for (size_t k = 0; k < bk.size() && (int)k < max_features; k++) m.push_back(bk[k]);
+  const size_t nb = (size_t)cols * rows, n = m.size();
+  // counting sort of match indices by bucket (stable = the reference's push_back order)
+  static thread_local std::vector<uint32_t> cell, start, order;
+  static thread_local std::vector<vsm_p_match> kept;
+  cell.resize(n);
+  start.assign(nb + 1, 0);
+  order.resize(n);
+  for (size_t i = 0; i < n; i++) {
+    const float qu = m[i].u1c / bw, qv = m[i].v1c / bh;  // floor == truncation for the usual non-negative quotients
+    cell[i] = (uint32_t)((qv >= 0 ? (int)qv : (int)floorf(qv)) * cols + (qu >= 0 ? (int)qu : (int)floorf(qu)));
+    start[cell[i] + 1]++;
   }
+  for (size_t b = 0; b < nb; b++) start[b + 1] += start[b];
+  for (size_t i = 0; i < n; i++) order[start[cell[i]]++] = (uint32_t)i;  // start[b] is now the END of bucket b
+  kept.clear();
+  constexpr uint32_t kModTable = 512;
+  static const uint64_t *mod_magic = [] {
+    static uint64_t t[kModTable + 1];
+    for (uint32_t d = 1; d <= kModTable; d++) t[d] = UINT64_MAX / d + 1;
+    return t;
+  }();
+  {
+    LibcRandStream rnd;
+    size_t lo = 0;
+    for (size_t b = 0; b < nb; b++) {
+      const size_t hi = start[b];
+      uint32_t *bk = order.data() + lo;
+      const size_t sz = hi - lo;
+      for (size_t i = 1; i < sz; i++) {
+        const uint32_t v = rnd.next(), d = (uint32_t)(i + 1);
+        // v % d without a divide for the usual small buckets (Lemire's fastmod, exact for 32-bit operands)
+        const size_t j = d <= kModTable ? (size_t)(((__uint128_t)(mod_magic[d] * v) * d) >> 64) : (size_t)(v % d);
+        if (i != j) std::swap(bk[i], bk[j]);
+      }
+      for (size_t k = 0; k < sz && (int)k < max_features; k++) kept.push_back(m[bk[k]]);
+      lo = hi;
+    }
+  }
+  m.assign(kept.begin(), kept.end());
 }
 
 // =======================================================================================

@@ -51,6 +51,12 @@ class VsmPool {
   int spin_us_ = 2000;
 };
 
+// shared with vsm_ego.cpp (defined in vsm_api.cpp)
+class VsmForkJoin;
+VsmPool *vsm_pool_of(vsm_handle *h);
+VsmForkJoin *vsm_forkjoin_of(vsm_handle *h);  // the spinning pool the per-frame host stages use
+double vsm_now_us();
+
 // Lock-free fork-join pool for the fine-grained phases inside ONE Delaunay (a dozen tasks of
 // 10-100 us each): task claiming is a CAS on (generation << 32 | next index), so a worker that
 // is late for generation g can never run g+1's task with g's closure.

@@ -29,11 +29,23 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
            "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
            "vsm_host_delaunay", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
-           "vsm_sequence_get_timings", "vsm_version"]
+           "vsm_sequence_get_timings", "vsm_version",
+           "vsm_vo_stereo_default_params", "vsm_vo_stereo_create", "vsm_vo_stereo_destroy", "vsm_vo_stereo_process",
+           "vsm_vo_stereo_process_device", "vsm_vo_stereo_process_matches", "vsm_vo_stereo_get_motion",
+           "vsm_vo_stereo_motion_valid", "vsm_vo_stereo_num_matches", "vsm_vo_stereo_get_matches",
+           "vsm_vo_stereo_num_inliers", "vsm_vo_stereo_get_inliers", "vsm_vo_stereo_gain", "vsm_vo_stereo_matcher",
+           "vsm_vo_stereo_get_timings", "vsm_vo_sampler_seed", "vsm_host_estimate_motion_stereo"]
 
 
 class VsmParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in INT_PARAMS] + [(n, C.c_double) for n in ("f", "cu", "cv", "base")]
+
+
+class VsmVoStereoParams(C.Structure):
+    _fields_ = [("match", VsmParams), ("bucket_max_features", C.c_int32), ("bucket_width", C.c_double),
+                ("bucket_height", C.c_double), ("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double),
+                ("base", C.c_double), ("ransac_iters", C.c_int32), ("inlier_threshold", C.c_double),
+                ("reweighting", C.c_int32)]
 
 
 class VisoMatchError(RuntimeError):
@@ -93,8 +105,63 @@ def lib():
         L.vsm_sequence_num_matches.argtypes = [vp, i32]
         L.vsm_sequence_get_matches.argtypes = [vp, i32, vp, i32]
         L.vsm_sequence_get_timings.argtypes = [vp, vp]
+        vop = C.POINTER(VsmVoStereoParams)
+        L.vsm_vo_stereo_default_params.argtypes = [vop]
+        L.vsm_vo_stereo_create.restype = vp
+        L.vsm_vo_stereo_create.argtypes = [vop]
+        L.vsm_vo_stereo_destroy.argtypes = [vp]
+        L.vsm_vo_stereo_process.argtypes = [vp, vp, vp, i32, i32, i32, C.c_int]
+        L.vsm_vo_stereo_process_device.argtypes = [vp, vp, vp, i32, i32, i32, C.c_int]
+        L.vsm_vo_stereo_process_matches.argtypes = [vp, vp, i32]
+        L.vsm_vo_stereo_get_motion.argtypes = [vp, vp]
+        L.vsm_vo_stereo_motion_valid.argtypes = [vp]
+        L.vsm_vo_stereo_num_matches.argtypes = [vp]
+        L.vsm_vo_stereo_get_matches.argtypes = [vp, vp, i32]
+        L.vsm_vo_stereo_num_inliers.argtypes = [vp]
+        L.vsm_vo_stereo_get_inliers.argtypes = [vp, vp, i32]
+        L.vsm_vo_stereo_gain.argtypes = [vp, vp, i32]
+        L.vsm_vo_stereo_gain.restype = f32
+        L.vsm_vo_stereo_matcher.restype = vp
+        L.vsm_vo_stereo_matcher.argtypes = [vp]
+        L.vsm_vo_stereo_get_timings.argtypes = [vp, vp]
+        L.vsm_vo_sampler_seed.argtypes = [C.c_uint32]
+        L.vsm_host_estimate_motion_stereo.argtypes = [vop, vp, i32, i32, vp, vp, vp, vp]
         _lib = L
     return _lib
+
+
+def vo_stereo_params(f=1.0, cu=0.0, cv=0.0, base=1.0, bucket=(2, 50.0, 50.0), ransac_iters=200, inlier_threshold=2.0,
+                     reweighting=True, **match):
+    """VisualOdometryStereo::parameters (viso/viso_stereo.h:33-44, viso/viso.h:33-60) as the C struct"""
+    p = VsmVoStereoParams()
+    lib().vsm_vo_stereo_default_params(C.byref(p))
+    for k, v in match.items():
+        if not hasattr(p.match, k):
+            raise TypeError(f"unknown matcher parameter {k}")
+        setattr(p.match, k, v)
+    p.bucket_max_features, p.bucket_width, p.bucket_height = int(bucket[0]), float(bucket[1]), float(bucket[2])
+    p.f, p.cu, p.cv, p.base = float(f), float(cu), float(cv), float(base)
+    p.ransac_iters, p.inlier_threshold, p.reweighting = int(ransac_iters), float(inlier_threshold), int(reweighting)
+    return p
+
+
+def vo_sampler_seed(seed=71):
+    """re-seed the process-wide RANSAC sampler (viso/viso.cpp:93 seeds it with 71 once per process)"""
+    lib().vsm_vo_sampler_seed(seed)
+
+
+def host_estimate_motion_stereo(matches, params, threads=1):
+    """egomotion solver of the product on a given match list (host code; no GPU needed)
+    -> (rc, tr6, T 4x4, inliers or None); rc 1 ok, 0 failed, -1 fewer than 6 matches (inliers None)"""
+    m = np.ascontiguousarray(matches, dtype=P_MATCH)
+    tr = np.zeros(6)
+    T = np.zeros(16)
+    inl = np.zeros(max(len(m), 1), dtype=np.int32)
+    n = C.c_int32(0)
+    rc = lib().vsm_host_estimate_motion_stereo(C.byref(params), m.ctypes.data_as(C.c_void_p), len(m), threads,
+                                               tr.ctypes.data_as(C.c_void_p), T.ctypes.data_as(C.c_void_p),
+                                               inl.ctypes.data_as(C.c_void_p), C.cast(C.byref(n), C.c_void_p))
+    return rc, tr, T.reshape(4, 4), (inl[: n.value].copy() if rc >= 0 else None)
 
 
 def host_delaunay(pts, threads=1):
@@ -322,3 +389,84 @@ class Matcher:
             self.close()
         except Exception:
             pass
+
+
+class VisualOdometryStereo:
+    """Mirror of the reference's VisualOdometryStereo (viso/viso_stereo.h:28-88): process() runs
+    pushBack + matchFeatures(2, Tr_delta) + bucketFeatures + egomotion and keeps Tr_delta."""
+
+    def __init__(self, f, cu, cv, base, bucket=(2, 50.0, 50.0), ransac_iters=200, inlier_threshold=2.0,
+                 reweighting=True, **match):
+        self.params = vo_stereo_params(f, cu, cv, base, bucket, ransac_iters, inlier_threshold, reweighting, **match)
+        h = lib().vsm_vo_stereo_create(C.byref(self.params))
+        if not h:
+            raise VisoMatchError("vsm_vo_stereo_create failed: no usable HIP device (there is no CPU path)")
+        self.h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().vsm_vo_stereo_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def get_motion(self):
+        t = np.zeros(16)
+        lib().vsm_vo_stereo_get_motion(self.h, t.ctypes.data_as(C.c_void_p))
+        return t.reshape(4, 4)
+
+    def process(self, I1, I2, replace=False):
+        """-> (success, Tr_valid before the call, Tr_delta before, Tr_delta after)"""
+        L = lib()
+        valid = bool(L.vsm_vo_stereo_motion_valid(self.h))
+        tin = self.get_motion()
+        if _is_torch(I1):
+            assert I1.is_cuda and I2.is_cuda and I1.shape == I2.shape and I1.stride() == I2.stride()
+            h, w = I1.shape
+            ok = L.vsm_vo_stereo_process_device(self.h, C.c_void_p(I1.data_ptr()), C.c_void_p(I2.data_ptr()), w, h,
+                                                I1.stride(0), int(replace))
+        else:
+            I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+            I2 = np.ascontiguousarray(I2, dtype=np.uint8)
+            h, w = I1.shape
+            ok = L.vsm_vo_stereo_process(self.h, I1.ctypes.data_as(C.c_void_p), I2.ctypes.data_as(C.c_void_p), w, h, w,
+                                         int(replace))
+        return bool(ok), valid, tin, self.get_motion()
+
+    def process_matches(self, m):
+        m = np.ascontiguousarray(m, dtype=P_MATCH)
+        ok = lib().vsm_vo_stereo_process_matches(self.h, m.ctypes.data_as(C.c_void_p), len(m))
+        return bool(ok), self.get_motion()
+
+    def get_matches(self):
+        n = lib().vsm_vo_stereo_num_matches(self.h)
+        out = np.zeros(n, dtype=P_MATCH)
+        if n:
+            lib().vsm_vo_stereo_get_matches(self.h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def get_inlier_indices(self):
+        n = lib().vsm_vo_stereo_num_inliers(self.h)
+        out = np.zeros(n, dtype=np.int32)
+        if n:
+            lib().vsm_vo_stereo_get_inliers(self.h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def get_number_of_matches(self):
+        return lib().vsm_vo_stereo_num_matches(self.h)
+
+    def get_number_of_inliers(self):
+        return lib().vsm_vo_stereo_num_inliers(self.h)
+
+    def get_gain(self, inliers):
+        a = np.ascontiguousarray(inliers, dtype=np.int32)
+        return float(lib().vsm_vo_stereo_gain(self.h, a.ctypes.data_as(C.c_void_p), len(a)))
+
+    def timings(self):
+        t = np.zeros(4)
+        lib().vsm_vo_stereo_get_timings(self.h, t.ctypes.data_as(C.c_void_p))
+        return t
+
+    # the face the golden drivers use (same names as oracle.bindings.OracleStereoVO)
+    bucketed = get_matches
+    inliers = get_inlier_indices

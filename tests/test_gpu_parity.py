@@ -275,3 +275,49 @@ def test_mono_then_stereo_and_replace_first(vm, B, synth):
             assert g.match(meth) == c.match(meth), (f, meth)
             assert _same(g.matches(), c.matches()), (f, meth)
     g.close()
+
+
+# ---- stereo egomotion on top of the matcher ------------------------
+
+def _load_golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+
+
+def test_vo_stereo_cases_golden(vm):
+    G.replay_ego_cases(_load_golden("ego_cases"), vm.VisualOdometryStereo, vm.vo_sampler_seed)
+
+
+@pytest.mark.parametrize("name", ["small_seq24_ego", "cfg2_seq200_ego"])
+def test_vo_stereo_live_feedback_golden(vm, synth, name):
+    """VisualOdometryStereo::process with LIVE Tr_delta feedback: flags, Tr_delta, bucketed lists and
+    inlier sets of every frame equal the all-reference run's"""
+    G.replay_ego_sequence(_load_golden(name), synth, vm.VisualOdometryStereo, vm.vo_sampler_seed)
+
+
+def test_vo_stereo_vs_oracle_params_and_device_inputs(vm, B, synth):
+    import torch
+    w, h, n = 480, 200, 8
+    seq = synth.stereo_sequence(31, w, h, n, disparity=14)
+    intr = (420.0, w / 2.0, h / 2.0, 0.45)
+    kw = dict(bucket=(3, 40.0, 30.0), ransac_iters=60, inlier_threshold=1.5, reweighting=False, nms_n=2, refinement=2)
+    B.oracle_sampler_seed(71)
+    o = B.OracleStereoVO(*intr, **kw)
+    ref = []
+    for f, (l, r) in enumerate(seq):
+        ok, _, _, T = o.process(l, r, replace=(f == 5))
+        ref.append((ok, T.copy(), o.bucketed().copy(), o.inliers().copy()))
+    o.close()
+    vm.vo_sampler_seed(71)
+    v = vm.VisualOdometryStereo(*intr, **kw)
+    for f, (l, r) in enumerate(seq):
+        dl, dr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+        ok, _, _, T = v.process(dl, dr, replace=(f == 5))
+        assert ok == ref[f][0], f
+        assert T.tobytes() == ref[f][1].tobytes(), f
+        assert _same(v.get_matches(), ref[f][2]), f
+        assert np.array_equal(v.get_inlier_indices(), ref[f][3]), f
+        assert v.get_number_of_matches() == len(ref[f][2]) and v.get_number_of_inliers() == len(ref[f][3])
+    inl = v.get_inlier_indices()
+    assert np.isfinite(v.get_gain(inl))
+    v.close()
