@@ -144,7 +144,7 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
     return o;
   };
   struct SetOff {
-    size_t feat, count, cand, cell_off, bin_start, bin_cnt, binid, s_idx, s_uv, s_desc, tmp;
+    size_t feat, count, cand, cell_off, bin_start, bin_cnt, binid, s_idx, s_uv, s_desc, s_rank, tmp;
   };
   struct ImgOff {
     size_t img, imgm, du, dv, duf, dvf;
@@ -164,8 +164,9 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
       io[i].set[k].count = take(4);
       io[i].set[k].cand = take((size_t)(ncu[k] * ncv[k] + 1) * 16);
       io[i].set[k].cell_off = take((size_t)(ncu[k] * ncv[k] + 2) * 4);
-      io[i].set[k].bin_start = take((size_t)(nb + 1) * 4);
-      io[i].set[k].bin_cnt = take((size_t)(nb + 1) * 4);
+      io[i].set[k].bin_start = take((size_t)(nb * VSM_VSUB + 1) * 4);
+      io[i].set[k].bin_cnt = take((size_t)(nb * VSM_VSUB + 1) * 4);
+      io[i].set[k].s_rank = take(cap * 4);
       io[i].set[k].binid = take(cap * 4);
       io[i].set[k].s_idx = take(cap * 4);
       io[i].set[k].s_uv = take(cap * 8);
@@ -229,8 +230,9 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
       s.bin_start = (int32_t *)(b + io[i].set[k].bin_start);
       s.bin_cnt = (int32_t *)(b + io[i].set[k].bin_cnt);
       s.binid = (int32_t *)(b + io[i].set[k].binid);
+      s.s_rank = (int32_t *)(b + io[i].set[k].s_rank);
       s.s_idx = (int32_t *)(b + io[i].set[k].s_idx);
-      s.s_uv = (int2 *)(b + io[i].set[k].s_uv);
+      s.s_uv = (uint32_t *)(b + io[i].set[k].s_uv);
       s.s_desc = (uint4 *)(b + io[i].set[k].s_desc);
       s.tmp = (int32_t *)(b + io[i].set[k].tmp);
       s.cap = c.cap_set[k];
@@ -311,6 +313,15 @@ struct vsm_handle {
   VsmPool *pool = nullptr;
   VsmForkJoin *fj = nullptr;
 };
+
+// Matcher::range records (u_min[4], u_max[4], v_min[4], v_max[4], viso/matcher.h:152-157) go to the
+// device stage-major -- {u_min, u_max, v_min, v_max} of stage 0, then stage 1, ... -- so that a chain
+// fetches the box of one stage with a single 16-byte load
+static void ranges_to_device_layout(float *dst, const float *src, size_t n_floats) {
+  for (size_t b = 0; b + 16 <= n_floats; b += 16)
+    for (int stage = 0; stage < 4; stage++)
+      for (int k = 0; k < 4; k++) dst[b + stage * 4 + k] = src[b + k * 4 + stage];
+}
 
 VsmPool *vsm_pool_of(vsm_handle *h) { return h->pool; }
 VsmForkJoin *vsm_forkjoin_of(vsm_handle *h) { return h->fj; }
@@ -559,7 +570,7 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
     h->stage[1] = h->stage[0];
     vsm_host_remove_outliers(h->work, p, h->stage[1], method);
     vsm_host_prior_statistics(p, h->dims_c, h->stage[1], method, h->ranges);
-    memcpy(c.h_ranges, h->ranges.data(), h->ranges.size() * sizeof(float));
+    ranges_to_device_layout(c.h_ranges, h->ranges.data(), h->ranges.size());
     HIPCHK(hipMemcpyAsync(c.d_ranges, c.h_ranges, h->ranges.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     t2 = now_us();
   }
@@ -807,7 +818,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
         if (valid[i]) m1.assign(c.hm_list1[pj], c.hm_list1[pj] + c.hm_lcount[2 * pj]);
         vsm_host_remove_outliers(tw, p, m1, method);
         vsm_host_prior_statistics(p, dims_c, m1, method, rg);
-        memcpy(c.h_ranges + (size_t)pj * c.ranges_stride, rg.data(), rg.size() * sizeof(float));
+        ranges_to_device_layout(c.h_ranges + (size_t)pj * c.ranges_stride, rg.data(), rg.size());
       });
       ta = now_us();
       thost += ta - tb;

@@ -24,11 +24,12 @@ struct VsmSet {
   int32_t *count_host; // the same number in host-mapped pinned memory (read after a stream sync)
   int32_t *cand;       // [ncu*ncv*4] packed NMS survivors: u | v<<14 | valid<<31
   int32_t *cell_off;   // [ncu*ncv+1] exclusive prefix of survivors per cell (emission order)
-  int32_t *bin_start;  // [4*ub*vb + 1]
-  int32_t *bin_cnt;    // [4*ub*vb] histogram, then scatter cursor
-  int32_t *binid;      // [cap] bin of every feature (emission order)
+  int32_t *bin_start;  // [4*ub*vb*VSM_VSUB + 1] start of every fine bin (class, u-bin, v sub-row) in the sorted arrays
+  int32_t *bin_cnt;    // [4*ub*vb*VSM_VSUB] histogram, then scatter cursor
+  int32_t *binid;      // [cap] fine bin of every feature (emission order)
+  int32_t *s_rank;     // [cap] by sorted position: place in the reference's (u_bin, v_bin, index) visiting order
   int32_t *s_idx;      // [cap] sorted position -> original index
-  int2 *s_uv;          // [cap]
+  uint32_t *s_uv;      // [cap] u | v << 16 (coordinates < 16384), bin-sorted; 16-byte loads may over-read <= 3 entries
   uint4 *s_desc;       // [cap][2]
   int32_t *tmp;        // [cap] scratch
   int32_t cap, nms_n, ncu, ncv;
@@ -41,6 +42,12 @@ struct VsmImage {
   uint8_t *du_full, *dv_full;  // full-resolution Sobel responses (half_resolution only; else == du,dv)
   VsmSet set[2];     // 0 sparse, 1 dense
 };
+
+// The match bins of the reference (match_binsize, "speed only") fix the order in which findMatch
+// visits candidates, i.e. who wins a cost tie.  The sorted arrays here use a finer key -- every
+// v-bin is cut into VSM_VSUB sub-rows -- so a search window touches far fewer candidates, and each
+// candidate carries its place in the reference's order (s_rank) to settle ties identically.
+#define VSM_VSUB 5
 
 struct VsmDims {
   int32_t w, h, bpl;     // full resolution

@@ -473,10 +473,16 @@ __global__ void __launch_bounds__(1024) k_scan_cells(const VsmImage *__restrict_
 __constant__ int8_t c_desc_dv[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
 __constant__ int8_t c_desc_du[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
 
+// fine v row of a (non-negative) coordinate: v-bin * VSM_VSUB + sub-row inside the bin; monotonic in v
+__device__ __forceinline__ int vfine_of(int v, int binsize, int vb) {
+  const int vbin = min(v / binsize, vb - 1);
+  return vbin * VSM_VSUB + min(((v - vbin * binsize) * VSM_VSUB) / binsize, VSM_VSUB - 1);
+}
+
+// fine bin id; id / VSM_VSUB is the reference's bin (class * ub + u_bin) * vb + v_bin (viso/matcher.cpp:881-888)
 __device__ __forceinline__ int bin_of(int u, int v, int c, int binsize, int ub, int vb) {
-  int ubin = min((int)floorf((float)u / (float)binsize), ub - 1);
-  int vbin = min((int)floorf((float)v / (float)binsize), vb - 1);
-  return (c * ub + ubin) * vb + vbin;
+  const int ubin = min(u / binsize, ub - 1);
+  return (c * ub + ubin) * (vb * VSM_VSUB) + vfine_of(v, binsize, vb);
 }
 
 __global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs, int first, VsmDims d, int set_lo,
@@ -523,13 +529,14 @@ __global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs,
 
 // ---------------------------------------------------------------------------------------
 // M1 createIndexVector, viso/matcher.cpp:870-890, as a stable counting sort into the
-// bin-contiguous SoA arrays (see VsmSet).  bin = (class*ub + u_bin)*vb + v_bin so that the
-// v-bins a query visits for one u_bin are one contiguous run.  Histogram: k_emit.  Then
+// bin-contiguous SoA arrays (see VsmSet).  fine bin = (class*ub + u_bin)*(vb*VSM_VSUB) + v sub-row,
+// so that the rows a query visits for one u_bin are one contiguous run.  Histogram: k_emit.  Then
 //   k_bin_scan    exclusive scan of the histogram (one block per image/set)
 //   k_bin_scatter every feature takes a slot of its bin (unordered, atomic cursor)
 //   k_bin_rank    every slot finds its stable rank = number of smaller feature indices in its
-//                 bin (a bin holds at most one feature per NMS cell and class: a few dozen) and
-//                 writes the sorted coordinate / descriptor / index arrays
+//                 fine bin, and its place in the reference's coarser (u_bin, v_bin, index) order
+//                 (a bin holds at most one feature per NMS cell and class: a few dozen), and
+//                 writes the sorted coordinate / descriptor / index / reference-rank arrays
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_bin_scan(const VsmImage *__restrict__ imgs, int first, int set_lo, int nb) {
   __shared__ int s_w[17];
@@ -566,13 +573,21 @@ __global__ void __launch_bounds__(256) k_bin_rank(const VsmImage *__restrict__ i
   const int idx = st.tmp[p];
   const int b = st.binid[idx];
   const int lo = st.bin_start[b], hi = st.bin_start[b + 1];
-  int rank = 0;
-  for (int q = lo; q < hi; q++) rank += st.tmp[q] < idx;
+  // the reference's bin = the VSM_VSUB fine bins b - b % VSM_VSUB ..., contiguous in the sorted order
+  const int cb = (b / VSM_VSUB) * VSM_VSUB;
+  const int clo = st.bin_start[cb], chi = st.bin_start[cb + VSM_VSUB];
+  int rank = 0, crank = 0;
+  for (int q = clo; q < chi; q++) {
+    const int before = st.tmp[q] < idx;
+    crank += before;
+    rank += (q >= lo && q < hi) ? before : 0;
+  }
   const int dst = lo + rank;
+  st.s_rank[dst] = clo + crank;
   const int32_t *rec = st.feat + (size_t)idx * 12;
   const int4 hd = *(const int4 *)rec;
   st.s_idx[dst] = idx;
-  st.s_uv[dst] = make_int2(hd.x, hd.y);
+  st.s_uv[dst] = (uint32_t)hd.x | ((uint32_t)hd.y << 16);  // coordinates are < 16384
   st.s_desc[2 * dst] = *(const uint4 *)(rec + 4);
   st.s_desc[2 * dst + 1] = *(const uint4 *)(rec + 8);
 }
@@ -580,11 +595,14 @@ __global__ void __launch_bounds__(256) k_bin_rank(const VsmImage *__restrict__ i
 // ---------------------------------------------------------------------------------------
 // M2/M3 findMatch + matching, viso/matcher.cpp:892-963 and :965-1153.
 // A group of G lanes owns one query and walks the whole dependent chain (2 stages for flow /
-// stereo, 4 for quad).  In each stage the lanes stride over the candidates of the visited bins
-// (coalesced 8-byte coordinate reads, 32-byte descriptor reads only for in-window candidates),
-// cost = v_sad_u8 x 8 (+ 4*sqrt(du^2+dv^2) in double when a prediction is active), per-lane
-// first-wins strict '<', then a lexicographic (cost, traversal position) min over the group --
-// exactly the reference's "first minimum in (u_bin, v_bin, index) order" (:937-958).
+// stereo, 4 for quad).  In each stage the lanes stride over the candidates of the fine bins the
+// window touches (packed 4-byte coordinates, 16-byte loads; 32-byte descriptor reads only for
+// in-window candidates), cost = v_sad_u8 x 8 (+ 4*sqrt(du^2+dv^2) in double when a prediction is
+// active), and the winner is the lexicographic minimum of (cost, place in the reference's visiting
+// order) over the group -- exactly the reference's "first minimum in (u_bin, v_bin, index) order"
+// (:937-958).  Measured on MI355X the kernel is bound by instruction issue and dependent L2 round
+// trips, not by bytes (SQ counters in profiles/): fewer visited candidates, a 3-instruction window
+// test and judging candidates per lane rather than per visited slot are what made it faster.
 // ---------------------------------------------------------------------------------------
 #define VSM_NONE 0xffffffffu
 
@@ -600,21 +618,40 @@ __device__ __forceinline__ uint32_t sad32(const uint4 &a0, const uint4 &a1, cons
   return s;
 }
 
+// Pointers that come out of the VsmImage / VsmSet tables are "generic" to the compiler, which then
+// emits flat_load (address-space check, and every wait on LDS traffic also waits for them).  They
+// all point into HBM: these helpers load through an explicit global-address-space pointer.
+#define VSM_AS1 __attribute__((address_space(1)))
+typedef uint32_t vsm_u4 __attribute__((ext_vector_type(4)));
+typedef int32_t vsm_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ldg_u4(const void *p) {
+  const vsm_u4 v = *(const VSM_AS1 vsm_u4 *)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int4 ldg_i4(const void *p) {
+  const vsm_i4 v = *(const VSM_AS1 vsm_i4 *)p;
+  return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int32_t ldg_i32(const void *p) { return *(const VSM_AS1 int32_t *)p; }
+__device__ __forceinline__ uint32_t ldg_u32(const void *p) { return *(const VSM_AS1 uint32_t *)p; }
+
 // the feature a chain stage starts from: position, class and 32-byte descriptor, in registers
 struct VsmQuery {
-  int u, v, c;
+  uint32_t uv;  // u | v << 16
+  int c;
   uint4 da, db;
+  __device__ __forceinline__ int u() const { return (int)(uv & 0xffffu); }
+  __device__ __forceinline__ int v() const { return (int)(uv >> 16); }
 };
 
 __device__ __forceinline__ VsmQuery load_query(const VsmSet &A, int i) {
   const int32_t *rec = A.feat + (size_t)i * 12;
-  const int4 hd = *(const int4 *)rec;
+  const int4 hd = ldg_i4(rec);
   VsmQuery q;
-  q.u = hd.x;
-  q.v = hd.y;
+  q.uv = (uint32_t)hd.x | ((uint32_t)hd.y << 16);
   q.c = hd.w;
-  q.da = *(const uint4 *)(rec + 4);
-  q.db = *(const uint4 *)(rec + 8);
+  q.da = ldg_u4(rec + 4);
+  q.db = ldg_u4(rec + 8);
   return q;
 }
 
@@ -624,93 +661,168 @@ __device__ __forceinline__ VsmQuery load_query(const VsmSet &A, int i) {
 // width-G shuffles), so the next stage of the chain starts without going back to memory; the
 // winner's feature index is only looked up once, at the end of the chain.  An empty window
 // yields feature 0 of B like the reference (min_ind = 0, :898), class included.
+#ifndef VSM_UVL
+#define VSM_UVL 2  // 16-byte coordinate loads in flight per lane
+#endif
+#ifndef VSM_RELOAD_WINNER
+#define VSM_RELOAD_WINNER 1  // 1: keep only the winner's position while scanning, fetch its record afterwards
+#endif
+typedef unsigned short vsm_us2 __attribute__((ext_vector_type(2)));
+
 template <int G>
 __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, const VsmDims &d, const VsmMatchCfg &cfg,
                                                bool prior, float r_umin, float r_umax, float r_vmin, float r_vmax,
                                                bool flow, double u_, double v_, int lane) {
   float u_min, u_max, v_min, v_max;
+  const int qu = q.u(), qv = q.v();
   if (prior) {
-    u_min = (float)q.u + r_umin;
-    u_max = (float)q.u + r_umax;
-    v_min = (float)q.v + r_vmin;
-    v_max = (float)q.v + r_vmax;
+    u_min = (float)qu + r_umin;
+    u_max = (float)qu + r_umax;
+    v_min = (float)qv + r_vmin;
+    v_max = (float)qv + r_vmax;
   } else {
-    u_min = (float)(q.u - cfg.radius);
-    u_max = (float)(q.u + cfg.radius);
-    v_min = (float)(q.v - cfg.radius);
-    v_max = (float)(q.v + cfg.radius);
+    u_min = (float)(qu - cfg.radius);
+    u_max = (float)(qu + cfg.radius);
+    v_min = (float)(qv - cfg.radius);
+    v_max = (float)(qv + cfg.radius);
   }
   if (!flow) {
-    v_min = (float)(q.v - cfg.disp_tol);
-    v_max = (float)(q.v + cfg.disp_tol);
+    v_min = (float)(qv - cfg.disp_tol);
+    v_max = (float)(qv + cfg.disp_tol);
   }
   const float bs = (float)cfg.binsize;
   const int ubmin = min(max((int)floorf(u_min / bs), 0), d.ub - 1);
   const int ubmax = min(max((int)floorf(u_max / bs), 0), d.ub - 1);
-  const int vbmin = min(max((int)floorf(v_min / bs), 0), d.vb - 1);
-  const int vbmax = min(max((int)floorf(v_max / bs), 0), d.vb - 1);
+  // The reference tests (float)u2 >= u_min && (float)u2 <= u_max (viso/matcher.cpp:943) on integer
+  // coordinates: the same as lo <= u2 <= hi with lo = ceil(u_min), hi = floor(u_max).  Coordinates
+  // are < 16384, so with both axes packed as 16-bit halves the whole window test is one wrapping
+  // packed subtract, one packed min and one compare per candidate.
+  const int lo_u = max((int)ceilf(u_min), 0), hi_u = min((int)floorf(u_max), 65535);
+  const int lo_v = max((int)ceilf(v_min), 0), hi_v = min((int)floorf(v_max), 65535);
+  const bool empty = hi_u < lo_u || hi_v < lo_v;
+  // fine rows that can hold an in-window candidate (a subset of the reference's v-bins vbmin..vbmax,
+  // :933-934; every candidate still takes the exact window test below)
+  const int vrows = d.vb * VSM_VSUB;
+  const int vfmin = vfine_of(min(lo_v, d.vb * cfg.binsize - 1), cfg.binsize, d.vb);
+  const int vfmax = vfine_of(min(max(hi_v, 0), d.vb * cfg.binsize - 1), cfg.binsize, d.vb);
+  const uint32_t lo_pk = (uint32_t)lo_u | ((uint32_t)lo_v << 16);
+  const uint32_t rng_pk = (uint32_t)(hi_u - lo_u) | ((uint32_t)(hi_v - lo_v) << 16);
   const bool pred = (u_ >= 0 && v_ >= 0);
   double best = 10000000.0;
-  uint32_t bestq = VSM_NONE;
-  int2 buv = make_int2(0, 0);
+  uint32_t bestq = VSM_NONE, brank = VSM_NONE;
+#if !VSM_RELOAD_WINNER
+  uint32_t buv = 0;
   uint4 ba = make_uint4(0, 0, 0, 0), bb = make_uint4(0, 0, 0, 0);
-  for (int ubin = ubmin; ubin <= ubmax; ubin++) {
-    const int b0 = (q.c * d.ub + ubin) * d.vb;
-    const int q0 = B.bin_start[b0 + vbmin], q1 = B.bin_start[b0 + vbmax + 1];
-    // coordinates of the next 4 candidates of this lane are fetched together (most candidates
-    // fail the window test, so these loads are what the chain waits for); descriptors only for
-    // the ones inside the window.  Candidates are still judged in ascending position order.
-    for (int p0 = q0 + lane; p0 < q1; p0 += 4 * G) {
-      int2 uvk[4];
+#endif
+  // Two phases per stage.  (1) Walk the candidates: coordinates are packed (u | v << 16) and sorted
+  // by fine bin, so one aligned 16-byte load brings 4 consecutive candidates of this lane
+  // (VSM_UVL such loads in flight); the positions of the few that fall inside the window are parked
+  // in a 4-deep per-lane register queue.  (2) Judge the parked candidates: descriptor + reference
+  // rank fetch, SAD, and the double-precision distance term of a predicted match (:948-953) only
+  // when the integer SAD alone does not already exceed the best cost (cost >= SAD).  A wavefront
+  // runs phase 2 as many times as its busiest lane has candidates, not once per visited slot.
+  // The reference keeps the FIRST minimum in its (u_bin, v_bin, index) visiting order (:937-958):
+  // that is the minimum of (cost, rank), whatever order the candidates are judged in.
+  int nq = 0, q0p = 0, q1p = 0, q2p = 0, q3p = 0;
+  auto judge = [&](int p) {
+    const uint4 a = ldg_u4(B.s_desc + 2 * p), b = ldg_u4(B.s_desc + 2 * p + 1);
+    const uint32_t rk = (uint32_t)ldg_i32(B.s_rank + p);
+    const uint32_t w = ldg_u32(B.s_uv + p);
+    double cost = (double)sad32(q.da, q.db, a, b);
+    if (cost <= best) {
+      if (pred) {
+        double du = (double)(int)(w & 0xffffu) - u_;
+        double dv = (double)(int)(w >> 16) - v_;
+        double dist = sqrt(du * du + dv * dv);
+        cost += 4 * dist;
+      }
+      if (cost < best || (cost == best && rk < brank)) {
+        best = cost;
+        brank = rk;
+        bestq = (uint32_t)p;
+#if !VSM_RELOAD_WINNER
+        buv = w;
+        ba = a;
+        bb = b;
+#endif
+      }
+    }
+  };
+  auto pop_and_judge = [&]() {  // lanes with a parked candidate take their newest one
+    if (nq > 0) {
+      const int p = q0p;
+      q0p = q1p;
+      q1p = q2p;
+      q2p = q3p;
+      nq--;
+      judge(p);
+    }
+  };
+  for (int ubin = ubmin; ubin <= ubmax && !empty; ubin++) {
+    const int b0 = (q.c * d.ub + ubin) * vrows;
+    const int q0 = ldg_i32(B.bin_start + b0 + vfmin), q1 = ldg_i32(B.bin_start + b0 + vfmax + 1);
+    for (int p0 = (q0 & ~3) + 4 * lane; p0 < q1; p0 += 4 * G * VSM_UVL) {
+      uint4 wk[VSM_UVL];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int p = p0 + k * G;
-        uvk[k] = p < q1 ? B.s_uv[p] : make_int2(-100000, -100000);
+      for (int j = 0; j < VSM_UVL; j++) {
+        const int pj = p0 + j * 4 * G;
+        wk[j] = pj < q1 ? ldg_u4(B.s_uv + pj) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int p = p0 + k * G;
-        const int2 uv = uvk[k];
-        if (p < q1 && (float)uv.x >= u_min && (float)uv.x <= u_max && (float)uv.y >= v_min && (float)uv.y <= v_max) {
-          const uint4 a = B.s_desc[2 * p], b = B.s_desc[2 * p + 1];
-          double cost = (double)sad32(q.da, q.db, a, b);
-          if (pred) {
-            double du = (double)uv.x - u_;
-            double dv = (double)uv.y - v_;
-            double dist = sqrt(du * du + dv * dv);
-            cost += 4 * dist;
-          }
-          if (cost < best) {
-            best = cost;
-            bestq = (uint32_t)p;
-            buv = uv;
-            ba = a;
-            bb = b;
+      for (int j = 0; j < VSM_UVL; j++) {
+        const uint32_t w4[4] = {wk[j].x, wk[j].y, wk[j].z, wk[j].w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int p = p0 + j * 4 * G + k;
+          const vsm_us2 off = __builtin_bit_cast(vsm_us2, w4[k]) - __builtin_bit_cast(vsm_us2, lo_pk);
+          const vsm_us2 cl = __builtin_elementwise_min(off, __builtin_bit_cast(vsm_us2, rng_pk));
+          if (__builtin_bit_cast(uint32_t, cl) == __builtin_bit_cast(uint32_t, off) && p >= q0 && p < q1) {
+            if (nq == 4) {  // queue full (rare): make room first
+              const int pf = q3p;
+              nq = 3;
+              judge(pf);
+            }
+            q3p = q2p;
+            q2p = q1p;
+            q1p = q0p;
+            q0p = p;
+            nq++;
           }
         }
       }
     }
   }
+  while (__any(nq > 0)) pop_and_judge();
+#if !VSM_RELOAD_WINNER
   const uint32_t myq = bestq;
+#endif
 #pragma unroll
   for (int m = G / 2; m >= 1; m >>= 1) {
     double oc = __shfl_xor(best, m, G);
     uint32_t oq = (uint32_t)__shfl_xor((int)bestq, m, G);
-    if (oc < best || (oc == best && oq < bestq)) {
+    uint32_t ork = (uint32_t)__shfl_xor((int)brank, m, G);
+    if (oc < best || (oc == best && ork < brank)) {
       best = oc;
       bestq = oq;
+      brank = ork;
     }
   }
   if (bestq == VSM_NONE) {  // group-uniform
     q = load_query(B, 0);
     return VSM_NONE;
   }
+#if VSM_RELOAD_WINNER
+  {  // every lane of the group fetches the winner's record (just touched, so it is in cache)
+    q.uv = ldg_u32(B.s_uv + bestq);
+    q.da = ldg_u4(B.s_desc + 2 * bestq);
+    q.db = ldg_u4(B.s_desc + 2 * bestq + 1);
+  }
+#else
   // the winner's lane (unique: positions are distinct) hands its candidate to the whole group
   int wl = (myq == bestq) ? lane : 0;
 #pragma unroll
   for (int m = G / 2; m >= 1; m >>= 1) wl |= __shfl_xor(wl, m, G);
-  q.u = __shfl(buv.x, wl, G);
-  q.v = __shfl(buv.y, wl, G);
+  q.uv = (uint32_t)__shfl((int)buv, wl, G);
   q.da.x = (uint32_t)__shfl((int)ba.x, wl, G);
   q.da.y = (uint32_t)__shfl((int)ba.y, wl, G);
   q.da.z = (uint32_t)__shfl((int)ba.z, wl, G);
@@ -719,6 +831,7 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
   q.db.y = (uint32_t)__shfl((int)bb.y, wl, G);
   q.db.z = (uint32_t)__shfl((int)bb.z, wl, G);
   q.db.w = (uint32_t)__shfl((int)bb.w, wl, G);
+#endif
   return bestq;
 }
 
@@ -728,10 +841,13 @@ __device__ __forceinline__ int stat_bin_of(int u, int v, int binsize, int ub, in
   return vbin * ub + ubin;
 }
 
-__device__ __forceinline__ int index_of(const VsmSet &B, uint32_t pos) { return pos == VSM_NONE ? 0 : B.s_idx[pos]; }
+__device__ __forceinline__ int index_of(const VsmSet &B, uint32_t pos) { return pos == VSM_NONE ? 0 : ldg_i32(B.s_idx + pos); }
 
+#ifndef VSM_MATCH_WAVES
+#define VSM_MATCH_WAVES 4  // waves per SIMD the register allocator must leave room for
+#endif
 template <int G>
-__global__ void __launch_bounds__(256)  // forcing more waves/SIMD only buys spills (measured)
+__global__ void __launch_bounds__(256, VSM_MATCH_WAVES)
     k_match(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
             VsmJob job0, VsmDims d, VsmMatchCfg cfg, int nbx, int npairs) {
   // flattened grid: logical block -> (frame pair, block within pair), XCD-contiguous
@@ -754,58 +870,66 @@ __global__ void __launch_bounds__(256)  // forcing more waves/SIMD only buys spi
   // the statistics bin of a chain is that of its start feature (:1020-1022, :1104-1106); its four
   // per-stage boxes are fetched once
   VsmQuery q = load_query(cfg.method == 2 ? s1p : s1c, qi);
-  float4 r_umin = make_float4(0, 0, 0, 0), r_umax = r_umin, r_vmin = r_umin, r_vmax = r_umin;
-  if (prior) {
-    const float4 *rg = (const float4 *)(pair.ranges + 16 * stat_bin_of(q.u, q.v, cfg.binsize, d.ub, d.vb));
-    r_umin = rg[0];
-    r_umax = rg[1];
-    r_vmin = rg[2];
-    r_vmax = rg[3];
-  }
-  const int u0 = q.u, v0 = q.v;
+  // (stage-major on the device: one 16-byte load per stage, issued one stage ahead of its use)
+  const float *rg = pair.ranges + 16 * stat_bin_of(q.u(), q.v(), cfg.binsize, d.ub, d.vb);
+  auto box = [&](int stage) {  // {u_min, u_max, v_min, v_max} offsets of a stage
+    if (!prior) return make_float4(0, 0, 0, 0);
+    const uint4 r = ldg_u4(rg + 4 * stage);
+    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+  };
+  const uint32_t w0 = q.uv;
+  const int u0 = q.u(), v0 = q.v();
   if (cfg.method == 0) {  // flow, :1006-1041
-    const uint32_t p1 = find_match<G>(q, s1p, d, cfg, prior, r_umin.x, r_umax.x, r_vmin.x, r_vmax.x, true, -1, -1, lane);
-    const int u1p = q.u, v1p = q.v;
-    const uint32_t p2 = find_match<G>(q, s1c, d, cfg, prior, r_umin.y, r_umax.y, r_vmin.y, r_vmax.y, true, -1, -1, lane);
+    const float4 r0 = box(0), r1 = box(1);
+    const uint32_t p1 = find_match<G>(q, s1p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, true, -1, -1, lane);
+    const int u1p = q.u(), v1p = q.v();
+    const uint32_t p2 = find_match<G>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, -1, -1, lane);
     const int i1p = index_of(s1p, p1), i1c2 = index_of(s1c, p2);
     ok = (i1c2 == qi);
     m = {(float)u1p, (float)v1p, i1p, -1.f, -1.f, -1, (float)u0, (float)v0, qi, -1.f, -1.f, -1};
   } else if (cfg.method == 1) {  // stereo, :1045-1084
-    const uint32_t p1 = find_match<G>(q, s2c, d, cfg, prior, r_umin.x, r_umax.x, r_vmin.x, r_vmax.x, false, -1, -1, lane);
-    const int u2c = q.u, v2c = q.v;
-    const uint32_t p2 = find_match<G>(q, s1c, d, cfg, prior, r_umin.y, r_umax.y, r_vmin.y, r_vmax.y, false, -1, -1, lane);
+    const float4 r0 = box(0), r1 = box(1);
+    const uint32_t p1 = find_match<G>(q, s2c, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane);
+    const int u2c = q.u(), v2c = q.v();
+    const uint32_t p2 = find_match<G>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, false, -1, -1, lane);
     const int i2c = index_of(s2c, p1), i1c2 = index_of(s1c, p2);
     ok = (i1c2 == qi) && (u0 >= u2c);
     m = {-1.f, -1.f, -1, -1.f, -1.f, -1, (float)u0, (float)v0, qi, (float)u2c, (float)v2c, i2c};
   } else {  // quad, :1088-1153
-    const int u1p = u0, v1p = v0;
-    const uint32_t p1 = find_match<G>(q, s2p, d, cfg, prior, r_umin.x, r_umax.x, r_vmin.x, r_vmax.x, false, -1, -1, lane);
-    const int u2p = q.u, v2p = q.v;
-    double u2c_ = -1, v2c_ = -1, u1p_ = -1, v1p_ = -1;
+    // (stage results stay packed u | v << 16 until the record is written: registers decide how many
+    // chains a SIMD keeps in flight)
+    const float4 r0 = box(0), r1 = box(1);
+    const uint32_t p1 = find_match<G>(q, s2p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane);
+    const uint32_t w2p = q.uv;
+    double u2c_ = -1, v2c_ = -1;
     if (jb.use_tr) {  // :1114-1126, contraction-free double arithmetic
-      double dd = (double)u1p - (double)u2p;
+      double dd = (double)u0 - (double)q.u();
       if (!(dd > 1.0)) dd = 1.0;
-      double x1p = ((double)u1p - cfg.cu) * cfg.base / dd;
-      double y1p = ((double)v1p - cfg.cv) * cfg.base / dd;
+      double x1p = ((double)u0 - cfg.cu) * cfg.base / dd;
+      double y1p = ((double)v0 - cfg.cv) * cfg.base / dd;
       double z1p = cfg.f * cfg.base / dd;
       double x2c = jb.t[0] * x1p + jb.t[1] * y1p + jb.t[2] * z1p + jb.t[3] - cfg.base;
       double y2c = jb.t[4] * x1p + jb.t[5] * y1p + jb.t[6] * z1p + jb.t[7];
       double z2c = jb.t[8] * x1p + jb.t[9] * y1p + jb.t[10] * z1p + jb.t[11];
       u2c_ = cfg.f * x2c / z2c + cfg.cu;
       v2c_ = cfg.f * y2c / z2c + cfg.cv;
-      u1p_ = (double)u1p;
-      v1p_ = (double)v1p;
     }
-    const uint32_t p2 = find_match<G>(q, s2c, d, cfg, prior, r_umin.y, r_umax.y, r_vmin.y, r_vmax.y, true, u2c_, v2c_, lane);
-    const int u2c = q.u, v2c = q.v;
-    const uint32_t p3 = find_match<G>(q, s1c, d, cfg, prior, r_umin.z, r_umax.z, r_vmin.z, r_vmax.z, false, -1, -1, lane);
-    const int u1c = q.u, v1c = q.v;
-    const uint32_t p4 = find_match<G>(q, s1p, d, cfg, prior, r_umin.w, r_umax.w, r_vmin.w, r_vmax.w, true, u1p_, v1p_, lane);
+    const float4 r2 = box(2);
+    const uint32_t p2 = find_match<G>(q, s2c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, u2c_, v2c_, lane);
+    const uint32_t w2c = q.uv;
+    const float4 r3 = box(3);
+    const uint32_t p3 = find_match<G>(q, s1c, d, cfg, prior, r2.x, r2.y, r2.z, r2.w, false, -1, -1, lane);
+    const uint32_t w1c = q.uv;
+    // stage 4 predicts the chain's own start (:1134)
+    const uint32_t p4 = find_match<G>(q, s1p, d, cfg, prior, r3.x, r3.y, r3.z, r3.w, true,
+                                      jb.use_tr ? (double)(int)(w0 & 0xffffu) : -1.0,
+                                      jb.use_tr ? (double)(int)(w0 >> 16) : -1.0, lane);
     const int i1p2 = index_of(s1p, p4);
-    ok = (i1p2 == qi) && (u1p >= u2p) && (u1c >= u2c);
+    const int u2p = (int)(w2p & 0xffffu), u2c = (int)(w2c & 0xffffu), u1c = (int)(w1c & 0xffffu);
+    ok = (i1p2 == qi) && (u0 >= u2p) && (u1c >= u2c);
     if (ok)
-      m = {(float)u1p, (float)v1p, qi, (float)u2p, (float)v2p, index_of(s2p, p1), (float)u1c, (float)v1c,
-           index_of(s1c, p3), (float)u2c, (float)v2c, index_of(s2c, p2)};
+      m = {(float)u0, (float)v0, qi, (float)u2p, (float)(int)(w2p >> 16), index_of(s2p, p1), (float)u1c,
+           (float)(int)(w1c >> 16), index_of(s1c, p3), (float)u2c, (float)(int)(w2c >> 16), index_of(s2c, p2)};
   }
   if (lane == 0) {
     pair.flag[qi] = ok ? 1 : 0;
@@ -1085,7 +1209,7 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
                      d.mbpl, d.mh, f1, f2, f_stride);
   pf.end(s);
   const int set_lo = multi_stage ? 0 : 1;
-  const int nb = 4 * d.ub * d.vb;
+  const int nb = 4 * d.ub * d.vb * VSM_VSUB;  // fine bins
   int max_cells = 0, max_cap = 0;
   for (int k = 0; k < 2; k++) {
     max_cells = max(max_cells, h_imgs[first].set[k].ncu * h_imgs[first].set[k].ncv);
@@ -1144,7 +1268,7 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
   if (Genv < 0) {
     const char *e = getenv("VSM_MATCH_G");
     Genv = e ? atoi(e) : 0;
-    if (Genv != 0 && Genv != 2 && Genv != 4 && Genv != 8 && Genv != 16) Genv = 0;
+    if (Genv != 0 && Genv != 1 && Genv != 2 && Genv != 4 && Genv != 8 && Genv != 16) Genv = 0;
   }
   const long total_q = (long)npairs * max_nq;
   const int G = Genv ? Genv : (total_q >= 200000 ? 2 : (total_q >= 30000 ? 4 : 8));
@@ -1153,7 +1277,9 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
     pf.begin(cfg.sparse ? VSM_K_MATCH1 : VSM_K_MATCH2, s);
     const int nbx = cdiv(max_nq * G, 256);
     const dim3 grid(((nbx * npairs + 7) / 8) * 8);
-    if (G == 2)
+    if (G == 1)
+      hipLaunchKernelGGL(k_match<1>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
+    else if (G == 2)
       hipLaunchKernelGGL(k_match<2>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
     else if (G == 4)
       hipLaunchKernelGGL(k_match<4>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);

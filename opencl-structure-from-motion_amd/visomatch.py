@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvisomatch.so")
+LIB_PATH = os.environ.get("VSM_LIB_PATH") or os.path.join(HERE, "libvisomatch.so")  # override: kernel experiments
 
 P_MATCH = np.dtype(
     [("u1p", "<f4"), ("v1p", "<f4"), ("i1p", "<i4"), ("u2p", "<f4"), ("v2p", "<f4"), ("i2p", "<i4"),
