@@ -18,6 +18,23 @@
 // round-robin over the XCDs).  Batched launches are flattened to 1-D and logical block
 // L = (b % 8) * ceil(n/8) + b / 8, so every XCD walks one contiguous eighth of the (pair-major)
 // work and the eight L2s stop fetching the same image lines.  Speed only, never correctness.
+// Pointers that come out of the VsmImage / VsmSet tables are "generic" to the compiler, which then
+// emits flat_load (address-space check, and every wait on LDS traffic also waits for them).  They
+// all point into HBM: these helpers load through an explicit global-address-space pointer.
+#define VSM_AS1 __attribute__((address_space(1)))
+typedef uint32_t vsm_u4 __attribute__((ext_vector_type(4)));
+typedef int32_t vsm_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ldg_u4(const void *p) {
+  const vsm_u4 v = *(const VSM_AS1 vsm_u4 *)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int4 ldg_i4(const void *p) {
+  const vsm_i4 v = *(const VSM_AS1 vsm_i4 *)p;
+  return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int32_t ldg_i32(const void *p) { return *(const VSM_AS1 int32_t *)p; }
+__device__ __forceinline__ uint32_t ldg_u32(const void *p) { return *(const VSM_AS1 uint32_t *)p; }
+
 __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
   const int per = (nblocks + 7) >> 3;
   return (b & 7) * per + (b >> 3);
@@ -397,6 +414,114 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Fixed-radius variants for the two radii the default parameters produce (dense n = 3, sparse n = 9;
+// viso/matcher.cpp:685-687): same LDS tiling as above, but with n a compile-time constant every
+// LDS read of the cell scan and of the (2n+1)^2 suppression window has an immediate offset from one
+// per-thread base address, and the window test is branch-free: a candidate is the extremum of its
+// own cell, so "no strictly better value in the window outside the cell" (:383-428) is simply
+// "the window extremum equals the candidate's value".  Tiles that touch the right/bottom clip limit
+// (w-1-margin, h-1-margin) take a bounded loop instead.  N = 3: one thread per (cell, filter);
+// N = 9: 8 lanes per (cell, filter), each owning window rows l8, l8+8, l8+16.
+template <int N, int TCU, int TCV, int LANES>
+__global__ void __launch_bounds__(256)
+    k_nms_fixed(const VsmImage *__restrict__ imgs, int first, VsmDims d, const int16_t *__restrict__ f1base,
+                const int16_t *__restrict__ f2base, size_t f_stride, int tau, int si, int nbx, int n_img) {
+  constexpr int N1 = N + 1, W = 2 * N + 1;
+  constexpr int TW = TCU * N1 + 2 * N, TH = TCV * N1 + 2 * N;
+  constexpr int STR = (((TW + 1) / 2) | 1) * 2;  // int16 per LDS row: an odd number of dwords
+  static_assert(TCU * TCV * 2 * LANES == 256, "one item per LANES threads");
+  static_assert((N1 & 1) == 0, "tile origins must stay dword aligned");
+  __shared__ int16_t s_f[2][TH][STR];
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int zi = lb / nbx, bx = lb - zi * nbx;  // (image, tile)
+  if (zi >= n_img) return;
+  const VsmSet &st = imgs[first + zi].set[si];
+  const int tiles_u = (st.ncu + TCU - 1) / TCU;
+  const int tu = bx % tiles_u, tv = bx / tiles_u;
+  const int cu0 = tu * TCU, cv0 = tv * TCV;
+  const int u0 = VSM_MARGIN + cu0 * N1, v0 = VSM_MARGIN + cv0 * N1;  // = first cell origin - N (even)
+  const int16_t *__restrict__ f1 = f1base + (size_t)zi * f_stride;
+  const int16_t *__restrict__ f2 = f2base + (size_t)zi * f_stride;
+  for (int e = threadIdx.x; e < (TW / 2) * TH; e += 256) {  // two pixels per load
+    const int y = e / (TW / 2), x = 2 * (e - y * (TW / 2));
+    const int u = u0 + x, v = v0 + y;
+    const bool in = u + 1 < d.mbpl && v < d.mh;
+    const uint32_t a = in ? *(const uint32_t *)(f1 + v * d.mbpl + u) : 0u;
+    const uint32_t b = in ? *(const uint32_t *)(f2 + v * d.mbpl + u) : 0u;
+    *(uint32_t *)&s_f[0][y][x] = a;
+    *(uint32_t *)&s_f[1][y][x] = b;
+  }
+  __syncthreads();
+  const int l8 = threadIdx.x % LANES, item = threadIdx.x / LANES;
+  const int k = item & 1, cl = item >> 1;
+  const int lcu = cl % TCU, lcv = cl / TCU;
+  const int ci = cu0 + lcu, cj = cv0 + lcv;
+  const bool live = ci < st.ncu && cj < st.ncv;  // dead items still take part in the shuffles
+  const int16_t(*f)[STR] = s_f[k];
+  const int li = N + lcu * N1, lj = N + lcv * N1;  // tile-local cell origin
+  // first-wins extrema of the cell in the reference's scan order (u outer, v inner, strict compare,
+  // :356-380): minimum of the key (value, scan position)
+  uint32_t kmin = 0xffffffffu, kmax = 0xffffffffu;
+  {
+    const int16_t *c0 = &f[lj][li];
+#pragma unroll
+    for (int t = 0; t < (N1 + LANES - 1) / LANES; t++) {
+      const int di = l8 + t * LANES;  // this lane's column(s) of the cell
+      if (di < N1) {
+#pragma unroll
+        for (int dj = 0; dj < N1; dj++) {
+          const int val = c0[dj * STR + di];
+          const uint32_t o = (uint32_t)(di * N1 + dj);
+          kmin = min(kmin, ((uint32_t)(val + 32768) << 10) | o);
+          kmax = min(kmax, ((uint32_t)(32767 - val) << 10) | o);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = LANES / 2; o >= 1; o >>= 1) {
+    kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, LANES));
+    kmax = min(kmax, (uint32_t)__shfl_xor((int)kmax, o, LANES));
+  }
+  const int mnv = (int)(kmin >> 10) - 32768, mno = kmin & 1023;
+  const int mxv = 32767 - (int)(kmax >> 10), mxo = kmax & 1023;
+  const int mni = li + mno / N1, mnj = lj + mno % N1, mxi = li + mxo / N1, mxj = lj + mxo % N1;
+  const int lim_i = d.mw - 1 - VSM_MARGIN - u0, lim_j = d.mh - 1 - VSM_MARGIN - v0;
+  int wmn = 32767, wmx = -32768;  // extrema over this lane's share of the two windows
+  if (lim_i >= TW - 1 && lim_j >= TH - 1) {  // block-uniform: no window of this tile is clipped
+    const int16_t *pn = &f[mnj - N][mni - N], *px = &f[mxj - N][mxi - N];
+#pragma unroll
+    for (int t = 0; t < (W + LANES - 1) / LANES; t++) {
+      const int r = l8 + t * LANES;
+      if (r < W) {
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+          wmn = min(wmn, (int)pn[r * STR + c]);
+          wmx = max(wmx, (int)px[r * STR + c]);
+        }
+      }
+    }
+  } else {
+    for (int r = l8; r < W; r += LANES) {
+      if (mnj - N + r <= lim_j)
+        for (int c = 0; c < W && mni - N + c <= lim_i; c++) wmn = min(wmn, (int)f[mnj - N + r][mni - N + c]);
+      if (mxj - N + r <= lim_j)
+        for (int c = 0; c < W && mxi - N + c <= lim_i; c++) wmx = max(wmx, (int)f[mxj - N + r][mxi - N + c]);
+    }
+  }
+#pragma unroll
+  for (int o = LANES / 2; o >= 1; o >>= 1) {
+    wmn = min(wmn, __shfl_xor(wmn, o, LANES));
+    wmx = max(wmx, __shfl_xor(wmx, o, LANES));
+  }
+  if (live && l8 == 0) {
+    const bool vmin = (mnv <= -tau) && wmn >= mnv, vmax = (mxv >= tau) && wmx <= mxv;
+    int32_t *c = st.cand + (size_t)(ci * st.ncv + cj) * 4 + 2 * k;
+    c[0] = vmin ? (int32_t)(0x80000000u | (uint32_t)(mni + u0) | ((uint32_t)(mnj + v0) << 14)) : 0;
+    c[1] = vmax ? (int32_t)(0x80000000u | (uint32_t)(mxi + u0) | ((uint32_t)(mxj + v0) << 14)) : 0;
+  }
+}
+
 // block-wide exclusive scan of one int per thread (blockDim.x == 1024); returns the exclusive
 // prefix and the block total.  Wave shuffles + one LDS hop.
 __device__ __forceinline__ int block_excl_scan_1024(int v, int &total, int *s_w /*[17]*/) {
@@ -485,45 +610,109 @@ __device__ __forceinline__ int bin_of(int u, int v, int c, int binsize, int ub, 
   return (c * ub + ubin) * (vb * VSM_VSUB) + vfine_of(v, binsize, vb);
 }
 
+// Tile kernel: a block owns a rectangle of NMS cells (up to 128 x 32 matching-resolution pixels).
+// It first stages the Sobel responses of that rectangle plus the 5-pixel descriptor halo in LDS,
+// du and dv interleaved per pixel (coalesced dword row reads of both planes), then one thread per
+// cell writes the records of the cell's survivors: the 16 taps of computeDescriptor are 16-bit LDS
+// reads at compile-time offsets, already in the byte order of the record (du,dv of tap 0, du,dv of
+// tap 1, ...; viso/matcher.cpp:445-476), and the 48 bytes leave as three 16-byte stores.
+#define EMIT_TW 128
+#define EMIT_TH 32
+#define EMIT_HALO 5
+#define EMIT_LW (EMIT_TW + 2 * EMIT_HALO + 4)  // + alignment slack of the row reads: 142 pixels
+#define EMIT_LH (EMIT_TH + 2 * EMIT_HALO)
 __global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs, int first, VsmDims d, int set_lo,
                                               int binsize, int nbx, int n_img) {
-  // (plain round-robin placement: the XCD-contiguous remap made this scatter-heavy kernel slower)
-  const int lb = blockIdx.x;
+  __shared__ uint16_t s_g[EMIT_LH][EMIT_LW + 2];  // du | dv << 8
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int zi = lb / nbx, bx = lb - zi * nbx;
   if (zi >= n_img) return;
   const VsmImage &im = imgs[first + zi];
   const int si = blockIdx.y;
   if (si < set_lo) return;
   const VsmSet &st = im.set[si];
-  // 16 lanes per cell (4 cells per wavefront); lane j < 12 writes dword j of each record
-  const int cell = (bx * 256 + threadIdx.x) >> 4;
-  if (cell >= st.ncu * st.ncv) return;
-  const int j = threadIdx.x & 15;
-  const int4 c4 = *(const int4 *)(st.cand + (size_t)cell * 4);
-  if ((c4.x | c4.y | c4.z | c4.w) >= 0 || j >= 12) return;
-  const int cc4[4] = {c4.x, c4.y, c4.z, c4.w};
-  int pos = st.cell_off[cell];
+  const int n1 = st.nms_n + 1;
+  const int tcu = max(EMIT_TW / n1, 1), tcv = max(EMIT_TH / n1, 1);  // cells per tile
+  const int tiles_u = (st.ncu + tcu - 1) / tcu, tiles_v = (st.ncv + tcv - 1) / tcv;
+  if (bx >= tiles_u * tiles_v) return;
+  const int tu = bx % tiles_u, tv = bx / tiles_u;
+  const int cu0 = tu * tcu, cv0 = tv * tcv;
+  // pixel rectangle covered by the descriptors of this tile's cells; cells wider than the tile
+  // (n > 31) cannot be staged and take the direct path below
+  const int ut = st.nms_n + VSM_MARGIN + cu0 * n1 - EMIT_HALO, vt = st.nms_n + VSM_MARGIN + cv0 * n1 - EMIT_HALO;
+  const int ua = ut & ~3;
+  const bool staged = n1 <= EMIT_TH;
+  if (staged) {
+    for (int e = threadIdx.x; e < (EMIT_LW / 4 + 1) * EMIT_LH; e += 256) {
+      const int y = e / (EMIT_LW / 4 + 1), x = 4 * (e - y * (EMIT_LW / 4 + 1));
+      const int u = ua + x, v = vt + y;
+      if (x + 3 < EMIT_LW + 2) {
+        uint32_t a = 0, b = 0;
+        if (u >= 0 && u + 3 < d.mbpl && v >= 0 && v < d.mh) {
+          a = ldg_u32(im.du + (size_t)v * d.mbpl + u);
+          b = ldg_u32(im.dv + (size_t)v * d.mbpl + u);
+        }
+        // interleave: pixel p -> du_p | dv_p << 8
+        const uint32_t lo = (a & 0xffu) | ((b & 0xffu) << 8) | ((a & 0xff00u) << 8) | ((b & 0xff00u) << 16);
+        const uint32_t hi = ((a >> 16) & 0xffu) | (((b >> 16) & 0xffu) << 8) | ((a >> 24) << 16) | ((b >> 24) << 24);
+        *(uint2 *)&s_g[y][x] = make_uint2(lo, hi);
+      }
+    }
+    __syncthreads();
+  }
+  for (int t = threadIdx.x; t < tcu * tcv; t += 256) {
+    const int lcv = t % tcv, lcu = t / tcv;  // v fastest: neighbouring threads own neighbouring cand[] entries
+    const int ci = cu0 + lcu, cj = cv0 + lcv;
+    if (ci >= st.ncu || cj >= st.ncv) continue;
+    const int cell = ci * st.ncv + cj;
+    const int4 c4 = ldg_i4(st.cand + (size_t)cell * 4);
+    if ((c4.x | c4.y | c4.z | c4.w) >= 0) continue;
+    const int cc4[4] = {c4.x, c4.y, c4.z, c4.w};
+    int pos = ldg_i32(st.cell_off + cell);
 #pragma unroll
-  for (int g = 0; g < 4; g++) {
-    const int cc = cc4[g];
-    if (cc >= 0) continue;
-    const int u = cc & 0x3fff, v = (cc >> 14) & 0x3fff;
-    if (j == 0) {  // M1 createIndexVector (viso/matcher.cpp:870-890): histogram of the search bins
+    for (int g = 0; g < 4; g++) {
+      const int cc = cc4[g];
+      if (cc >= 0) continue;
+      const int u = cc & 0x3fff, v = (cc >> 14) & 0x3fff;
+      uint32_t t16[16];
+      if (staged) {
+        const uint16_t *c0 = &s_g[v - vt][u - ua];
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+          constexpr int8_t kdv[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
+          constexpr int8_t kdu[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
+          t16[m] = c0[kdv[m] * (EMIT_LW + 2) + kdu[m]];
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+          const int a = (v + c_desc_dv[m]) * d.mbpl + u + c_desc_du[m];
+          t16[m] = (uint32_t)im.du[a] | ((uint32_t)im.dv[a] << 8);
+        }
+      }
+      vsm_u4 r0, r1, r2;
+      r0.x = (uint32_t)(u * d.scale);
+      r0.y = (uint32_t)(v * d.scale);
+      r0.z = 0u;
+      r0.w = (uint32_t)g;
+      r1.x = t16[0] | (t16[1] << 16);
+      r1.y = t16[2] | (t16[3] << 16);
+      r1.z = t16[4] | (t16[5] << 16);
+      r1.w = t16[6] | (t16[7] << 16);
+      r2.x = t16[8] | (t16[9] << 16);
+      r2.y = t16[10] | (t16[11] << 16);
+      r2.z = t16[12] | (t16[13] << 16);
+      r2.w = t16[14] | (t16[15] << 16);
+      VSM_AS1 vsm_u4 *rec = (VSM_AS1 vsm_u4 *)(st.feat + (size_t)pos * 12);
+      rec[0] = r0;
+      rec[1] = r1;
+      rec[2] = r2;
+      // M1 createIndexVector (viso/matcher.cpp:870-890): histogram of the search bins
       const int b = bin_of(u * d.scale, v * d.scale, g, binsize, d.ub, d.vb);
       st.binid[pos] = b;
       atomicAdd(&st.bin_cnt[b], 1);
+      pos++;
     }
-    uint32_t val;
-    if (j < 4) {
-      val = j == 0 ? (uint32_t)(u * d.scale) : (j == 1 ? (uint32_t)(v * d.scale) : (j == 2 ? 0u : (uint32_t)g));
-    } else {
-      const int m = j - 4;
-      const int a0 = (v + c_desc_dv[2 * m]) * d.mbpl + u + c_desc_du[2 * m];
-      const int a1 = (v + c_desc_dv[2 * m + 1]) * d.mbpl + u + c_desc_du[2 * m + 1];
-      val = (uint32_t)im.du[a0] | ((uint32_t)im.dv[a0] << 8) | ((uint32_t)im.du[a1] << 16) | ((uint32_t)im.dv[a1] << 24);
-    }
-    st.feat[(size_t)pos * 12 + j] = (int32_t)val;
-    pos++;
   }
 }
 
@@ -617,23 +806,6 @@ __device__ __forceinline__ uint32_t sad32(const uint4 &a0, const uint4 &a1, cons
   s = __builtin_amdgcn_sad_u8(a1.w, b1.w, s);
   return s;
 }
-
-// Pointers that come out of the VsmImage / VsmSet tables are "generic" to the compiler, which then
-// emits flat_load (address-space check, and every wait on LDS traffic also waits for them).  They
-// all point into HBM: these helpers load through an explicit global-address-space pointer.
-#define VSM_AS1 __attribute__((address_space(1)))
-typedef uint32_t vsm_u4 __attribute__((ext_vector_type(4)));
-typedef int32_t vsm_i4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 ldg_u4(const void *p) {
-  const vsm_u4 v = *(const VSM_AS1 vsm_u4 *)p;
-  return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ int4 ldg_i4(const void *p) {
-  const vsm_i4 v = *(const VSM_AS1 vsm_i4 *)p;
-  return make_int4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ int32_t ldg_i32(const void *p) { return *(const VSM_AS1 int32_t *)p; }
-__device__ __forceinline__ uint32_t ldg_u32(const void *p) { return *(const VSM_AS1 uint32_t *)p; }
 
 // the feature a chain stage starts from: position, class and 32-byte descriptor, in registers
 struct VsmQuery {
@@ -1221,7 +1393,15 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
       const VsmSet &st = h_imgs[first].set[k];
       if (st.ncu * st.ncv <= 0) continue;
       pf.begin(k == 1 ? VSM_K_NMS : VSM_K_NMS_SPARSE, s);
-      if (st.nms_n <= NMS_TILE_MAXN) {
+      if (st.nms_n == 3) {
+        const int nbx = cdiv(st.ncu, 16) * cdiv(st.ncv, 8);
+        hipLaunchKernelGGL((k_nms_fixed<3, 16, 8, 1>), dim3(((nbx * n_img + 7) / 8) * 8), dim3(256), 0, s, d_imgs, first, d,
+                           f1, f2, f_stride, nms_tau, k, nbx, n_img);
+      } else if (st.nms_n == 9) {
+        const int nbx = cdiv(st.ncu, 4) * cdiv(st.ncv, 4);
+        hipLaunchKernelGGL((k_nms_fixed<9, 4, 4, 8>), dim3(((nbx * n_img + 7) / 8) * 8), dim3(256), 0, s, d_imgs, first, d,
+                           f1, f2, f_stride, nms_tau, k, nbx, n_img);
+      } else if (st.nms_n <= NMS_TILE_MAXN) {
         const int nbx = cdiv(st.ncu, NMS_TCU) * cdiv(st.ncv, NMS_TCV);
         hipLaunchKernelGGL(k_nms_tile, dim3(((nbx * n_img + 7) / 8) * 8), dim3(256), 0, s, d_imgs, first, d, f1, f2, f_stride,
                            nms_tau, k, nbx, n_img);
@@ -1241,7 +1421,12 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
   pf.end(s);
   if (max_cells > 0) {
     pf.begin(VSM_K_EMIT, s);
-    const int nbx = cdiv(max_cells, 16);
+    int nbx = 1;  // tiles per image: the larger of the two sets decides the grid
+    for (int k = set_lo; k < 2; k++) {
+      const VsmSet &st = h_imgs[first].set[k];
+      const int n1 = st.nms_n + 1;
+      nbx = max(nbx, cdiv(st.ncu, max(EMIT_TW / n1, 1)) * cdiv(st.ncv, max(EMIT_TH / n1, 1)));
+    }
     hipLaunchKernelGGL(k_emit, dim3(((nbx * n_img + 7) / 8) * 8, 2), dim3(256), 0, s, d_imgs, first, d, set_lo, binsize, nbx,
                        n_img);
     pf.end(s);
