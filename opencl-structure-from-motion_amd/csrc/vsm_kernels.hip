@@ -46,24 +46,29 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_ingest(const VsmImage *__restrict__ imgs, int first, const uint8_t *__restrict__ src0,
                                                 const uint8_t *__restrict__ src1, size_t frame_stride, int src_bpl,
-                                                int sides, int w, int h, int bpl, int aligned) {
-  // blockIdx.z = frame*sides + side; image id = first + 2*frame + side
+                                                int sides, int w, int h, int bpl) {
+  // blockIdx.z = frame*sides + side; image id = first + 2*frame + side.  Threads are laid over the
+  // padded image as one stream of dwords.  Caller rows need not be dword aligned (a 1242-pixel row
+  // stride is not): every output dword comes from the two aligned source dwords around it and a byte
+  // funnel shift; nothing past the last pixel of a row is touched.
   const int fr = blockIdx.z / sides, side = blockIdx.z - fr * sides;
   const uint8_t *__restrict__ src = (side ? src1 : src0) + (size_t)fr * frame_stride;
   uint8_t *__restrict__ dst = imgs[first + 2 * fr + side].img;
-  int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  int y = blockIdx.y;
-  if (x4 >= bpl || y >= h) return;
-  const uint8_t *row = src + (size_t)y * src_bpl;
+  const int per_row = bpl >> 2;
+  const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = gidx / per_row, x4 = (gidx - y * per_row) * 4;
+  if (y >= h) return;
   uint32_t v = 0;
-  if (aligned && x4 + 3 < w) {
-    v = *(const uint32_t *)(row + x4);
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (x4 + k < w) v |= (uint32_t)row[x4 + k] << (8 * k);
+  if (x4 < w) {
+    const uintptr_t a = (uintptr_t)(src + (size_t)y * src_bpl + x4);
+    const uint32_t sh = (uint32_t)(a & 3);
+    const int nvalid = min(4, w - x4);  // bytes of this dword that belong to the row
+    const uint32_t lo = ldg_u32((const void *)(a - sh));
+    const uint32_t hi = ((int)(4 - sh) < nvalid) ? ldg_u32((const void *)(a - sh + 4)) : 0u;
+    v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    if (nvalid < 4) v &= (1u << (8 * nvalid)) - 1u;
   }
-  *(uint32_t *)(dst + (size_t)y * bpl + x4) = v;
+  *(VSM_AS1 uint32_t *)(dst + (size_t)y * bpl + x4) = v;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1355,12 +1360,10 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0,
                        const uint8_t *src1, size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d) {
   const int sides = src1 ? 2 : 1;
-  int aligned = ((src_bpl & 3) == 0) && ((((uintptr_t)src0) & 3) == 0) && ((((uintptr_t)src1) & 3) == 0) &&
-                ((frame_stride & 3) == 0);
-  dim3 grid(cdiv(d.bpl / 4, 256), d.h, n_frames * sides);
+  dim3 grid(cdiv((d.bpl / 4) * d.h, 256), 1, n_frames * sides);
   pf.begin(VSM_K_INGEST, s);
   hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, d_imgs, first, src0, src1, frame_stride, src_bpl, sides, d.w, d.h,
-                     d.bpl, aligned);
+                     d.bpl);
   pf.end(s);
 }
 

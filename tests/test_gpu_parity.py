@@ -155,14 +155,17 @@ def test_full_size_properties(vm, synth):
     assert _same(m.matches(), fin)
 
 
-def test_reference_vo_runs_on_dropin_matcher(synth, tmp_path):
+@pytest.mark.parametrize("binary", ["vo_dropin", "vo_native"])
+def test_reference_vo_runs_on_dropin_matcher(synth, tmp_path, binary):
     """tools/dropin/_build/vo_dropin = the reference's unmodified VisualOdometryStereo sources
-    compiled against include/matcher.h + libvisomatch.so (built where /root/reference exists).
-    Its per-frame Tr_delta must equal what the all-reference build produced (golden cfg2)."""
+    compiled against include/matcher.h + libvisomatch.so (built where /root/reference exists);
+    vo_native = the same driver compiled against include/viso_stereo.h (the C-ABI's own
+    VisualOdometryStereo; only the reference's Matrix class is compiled in).
+    Their per-frame Tr_delta must equal what the all-reference build produced (golden cfg2)."""
     import os
     import subprocess
     from conftest import ROOT
-    exe = os.path.join(ROOT, "tools", "dropin", "_build", "vo_dropin")
+    exe = os.path.join(ROOT, "tools", "dropin", "_build", binary)
     if not os.path.exists(exe):
         pytest.skip("drop-in binary not built (needs the reference sources at build time)")
     g = G.load("cfg2_seq200_tr")

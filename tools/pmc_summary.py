@@ -15,7 +15,8 @@ import csv
 import sys
 
 NAMES = {"k_match<2>": "k_match<16>:pass2", "k_match<4>": "k_match<16>:pass1", "k_nms_tile": "k_nms:dense",
-         "k_nms_tile8": "k_nms:sparse", "k_compact_write": "k_compact_matches"}
+         "k_nms_tile8": "k_nms:sparse", "k_nms_fixed<3, 16, 8, 1>": "k_nms:dense", "k_nms_fixed<9, 4, 4, 8>": "k_nms:sparse",
+         "k_compact_write": "k_compact_matches"}
 
 
 def agg(path, counter):
@@ -28,11 +29,13 @@ def agg(path, counter):
 
 f = agg(sys.argv[1], "FETCH_SIZE")
 w = agg(sys.argv[2], "WRITE_SIZE")
-with open(sys.argv[3], "w") as o:
-    o.write("kernel,bench_name,avg_FETCH_SIZE_raw_KB,avg_WRITE_SIZE_raw_KB,dispatches,traffic_bytes_per_launch\n")
+with open(sys.argv[3], "w", newline="") as o:
+    wr = csv.writer(o)  # kernel names contain commas (template arguments)
+    wr.writerow(["kernel", "bench_name", "avg_FETCH_SIZE_raw_KB", "avg_WRITE_SIZE_raw_KB", "dispatches",
+                 "traffic_bytes_per_launch"])
     for k in sorted(set(f) | set(w)):
         if k.startswith("__amd"):
             continue
         a, b = f.get(k, (0, 0)), w.get(k, (0, 0))
-        o.write(f"{k},{NAMES.get(k, k)},{a[0]:.2f},{b[0]:.2f},{a[1]},{(2 * a[0] + b[0]) * 1024:.0f}\n")
+        wr.writerow([k, NAMES.get(k, k), f"{a[0]:.2f}", f"{b[0]:.2f}", a[1], f"{(2 * a[0] + b[0]) * 1024:.0f}"])
 print("wrote", sys.argv[3])
