@@ -135,6 +135,21 @@ def oracle_lib():
         L.vo_stereo_get_inliers.argtypes = [C.c_void_p, _p_i32]
         L.vo_stereo_matcher.restype = C.c_void_p
         L.vo_stereo_matcher.argtypes = [C.c_void_p]
+        L.vo_matrix_svd.argtypes = [_p_f64, C.c_int32, C.c_int32, _p_f64, _p_f64, _p_f64]
+        L.vo_matrix_det.argtypes = [_p_f64, C.c_int32]
+        L.vo_matrix_det.restype = C.c_double
+        L.vo_mono_fundamental.argtypes = [C.c_void_p, _p_i32, C.c_int32, _p_f64]
+        L.vo_estimate_motion_mono.argtypes = [C.c_void_p, C.c_int32, C.POINTER(VoMonoParams), _p_f64, _p_i32, _p_i32]
+        L.vo_mono_create.restype = C.c_void_p
+        L.vo_mono_create.argtypes = [C.POINTER(VoParams), C.c_int32, C.c_double, C.c_double, C.POINTER(VoMonoParams)]
+        L.vo_mono_destroy.argtypes = [C.c_void_p]
+        L.vo_mono_process.argtypes = [C.c_void_p, _p_u8, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.vo_mono_process_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.vo_mono_get_motion.argtypes = [C.c_void_p, _p_f64]
+        L.vo_mono_num_matches.argtypes = [C.c_void_p]
+        L.vo_mono_get_matches.argtypes = [C.c_void_p, C.c_void_p]
+        L.vo_mono_num_inliers.argtypes = [C.c_void_p]
+        L.vo_mono_get_inliers.argtypes = [C.c_void_p, _p_i32]
         _oracle = L
     return _oracle
 
@@ -182,6 +197,20 @@ def ref_lib():
         L.ref_vo_get_bucketed.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_vo_num_inliers.argtypes = [C.c_void_p]
         L.ref_vo_get_inliers.argtypes = [C.c_void_p, _p_i32]
+        L.ref_vo_mono_create.restype = C.c_void_p
+        L.ref_vo_mono_create.argtypes = [_p_i32] + [C.c_double] * 5 + [C.c_int32, C.c_double, C.c_double, C.c_int32,
+                                                                         C.c_double, C.c_double]
+        L.ref_vo_mono_destroy.argtypes = [C.c_void_p]
+        L.ref_vo_mono_process.argtypes = [C.c_void_p, _p_u8, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p_f64]
+        L.ref_vo_mono_process_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, _p_f64]
+        L.ref_vo_mono_num_bucketed.argtypes = [C.c_void_p]
+        L.ref_vo_mono_get_bucketed.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_vo_mono_num_inliers.argtypes = [C.c_void_p]
+        L.ref_vo_mono_get_inliers.argtypes = [C.c_void_p, _p_i32]
+        L.ref_matrix_svd.argtypes = [_p_f64, C.c_int32, C.c_int32, _p_f64, _p_f64, _p_f64]
+        L.ref_matrix_det.argtypes = [_p_f64, C.c_int32]
+        L.ref_matrix_det.restype = C.c_double
+        L.ref_mono_fundamental.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, _p_i32, C.c_int32, _p_f64]
         _ref = L
     return _ref
 
@@ -502,4 +531,158 @@ class OracleStereoVO:
     def close(self):
         if self.h:
             self.L.vo_stereo_destroy(self.h)
+            self.h = None
+
+
+MONO_DEFAULTS = dict(height=1.0, pitch=0.0, ransac_iters=2000, inlier_threshold=0.00001, motion_threshold=100.0)
+
+
+class RefMonoVO:
+    """VisualOdometryMono of the reference (viso/viso_mono.h:28-90)."""
+
+    def __init__(self, f, cu, cv, bucket=(2, 50.0, 50.0), **kw):
+        self.L = ref_lib()
+        mono = dict(MONO_DEFAULTS)
+        mono.update({k: kw.pop(k) for k in list(kw) if k in MONO_DEFAULTS})
+        p = make_params(**kw)
+        ip, _ = _ip_dp(p)
+        self.h = C.c_void_p(self.L.ref_vo_mono_create(_i32(ip), f, cu, cv, mono["height"], mono["pitch"],
+                                                      mono["ransac_iters"], mono["inlier_threshold"],
+                                                      mono["motion_threshold"], bucket[0], bucket[1], bucket[2]))
+
+    def process(self, I, replace=False):
+        I = np.ascontiguousarray(I, dtype=np.uint8)
+        h, w = I.shape
+        t = np.zeros(16)
+        ok = self.L.ref_vo_mono_process(self.h, _u8(I), w, h, w, int(replace), t.ctypes.data_as(_p_f64))
+        return bool(ok), t.reshape(4, 4)
+
+    def process_matches(self, m):
+        m = np.ascontiguousarray(m, dtype=MATCH_DTYPE)
+        t = np.zeros(16)
+        ok = self.L.ref_vo_mono_process_matches(self.h, m.ctypes.data, len(m), t.ctypes.data_as(_p_f64))
+        return bool(ok), t.reshape(4, 4)
+
+    def bucketed(self):
+        n = self.L.ref_vo_mono_num_bucketed(self.h)
+        out = np.zeros(n, dtype=MATCH_DTYPE)
+        if n:
+            self.L.ref_vo_mono_get_bucketed(self.h, out.ctypes.data)
+        return out
+
+    def inliers(self):
+        n = self.L.ref_vo_mono_num_inliers(self.h)
+        out = np.zeros(n, dtype=np.int32)
+        if n:
+            self.L.ref_vo_mono_get_inliers(self.h, _i32(out))
+        return out
+
+    def fundamental(self, m, active):
+        m = np.ascontiguousarray(m, dtype=MATCH_DTYPE)
+        a = np.ascontiguousarray(active, dtype=np.int32)
+        F = np.zeros(9)
+        self.L.ref_mono_fundamental(self.h, m.ctypes.data, len(m), _i32(a), len(a), F.ctypes.data_as(_p_f64))
+        return F.reshape(3, 3)
+
+    def close(self):
+        if self.h:
+            self.L.ref_vo_mono_destroy(self.h)
+            self.h = None
+
+
+def ref_svd(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    m, n = A.shape
+    U, W, V = np.zeros((m, m)), np.zeros(min(m, n)), np.zeros((n, n))
+    ref_lib().ref_matrix_svd(A.ctypes.data_as(_p_f64), m, n, U.ctypes.data_as(_p_f64), W.ctypes.data_as(_p_f64),
+                             V.ctypes.data_as(_p_f64))
+    return U, W, V
+
+
+def ref_det(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    return float(ref_lib().ref_matrix_det(A.ctypes.data_as(_p_f64), A.shape[0]))
+
+
+class VoMonoParams(C.Structure):
+    _fields_ = [("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double), ("height", C.c_double),
+                ("pitch", C.c_double), ("ransac_iters", C.c_int32), ("inlier_threshold", C.c_double),
+                ("motion_threshold", C.c_double)]
+
+
+def mono_params(f, cu, cv, **kw):
+    d = dict(MONO_DEFAULTS)
+    d.update(kw)
+    e = VoMonoParams()
+    e.f, e.cu, e.cv = float(f), float(cu), float(cv)
+    e.height, e.pitch, e.ransac_iters = float(d["height"]), float(d["pitch"]), int(d["ransac_iters"])
+    e.inlier_threshold, e.motion_threshold = float(d["inlier_threshold"]), float(d["motion_threshold"])
+    return e
+
+
+def oracle_svd(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    m, n = A.shape
+    U, W, V = np.zeros((m, m)), np.zeros(min(m, n)), np.zeros((n, n))
+    oracle_lib().vo_matrix_svd(A.ctypes.data_as(_p_f64), m, n, U.ctypes.data_as(_p_f64), W.ctypes.data_as(_p_f64),
+                               V.ctypes.data_as(_p_f64))
+    return U, W, V
+
+
+def oracle_det(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    return float(oracle_lib().vo_matrix_det(A.ctypes.data_as(_p_f64), A.shape[0]))
+
+
+def oracle_fundamental(m, active):
+    m = np.ascontiguousarray(m, dtype=MATCH_DTYPE)
+    a = np.ascontiguousarray(active, dtype=np.int32)
+    F = np.zeros(9)
+    oracle_lib().vo_mono_fundamental(m.ctypes.data, _i32(a), len(a), F.ctypes.data_as(_p_f64))
+    return F.reshape(3, 3)
+
+
+class OracleMonoVO:
+    """The oracle's VisualOdometryMono; same face as RefMonoVO."""
+
+    def __init__(self, f, cu, cv, bucket=(2, 50.0, 50.0), **kw):
+        self.L = oracle_lib()
+        mono = {k: kw.pop(k) for k in list(kw) if k in MONO_DEFAULTS}
+        sp = _vo_params(make_params(**kw))
+        ep = mono_params(f, cu, cv, **mono)
+        self.h = C.c_void_p(self.L.vo_mono_create(C.byref(sp), bucket[0], bucket[1], bucket[2], C.byref(ep)))
+
+    def motion(self):
+        t = np.zeros(16)
+        self.L.vo_mono_get_motion(self.h, t.ctypes.data_as(_p_f64))
+        return t.reshape(4, 4)
+
+    def process(self, I, replace=False):
+        I = np.ascontiguousarray(I, dtype=np.uint8)
+        h, w = I.shape
+        ok = self.L.vo_mono_process(self.h, _u8(I), w, h, w, int(replace))
+        return bool(ok), self.motion()
+
+    def process_matches(self, m):
+        m = np.ascontiguousarray(m, dtype=MATCH_DTYPE)
+        ok = self.L.vo_mono_process_matches(self.h, m.ctypes.data, len(m))
+        return bool(ok), self.motion()
+
+    def bucketed(self):
+        n = self.L.vo_mono_num_matches(self.h)
+        out = np.zeros(n, dtype=MATCH_DTYPE)
+        if n:
+            self.L.vo_mono_get_matches(self.h, out.ctypes.data)
+        return out
+
+    def inliers(self):
+        n = self.L.vo_mono_num_inliers(self.h)
+        out = np.zeros(n, dtype=np.int32)
+        if n:
+            self.L.vo_mono_get_inliers(self.h, _i32(out))
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.vo_mono_destroy(self.h)
             self.h = None

@@ -32,6 +32,7 @@
 #define protected public
 #include "matcher.h"
 #include "viso_stereo.h"
+#include "viso_mono.h"
 #undef private
 #undef protected
 #include "filter.h"
@@ -446,6 +447,97 @@ int32_t ref_vo_num_inliers(void *h) { return (int32_t)((VisualOdometryStereo *)h
 void ref_vo_get_inliers(void *h, int32_t *out) {
   std::vector<int32_t> &v = ((VisualOdometryStereo *)h)->inliers;
   if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(int32_t));
+}
+
+// ---- VisualOdometryMono (viso/viso_mono.cpp) and the Matrix routines it leans on ----------------
+// estimateMotion prints timer lines to std::cout (viso/timer.hh); they are swallowed here.
+namespace {
+struct QuietCout {
+  std::streambuf *old;
+  QuietCout() : old(std::cout.rdbuf(nullptr)) {}
+  ~QuietCout() { std::cout.rdbuf(old); }
+};
+void copy_T(VisualOdometry *vo, double *out) {
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) out[i * 4 + j] = vo->Tr_delta.val[i][j];
+}
+}  // namespace
+
+void *ref_vo_mono_create(const int32_t *ip, double f, double cu, double cv, double height, double pitch,
+                         int32_t ransac_iters, double inlier_threshold, double motion_threshold, int32_t bucket_max,
+                         double bucket_w, double bucket_h) {
+  VisualOdometryMono::parameters p;
+  double dp[4] = {1, 0, 0, 1};
+  p.match = make_params(ip, dp);
+  p.calib.f = f;
+  p.calib.cu = cu;
+  p.calib.cv = cv;
+  p.height = height;
+  p.pitch = pitch;
+  p.ransac_iters = ransac_iters;
+  p.inlier_threshold = inlier_threshold;
+  p.motion_threshold = motion_threshold;
+  p.bucket.max_features = bucket_max;
+  p.bucket.bucket_width = bucket_w;
+  p.bucket.bucket_height = bucket_h;
+  return new VisualOdometryMono(p);
+}
+void ref_vo_mono_destroy(void *h) { delete (VisualOdometryMono *)h; }
+
+int32_t ref_vo_mono_process(void *h, uint8_t *I, int32_t w, int32_t hh, int32_t bpl, int32_t replace, double *tr_out) {
+  VisualOdometryMono *vo = (VisualOdometryMono *)h;
+  uint32_t dims[3] = {(uint32_t)w, (uint32_t)hh, (uint32_t)bpl};
+  QuietCout q;
+  bool ok = vo->process(I, dims, replace != 0);
+  copy_T(vo, tr_out);
+  return ok ? 1 : 0;
+}
+
+int32_t ref_vo_mono_process_matches(void *h, const void *m, int32_t n, double *tr_out) {
+  VisualOdometryMono *vo = (VisualOdometryMono *)h;
+  std::vector<Matcher::p_match> v((size_t)n);
+  if (n) memcpy(v.data(), m, (size_t)n * sizeof(Matcher::p_match));
+  QuietCout q;
+  bool ok = ((VisualOdometry *)vo)->process(v);
+  copy_T(vo, tr_out);
+  return ok ? 1 : 0;
+}
+int32_t ref_vo_mono_num_bucketed(void *h) { return (int32_t)((VisualOdometryMono *)h)->p_matched.size(); }
+void ref_vo_mono_get_bucketed(void *h, void *out) {
+  std::vector<Matcher::p_match> &v = ((VisualOdometryMono *)h)->p_matched;
+  if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(Matcher::p_match));
+}
+int32_t ref_vo_mono_num_inliers(void *h) { return (int32_t)((VisualOdometryMono *)h)->inliers.size(); }
+void ref_vo_mono_get_inliers(void *h, int32_t *out) {
+  std::vector<int32_t> &v = ((VisualOdometryMono *)h)->inliers;
+  if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(int32_t));
+}
+
+// Matrix::svd (viso/matrix.cpp:586-850) on a row-major m x n matrix: U m x m, W min(m,n), V n x n
+void ref_matrix_svd(const double *A, int32_t m, int32_t n, double *U, double *W, double *V) {
+  Matrix a(m, n, A), u, w, v;
+  a.svd(u, w, v);
+  for (int i = 0; i < m; i++)
+    for (int j = 0; j < m; j++) U[i * m + j] = u.val[i][j];
+  for (int i = 0; i < std::min(m, n); i++) W[i] = w.val[i][0];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) V[i * n + j] = v.val[i][j];
+}
+// Matrix::det (viso/matrix.cpp:407-422) of a row-major n x n matrix
+double ref_matrix_det(const double *A, int32_t n) {
+  Matrix a(n, n, A);
+  return a.det();
+}
+// VisualOdometryMono::fundamentalMatrix (viso/viso_mono.cpp:254-284) on (already normalised) matches
+void ref_mono_fundamental(void *h, const void *m, int32_t n, const int32_t *active, int32_t na, double *F9) {
+  VisualOdometryMono *vo = (VisualOdometryMono *)h;
+  std::vector<Matcher::p_match> v((size_t)n);
+  if (n) memcpy(v.data(), m, (size_t)n * sizeof(Matcher::p_match));
+  std::vector<int32_t> act(active, active + na);
+  Matrix F;
+  vo->fundamentalMatrix(v, act, F);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) F9[i * 3 + j] = F.val[i][j];
 }
 
 }  // extern "C"

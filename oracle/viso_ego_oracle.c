@@ -59,6 +59,8 @@ static uint32_t draw_between(uint32_t lo, uint32_t hi) {
   return (uint32_t)(r + lo);
 }
 
+uint32_t vo_ego_draw_between(uint32_t lo, uint32_t hi) { return draw_between(lo, hi); } /* for viso_mono_oracle.c */
+
 /* partial Fisher-Yates over 0..n-1, first `k` entries (viso/viso.cpp:96-105) */
 static void sample_k(int32_t *scratch, int32_t n, int32_t k, int32_t *out) {
   for (int32_t i = 0; i < n; i++) scratch[i] = i;

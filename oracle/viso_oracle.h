@@ -122,6 +122,36 @@ int32_t vo_stereo_num_inliers(const vo_stereo *v);
 void vo_stereo_get_inliers(const vo_stereo *v, int32_t *out);
 vo_matcher *vo_stereo_matcher(vo_stereo *v);
 
+/* ---- monocular egomotion (viso_mono_oracle.c), the path the reference offloads to OpenCL ---- */
+/* VisualOdometryMono::parameters + calibration, viso/viso_mono.h:33-46, viso/viso.h:33-42 */
+typedef struct {
+  double f, cu, cv;
+  double height, pitch;
+  int32_t ransac_iters;
+  double inlier_threshold, motion_threshold;
+} vo_mono_params;
+void vo_mono_default_params(vo_mono_params *p);
+/* Matrix::svd / Matrix::det of the reference (viso/matrix.cpp:586-850, :407-422), row-major */
+void vo_matrix_svd(const double *A, int32_t m, int32_t n, double *U, double *W, double *V);
+double vo_matrix_det(const double *A, int32_t n);
+/* VisualOdometryMono::fundamentalMatrix on (normalised) matches, viso/viso_mono.cpp:264-294 */
+void vo_mono_fundamental(const vo_match *m, const int32_t *active, int32_t na, double *F9);
+/* VisualOdometryMono::estimateMotion; 1 ok (tr6 filled) / 0; *n_inliers = -1 when the reference's
+ * inlier list would be left untouched (early exits before the RANSAC) */
+int32_t vo_estimate_motion_mono(const vo_match *m, int32_t n, const vo_mono_params *p, double *tr6, int32_t *inliers,
+                                int32_t *n_inliers);
+typedef struct vo_mono vo_mono; /* VisualOdometryMono, viso/viso_mono.h:28-90 */
+vo_mono *vo_mono_create(const vo_params *mp, int32_t bucket_max, double bucket_w, double bucket_h,
+                        const vo_mono_params *ep);
+void vo_mono_destroy(vo_mono *v);
+int32_t vo_mono_process(vo_mono *v, const uint8_t *I, int32_t w, int32_t h, int32_t bpl, int32_t replace);
+int32_t vo_mono_process_matches(vo_mono *v, const vo_match *m, int32_t n);
+void vo_mono_get_motion(const vo_mono *v, double *T16);
+int32_t vo_mono_num_matches(const vo_mono *v);
+void vo_mono_get_matches(const vo_mono *v, vo_match *out);
+int32_t vo_mono_num_inliers(const vo_mono *v);
+void vo_mono_get_inliers(const vo_mono *v, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

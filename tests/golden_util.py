@@ -162,3 +162,40 @@ def replay_ego_sequence(g, synth, make_vo, reset_sampler, n_frames=None):
         assert len(i) == int(g["n_inliers"][f]) and sha(i) == str(g["inliers_sha"][f]), f
         assert tout.tobytes() == g["tr_out"][f].tobytes(), (f, np.abs(tout - g["tr_out"][f]).max())
     vo.close()
+
+
+def replay_mono_cases(g, make_vo, reset_sampler):
+    """mono_cases.npz: monocular egomotion on given flow-match lists (see replay_ego_cases)"""
+    reset_sampler()
+    f, cu, cv = [float(x) for x in g["calib"]]
+    for ci in range(int(g["n_cases"])):
+        m = g[f"c{ci}_matches"]
+        height, pitch, it, thr, mot = g[f"c{ci}_mono"]
+        vo = make_vo(f, cu, cv, height=float(height), pitch=float(pitch), ransac_iters=int(it),
+                     inlier_threshold=float(thr), motion_threshold=float(mot))
+        ok, T = vo.process_matches(m)
+        assert ok == bool(g[f"c{ci}_ok"][0]), ci
+        assert np.array_equal(vo.inliers(), g[f"c{ci}_inliers"]), ci
+        assert T.tobytes() == g[f"c{ci}_T"][0].tobytes(), (ci, np.abs(T - g[f"c{ci}_T"][0]).max())
+        ok2, T2 = vo.process_matches(m[: max(len(m) // 3, 5)])
+        assert ok2 == bool(g[f"c{ci}_ok"][1]), ci
+        assert np.array_equal(vo.inliers(), g[f"c{ci}_inliers2"]), ci
+        assert T2.tobytes() == g[f"c{ci}_T"][1].tobytes(), ci
+        vo.close()
+
+
+def replay_mono_sequence(g, synth, make_vo, reset_sampler):
+    """mono_seq*.npz: VisualOdometryMono::process on images, frame by frame"""
+    reset_sampler()
+    w, h, nf = int(g["w"]), int(g["h"]), int(g["n_frames"])
+    seq = synth.mono_sequence(int(g["seed"]), w, h, nf)
+    vo = make_vo(float(g["f"]), w / 2.0, h / 2.0, height=1.65, pitch=-0.08, ransac_iters=300)
+    for f in range(nf):
+        assert sha(seq[f]) == str(g["input_sha"][f])
+        ok, T = vo.process(seq[f])
+        assert ok == bool(g["ok"][f]), f
+        b, i = vo.bucketed(), vo.inliers()
+        assert len(b) == int(g["n_bucketed"][f]) and sha(b) == str(g["bucketed_sha"][f]), f
+        assert len(i) == int(g["n_inliers"][f]) and sha(i) == str(g["inliers_sha"][f]), f
+        assert T.tobytes() == g["T"][f].tobytes(), f
+    vo.close()
