@@ -209,6 +209,50 @@ void vsm_vo_stereo_get_timings(vsm_vo_stereo *v, double *out4);
  * were recorded from a fresh process). */
 void vsm_vo_sampler_seed(uint32_t seed);
 
+/* ---- monocular visual odometry ----
+ * class VisualOdometryMono, viso/viso_mono.h:28-90: process() = pushBack + matchFeatures(0) +
+ * bucketFeatures + getMatches + updateMotion (viso/viso_mono.cpp:33-39); estimateMotion
+ * (viso/viso_mono.cpp:103-187) with the two inner loops the reference offloads to OpenCL
+ * (viso/viso_mono_cl.cpp, viso/kernels/plane_and_inliers.cl) as HIP kernels.  Results equal the
+ * reference's CPU class (double arithmetic) bit for bit. */
+typedef struct {
+  vsm_params match;              /* VisualOdometry::parameters::match */
+  int32_t bucket_max_features;   /* VisualOdometry::bucketing, viso/viso.h:45-54 */
+  double bucket_width, bucket_height;
+  double f, cu, cv;              /* VisualOdometry::calibration, viso/viso.h:33-42 */
+  double height, pitch;          /* VisualOdometryMono::parameters, viso/viso_mono.h:33-46 */
+  int32_t ransac_iters;
+  double inlier_threshold, motion_threshold;
+} vsm_vo_mono_params;
+typedef struct vsm_vo_mono vsm_vo_mono;
+
+void vsm_vo_mono_default_params(vsm_vo_mono_params *p);
+vsm_vo_mono *vsm_vo_mono_create(const vsm_vo_mono_params *p);      /* viso/viso_mono.cpp:27-28 */
+void vsm_vo_mono_destroy(vsm_vo_mono *v);
+/* VisualOdometryMono::process, viso/viso_mono.cpp:33-39; returns 1 (true) / 0 (false) */
+int vsm_vo_mono_process(vsm_vo_mono *v, const uint8_t *I, int32_t width, int32_t height, int32_t bpl, int replace);
+int vsm_vo_mono_process_device(vsm_vo_mono *v, const uint8_t *dI, int32_t width, int32_t height, int32_t bpl, int replace);
+int vsm_vo_mono_process_matches(vsm_vo_mono *v, const vsm_p_match *m, int32_t n);   /* viso/viso.h:74-77 */
+void vsm_vo_mono_get_motion(vsm_vo_mono *v, double *T16);
+int vsm_vo_mono_motion_valid(vsm_vo_mono *v);
+int32_t vsm_vo_mono_num_matches(vsm_vo_mono *v);
+int32_t vsm_vo_mono_get_matches(vsm_vo_mono *v, vsm_p_match *out, int32_t cap);
+int32_t vsm_vo_mono_num_inliers(vsm_vo_mono *v);
+int32_t vsm_vo_mono_get_inliers(vsm_vo_mono *v, int32_t *out, int32_t cap);
+float vsm_vo_mono_gain(vsm_vo_mono *v, const int32_t *inliers, int32_t n);
+vsm_handle *vsm_vo_mono_matcher(vsm_vo_mono *v);
+/* 1 if the hypothesis fits and triangulations run on the GPU (the device reproduced the host's SVD
+ * bit for bit in the creation-time self-test), 0 if they run on the host pool */
+int vsm_vo_mono_device_svd(vsm_vo_mono *v);
+/* microseconds of the last process(): {matchFeatures, bucketing + copy, egomotion, total after the
+ * push, then inside the egomotion: fundamental matrices, inlier counting, R|t + triangulation,
+ * plane vote, 0, 0} */
+void vsm_vo_mono_get_timings(vsm_vo_mono *v, double *out10);
+/* host-only view of VisualOdometryMono::estimateMotion (no GPU: the two inner loops run on the host
+ * threads).  1 = success, 0 = failure, -1 = failure before the RANSAC (inliers untouched). */
+int32_t vsm_host_estimate_motion_mono(const vsm_vo_mono_params *p, const vsm_p_match *m, int32_t n, int32_t threads,
+                                      double *tr6, double *T16, int32_t *inliers, int32_t *n_inliers);
+
 /* host-only view of the egomotion solver (VisualOdometryStereo::estimateMotion,
  * viso/viso_stereo.cpp:42-146); needs no GPU.  Returns 1 = success (tr6 = rx,ry,rz,tx,ty,tz),
  * 0 = failure, -1 = fewer than 6 matches (inliers/n_inliers untouched, like the reference's early

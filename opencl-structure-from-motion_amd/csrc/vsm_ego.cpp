@@ -351,6 +351,11 @@ void pose_matrix(const double *tr, double *T) {  // transformationVectorToMatrix
 
 }  // namespace
 
+void vsm_sampler_lock() { g_sampler.mu.lock(); }
+void vsm_sampler_unlock() { g_sampler.mu.unlock(); }
+uint32_t vsm_sampler_between(uint32_t lo, uint32_t hi) { return g_sampler.between(lo, hi); }
+void vsm_pose_matrix(const double *tr6, double *T16) { pose_matrix(tr6, T16); }
+
 struct vsm_vo_stereo {
   vsm_handle *matcher = nullptr;
   EgoStereo ego;

@@ -56,6 +56,12 @@ class VsmForkJoin;
 VsmPool *vsm_pool_of(vsm_handle *h);
 VsmForkJoin *vsm_forkjoin_of(vsm_handle *h);  // the spinning pool the per-frame host stages use
 double vsm_now_us();
+// the process-wide RANSAC sampler of VisualOdometry::getRandomSample (vsm_ego.cpp) and the pose
+// matrix of a (rx,ry,rz,tx,ty,tz) vector (viso/viso.cpp:60-89), shared by the stereo and mono egomotion
+void vsm_sampler_lock();
+void vsm_sampler_unlock();
+uint32_t vsm_sampler_between(uint32_t lo, uint32_t hi);  // call with the lock held
+void vsm_pose_matrix(const double *tr6, double *T16);
 
 // Lock-free fork-join pool for the fine-grained phases inside ONE Delaunay (a dozen tasks of
 // 10-100 us each): task claiming is a CAS on (generation << 32 | next index), so a worker that

@@ -34,7 +34,13 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_vo_stereo_process_device", "vsm_vo_stereo_process_matches", "vsm_vo_stereo_get_motion",
            "vsm_vo_stereo_motion_valid", "vsm_vo_stereo_num_matches", "vsm_vo_stereo_get_matches",
            "vsm_vo_stereo_num_inliers", "vsm_vo_stereo_get_inliers", "vsm_vo_stereo_gain", "vsm_vo_stereo_matcher",
-           "vsm_vo_stereo_get_timings", "vsm_vo_sampler_seed", "vsm_host_estimate_motion_stereo"]
+           "vsm_vo_stereo_get_timings", "vsm_vo_sampler_seed", "vsm_host_estimate_motion_stereo",
+           "vsm_vo_mono_default_params", "vsm_vo_mono_create", "vsm_vo_mono_destroy", "vsm_vo_mono_process",
+           "vsm_vo_mono_process_device", "vsm_vo_mono_process_matches", "vsm_vo_mono_get_motion",
+           "vsm_vo_mono_motion_valid", "vsm_vo_mono_num_matches", "vsm_vo_mono_get_matches", "vsm_vo_mono_num_inliers",
+           "vsm_vo_mono_get_inliers", "vsm_vo_mono_gain", "vsm_vo_mono_matcher", "vsm_vo_mono_get_timings",
+           "vsm_vo_mono_device_svd",
+           "vsm_host_estimate_motion_mono"]
 
 
 class VsmParams(C.Structure):
@@ -46,6 +52,13 @@ class VsmVoStereoParams(C.Structure):
                 ("bucket_height", C.c_double), ("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double),
                 ("base", C.c_double), ("ransac_iters", C.c_int32), ("inlier_threshold", C.c_double),
                 ("reweighting", C.c_int32)]
+
+
+class VsmVoMonoParams(C.Structure):
+    _fields_ = [("match", VsmParams), ("bucket_max_features", C.c_int32), ("bucket_width", C.c_double),
+                ("bucket_height", C.c_double), ("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double),
+                ("height", C.c_double), ("pitch", C.c_double), ("ransac_iters", C.c_int32),
+                ("inlier_threshold", C.c_double), ("motion_threshold", C.c_double)]
 
 
 class VisoMatchError(RuntimeError):
@@ -126,8 +139,63 @@ def lib():
         L.vsm_vo_stereo_get_timings.argtypes = [vp, vp]
         L.vsm_vo_sampler_seed.argtypes = [C.c_uint32]
         L.vsm_host_estimate_motion_stereo.argtypes = [vop, vp, i32, i32, vp, vp, vp, vp]
+        mop = C.POINTER(VsmVoMonoParams)
+        L.vsm_vo_mono_default_params.argtypes = [mop]
+        L.vsm_vo_mono_create.restype = vp
+        L.vsm_vo_mono_create.argtypes = [mop]
+        L.vsm_vo_mono_destroy.argtypes = [vp]
+        L.vsm_vo_mono_process.argtypes = [vp, vp, i32, i32, i32, C.c_int]
+        L.vsm_vo_mono_process_device.argtypes = [vp, vp, i32, i32, i32, C.c_int]
+        L.vsm_vo_mono_process_matches.argtypes = [vp, vp, i32]
+        L.vsm_vo_mono_get_motion.argtypes = [vp, vp]
+        L.vsm_vo_mono_motion_valid.argtypes = [vp]
+        L.vsm_vo_mono_num_matches.argtypes = [vp]
+        L.vsm_vo_mono_get_matches.argtypes = [vp, vp, i32]
+        L.vsm_vo_mono_num_inliers.argtypes = [vp]
+        L.vsm_vo_mono_get_inliers.argtypes = [vp, vp, i32]
+        L.vsm_vo_mono_gain.argtypes = [vp, vp, i32]
+        L.vsm_vo_mono_gain.restype = f32
+        L.vsm_vo_mono_matcher.restype = vp
+        L.vsm_vo_mono_matcher.argtypes = [vp]
+        L.vsm_vo_mono_get_timings.argtypes = [vp, vp]
+        L.vsm_vo_mono_device_svd.argtypes = [vp]
+        L.vsm_host_estimate_motion_mono.argtypes = [mop, vp, i32, i32, vp, vp, vp, vp]
         _lib = L
     return _lib
+
+
+MONO_DEFAULTS = dict(height=1.0, pitch=0.0, ransac_iters=2000, inlier_threshold=0.00001, motion_threshold=100.0)
+
+
+def vo_mono_params(f=1.0, cu=0.0, cv=0.0, bucket=(2, 50.0, 50.0), **kw):
+    """VisualOdometryMono::parameters (viso/viso_mono.h:33-46, viso/viso.h:33-60) as the C struct"""
+    p = VsmVoMonoParams()
+    lib().vsm_vo_mono_default_params(C.byref(p))
+    for k in list(kw):
+        if k in MONO_DEFAULTS:
+            v = kw.pop(k)
+            setattr(p, k, int(v) if k == "ransac_iters" else float(v))
+    for k, v in kw.items():
+        if not hasattr(p.match, k):
+            raise TypeError(f"unknown matcher parameter {k}")
+        setattr(p.match, k, v)
+    p.bucket_max_features, p.bucket_width, p.bucket_height = int(bucket[0]), float(bucket[1]), float(bucket[2])
+    p.f, p.cu, p.cv = float(f), float(cu), float(cv)
+    return p
+
+
+def host_estimate_motion_mono(matches, params, threads=1):
+    """mono egomotion of the product on a given flow-match list, host code only (no GPU)
+    -> (rc, tr6, T 4x4, inliers or None)"""
+    m = np.ascontiguousarray(matches, dtype=P_MATCH)
+    tr = np.zeros(6)
+    T = np.zeros(16)
+    inl = np.zeros(max(len(m), 1), dtype=np.int32)
+    n = C.c_int32(0)
+    rc = lib().vsm_host_estimate_motion_mono(C.byref(params), m.ctypes.data_as(C.c_void_p), len(m), threads,
+                                             tr.ctypes.data_as(C.c_void_p), T.ctypes.data_as(C.c_void_p),
+                                             inl.ctypes.data_as(C.c_void_p), C.cast(C.byref(n), C.c_void_p))
+    return rc, tr, T.reshape(4, 4), (inl[: n.value].copy() if rc >= 0 else None)
 
 
 def vo_stereo_params(f=1.0, cu=0.0, cv=0.0, base=1.0, bucket=(2, 50.0, 50.0), ransac_iters=200, inlier_threshold=2.0,
@@ -468,5 +536,82 @@ class VisualOdometryStereo:
         return t
 
     # the face the golden drivers use (same names as oracle.bindings.OracleStereoVO)
+    bucketed = get_matches
+    inliers = get_inlier_indices
+
+
+class VisualOdometryMono:
+    """Mirror of the reference's VisualOdometryMono (viso/viso_mono.h:28-90): process() runs
+    pushBack + matchFeatures(0) + bucketFeatures + the monocular egomotion."""
+
+    def __init__(self, f, cu, cv, bucket=(2, 50.0, 50.0), **kw):
+        self.params = vo_mono_params(f, cu, cv, bucket, **kw)
+        h = lib().vsm_vo_mono_create(C.byref(self.params))
+        if not h:
+            raise VisoMatchError("vsm_vo_mono_create failed: no usable HIP device (there is no CPU path)")
+        self.h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().vsm_vo_mono_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def get_motion(self):
+        t = np.zeros(16)
+        lib().vsm_vo_mono_get_motion(self.h, t.ctypes.data_as(C.c_void_p))
+        return t.reshape(4, 4)
+
+    def process(self, I, replace=False):
+        """-> (success, Tr_delta after the call)"""
+        L = lib()
+        if _is_torch(I):
+            assert I.is_cuda and I.dim() == 2 and I.stride(1) == 1
+            h, w = I.shape
+            ok = L.vsm_vo_mono_process_device(self.h, C.c_void_p(I.data_ptr()), w, h, I.stride(0), int(replace))
+        else:
+            I = np.ascontiguousarray(I, dtype=np.uint8)
+            h, w = I.shape
+            ok = L.vsm_vo_mono_process(self.h, I.ctypes.data_as(C.c_void_p), w, h, w, int(replace))
+        return bool(ok), self.get_motion()
+
+    def process_matches(self, m):
+        m = np.ascontiguousarray(m, dtype=P_MATCH)
+        ok = lib().vsm_vo_mono_process_matches(self.h, m.ctypes.data_as(C.c_void_p), len(m))
+        return bool(ok), self.get_motion()
+
+    def get_matches(self):
+        n = lib().vsm_vo_mono_num_matches(self.h)
+        out = np.zeros(n, dtype=P_MATCH)
+        if n:
+            lib().vsm_vo_mono_get_matches(self.h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def get_inlier_indices(self):
+        n = lib().vsm_vo_mono_num_inliers(self.h)
+        out = np.zeros(n, dtype=np.int32)
+        if n:
+            lib().vsm_vo_mono_get_inliers(self.h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def get_number_of_matches(self):
+        return lib().vsm_vo_mono_num_matches(self.h)
+
+    def get_number_of_inliers(self):
+        return lib().vsm_vo_mono_num_inliers(self.h)
+
+    def get_gain(self, inliers):
+        a = np.ascontiguousarray(inliers, dtype=np.int32)
+        return float(lib().vsm_vo_mono_gain(self.h, a.ctypes.data_as(C.c_void_p), len(a)))
+
+    def timings(self):
+        t = np.zeros(10)
+        lib().vsm_vo_mono_get_timings(self.h, t.ctypes.data_as(C.c_void_p))
+        return t
+
+    def device_svd(self):
+        return bool(lib().vsm_vo_mono_device_svd(self.h))
+
     bucketed = get_matches
     inliers = get_inlier_indices

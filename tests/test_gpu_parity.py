@@ -324,3 +324,41 @@ def test_vo_stereo_vs_oracle_params_and_device_inputs(vm, B, synth):
     inl = v.get_inlier_indices()
     assert np.isfinite(v.get_gain(inl))
     v.close()
+
+
+# ---- monocular egomotion: HIP inlier counting + plane vote ----------
+
+def test_vo_mono_cases_golden(vm):
+    G.replay_mono_cases(_load_golden("mono_cases"), vm.VisualOdometryMono, vm.vo_sampler_seed)
+
+
+def test_vo_mono_sequence_golden(vm, synth):
+    G.replay_mono_sequence(_load_golden("mono_seq12_640x480"), synth, vm.VisualOdometryMono, vm.vo_sampler_seed)
+
+
+def test_vo_mono_large_vs_oracle(vm, B):
+    """enough matches for the GPU plane vote (>= 512 points in front of the camera) and 2000 hypotheses
+    in one inlier-count launch; the host-only entry point must agree as well"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as MG
+    rs = np.random.RandomState(99)
+    f, cu, cv = MG.KITTI["f"], MG.KITTI["cu"], MG.KITTI["cv"]
+    kw = dict(height=1.65, pitch=-0.08, ransac_iters=600)
+    for n, motion in ((2500, (0.002, 0.012, -0.001, 0.03, -0.01, -0.9)), (700, (0.0, -0.02, 0.001, -0.05, 0.0, -0.6))):
+        m = MG.mono_scene(rs, n, motion)
+        B.oracle_sampler_seed(71)
+        o = B.OracleMonoVO(f, cu, cv, **kw)
+        ok_o, T_o = o.process_matches(m)
+        inl_o = o.inliers()
+        o.close()
+        vm.vo_sampler_seed(71)
+        v = vm.VisualOdometryMono(f, cu, cv, **kw)
+        ok_v, T_v = v.process_matches(m)
+        assert ok_v == ok_o and ok_o
+        assert np.array_equal(v.get_inlier_indices(), inl_o)
+        assert T_v.tobytes() == T_o.tobytes()
+        v.close()
+        vm.vo_sampler_seed(71)
+        rc, _, T_h, inl_h = vm.host_estimate_motion_mono(m, vm.vo_mono_params(f, cu, cv, **kw), threads=4)
+        assert rc == 1 and np.array_equal(inl_h, inl_o) and T_h.tobytes() == T_o.tobytes()
