@@ -191,6 +191,14 @@ def main():
             ge = np.load(os.path.join(ROOT, "tests", "golden", "cfg2_seq200_ego.npz"))
             vo_ok = bool(trail.tobytes() == ge["tr_out"][:nf].tobytes())
 
+    # ---- monocular egomotion (row f-4): 2000 hypotheses on a synthetic 5000-match scene -----------
+    mono = None
+    if rank == 0 and not args.no_per_frame:
+        try:
+            mono = mono_leg(vm, not args.no_cpu_baseline)
+        except Exception as e:  # informational leg: never takes the headline down with it
+            mono = {"error": repr(e)}
+
     # ---- verification (outside the timed region): final lists vs the reference's hashes -----
     verified = None
     if not args.no_verify and key == f"s{seed}":
@@ -278,6 +286,7 @@ def main():
                            "tr_delta_trail_bit_exact_vs_reference": vo_ok,
                            "what": "vsm_vo_stereo_process_device per frame: pushBack + matchFeatures(2, live Tr_delta) + "
                                    "bucketFeatures + RANSAC/Gauss-Newton egomotion (VisualOdometryStereo::process)"},
+        "vo_mono_egomotion": mono,
         "verified_bit_exact_vs_reference_hashes": verified,
         "roofline": roof,
         "roofline_by_kernel": {k: {"achieved_GBps": r["achieved"], "frac": r["frac"], "avg_launch_us": r["avg_launch_us"]}
@@ -293,6 +302,58 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def mono_leg(vm, with_cpu):
+    """VisualOdometryMono::estimateMotion (the path the reference offloads to OpenCL) on flow matches of
+    a synthetic ground-plane scene: HIP kernels for the hypothesis fits, Sampson inlier counts,
+    triangulation and plane vote.  Checked against the oracle restatement of the reference's CPU class."""
+    rs = np.random.RandomState(7)
+    n, iters = 5000, 2000
+    f, cu, cv = 721.5377, 609.5593, 172.854
+    ng = n // 2
+    X = np.concatenate([rs.uniform(-8, 8, ng), rs.uniform(-10, 10, n - ng)])
+    Y = np.concatenate([np.full(ng, 1.65), rs.uniform(-3, 1.2, n - ng)])
+    Z = np.concatenate([rs.uniform(4, 40, ng), rs.uniform(5, 50, n - ng)])
+    ry, tz = 0.012, -0.9
+    P = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]]) @ np.stack([X, Y, Z])
+    P[2] += tz
+    m = np.zeros(n, dtype=vm.P_MATCH)
+    m["u1p"], m["v1p"] = f * X / Z + cu, f * Y / Z + cv
+    m["u1c"], m["v1c"] = f * P[0] / P[2] + cu, f * P[1] / P[2] + cv
+    for k in ("u1p", "v1p", "u1c", "v1c"):
+        m[k] += rs.normal(0, 0.1, n).astype(np.float32)
+    bad = rs.permutation(n)[: n // 5]
+    for k in ("u1c", "v1c"):
+        m[k][bad] += rs.uniform(-30, 30, len(bad)).astype(np.float32)
+    for k in ("u2p", "v2p", "u2c", "v2c"):
+        m[k] = -1
+    kw = dict(height=1.65, pitch=-0.08, ransac_iters=iters)
+    v = vm.VisualOdometryMono(f, cu, cv, **kw)
+    best = 1e9
+    for _ in range(5):
+        vm.vo_sampler_seed(71)
+        t = time.perf_counter()
+        ok, T = v.process_matches(m)
+        best = min(best, time.perf_counter() - t)
+    inl = v.get_inlier_indices()
+    out = {"matches": n, "ransac_iters": iters, "ms_per_estimate": round(best * 1e3, 3), "success": bool(ok),
+           "inliers": int(len(inl)), "fits_and_triangulation_on_gpu": v.device_svd(),
+           "split_us": {k: round(float(x), 1) for k, x in zip(("fits", "inlier_count", "rt_triangulation", "plane_vote"),
+                                                              v.timings()[4:8])}}
+    v.close()
+    if with_cpu:
+        from oracle import bindings as B
+        B.oracle_sampler_seed(71)
+        o = B.OracleMonoVO(f, cu, cv, **kw)
+        t = time.perf_counter()
+        ok_o, T_o = o.process_matches(m)
+        dt = time.perf_counter() - t
+        out["cpu_ms_per_estimate"] = round(dt * 1e3, 2)
+        out["cpu_kind"] = "port (oracle restatement of the reference's CPU class, 1 thread)"
+        out["bit_exact_vs_cpu"] = bool(ok_o == ok and T_o.tobytes() == T.tobytes() and np.array_equal(o.inliers(), inl))
+        o.close()
+    return out
 
 
 def cpu_baseline(host, tr_in, tr_valid, intr, budget_s=20.0):

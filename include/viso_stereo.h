@@ -23,20 +23,10 @@ public:
   };
 
   // viso/viso_stereo.cpp:27-29 (+ the base constructor's srand(0), viso/viso.cpp:35)
-  VisualOdometryStereo (parameters param) {
+  VisualOdometryStereo (parameters param) : vo(0) {
     vsm_vo_stereo_params p;
     vsm_vo_stereo_default_params(&p);
-    p.match.nms_n = param.match.nms_n;
-    p.match.nms_tau = param.match.nms_tau;
-    p.match.match_binsize = param.match.match_binsize;
-    p.match.match_radius = param.match.match_radius;
-    p.match.match_disp_tolerance = param.match.match_disp_tolerance;
-    p.match.outlier_disp_tolerance = param.match.outlier_disp_tolerance;
-    p.match.outlier_flow_tolerance = param.match.outlier_flow_tolerance;
-    p.match.multi_stage = param.match.multi_stage;
-    p.match.half_resolution = param.match.half_resolution;
-    p.match.refinement = param.match.refinement;
-    p.match.f = param.match.f; p.match.cu = param.match.cu; p.match.cv = param.match.cv; p.match.base = param.match.base;
+    copyMatchParameters(param.match,p.match);
     p.bucket_max_features = param.bucket.max_features;
     p.bucket_width = param.bucket.bucket_width;
     p.bucket_height = param.bucket.bucket_height;
@@ -46,13 +36,10 @@ public:
     p.inlier_threshold = param.inlier_threshold;
     p.reweighting = param.reweighting ? 1 : 0;
     vo = vsm_vo_stereo_create(&p);
-    if (!vo) {
-      std::cerr << "ERROR: visomatch: no usable HIP device (this library has no CPU path)" << std::endl;
-      abort();
-    }
+    if (!vo) noDevice();
   }
 
-  ~VisualOdometryStereo () {}
+  ~VisualOdometryStereo () { vsm_vo_stereo_destroy(vo); }
 
   // viso/viso_stereo.cpp:33-40: dims = {width, height, bytes per line}; false on failure
   bool process (uint8_t *I1,uint8_t *I2,uint32_t* dims,bool replace=false) {
@@ -60,6 +47,20 @@ public:
   }
 
   using VisualOdometry::process;
+
+  vsm_vo_stereo* native () { return vo; }
+
+protected:
+
+  int     hookProcessMatches (const vsm_p_match *m,int32_t n) { return vsm_vo_stereo_process_matches(vo,m,n); }
+  void    hookMotion (double *t16) { vsm_vo_stereo_get_motion(vo,t16); }
+  int32_t hookMatches (vsm_p_match *out,int32_t cap) { return out ? vsm_vo_stereo_get_matches(vo,out,cap) : vsm_vo_stereo_num_matches(vo); }
+  int32_t hookInliers (int32_t *out,int32_t cap) { return out ? vsm_vo_stereo_get_inliers(vo,out,cap) : vsm_vo_stereo_num_inliers(vo); }
+  float   hookGain (const int32_t *inliers,int32_t n) { return vsm_vo_stereo_gain(vo,inliers,n); }
+
+private:
+
+  vsm_vo_stereo *vo;
 };
 
 #endif

@@ -362,3 +362,31 @@ def test_vo_mono_large_vs_oracle(vm, B):
         vm.vo_sampler_seed(71)
         rc, _, T_h, inl_h = vm.host_estimate_motion_mono(m, vm.vo_mono_params(f, cu, cv, **kw), threads=4)
         assert rc == 1 and np.array_equal(inl_h, inl_o) and T_h.tobytes() == T_o.tobytes()
+
+
+def test_vo_mono_dropin_header(vm, tmp_path):
+    """tools/dropin/_build/mono_native = a C++ caller of include/viso_mono.h (VisualOdometryMono over
+    the C-ABI): same result as the Python mirror on the same match list, both from a fresh sampler"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "dropin", "_build", "mono_native")
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binary not built (needs the reference's matrix.cpp at build time)")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden as MG
+    m = MG.mono_scene(np.random.RandomState(3), 900, (0.001, 0.02, 0.0, 0.02, 0.0, -0.8))
+    f, cu, cv = MG.KITTI["f"], MG.KITTI["cu"], MG.KITTI["cv"]
+    src, out = tmp_path / "m.bin", tmp_path / "o.bin"
+    with open(src, "wb") as fh:
+        fh.write(np.array([len(m)], dtype=np.int32).tobytes())
+        fh.write(m.tobytes())
+    subprocess.check_call([exe, str(src), str(out), repr(f), repr(cu), repr(cv), "1.65", "-0.08", "300"], timeout=120)
+    rec = np.fromfile(out, dtype=np.float64)
+    vm.vo_sampler_seed(71)
+    v = vm.VisualOdometryMono(f, cu, cv, height=1.65, pitch=-0.08, ransac_iters=300)
+    ok, T = v.process_matches(m)
+    assert bool(rec[0]) == ok and int(rec[1]) == v.get_number_of_inliers()
+    assert rec[2:].reshape(4, 4).tobytes() == T.tobytes()
+    v.close()
