@@ -390,3 +390,51 @@ def test_vo_mono_dropin_header(vm, tmp_path):
     assert bool(rec[0]) == ok and int(rec[1]) == v.get_number_of_inliers()
     assert rec[2:].reshape(4, 4).tobytes() == T.tobytes()
     v.close()
+
+
+# ---- kernel-variant coverage: every NMS kernel, odd bin sizes for the fine-bin search, unaligned rows ---
+
+@pytest.mark.parametrize("params", [
+    dict(nms_n=1), dict(nms_n=2), dict(nms_n=3, multi_stage=0), dict(nms_n=4), dict(nms_n=7), dict(nms_n=11),
+    dict(match_binsize=7), dict(match_binsize=23, match_radius=60), dict(match_binsize=100), dict(match_binsize=301),
+    dict(half_resolution=0, nms_n=3), dict(half_resolution=0, nms_n=9, multi_stage=0, match_binsize=33),
+    dict(match_radius=20, match_disp_tolerance=0), dict(nms_tau=10, outlier_flow_tolerance=2, outlier_disp_tolerance=2),
+])
+def test_kernel_variants_vs_oracle(vm, B, synth, params):
+    """nms_n 3 / 9 (sparse of 3) take k_nms_fixed, 1,2,4 k_nms_tile, 5..10 k_nms_tile8, larger k_nms; the
+    bin sizes exercise the fine-bin decomposition (VSM_VSUB sub-rows need not divide the bin)"""
+    w, h = (333, 141) if params.get("half_resolution", 1) else (215, 117)
+    seq = synth.stereo_sequence(91, w, h, 3, disparity=9, ramp=(1, 9))
+    for method in (2, 0, 1):
+        g, c = vm.Matcher(stage_capture=True, **params), B.CpuMatcher("oracle", **params)
+        for f, (l, r) in enumerate(seq):
+            g.push_back(l, r if method else None)
+            c.push_back(l, r if method else None)
+            for s in ("1c1", "1c2"):
+                assert _same(g.features(s), c.features(s)), (params, method, f, s)
+            assert g.match(method) == c.match(method)
+            for s in range(5):
+                assert _same(g.stage(s), c.stage(s)), (params, method, f, s)
+        g.close()
+        c.close()
+
+
+def test_device_inputs_unaligned_rows_and_strides(vm, B, synth):
+    """k_ingest: device images whose rows start at every byte alignment (width 1..3 mod 4, a strided
+    view, and a view that starts in the middle of an allocation)"""
+    import torch
+    for w, h in ((201, 75), (202, 76), (203, 77), (204, 78)):
+        seq = synth.stereo_sequence(13, w, h, 2, disparity=8)
+        g, c = vm.Matcher(), B.CpuMatcher("oracle")
+        for f, (l, r) in enumerate(seq):
+            big = torch.zeros((2, h, w + 7), dtype=torch.uint8, device="cuda")   # row stride w+7, odd offsets
+            big[0, :, 3:3 + w] = torch.from_numpy(l).cuda()
+            big[1, :, 3:3 + w] = torch.from_numpy(r).cuda()
+            assert g.push_back(big[0, :, 3:3 + w], big[1, :, 3:3 + w]) == 0
+            c.push_back(l, r)
+            for s in ("1c1", "1c2", "2c1", "2c2"):
+                assert _same(g.features(s), c.features(s)), (w, f, s)
+            assert g.match(2) == c.match(2)
+            assert _same(g.get_matches(), c.matches()), (w, f)
+        g.close()
+        c.close()
