@@ -54,6 +54,12 @@ static int cpu_budget() {
   return budget;
 }
 
+// VSM_DEBUG_TIMING=1: per-chunk phase times of vsm_sequence_run on stderr (read once)
+static bool vsm_debug_timing() {
+  static const bool on = getenv("VSM_DEBUG_TIMING") != nullptr;
+  return on;
+}
+
 static inline double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -744,7 +750,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     const double tl0 = now_us();
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
-    if (getenv("VSM_DEBUG_TIMING")) fprintf(stderr, "  chunk %d: launch %.0f us, feature sync %.0f us\n", k, tl0 - ta, now_us() - tl0);
+    if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: launch %.0f us, feature sync %.0f us\n", k, tl0 - ta, now_us() - tl0);
     // ---- one job per frame of the chunk ----
     int max_nq[2] = {0, 0};
     std::shared_ptr<std::vector<char>> validp = std::make_shared<std::vector<char>>(n, 0);
@@ -807,7 +813,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       const double tl1 = now_us();
       HIPCHK(hipStreamSynchronize(h->stream));
       double tb = now_us();
-      if (getenv("VSM_DEBUG_TIMING")) fprintf(stderr, "  chunk %d: pass1 sync %.0f us\n", k, tb - tl1);
+      if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass1 sync %.0f us\n", k, tb - tl1);
       tg += tb - ta;
       h->pool->run(n, [&](int i) {  // queued behind the previous chunk's final stage (FIFO)
         static thread_local VsmHostWork tw;
@@ -828,7 +834,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     // the export below overwrites this pair bank's host lists: chunk k-2 must be done with them
     const double tw0 = now_us();
     if (k >= 2) h->pool->wait(tickets[k - 2]);
-    if (getenv("VSM_DEBUG_TIMING") && now_us() - tw0 > 2000) fprintf(stderr, "  chunk %d: waited %.0f us for chunk %d's final stage\n", k, now_us() - tw0, k - 2);
+    if (vsm_debug_timing() && now_us() - tw0 > 2000) fprintf(stderr, "  chunk %d: waited %.0f us for chunk %d's final stage\n", k, now_us() - tw0, k - 2);
     cfg.sparse = 0;
     cfg.use_prior = p.multi_stage ? 1 : 0;
     vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, cfg, max_nq[1]);
@@ -840,7 +846,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     h->prof.resolve();
-    if (getenv("VSM_DEBUG_TIMING")) fprintf(stderr, "  chunk %d: pass2 launch %.0f us sync %.0f us\n", k, tl2 - ta, now_us() - tl2);
+    if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass2 launch %.0f us sync %.0f us\n", k, tl2 - ta, now_us() - tl2);
     tg += now_us() - ta;
     // final host stage of this chunk: asynchronous, overlapped with the next chunk's GPU work
     VsmCtx *cp = &c;
@@ -863,7 +869,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   h->seq_timings[1] = thost;
   h->seq_timings[2] = now_us() - tstart;
   h->seq_timings[3] = (double)C;
-  if (getenv("VSM_DEBUG_TIMING"))
+  if (vsm_debug_timing())
     fprintf(stderr, "seq: entry->start %.0f us, gpu %.0f, host %.0f, total %.0f\n", tstart - t_entry, tg, thost,
             h->seq_timings[2]);
   return VSM_OK;
