@@ -285,6 +285,7 @@ struct vsm_handle {
   vsm_params param;  // match_radius already halved for half_resolution (viso/matcher.cpp:59-60)
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t idle_wait = nullptr;  // blocking-sync event: the look-ahead caller yields its CPU to the host pool
   VsmCtx ring;  // streaming ring buffer: 2 frame slots, 1 pair
   VsmCtx seq;   // look-ahead sequences: 2 banks of C frame slots, C pairs
   int seq_chunk = 0;
@@ -366,11 +367,14 @@ vsm_handle *vsm_create(const vsm_params *p) {
     int nt = 16;
     if (const char *e = getenv("VSM_HOST_THREADS")) nt = atoi(e);
     nt = std::max(1, std::min(nt, cpu_budget()));
-    h->pool = new VsmPool(nt);
+    // (the look-ahead caller sleeps in a blocking event wait while the GPU works, so all nt budgeted
+    // CPUs go to pool workers: nt workers + the caller's thread)
+    h->pool = new VsmPool(nt + 1);
     h->fj = new VsmForkJoin(nt < 8 ? nt : 8);
     h->work.pool = h->fj;
   }
-  if (hipGetDevice(&h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipGetDevice(&h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->idle_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
     fprintf(stderr, "visomatch: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
     delete h->pool;
     delete h->fj;
@@ -393,6 +397,7 @@ void vsm_destroy(vsm_handle *h) {
   ctx_destroy(h->ring);
   ctx_destroy(h->seq);
   if (h->stage_host) (void)hipHostFree(h->stage_host);
+  if (h->idle_wait) (void)hipEventDestroy(h->idle_wait);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h->pool;
   delete h->fj;
@@ -669,6 +674,14 @@ float vsm_gain(vsm_handle *h, const int32_t *inliers, int32_t n) {
   return vsm_host_gain(h->gainI[0].data(), h->gainI[1].data(), h->dims_p, h->dims_c, h->matched, inliers, n);
 }
 
+// stream sync that puts the calling thread to sleep (the per-frame path keeps the spinning
+// hipStreamSynchronize: there a wake-up latency of tens of microseconds matters, here the CPU does)
+static hipError_t sync_sleeping(vsm_handle *h) {
+  hipError_t e = hipEventRecord(h->idle_wait, h->stream);
+  if (e != hipSuccess) return e;
+  return hipEventSynchronize(h->idle_wait);
+}
+
 // ---------------------------------------------------------------------------------------
 // Look-ahead sequence API.  Semantics: exactly pushBack(frame f) + matchFeatures(method, Tr[f])
 // for f = 0..n-1 on a fresh matcher.  Frames are processed in chunks of C: every kernel runs once
@@ -748,7 +761,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     vsm_launch_features(h->stream, h->prof, c.d_imgs, first_img, 2 * n, c.dims, c.f1, c.f2, c.f_stride, p.nms_tau,
                         p.multi_stage, p.half_resolution, p.match_binsize, c.h_imgs.data());
     const double tl0 = now_us();
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_sleeping(h));
     HIPCHK(hipGetLastError());
     if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: launch %.0f us, feature sync %.0f us\n", k, tl0 - ta, now_us() - tl0);
     // ---- one job per frame of the chunk ----
@@ -811,7 +824,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, cfg, max_nq[0]);
       vsm_launch_export(h->stream, h->prof, d_pairs, n, 0, max_nq[0]);
       const double tl1 = now_us();
-      HIPCHK(hipStreamSynchronize(h->stream));
+      HIPCHK(sync_sleeping(h));
       double tb = now_us();
       if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass1 sync %.0f us\n", k, tb - tl1);
       tg += tb - ta;
@@ -843,7 +856,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
                         max_nq[1]);
     vsm_launch_export(h->stream, h->prof, d_pairs, n, 1, max_nq[1]);
     const double tl2 = now_us();
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_sleeping(h));
     HIPCHK(hipGetLastError());
     h->prof.resolve();
     if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass2 launch %.0f us sync %.0f us\n", k, tl2 - ta, now_us() - tl2);
