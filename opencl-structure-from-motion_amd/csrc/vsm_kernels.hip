@@ -1264,7 +1264,31 @@ __global__ void __launch_bounds__(256)
       V[r][0] = V[r][1] = V[r][2] = 0;
     }
   }
-  const uint4 rd = small_desc(ref.du_full, ref.dv_full, dc.bpl, (int)m->u1c, (int)m->v1c);
+  // reference descriptor at (u1c, v1c) of the current left image (computeSmallDescriptor, :479-506):
+  // 5 du rows + 3 dv rows, columns u-2..u+2, each as two aligned dwords re-based with a funnel shift
+  // (8 wide loads instead of 16 byte gathers)
+  uint4 rd;
+  {
+    const int ru = (int)m->u1c, rv = (int)m->v1c;
+    const int b0 = (ru - 2) & ~3, rsh = 8 * ((ru - 2) - b0);
+    uint64_t wu[5], wv[3];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      const uint32_t *pr = (const uint32_t *)(ref.du_full + (size_t)(rv - 2 + r) * dc.bpl + b0);
+      wu[r] = ((((uint64_t)pr[1]) << 32) | pr[0]) >> rsh;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const uint32_t *pr = (const uint32_t *)(ref.dv_full + (size_t)(rv - 1 + r) * dc.bpl + b0);
+      wv[r] = ((((uint64_t)pr[1]) << 32) | pr[0]) >> rsh;
+    }
+#define WB(w, c) ((uint32_t)((w) >> (8 * (c))) & 0xffu)
+    rd.x = WB(wu[0], 2) | (WB(wu[1], 0) << 8) | (WB(wu[1], 2) << 16) | (WB(wu[1], 4) << 24);
+    rd.y = WB(wu[2], 1) | (WB(wu[2], 2) << 8) | (WB(wu[2], 2) << 16) | (WB(wu[2], 3) << 24);
+    rd.z = WB(wu[3], 0) | (WB(wu[3], 2) << 8) | (WB(wu[3], 4) << 16) | (WB(wu[4], 2) << 24);
+    rd.w = WB(wv[0], 2) | (WB(wv[1], 1) << 8) | (WB(wv[1], 3) << 16) | (WB(wv[2], 2) << 24);
+#undef WB
+  }
 #define UB(r, c) ((U[(r)][(c) >> 2] >> (8 * ((c)&3))) & 0xffu)
 #define VB(r, c) ((V[(r)][(c) >> 2] >> (8 * ((c)&3))) & 0xffu)
   uint32_t best = 0xffffffffu;
