@@ -81,3 +81,75 @@ def stereo_sequence(seed, W, H, n_frames, disparity=20, ramp=(0, 1), blur=5):
 def mono_sequence(seed, W, H, n_frames, blur=5):
     cv = canvas(seed, W, H, blur=blur)
     return [mono_frame(cv, f, W, H) for f in range(n_frames)]
+
+
+# ---------------------------------------------------------------------------------------------
+# Street scene with real depth structure (integer arithmetic only): a ground plane 1.65 m below
+# the camera and two facades at x = +-wall_mm, textured from a mip pyramid of one canvas, seen by
+# a camera (or a rectified stereo pair) that drives straight ahead.  Unlike the planar crops
+# above it has depth-dependent disparities and flow, and the monocular egomotion (which needs
+# a ground plane to fix the scale) succeeds on it.
+#   pixel (u, v), camera at (cam_x, 0, cam_z), focal f_px, principal point (cu, cv) [integers]:
+#     ground:  Z = f*h/(v-cv) for v > cv;   facade: Z = f*(wall -+ cam_x)/|u-cu|;   nearer one wins
+#     texel size 2^level * cell_mm with level = floor(log2(Z / z0)): the footprint of a pixel stays
+#     within a factor of two of a texel at every depth
+# ---------------------------------------------------------------------------------------------
+ROAD_F, ROAD_H_MM, ROAD_WALL_MM, ROAD_CELL_MM = 720, 1650, 6000, 4
+
+
+def road_pyramid(seed, levels=10, size=2048):
+    """levels of one size x size texture, each a 2x2 box reduction of the previous (integer mean)
+    with the contrast restored, tiled back to size x size (the textures are used periodically)"""
+    base = canvas(seed, size - CANVAS_PAD_W, size - CANVAS_PAD_H)[:size, :size]
+    pyr = [base]
+    for _ in range(1, levels):
+        b = pyr[-1].astype(np.int32)
+        b = (b[0::2, 0::2] + b[0::2, 1::2] + b[1::2, 0::2] + b[1::2, 1::2]) // 4
+        b = np.clip((b - 128) * 2 + 128, 0, 255)
+        pyr.append(np.tile(b, (2, 2)).astype(np.uint8))
+    return pyr
+
+
+def road_view(pyr, W, H, cam_x_mm, cam_z_mm, cu=None, cv=None):
+    """one uint8 image of the street from a camera at lateral offset cam_x_mm, advanced by cam_z_mm.
+    The mip level follows the footprint of a pixel ALONG the surface (Z^2 / (f * distance to the
+    surface plane)), the direction in which a grazing view compresses the texture."""
+    cu = W // 2 if cu is None else cu
+    cv = (H * 2) // 5 if cv is None else cv
+    size = pyr[0].shape[0]
+    u = np.arange(W, dtype=np.int64)[None, :] - cu
+    v = np.arange(H, dtype=np.int64)[:, None] - cv
+    big = np.int64(1) << 40
+    zg = np.where(v > 0, (ROAD_F * ROAD_H_MM) // np.maximum(v, 1), big) + 0 * u              # ground hit
+    wall_off = np.where(u > 0, ROAD_WALL_MM - cam_x_mm, ROAD_WALL_MM + cam_x_mm) + 0 * v      # distance to the facade
+    zw = np.where(u != 0, (ROAD_F * wall_off) // np.maximum(np.abs(u), 1), big) + 0 * v       # facade hit
+    on_ground = zg <= zw
+    z = np.minimum(zg, zw)
+    far = z >= 120000                                                                         # sky beyond 120 m
+    z = np.minimum(z, 120000)
+    x = (u * z) // ROAD_F + cam_x_mm
+    y = (v * z) // ROAD_F
+    zz = z + cam_z_mm
+    ta = np.where(on_ground, x + 50000, y + 70000 + np.where(u > 0, 0, 33331))                # across the surface
+    tb = zz                                                                                   # along the street
+    foot = (z * z) // (ROAD_F * np.where(on_ground, ROAD_H_MM, wall_off))                     # mm per pixel along the street
+    lvl = np.zeros_like(z)
+    for k in range(1, len(pyr)):
+        lvl += (foot > (ROAD_CELL_MM << (k - 1))).astype(np.int64)
+    out = np.zeros((H, W), dtype=np.uint8)
+    for k in range(len(pyr)):
+        sel = lvl == k
+        if sel.any():
+            cell = ROAD_CELL_MM << k
+            out[sel] = pyr[k][((tb // cell) % size)[sel], ((ta // cell) % size)[sel]]
+    out[far | (foot > (ROAD_CELL_MM << len(pyr)))] = 96                                       # too far to resolve
+    return out
+
+
+def road_stereo_frame(pyr, f, W, H, step_mm=600, base_mm=540):
+    """rectified pair after f steps of step_mm forward motion; disparity = f*base/Z"""
+    return road_view(pyr, W, H, 0, f * step_mm), road_view(pyr, W, H, base_mm, f * step_mm)
+
+
+def road_mono_frame(pyr, f, W, H, step_mm=600):
+    return road_view(pyr, W, H, 0, f * step_mm)

@@ -199,3 +199,34 @@ def replay_mono_sequence(g, synth, make_vo, reset_sampler):
         assert len(i) == int(g["n_inliers"][f]) and sha(i) == str(g["inliers_sha"][f]), f
         assert T.tobytes() == g["T"][f].tobytes(), f
     vo.close()
+
+
+def replay_road(g, synth, make_stereo, make_mono, reset_sampler):
+    """road_*.npz: street scene with real depth structure; the live stereo VO loop, then the mono VO
+    loop, every frame's result flag, Tr_delta, bucketed list and inlier set equal to the reference's"""
+    reset_sampler()
+    w, h = int(g["w"]), int(g["h"])
+    pyr = synth.road_pyramid(int(g["seed"]))
+    f, cu, cv, base = [float(x) for x in g["calib"]]
+    vo = make_stereo(f, cu, cv, base)
+    for k in range(int(g["n_stereo"])):
+        l, r = synth.road_stereo_frame(pyr, k, w, h)
+        assert sha(l) + sha(r) == str(g["s_in"][k])
+        res = vo.process(l, r)
+        assert res[0] == bool(g["s_ok"][k]), k
+        b, i = vo.bucketed(), vo.inliers()
+        assert len(b) == int(g["s_nb"][k]) and sha(b) == str(g["s_hb"][k]), k
+        assert len(i) == int(g["s_ni"][k]) and sha(i) == str(g["s_hi"][k]), k
+        assert res[-1].tobytes() == g["s_T"][k].tobytes(), k
+    vo.close()
+    mo = make_mono(f, cu, cv, height=1.65, pitch=0.0)
+    for k in range(int(g["n_mono"])):
+        img = synth.road_mono_frame(pyr, k, w, h)
+        assert sha(img) == str(g["m_in"][k])
+        ok, T = mo.process(img)
+        assert ok == bool(g["m_ok"][k]), k
+        b, i = mo.bucketed(), mo.inliers()
+        assert len(b) == int(g["m_nb"][k]) and sha(b) == str(g["m_hb"][k]), k
+        assert len(i) == int(g["m_ni"][k]) and sha(i) == str(g["m_hi"][k]), k
+        assert T.tobytes() == g["m_T"][k].tobytes(), k
+    mo.close()

@@ -438,3 +438,9 @@ def test_device_inputs_unaligned_rows_and_strides(vm, B, synth):
             assert _same(g.get_matches(), c.matches()), (w, f)
         g.close()
         c.close()
+
+
+def test_road_scene_golden(vm, synth):
+    """street scene with real depth structure: the live stereo VO loop and the mono VO loop (success on
+    every frame pair) against the all-reference run, frame by frame"""
+    G.replay_road(_load_golden("road_1242x375"), synth, vm.VisualOdometryStereo, vm.VisualOdometryMono, vm.vo_sampler_seed)

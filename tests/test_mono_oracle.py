@@ -80,3 +80,8 @@ def test_mono_live_vs_reference(B, have_ref):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "RESULT 0" in out.stdout, out.stdout[-3000:]
+
+
+def test_road_scene_golden(B, synth):
+    """stereo + mono VO loops of the oracle on the street scene (depth-dependent disparity and flow)"""
+    G.replay_road(load("road_1242x375"), synth, B.OracleStereoVO, B.OracleMonoVO, B.oracle_sampler_seed)
