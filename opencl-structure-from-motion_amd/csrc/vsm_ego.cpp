@@ -51,6 +51,15 @@ struct Sampler {
     }
     return (uint32_t)(v + lo);
   }
+  // the same draw with the two divisions of a (lo, hi) pair hoisted out: RANSAC draws from the same
+  // few ranges thousands of times.  v / per_cell = (v * magic) >> 64 exactly for v < 2^32.
+  uint32_t between(const VsmDrawPlan &p) {
+    uint64_t v;
+    do v = next() - 1;
+    while (v >= p.reject_from);
+    if (p.per_cell) v = (uint64_t)(((__uint128_t)v * p.magic) >> 64);
+    return (uint32_t)(v + p.lo);
+  }
 };
 Sampler g_sampler;
 
@@ -290,10 +299,17 @@ class EgoStereo {
     deck.resize((size_t)n);
     {
       std::lock_guard<std::mutex> lock(g_sampler.mu);
-      for (int k = 0; k < iters; k++) {  // partial shuffle of 0..n-1, first three (viso.cpp:96-105)
-        for (int i = 0; i < n; i++) deck[i] = i;
-        for (int i = 0; i < 3; i++) std::swap(deck[i], deck[g_sampler.between((uint32_t)i, (uint32_t)(n - 1))]);
+      const VsmDrawPlan plan[3] = {vsm_sampler_plan(0, (uint32_t)(n - 1)), vsm_sampler_plan(1, (uint32_t)(n - 1)),
+                                   vsm_sampler_plan(2, (uint32_t)(n - 1))};
+      for (int i = 0; i < n; i++) deck[i] = i;
+      for (int k = 0; k < iters; k++) {  // partial shuffle of 0..n-1, first three (viso.cpp:96-105), undone afterwards
+        int swapped[3];
+        for (int i = 0; i < 3; i++) {
+          swapped[i] = (int)g_sampler.between(plan[i]);
+          std::swap(deck[i], deck[swapped[i]]);
+        }
         for (int i = 0; i < 3; i++) hyp[k].pick[i] = deck[i];
+        for (int i = 2; i >= 0; i--) std::swap(deck[i], deck[swapped[i]]);
       }
     }
     std::atomic<int> reached{0};  // best count seen so far by any hypothesis (only ever a lower bound)
@@ -354,6 +370,24 @@ void pose_matrix(const double *tr, double *T) {  // transformationVectorToMatrix
 void vsm_sampler_lock() { g_sampler.mu.lock(); }
 void vsm_sampler_unlock() { g_sampler.mu.unlock(); }
 uint32_t vsm_sampler_between(uint32_t lo, uint32_t hi) { return g_sampler.between(lo, hi); }
+VsmDrawPlan vsm_sampler_plan(uint32_t lo, uint32_t hi) {
+  VsmDrawPlan p;
+  const uint64_t engine_span = 2147483645ull, want = (uint64_t)hi - lo;
+  p.lo = lo;
+  if (engine_span > want) {
+    const uint64_t cells = want + 1;
+    p.per_cell = engine_span / cells;
+    p.reject_from = cells * p.per_cell;
+    p.magic = p.per_cell > 1 ? UINT64_MAX / p.per_cell + 1 : 0;
+    if (p.per_cell == 1) p.per_cell = 0;  // division by one: nothing to do
+  } else {
+    p.per_cell = 0;
+    p.reject_from = UINT64_MAX;
+    p.magic = 0;
+  }
+  return p;
+}
+uint32_t vsm_sampler_draw(const VsmDrawPlan &p) { return g_sampler.between(p); }
 void vsm_pose_matrix(const double *tr6, double *T16) { pose_matrix(tr6, T16); }
 
 struct vsm_vo_stereo {

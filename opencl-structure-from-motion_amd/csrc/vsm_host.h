@@ -61,6 +61,12 @@ double vsm_now_us();
 void vsm_sampler_lock();
 void vsm_sampler_unlock();
 uint32_t vsm_sampler_between(uint32_t lo, uint32_t hi);  // call with the lock held
+struct VsmDrawPlan {  // a (lo, hi) range with the divisions of the distribution done once
+  uint64_t per_cell, reject_from, magic;
+  uint32_t lo;
+};
+VsmDrawPlan vsm_sampler_plan(uint32_t lo, uint32_t hi);
+uint32_t vsm_sampler_draw(const VsmDrawPlan &p);          // call with the lock held
 void vsm_pose_matrix(const double *tr6, double *T16);
 
 // Lock-free fork-join pool for the fine-grained phases inside ONE Delaunay (a dozen tasks of

@@ -35,16 +35,22 @@ VSM_HD inline double with_sign(double a, double b) { return b >= 0.0 ? fabs(a) :
 // m x n factor U.  w[n], v[n*n] (row-major), rv1[n] scratch, col[m > n ? m : n] scratch.
 // On return the singular values are in decreasing order and every (u column, v column) pair has
 // at most half of its entries negative, exactly as Matrix::svd leaves them.
-VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w, double *v, double *rv1, double *col) {
-#define U_(i, j) u[(i) * ldu + (j)]
-#define V_(i, j) v[(i) * n + (j)]
+// ES = distance between consecutive elements of every array: 1 for ordinary arrays; a kernel that
+// keeps one matrix per lane in LDS uses its block size, so that lanes never share a bank.
+template <int ES = 1>
+VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w_, double *v, double *rv1_, double *col_) {
+#define U_(i, j) u[((i) * ldu + (j)) * ES]
+#define V_(i, j) v[((i) * n + (j)) * ES]
+#define w(i) w_[(i) * ES]
+#define rv1(i) rv1_[(i) * ES]
+#define col(i) col_[(i) * ES]
   int flag, i, its, j, jj, k, l = 0, nm = 0;
   double anorm = 0.0, c, f, g = 0.0, h, s, scale = 0.0, x, y, z;
-  for (i = 0; i < n * n; i++) v[i] = 0.0;
+  for (i = 0; i < n * n; i++) v[i * ES] = 0.0;
   // Householder reduction to bidiagonal form
   for (i = 0; i < n; i++) {
     l = i + 1;
-    rv1[i] = scale * g;
+    rv1(i) = scale * g;
     g = s = scale = 0.0;
     if (i < m) {
       for (k = i; k < m; k++) scale += fabs(U_(k, i));
@@ -65,7 +71,7 @@ VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w, double *v
         for (k = i; k < m; k++) U_(k, i) *= scale;
       }
     }
-    w[i] = scale * g;
+    w(i) = scale * g;
     g = s = scale = 0.0;
     if (i < m && i != n - 1) {
       for (k = l; k < n; k++) scale += fabs(U_(i, k));
@@ -78,15 +84,15 @@ VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w, double *v
         g = -with_sign(sqrt(s), f);
         h = f * g - s;
         U_(i, l) = f - g;
-        for (k = l; k < n; k++) rv1[k] = U_(i, k) / h;
+        for (k = l; k < n; k++) rv1(k) = U_(i, k) / h;
         for (j = l; j < m; j++) {
           for (s = 0.0, k = l; k < n; k++) s += U_(j, k) * U_(i, k);
-          for (k = l; k < n; k++) U_(j, k) += s * rv1[k];
+          for (k = l; k < n; k++) U_(j, k) += s * rv1(k);
         }
         for (k = l; k < n; k++) U_(i, k) *= scale;
       }
     }
-    const double t = fabs(w[i]) + fabs(rv1[i]);
+    const double t = fabs(w(i)) + fabs(rv1(i));
     anorm = anorm > t ? anorm : t;
   }
   // accumulate the right-hand transformations
@@ -102,13 +108,13 @@ VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w, double *v
       for (j = l; j < n; j++) V_(i, j) = V_(j, i) = 0.0;
     }
     V_(i, i) = 1.0;
-    g = rv1[i];
+    g = rv1(i);
     l = i;
   }
   // accumulate the left-hand transformations
   for (i = (m < n ? m : n) - 1; i >= 0; i--) {
     l = i + 1;
-    g = w[i];
+    g = w(i);
     for (j = l; j < n; j++) U_(i, j) = 0.0;
     if (g) {
       g = 1.0 / g;
@@ -129,22 +135,22 @@ VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w, double *v
       flag = 1;
       for (l = k; l >= 0; l--) {
         nm = l - 1;
-        if ((double)(fabs(rv1[l]) + anorm) == anorm) {
+        if ((double)(fabs(rv1(l)) + anorm) == anorm) {
           flag = 0;
           break;
         }
-        if ((double)(fabs(w[nm]) + anorm) == anorm) break;
+        if ((double)(fabs(w(nm)) + anorm) == anorm) break;
       }
       if (flag) {
         c = 0.0;
         s = 1.0;
         for (i = l; i <= k; i++) {
-          f = s * rv1[i];
-          rv1[i] = c * rv1[i];
+          f = s * rv1(i);
+          rv1(i) = c * rv1(i);
           if ((double)(fabs(f) + anorm) == anorm) break;
-          g = w[i];
+          g = w(i);
           h = hypot_nr(f, g);
-          w[i] = h;
+          w(i) = h;
           h = 1.0 / h;
           c = g * h;
           s = -f * h;
@@ -156,31 +162,31 @@ VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w, double *v
           }
         }
       }
-      z = w[k];
+      z = w(k);
       if (l == k) {  // converged; make the singular value non-negative
         if (z < 0.0) {
-          w[k] = -z;
+          w(k) = -z;
           for (j = 0; j < n; j++) V_(j, k) = -V_(j, k);
         }
         break;
       }
-      x = w[l];
+      x = w(l);
       nm = k - 1;
-      y = w[nm];
-      g = rv1[nm];
-      h = rv1[k];
+      y = w(nm);
+      g = rv1(nm);
+      h = rv1(k);
       f = ((y - z) * (y + z) + (g - h) * (g + h)) / (2.0 * h * y);
       g = hypot_nr(f, 1.0);
       f = ((x - z) * (x + z) + h * ((y / (f + with_sign(g, f))) - h)) / x;
       c = s = 1.0;
       for (j = l; j <= nm; j++) {
         i = j + 1;
-        g = rv1[i];
-        y = w[i];
+        g = rv1(i);
+        y = w(i);
         h = s * g;
         g = c * g;
         z = hypot_nr(f, h);
-        rv1[j] = z;
+        rv1(j) = z;
         c = f / z;
         s = h / z;
         f = x * c + g * s;
@@ -194,7 +200,7 @@ VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w, double *v
           V_(jj, i) = z * c - x * s;
         }
         z = hypot_nr(f, h);
-        w[j] = z;
+        w(j) = z;
         if (z) {
           z = 1.0 / z;
           c = f * z;
@@ -209,9 +215,9 @@ VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w, double *v
           U_(jj, i) = z * c - y * s;
         }
       }
-      rv1[l] = 0.0;
-      rv1[k] = f;
-      w[k] = x;
+      rv1(l) = 0.0;
+      rv1(k) = f;
+      w(k) = x;
     }
   }
   // decreasing order (shell sort with the 1, 4, 13, ... increments), columns of u and v follow
@@ -222,21 +228,21 @@ VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w, double *v
   do {
     inc /= 3;
     for (i = inc; i < n; i++) {
-      const double sw = w[i];
-      for (k = 0; k < m; k++) col[k] = U_(k, i);
+      const double sw = w(i);
+      for (k = 0; k < m; k++) col(k) = U_(k, i);
       j = i;
       // (the v column is moved through rv1, which is free now)
-      for (k = 0; k < n; k++) rv1[k] = V_(k, i);
-      while (w[j - inc] < sw) {
-        w[j] = w[j - inc];
+      for (k = 0; k < n; k++) rv1(k) = V_(k, i);
+      while (w(j - inc) < sw) {
+        w(j) = w(j - inc);
         for (k = 0; k < m; k++) U_(k, j) = U_(k, j - inc);
         for (k = 0; k < n; k++) V_(k, j) = V_(k, j - inc);
         j -= inc;
         if (j < inc) break;
       }
-      w[j] = sw;
-      for (k = 0; k < m; k++) U_(k, j) = col[k];
-      for (k = 0; k < n; k++) V_(k, j) = rv1[k];
+      w(j) = sw;
+      for (k = 0; k < m; k++) U_(k, j) = col(k);
+      for (k = 0; k < n; k++) V_(k, j) = rv1(k);
     }
   } while (inc > 1);
   // sign convention: flip a (u, v) column pair when more than half of its entries are negative
@@ -251,6 +257,9 @@ VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w, double *v
   }
 #undef U_
 #undef V_
+#undef w
+#undef rv1
+#undef col
 }
 
 // C (m x p) = A (m x n) * B (n x p), row-major; every entry is 0 + a_i0*b_0j + a_i1*b_1j + ...

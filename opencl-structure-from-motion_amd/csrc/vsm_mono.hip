@@ -95,26 +95,30 @@ __global__ void __launch_bounds__(256)
 // the 8x9 constraint matrix, its SVD and the rank-2 projection in private memory.  vsm_linalg.h is the
 // same code the host runs; f64 +, *, /, sqrt are correctly rounded on gfx950 and contraction is off,
 // so the nine doubles are the host's (checked by a self-test when the context is created).
+// The matrices of a lane live in LDS, element e of lane l at [e * 64 + l]: runtime-indexed private
+// arrays would go to scratch memory, and interleaving by lane keeps every access conflict-free.
 __global__ void __launch_bounds__(64)
     k_mono_fit(const MonoPt *__restrict__ pts, const int32_t *__restrict__ picks, int K, double *__restrict__ Fs) {
+  __shared__ double s_m[(72 + 81 + 9 + 9 + 9) * 64];
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
-  double A[72], w[9], v[81], rv1[9], col[9], F0[9], F[9];
+  double *A = s_m + threadIdx.x, *v = A + 72 * 64, *w = v + 81 * 64, *rv1 = w + 9 * 64, *col = rv1 + 9 * 64;
   for (int i = 0; i < 8; i++) {
     const MonoPt q = pts[picks[k * 8 + i]];
-    double *r = A + i * 9;
-    r[0] = q.u1c * q.u1p;
-    r[1] = q.u1c * q.v1p;
-    r[2] = q.u1c;
-    r[3] = q.v1c * q.u1p;
-    r[4] = q.v1c * q.v1p;
-    r[5] = q.v1c;
-    r[6] = q.u1p;
-    r[7] = q.v1p;
-    r[8] = 1;
+    double *r = A + i * 9 * 64;
+    r[0 * 64] = q.u1c * q.u1p;
+    r[1 * 64] = q.u1c * q.v1p;
+    r[2 * 64] = q.u1c;
+    r[3 * 64] = q.v1c * q.u1p;
+    r[4 * 64] = q.v1c * q.v1p;
+    r[5 * 64] = q.v1c;
+    r[6 * 64] = q.u1p;
+    r[7 * 64] = q.v1p;
+    r[8 * 64] = 1;
   }
-  vsm_la::svd_nr(A, 8, 9, 9, w, v, rv1, col);
-  for (int i = 0; i < 9; i++) F0[i] = v[i * 9 + 8];
+  vsm_la::svd_nr<64>(A, 8, 9, 9, w, v, rv1, col);
+  double F0[9], F[9];
+  for (int i = 0; i < 9; i++) F0[i] = v[(i * 9 + 8) * 64];
   vsm_la::rank2_3x3(F0, F);
   for (int i = 0; i < 9; i++) Fs[(size_t)k * 9 + i] = F[i];
 }
@@ -126,21 +130,22 @@ struct MonoCams {
 };
 __global__ void __launch_bounds__(64)
     k_mono_triangulate(const MonoPt *__restrict__ raw, int n, MonoCams cams, double *__restrict__ X, int32_t *__restrict__ chir) {
+  __shared__ double s_m[(16 + 16 + 4 + 4 + 4) * 64];
   const int i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
   bool front = false;
   if (i < n) {
     const MonoPt q = raw[i];
     const double *P1 = cams.P1, *P2 = cams.P2[c];
-    double J[16], w4[4], v4[16], r4[4], c4[4];
+    double *J = s_m + threadIdx.x, *v4 = J + 16 * 64, *w4 = v4 + 16 * 64, *r4 = w4 + 4 * 64, *c4 = r4 + 4 * 64;
     for (int j = 0; j < 4; j++) {
-      J[0 * 4 + j] = P1[2 * 4 + j] * q.u1p - P1[0 * 4 + j];
-      J[1 * 4 + j] = P1[2 * 4 + j] * q.v1p - P1[1 * 4 + j];
-      J[2 * 4 + j] = P2[2 * 4 + j] * q.u1c - P2[0 * 4 + j];
-      J[3 * 4 + j] = P2[2 * 4 + j] * q.v1c - P2[1 * 4 + j];
+      J[(0 * 4 + j) * 64] = P1[2 * 4 + j] * q.u1p - P1[0 * 4 + j];
+      J[(1 * 4 + j) * 64] = P1[2 * 4 + j] * q.v1p - P1[1 * 4 + j];
+      J[(2 * 4 + j) * 64] = P2[2 * 4 + j] * q.u1c - P2[0 * 4 + j];
+      J[(3 * 4 + j) * 64] = P2[2 * 4 + j] * q.v1c - P2[1 * 4 + j];
     }
-    vsm_la::svd_nr(J, 4, 4, 4, w4, v4, r4, c4);
+    vsm_la::svd_nr<64>(J, 4, 4, 4, w4, v4, r4, c4);
     double x[4];
-    for (int r = 0; r < 4; r++) x[r] = X[((size_t)c * 4 + r) * n + i] = v4[r * 4 + 3];
+    for (int r = 0; r < 4; r++) x[r] = X[((size_t)c * 4 + r) * n + i] = v4[(r * 4 + 3) * 64];
     double ax = 0, bx = 0;
     for (int k = 0; k < 4; k++) ax += P1[2 * 4 + k] * x[k];
     for (int k = 0; k < 4; k++) bx += P2[2 * 4 + k] * x[k];
@@ -364,11 +369,13 @@ class MonoEgo {
     picks.resize((size_t)K * 8);
     deck.resize((size_t)n);
     for (int i = 0; i < n; i++) deck[i] = i;
+    VsmDrawPlan plan[8];
+    for (int i = 0; i < 8; i++) plan[i] = vsm_sampler_plan((uint32_t)i, (uint32_t)(n - 1));
     vsm_sampler_lock();
     for (int k = 0; k < K; k++) {
       int swapped[8];
       for (int i = 0; i < 8; i++) {
-        swapped[i] = (int)vsm_sampler_between((uint32_t)i, (uint32_t)(n - 1));
+        swapped[i] = (int)vsm_sampler_draw(plan[i]);
         std::swap(deck[i], deck[swapped[i]]);
       }
       for (int i = 0; i < 8; i++) picks[(size_t)k * 8 + i] = deck[i];

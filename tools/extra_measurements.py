@@ -2,7 +2,9 @@
 """Side measurements quoted in DESIGN.md / profiles/README.md (never bench.py's `value`):
   * per-frame API fed from pageable HOST buffers (PCIe-inclusive rate) at 1242x375,
   * config 5: 2048x1024 stereo, per-frame and look-ahead,
-  * config 3: 640x480 mono, flow matching (per-frame API).
+  * config 3: 640x480 mono, flow matching (per-frame API),
+  * the street scene (synth.road_*, depth-dependent disparity/flow): whole VisualOdometryStereo::process
+    and VisualOdometryMono::process per frame, with the recovered forward motion.
 """
 import importlib
 import json
@@ -65,4 +67,32 @@ per_frame(m, seq3[:10], 0)
 out["cfg3_640x480_mono_flow_per_frame_fps"] = round(per_frame(m, seq3, 0), 2)
 out["cfg3_matches_last_frame"] = int(len(m.get_matches()))
 m.close()
+# 4. street scene: live stereo VO and mono VO loops on images with real depth structure
+pyr = synth.road_pyramid(1234)
+W4, H4, n4 = 1242, 375, 40
+road = [synth.road_stereo_frame(pyr, f, W4, H4) for f in range(n4)]
+cu, cv = W4 // 2, (H4 * 2) // 5
+droad = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in road]
+for rep in range(2):
+    vm.vo_sampler_seed(71)
+    vo = vm.VisualOdometryStereo(float(synth.ROAD_F), float(cu), float(cv), 0.54)
+    t0 = time.perf_counter()
+    res = [vo.process(l, r) for l, r in droad]
+    dt = time.perf_counter() - t0
+    out["road_stereo_vo_fps"] = round(n4 / dt, 2)
+    out["road_stereo_vo_success"] = int(sum(r[0] for r in res))
+    out["road_stereo_vo_tz_mean"] = round(float(np.mean([r[3][2, 3] for r in res[1:]])), 4)
+    out["road_stereo_matches_last_frame"] = int(vm.lib().vsm_num_matches(vm.lib().vsm_vo_stereo_matcher(vo.h)))
+    vo.close()
+for rep in range(2):
+    vm.vo_sampler_seed(71)
+    mo = vm.VisualOdometryMono(float(synth.ROAD_F), float(cu), float(cv), height=1.65, pitch=0.0)
+    t0 = time.perf_counter()
+    res = [mo.process(l) for l, _ in droad]
+    dt = time.perf_counter() - t0
+    out["road_mono_vo_fps"] = round(n4 / dt, 2)
+    out["road_mono_vo_success"] = int(sum(r[0] for r in res))
+    out["road_mono_vo_tz_mean"] = round(float(np.mean([r[1][2, 3] for r in res[1:]])), 4)
+    out["road_mono_timings_us"] = [round(float(x), 1) for x in mo.timings()[:8]]
+    mo.close()
 print(json.dumps(out))

@@ -1,0 +1,47 @@
+"""per-frame API: where one pushBack + matchFeatures(2) goes (mean over frames, us); with --trace the
+kernel-level busy time per frame from the library's HIP-event profiling"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+vm = importlib.import_module("opencl-structure-from-motion_amd.visomatch")
+synth = importlib.import_module("opencl-structure-from-motion_amd.synth")
+W, H, nf = 1242, 375, 120
+cv = synth.canvas(1234, W, H)
+host = np.stack([np.stack(synth.stereo_frame(cv, f, W, H)) for f in range(nf)])
+frames = torch.from_numpy(host).cuda()
+g = np.load(os.path.join(ROOT, "tests", "golden", "cfg4_seq200_tr_8seeds.npz"))
+tr_in, tr_valid = g["s1234_tr_in"], g["s1234_tr_valid"]
+m = vm.Matcher()
+m.set_intrinsics(*[float(x) for x in g["intr"]])
+for rep in range(2):
+    T, push, match = [], [], []
+    for f in range(nf):
+        t0 = time.perf_counter()
+        m.push_back(frames[f, 0], frames[f, 1])
+        t1 = time.perf_counter()
+        m.match_features(2, tr_in[f] if tr_valid[f] else None)
+        t2 = time.perf_counter()
+        push.append((t1 - t0) * 1e6)
+        match.append((t2 - t1) * 1e6)
+        T.append(list(m.timings().values()) if isinstance(m.timings(), dict) else m.timings())
+    T = np.array(T)[5:]
+    print("rep", rep, "push call %.0f us, match call %.0f us; inside match:" % (np.mean(push[5:]), np.mean(match[5:])), m.timings().keys() if isinstance(m.timings(), dict) else "", np.round(T.mean(0), 0))
+m.set_profiling(True)
+for f in range(nf):
+    m.push_back(frames[f, 0], frames[f, 1])
+    m.match_features(2, tr_in[f] if tr_valid[f] else None)
+torch.cuda.synchronize()
+st = m.kernel_stats()
+tot = 0
+for k, (ms, n) in st.items():
+    if n:
+        print("  %-28s %6.1f us/frame (%d launches/frame)" % (k, ms * 1e3 / nf, round(n / nf)))
+        tot += ms * 1e3 / nf
+print("  kernel busy total %.0f us/frame" % tot)
