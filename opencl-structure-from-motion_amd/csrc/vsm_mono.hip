@@ -35,6 +35,7 @@
 
 #include "vsm_host.h"
 #include "vsm_linalg.h"
+#include "vsm_svd_coop.h"
 
 // ---------------------------------------------------------------------------------------
 // kernels
@@ -68,59 +69,83 @@ __global__ void __launch_bounds__(256)
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counts[blockIdx.y], (int32_t)__popcll(b));
 }
 
-// findBestPlane (viso/viso_mono.cpp:75-101): sums[i] = sum_j exp(-(d_j - d_i)^2 * weight) for the
-// candidates d_i > threshold, 0 otherwise.  d is staged through LDS 256 values at a time.
+// findBestPlane (viso/viso_mono.cpp:75-101): sum_j exp(-(d_j - d_i)^2 * weight) for the candidates
+// d_i > threshold.  blockIdx.x = tile of 256 candidates, blockIdx.y = one of VOTE_SPLIT slices of the
+// j range (a few thousand points would otherwise occupy a few dozen CUs only); every slice writes
+// its partial sums to part[slice][i] and the host adds them up.  The sums are proposals only (see
+// the header comment), so their summation order is free.
+#define VOTE_SPLIT 16
 __global__ void __launch_bounds__(256)
-    k_mono_plane_vote(const double *__restrict__ d, int n, double threshold, double weight, double *__restrict__ sums) {
+    k_mono_plane_vote(const double *__restrict__ d, int n, double threshold, double weight, double *__restrict__ part) {
   __shared__ double s_d[256];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const double di = i < n ? d[i] : 0.0;
   const bool active = i < n && di > threshold;
+  const int per = (n + VOTE_SPLIT - 1) / VOTE_SPLIT;
+  const int jlo = blockIdx.y * per, jhi = min(n, jlo + per);
   double sum = 0;
-  for (int j0 = 0; j0 < n; j0 += 256) {
+  for (int j0 = jlo; j0 < jhi; j0 += 256) {
     __syncthreads();
-    s_d[threadIdx.x] = j0 + (int)threadIdx.x < n ? d[j0 + threadIdx.x] : 0.0;
+    s_d[threadIdx.x] = j0 + (int)threadIdx.x < jhi ? d[j0 + threadIdx.x] : 0.0;
     __syncthreads();
-    const int lim = min(256, n - j0);
+    const int lim = min(256, jhi - j0);
     if (active)
       for (int j = 0; j < lim; j++) {
         const double dist = s_d[j] - di;
         sum += exp(-dist * dist * weight);
       }
   }
-  if (i < n) sums[i] = active ? sum : 0.0;
+  if (i < n) part[(size_t)blockIdx.y * n + i] = active ? sum : 0.0;
 }
 
 // fundamentalMatrix for 8 sampled matches (viso/viso_mono.cpp:264-294): one thread per hypothesis,
 // the 8x9 constraint matrix, its SVD and the rank-2 projection in private memory.  vsm_linalg.h is the
 // same code the host runs; f64 +, *, /, sqrt are correctly rounded on gfx950 and contraction is off,
 // so the nine doubles are the host's (checked by a self-test when the context is created).
-// The matrices of a lane live in LDS, element e of lane l at [e * 64 + l]: runtime-indexed private
-// arrays would go to scratch memory, and interleaving by lane keeps every access conflict-free.
-__global__ void __launch_bounds__(64)
+// 16 lanes per hypothesis (vsm_svd_coop.h): the matrices of a group live in LDS, the lanes share the
+// independent column / row loops of the SVD, 16 hypotheses per 256-thread block.
+#define FIT_GROUP_DOUBLES 192  // U 72 + V 81 + W 9 + RV 9, padded
+__global__ void __launch_bounds__(256)
     k_mono_fit(const MonoPt *__restrict__ pts, const int32_t *__restrict__ picks, int K, double *__restrict__ Fs) {
-  __shared__ double s_m[(72 + 81 + 9 + 9 + 9) * 64];
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
-  double *A = s_m + threadIdx.x, *v = A + 72 * 64, *w = v + 81 * 64, *rv1 = w + 9 * 64, *col = rv1 + 9 * 64;
-  for (int i = 0; i < 8; i++) {
-    const MonoPt q = pts[picks[k * 8 + i]];
-    double *r = A + i * 9 * 64;
-    r[0 * 64] = q.u1c * q.u1p;
-    r[1 * 64] = q.u1c * q.v1p;
-    r[2 * 64] = q.u1c;
-    r[3 * 64] = q.v1c * q.u1p;
-    r[4 * 64] = q.v1c * q.v1p;
-    r[5 * 64] = q.v1c;
-    r[6 * 64] = q.u1p;
-    r[7 * 64] = q.v1p;
-    r[8 * 64] = 1;
+  __shared__ double s_m[16 * FIT_GROUP_DOUBLES];
+  const int grp = threadIdx.x >> 4, ln = threadIdx.x & 15;
+  const int k = blockIdx.x * 16 + grp;
+  if (k >= K) return;  // whole groups leave together
+  volatile double *A = s_m + grp * FIT_GROUP_DOUBLES, *v = A + 72, *w = v + 81, *rv1 = w + 9;
+  if (ln < 8) {  // lane i fills row i of the constraint matrix
+    const MonoPt q = pts[picks[k * 8 + ln]];
+    volatile double *r = A + ln * 9;
+    r[0] = q.u1c * q.u1p;
+    r[1] = q.u1c * q.v1p;
+    r[2] = q.u1c;
+    r[3] = q.v1c * q.u1p;
+    r[4] = q.v1c * q.v1p;
+    r[5] = q.v1c;
+    r[6] = q.u1p;
+    r[7] = q.v1p;
+    r[8] = 1;
   }
-  vsm_la::svd_nr<64>(A, 8, 9, 9, w, v, rv1, col);
-  double F0[9], F[9];
-  for (int i = 0; i < 9; i++) F0[i] = v[(i * 9 + 8) * 64];
-  vsm_la::rank2_3x3(F0, F);
-  for (int i = 0; i < 9; i++) Fs[(size_t)k * 9 + i] = F[i];
+  VSM_GROUP_SYNC();
+  vsm_la::svd_group<8, 9>(A, v, w, rv1, ln);
+  // rank 2: the 3x3 built from the last column of V goes through the same group SVD
+  double f0 = 0;
+  if (ln < 9) f0 = v[ln * 9 + 8];
+  VSM_GROUP_SYNC();
+  volatile double *U3 = A, *V3 = A + 16, *W3 = A + 32, *R3 = A + 40;
+  if (ln < 9) U3[ln] = f0;
+  VSM_GROUP_SYNC();
+  vsm_la::svd_group<3, 3>(U3, V3, W3, R3, ln);
+  if (ln == 0) {
+    double u[9], vv[9], D[9] = {W3[0], 0, 0, 0, W3[1], 0, 0, 0, 0}, UD[9], Vt[9], F[9];
+    for (int i = 0; i < 9; i++) {
+      u[i] = U3[i];
+      vv[i] = V3[i];
+    }
+    vsm_la::mul(u, D, UD, 3, 3, 3);
+    vsm_la::transpose(vv, Vt, 3, 3);
+    vsm_la::mul(UD, Vt, F, 3, 3, 3);
+    for (int i = 0; i < 9; i++) Fs[(size_t)k * 9 + i] = F[i];
+  }
 }
 
 // triangulateChieral (viso/viso_mono.cpp:394-431): thread per (candidate blockIdx.y, match).
@@ -165,6 +190,9 @@ struct MonoGpu {  // device side of one estimator
   int32_t *h_counts = nullptr;  // pinned
   double *h_sums = nullptr;     // pinned
   double *h_X = nullptr;        // pinned, one candidate's 4 x n
+  MonoPt *h_pts = nullptr;      // pinned staging of the normalised points / raw points
+  int32_t *h_picks = nullptr;   // pinned staging of the samples
+  double *h_F = nullptr;        // pinned, the fitted matrices coming back
   int cap_n = 0, cap_k = 0;
   bool ok = false;
   bool svd_on_device = false;   // the device reproduces the host's SVD bit for bit (self-test)
@@ -191,7 +219,7 @@ struct MonoGpu {  // device side of one estimator
     std::vector<double> dev(K * 9);
     if (hipMemcpyAsync(d_pts, pts.data(), sizeof(MonoPt) * n, hipMemcpyHostToDevice, stream) != hipSuccess) return false;
     if (hipMemcpyAsync(d_picks, picks.data(), sizeof(int32_t) * K * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return false;
-    hipLaunchKernelGGL(k_mono_fit, dim3((K + 63) / 64), dim3(64), 0, stream, d_pts, d_picks, K, d_F);
+    hipLaunchKernelGGL(k_mono_fit, dim3((K + 15) / 16), dim3(256), 0, stream, d_pts, d_picks, K, d_F);
     if (hipMemcpyAsync(dev.data(), d_F, sizeof(double) * K * 9, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
     if (hipStreamSynchronize(stream) != hipSuccess) return false;
     for (int k = 0; k < K; k++) {
@@ -218,22 +246,28 @@ struct MonoGpu {  // device side of one estimator
       (void)hipFree(d_X);
       (void)hipHostFree(h_sums);
       (void)hipHostFree(h_X);
+      (void)hipHostFree(h_pts);
       cap_n = n + n / 2 + 256;
+      if (hipHostMalloc((void **)&h_pts, sizeof(MonoPt) * cap_n, hipHostMallocDefault) != hipSuccess) return false;
       if (hipMalloc((void **)&d_pts, sizeof(MonoPt) * cap_n) != hipSuccess) return false;
       if (hipMalloc((void **)&d_raw, sizeof(MonoPt) * cap_n) != hipSuccess) return false;
       if (hipMalloc((void **)&d_X, sizeof(double) * 16 * cap_n) != hipSuccess) return false;
       if (hipHostMalloc((void **)&h_X, sizeof(double) * 4 * cap_n, hipHostMallocDefault) != hipSuccess) return false;
       if (hipMalloc((void **)&d_d, sizeof(double) * cap_n) != hipSuccess) return false;
-      if (hipMalloc((void **)&d_sums, sizeof(double) * cap_n) != hipSuccess) return false;
-      if (hipHostMalloc((void **)&h_sums, sizeof(double) * cap_n, hipHostMallocDefault) != hipSuccess) return false;
+      if (hipMalloc((void **)&d_sums, sizeof(double) * VOTE_SPLIT * cap_n) != hipSuccess) return false;
+      if (hipHostMalloc((void **)&h_sums, sizeof(double) * VOTE_SPLIT * cap_n, hipHostMallocDefault) != hipSuccess) return false;
     }
     if (k > cap_k) {
       (void)hipFree(d_F);
       (void)hipFree(d_counts);
       (void)hipFree(d_picks);
       (void)hipHostFree(h_counts);
+      (void)hipHostFree(h_picks);
+      (void)hipHostFree(h_F);
       cap_k = k + 64;
       if (hipMalloc((void **)&d_picks, sizeof(int32_t) * 8 * cap_k) != hipSuccess) return false;
+      if (hipHostMalloc((void **)&h_picks, sizeof(int32_t) * 8 * cap_k, hipHostMallocDefault) != hipSuccess) return false;
+      if (hipHostMalloc((void **)&h_F, sizeof(double) * 9 * cap_k, hipHostMallocDefault) != hipSuccess) return false;
       if (hipMalloc((void **)&d_F, sizeof(double) * 9 * cap_k) != hipSuccess) return false;
       if (hipMalloc((void **)&d_counts, sizeof(int32_t) * cap_k) != hipSuccess) return false;
       if (hipHostMalloc((void **)&h_counts, sizeof(int32_t) * cap_k, hipHostMallocDefault) != hipSuccess) return false;
@@ -254,6 +288,9 @@ struct MonoGpu {  // device side of one estimator
     (void)hipHostFree(h_counts);
     (void)hipHostFree(h_sums);
     (void)hipHostFree(h_X);
+    (void)hipHostFree(h_pts);
+    (void)hipHostFree(h_picks);
+    (void)hipHostFree(h_F);
     (void)hipStreamDestroy(stream);
   }
 };
@@ -307,7 +344,7 @@ void parallel_for(Runner *pool, int n, int min_chunk, const std::function<void(i
 class MonoEgo {
  public:
   vsm_vo_mono_params par;
-  std::vector<MonoPt> pts, raw;
+  std::vector<MonoPt> pts;
   std::vector<double> Fs, X4, dvals, sums, scratch;
   std::vector<int32_t> counts, picks, deck;
   double timings[6] = {0, 0, 0, 0, 0, 0};
@@ -388,15 +425,16 @@ class MonoEgo {
     bool on_gpu = gpu && gpu->ok && K > 0 && gpu->reserve(n, K);
     bool fitted = false;
     double t1 = t0;
-    if (on_gpu) {
-      on_gpu = hipMemcpyAsync(gpu->d_pts, pts.data(), sizeof(MonoPt) * n, hipMemcpyHostToDevice, gpu->stream) == hipSuccess;
-      if (on_gpu && gpu->svd_on_device) {  // hypotheses fitted on the device, F never leaves it before counting
-        on_gpu = hipMemcpyAsync(gpu->d_picks, picks.data(), sizeof(int32_t) * 8 * K, hipMemcpyHostToDevice, gpu->stream) ==
+    if (on_gpu) {  // everything is staged through pinned memory, so nothing below blocks before the one sync
+      memcpy(gpu->h_pts, pts.data(), sizeof(MonoPt) * n);
+      on_gpu = hipMemcpyAsync(gpu->d_pts, gpu->h_pts, sizeof(MonoPt) * n, hipMemcpyHostToDevice, gpu->stream) == hipSuccess;
+      if (on_gpu && gpu->svd_on_device) {  // hypotheses fitted on the device, F is counted where it was produced
+        memcpy(gpu->h_picks, picks.data(), sizeof(int32_t) * 8 * K);
+        on_gpu = hipMemcpyAsync(gpu->d_picks, gpu->h_picks, sizeof(int32_t) * 8 * K, hipMemcpyHostToDevice, gpu->stream) ==
                  hipSuccess;
         if (on_gpu) {
-          hipLaunchKernelGGL(k_mono_fit, dim3((K + 63) / 64), dim3(64), 0, gpu->stream, gpu->d_pts, gpu->d_picks, K, gpu->d_F);
-          on_gpu = hipMemcpyAsync(Fs.data(), gpu->d_F, sizeof(double) * 9 * K, hipMemcpyDeviceToHost, gpu->stream) == hipSuccess;
-          fitted = on_gpu;
+          hipLaunchKernelGGL(k_mono_fit, dim3((K + 15) / 16), dim3(256), 0, gpu->stream, gpu->d_pts, gpu->d_picks, K, gpu->d_F);
+          fitted = true;
         }
       }
     }
@@ -405,8 +443,10 @@ class MonoEgo {
         double A[72], col[9];
         for (int k = lo; k < hi; k++) fundamental(pts.data(), &picks[(size_t)k * 8], 8, A, col, &Fs[(size_t)k * 9]);
       });
-      if (on_gpu)
-        on_gpu = hipMemcpyAsync(gpu->d_F, Fs.data(), sizeof(double) * 9 * K, hipMemcpyHostToDevice, gpu->stream) == hipSuccess;
+      if (on_gpu) {
+        memcpy(gpu->h_F, Fs.data(), sizeof(double) * 9 * K);
+        on_gpu = hipMemcpyAsync(gpu->d_F, gpu->h_F, sizeof(double) * 9 * K, hipMemcpyHostToDevice, gpu->stream) == hipSuccess;
+      }
     }
     t1 = vsm_now_us();
     if (on_gpu) {
@@ -415,9 +455,14 @@ class MonoEgo {
         hipLaunchKernelGGL(k_mono_inlier_count, dim3((n + 255) / 256, K), dim3(256), 0, gpu->stream, gpu->d_pts, n, gpu->d_F,
                            par.inlier_threshold, gpu->d_counts);
         on_gpu = hipMemcpyAsync(gpu->h_counts, gpu->d_counts, sizeof(int32_t) * K, hipMemcpyDeviceToHost, gpu->stream) ==
-                     hipSuccess &&
-                 hipStreamSynchronize(gpu->stream) == hipSuccess;
-        if (on_gpu) memcpy(counts.data(), gpu->h_counts, sizeof(int32_t) * K);
+                 hipSuccess;
+        if (on_gpu && fitted)
+          on_gpu = hipMemcpyAsync(gpu->h_F, gpu->d_F, sizeof(double) * 9 * K, hipMemcpyDeviceToHost, gpu->stream) == hipSuccess;
+        on_gpu = on_gpu && hipStreamSynchronize(gpu->stream) == hipSuccess;
+        if (on_gpu) {
+          memcpy(counts.data(), gpu->h_counts, sizeof(int32_t) * K);
+          if (fitted) memcpy(Fs.data(), gpu->h_F, sizeof(double) * 9 * K);
+        }
       }
     }
     if (!on_gpu) {
@@ -502,9 +547,8 @@ class MonoEgo {
     }
     bool tri_gpu = gpu && gpu->ok && gpu->svd_on_device && gpu->reserve(n, 1);
     if (tri_gpu) {
-      raw.resize((size_t)n);
-      for (int i = 0; i < n; i++) raw[i] = {m[i].u1p, m[i].v1p, m[i].u1c, m[i].v1c};
-      tri_gpu = hipMemcpyAsync(gpu->d_raw, raw.data(), sizeof(MonoPt) * n, hipMemcpyHostToDevice, gpu->stream) == hipSuccess &&
+      for (int i = 0; i < n; i++) gpu->h_pts[i] = {m[i].u1p, m[i].v1p, m[i].u1c, m[i].v1c};
+      tri_gpu = hipMemcpyAsync(gpu->d_raw, gpu->h_pts, sizeof(MonoPt) * n, hipMemcpyHostToDevice, gpu->stream) == hipSuccess &&
                 hipMemsetAsync(gpu->d_chir, 0, sizeof(int32_t) * 4, gpu->stream) == hipSuccess;
       if (tri_gpu) {
         hipLaunchKernelGGL(k_mono_triangulate, dim3((n + 63) / 64, 4), dim3(64), 0, gpu->stream, gpu->d_raw, n, cams, gpu->d_X,
@@ -624,9 +668,10 @@ class MonoEgo {
     if (on_gpu) {
       on_gpu = hipMemcpyAsync(gpu->d_d, dvals.data(), sizeof(double) * np, hipMemcpyHostToDevice, gpu->stream) == hipSuccess;
       if (on_gpu) {
-        hipLaunchKernelGGL(k_mono_plane_vote, dim3((np + 255) / 256), dim3(256), 0, gpu->stream, gpu->d_d, np, threshold,
-                           weight, gpu->d_sums);
-        on_gpu = hipMemcpyAsync(gpu->h_sums, gpu->d_sums, sizeof(double) * np, hipMemcpyDeviceToHost, gpu->stream) ==
+        hipLaunchKernelGGL(k_mono_plane_vote, dim3((np + 255) / 256, VOTE_SPLIT), dim3(256), 0, gpu->stream, gpu->d_d, np,
+                           threshold, weight, gpu->d_sums);
+        on_gpu = hipMemcpyAsync(gpu->h_sums, gpu->d_sums, sizeof(double) * VOTE_SPLIT * np, hipMemcpyDeviceToHost,
+                                gpu->stream) ==
                      hipSuccess &&
                  hipStreamSynchronize(gpu->stream) == hipSuccess;
       }
@@ -635,7 +680,12 @@ class MonoEgo {
       // the device exp() is within a few ulp of libm's: only candidates this close to the proposed
       // maximum can be the true first maximum; they are judged exactly, in index order
       double top = 0;
-      for (int i = 0; i < np; i++) top = std::max(top, gpu->h_sums[i]);
+      for (int i = 0; i < np; i++) {  // add the slices up (into slice 0)
+        double t = 0;
+        for (int c = 0; c < VOTE_SPLIT; c++) t += gpu->h_sums[(size_t)c * np + i];
+        gpu->h_sums[i] = t;
+        top = std::max(top, t);
+      }
       double best_sum = 0;
       int best_idx = 0;
       for (int i = 0; i < np; i++)
