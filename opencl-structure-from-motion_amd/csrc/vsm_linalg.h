@@ -63,10 +63,26 @@ VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w_, double *
         g = -with_sign(sqrt(s), f);
         h = f * g - s;
         U_(i, i) = f - g;
-        for (j = l; j < n; j++) {
-          for (s = 0.0, k = i; k < m; k++) s += U_(k, i) * U_(k, j);
-          f = s / h;
-          for (k = i; k < m; k++) U_(k, j) += f * U_(k, i);
+        if (n <= 16) {
+          // the columns j are independent: walk the rows once for all of them (rows are contiguous),
+          // every column's sum still adds its terms in row order
+          double sj[16];
+          for (j = l; j < n; j++) sj[j] = 0.0;
+          for (k = i; k < m; k++) {
+            const double ui = U_(k, i);
+            for (j = l; j < n; j++) sj[j] += ui * U_(k, j);
+          }
+          for (j = l; j < n; j++) sj[j] = sj[j] / h;
+          for (k = i; k < m; k++) {
+            const double ui = U_(k, i);
+            for (j = l; j < n; j++) U_(k, j) += sj[j] * ui;
+          }
+        } else {
+          for (j = l; j < n; j++) {
+            for (s = 0.0, k = i; k < m; k++) s += U_(k, i) * U_(k, j);
+            f = s / h;
+            for (k = i; k < m; k++) U_(k, j) += f * U_(k, i);
+          }
         }
         for (k = i; k < m; k++) U_(k, i) *= scale;
       }
@@ -118,10 +134,25 @@ VSM_HD inline void svd_nr(double *u, int m, int n, int ldu, double *w_, double *
     for (j = l; j < n; j++) U_(i, j) = 0.0;
     if (g) {
       g = 1.0 / g;
-      for (j = l; j < n; j++) {
-        for (s = 0.0, k = l; k < m; k++) s += U_(k, i) * U_(k, j);
-        f = (s / U_(i, i)) * g;
-        for (k = i; k < m; k++) U_(k, j) += f * U_(k, i);
+      if (n <= 16) {
+        double sj[16];
+        for (j = l; j < n; j++) sj[j] = 0.0;
+        for (k = l; k < m; k++) {
+          const double ui = U_(k, i);
+          for (j = l; j < n; j++) sj[j] += ui * U_(k, j);
+        }
+        const double uii = U_(i, i);
+        for (j = l; j < n; j++) sj[j] = (sj[j] / uii) * g;
+        for (k = i; k < m; k++) {
+          const double ui = U_(k, i);
+          for (j = l; j < n; j++) U_(k, j) += sj[j] * ui;
+        }
+      } else {
+        for (j = l; j < n; j++) {
+          for (s = 0.0, k = l; k < m; k++) s += U_(k, i) * U_(k, j);
+          f = (s / U_(i, i)) * g;
+          for (k = i; k < m; k++) U_(k, j) += f * U_(k, i);
+        }
       }
       for (j = i; j < m; j++) U_(j, i) *= g;
     } else {
