@@ -721,44 +721,71 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
 // =======================================================================================
 // O1 removeOutliers, viso/matcher.cpp:1207-1377
 // =======================================================================================
-void vsm_host_remove_outliers(VsmHostWork &w, const vsm_params &p, std::vector<vsm_p_match> &m, int method) {
-  const int32_t n = (int32_t)m.size();
-  if (n <= 3) return;
+// `in` may be the list the GPU exported (host-mapped memory): it is read twice, sequentially, and
+// only the survivors are copied.  The per-match quantities the support test compares (flow and
+// disparity, :1290-1340) are gathered into compact arrays first, so the triangle loop touches
+// 12 bytes per vertex instead of a 48-byte record.
+void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,
+                                   std::vector<vsm_p_match> &out) {
+  if (n <= 3) {  // the reference leaves short lists alone (:1210)
+    out.assign(in, in + std::max(n, 0));
+    return;
+  }
   w.x.resize(n);
   w.y.resize(n);
+  w.fu.resize(n);
+  w.fv.resize(n);
+  w.dp.resize(n);
   for (int32_t i = 0; i < n; i++) {
-    w.x[i] = (int32_t)m[i].u1c;
-    w.y[i] = (int32_t)m[i].v1c;
+    const vsm_p_match &a = in[i];
+    w.x[i] = (int32_t)a.u1c;
+    w.y[i] = (int32_t)a.v1c;
+    w.fu[i] = a.u1c - a.u1p;
+    w.fv[i] = a.v1c - a.v1p;
+    w.dp[i] = method == 1 ? a.u1c - a.u2c : a.u1p - a.u2p;
   }
+  static const bool dbg = getenv("VSM_DEBUG_TIMING") != nullptr;
+  const auto c0 = std::chrono::steady_clock::now();
   w.del.run(w.x.data(), w.y.data(), n, w.pool);
+  const auto c1 = std::chrono::steady_clock::now();
   w.support.assign(n, 0);
   const float ftol = (float)p.outlier_flow_tolerance, dtol = (float)p.outlier_disp_tolerance;
   const int32_t *tri = w.del.triangles();
+  const float *fu = w.fu.data(), *fv = w.fv.data(), *dp = w.dp.data();
+  int32_t *support = w.support.data();
   for (int32_t t = 0; t < w.del.num_triangles(); t++) {
     const int32_t q[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
-    float fu[3], fv[3], dp[3];
-    for (int k = 0; k < 3; k++) {
-      const vsm_p_match &a = m[q[k]];
-      fu[k] = a.u1c - a.u1p;
-      fv[k] = a.v1c - a.v1p;
-      dp[k] = method == 1 ? a.u1c - a.u2c : a.u1p - a.u2p;
-    }
     static const int E[3][2] = {{0, 1}, {1, 2}, {0, 2}};
     for (int e = 0; e < 3; e++) {
-      const int a = E[e][0], b = E[e][1];
+      const int32_t a = q[E[e][0]], b = q[E[e][1]];
       const bool flow_ok = fabsf(fu[a] - fu[b]) + fabsf(fv[a] - fv[b]) < ftol;
       const bool disp_ok = fabsf(dp[a] - dp[b]) < dtol;
       const bool ok = method == 0 ? flow_ok : (method == 1 ? disp_ok : (disp_ok && flow_ok));
       if (ok) {
-        w.support[q[a]]++;
-        w.support[q[b]]++;
+        support[a]++;
+        support[b]++;
       }
     }
   }
-  int32_t k = 0;
+  out.clear();
+  out.reserve((size_t)n);
   for (int32_t i = 0; i < n; i++)
-    if (w.support[i] >= 4) m[k++] = m[i];
-  m.resize(k);
+    if (support[i] >= 4) out.push_back(in[i]);
+  if (dbg && n > 3000) {
+    static std::atomic<long> calls{0}, us_del{0}, us_rest{0};
+    const auto c2 = std::chrono::steady_clock::now();
+    us_del += std::chrono::duration_cast<std::chrono::microseconds>(c1 - c0).count();
+    us_rest += std::chrono::duration_cast<std::chrono::microseconds>(c2 - c1).count();
+    if (++calls % 199 == 0)
+      fprintf(stderr, "  removeOutliers (n > 3000), mean: Delaunay %.1f us, support + compaction %.1f us\n",
+              (double)us_del / calls, (double)us_rest / calls);
+  }
+}
+
+void vsm_host_remove_outliers(VsmHostWork &w, const vsm_params &p, std::vector<vsm_p_match> &m, int method) {
+  if ((int32_t)m.size() <= 3) return;
+  w.tmp_list.swap(m);
+  vsm_host_remove_outliers_from(w, p, w.tmp_list.data(), (int32_t)w.tmp_list.size(), method, m);
 }
 
 // =======================================================================================

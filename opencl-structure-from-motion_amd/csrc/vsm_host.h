@@ -182,11 +182,16 @@ class ExactDelaunay {
 struct VsmHostWork {
   ExactDelaunay del;
   std::vector<int32_t> x, y, support;
+  std::vector<float> fu, fv, dp;        // per match: flow and disparity, what the support test compares
+  std::vector<vsm_p_match> tmp_list;
   VsmForkJoin *pool = nullptr;  // optional: threads for the sub-problems of one triangulation
 };
 
 // Matcher::removeOutliers, viso/matcher.cpp:1207-1377 (in place; order preserved)
 void vsm_host_remove_outliers(VsmHostWork &w, const vsm_params &p, std::vector<vsm_p_match> &m, int method);
+// the same from a read-only list (e.g. the host-mapped export of the GPU) into `out`
+void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,
+                                   std::vector<vsm_p_match> &out);
 
 // Matcher::computePriorStatistics, viso/matcher.cpp:734-868 -> ranges[bin][16]
 void vsm_host_prior_statistics(const vsm_params &p, const int32_t *dims_c, const std::vector<vsm_p_match> &m,
