@@ -274,7 +274,7 @@ void ExactDelaunay::vertex_sort(uint64_t *a, int32_t n) {
 // in y order; a cut along one axis halves that list in place and stable-partitions the other
 // (one branch-free pass with an L1-resident rank lookup).  O(n) sequential work per level
 // instead of an nth_element per node.  Points are named by their rank in the (x,y)-sorted array.
-void ExactDelaunay::kd_order(int32_t m) {
+void ExactDelaunay::kd_order(int32_t m, VsmForkJoin *pool) {
   xl_.resize(m);
   yl_.resize(m);
   yr_.resize(m);
@@ -302,23 +302,15 @@ void ExactDelaunay::kd_order(int32_t m) {
     }
   }
   for (int32_t i = 0; i < m; i++) xl_[i] = (uint32_t)i;
-  // explicit stack of (offset, n, axis); lists of a node occupy [off, off+n) of xl_/yl_
+  // explicit stack of (offset, n, axis); lists of a node occupy [off, off+n) of xl_/yl_.  Sub-trees
+  // touch disjoint slices, so once the top levels have produced enough of them they are dealt out
+  // to the pool (each task with its own partition scratch, a slice of tmp_).
   struct Nd {
     int32_t off, n, axis;
   };
-  std::vector<Nd> st;
-  st.reserve(64);
-  st.push_back(Nd{0, m, 0});
   const uint32_t *yr = yr_.data();
-  uint32_t *tmp = tmp_.data();
-  while (!st.empty()) {
-    const Nd nd = st.back();
-    st.pop_back();
+  auto split = [&](const Nd &nd, uint32_t *tmp) -> int32_t {  // partitions the node's lists, returns the cut
     uint32_t *xl = xl_.data() + nd.off, *yl = yl_.data() + nd.off;
-    if (nd.n <= 3) {
-      for (int32_t i = 0; i < nd.n; i++) ord_[nd.off + i] = xl[i];
-      continue;
-    }
     const int32_t div = nd.n >> 1;
     int32_t l = 0, r = 0;
     if (nd.axis == 0) {  // cut in x: xl splits in place, yl is partitioned by x-rank
@@ -344,8 +336,40 @@ void ExactDelaunay::kd_order(int32_t m) {
       }
       memcpy(xl + l, tmp, (size_t)r * sizeof(uint32_t));
     }
-    st.push_back(Nd{nd.off + div, nd.n - div, 1 - nd.axis});
-    st.push_back(Nd{nd.off, div, 1 - nd.axis});
+    return div;
+  };
+  auto subtree = [&](Nd root) {  // depth-first over one sub-tree; scratch = tmp_ over the node's own slice
+    Nd st[64];
+    int sp = 0;
+    st[sp++] = root;
+    uint32_t *tmp = tmp_.data() + root.off;
+    while (sp > 0) {
+      const Nd nd = st[--sp];
+      if (nd.n <= 3) {
+        const uint32_t *xl = xl_.data() + nd.off;
+        for (int32_t i = 0; i < nd.n; i++) ord_[nd.off + i] = xl[i];
+        continue;
+      }
+      const int32_t div = split(nd, tmp);
+      st[sp++] = Nd{nd.off + div, nd.n - div, 1 - nd.axis};
+      st[sp++] = Nd{nd.off, div, 1 - nd.axis};
+    }
+  };
+  const int nthreads = pool ? pool->size() : 1;
+  if (nthreads <= 1 || m < 2048) {
+    subtree(Nd{0, m, 0});
+  } else {
+    std::vector<Nd> level{Nd{0, m, 0}};
+    while ((int)level.size() < nthreads) {  // top levels, sequential
+      std::vector<Nd> next;
+      for (const Nd &nd : level) {
+        const int32_t div = split(nd, tmp_.data() + nd.off);
+        next.push_back(Nd{nd.off, div, 1 - nd.axis});
+        next.push_back(Nd{nd.off + div, nd.n - div, 1 - nd.axis});
+      }
+      level.swap(next);
+    }
+    pool->run((int)level.size(), [&](int t) { subtree(level[t]); });
   }
   // bring the keys into their final order
   k2_.resize(m);
@@ -635,15 +659,30 @@ int32_t ExactDelaunay::build_tree(int32_t off, int32_t n, int axis, int32_t tbas
   return me;
 }
 
+void ExactDelaunay::list_triangles() {
+  if (listed_) return;
+  listed_ = true;
+  ntri_out_ = 0;
+  tri_out_.resize((size_t)m_ * 6);
+  for (int32_t t = 0; t < 2 * m_; t++)
+    if (slot_vertices(t, &tri_out_[(size_t)ntri_out_ * 3])) ntri_out_++;
+}
+
 void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool) {
   ntri_out_ = 0;
+  m_ = 0;
+  listed_ = true;
   seed_ = 1;  // triangleinit(), :4031
   if (n < 2) return;
   key_.resize(n);
   stop_.resize((size_t)2 * n);
   for (int32_t i = 0; i < n; i++) key_[i] = ((uint64_t)(uint32_t)x[i] << 34) | ((uint64_t)(uint32_t)y[i] << 20) | (uint32_t)i;
   uint64_t *a = key_.data();
+  static const bool dbg = getenv("VSM_DEBUG_TIMING") != nullptr;
+  auto clk = [] { return std::chrono::steady_clock::now(); };
+  const auto p0 = clk();
   vertex_sort(a, n);
+  const auto p1 = clk();
   int32_t m = 0;  // duplicates: the first one in sorted order survives (:6183)
   for (int32_t j = 1; j < n; j++)
     if (KXY(a[m]) != KXY(a[j])) a[++m] = a[j];
@@ -655,7 +694,8 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
   for (int t = 2 * m - 2; t < 2 * m; t++)  // the two unused slots
     for (int k = 0; k < 3; k++) tri_[(size_t)t * 8 + 4 + k] = -1;
   key_.resize(m);
-  kd_order(m);
+  kd_order(m, pool);
+  const auto p2 = clk();
   a = key_.data();
   OTri hl, hr;
   int32_t dummy = 0;
@@ -705,16 +745,21 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
       });
     }
   }
-  tri_out_.resize((size_t)2 * m * 3);
-  const int32_t *idp = id_.data();
-  for (int32_t t = 0; t < 2 * m; t++) {
-    const int32_t *v = &tri_[(size_t)t * 8 + 4];
-    if ((v[0] | v[1] | v[2]) >= 0) {
-      tri_out_[ntri_out_ * 3 + 0] = idp[v[1]];
-      tri_out_[ntri_out_ * 3 + 1] = idp[v[2]];
-      tri_out_[ntri_out_ * 3 + 2] = idp[v[0]];
-      ntri_out_++;
-    }
+  const auto p3 = clk();
+  m_ = m;
+  listed_ = false;
+  if (dbg && n > 3000) {
+    static std::atomic<long> calls{0}, t_sort{0}, t_kd{0}, t_dc{0}, t_out{0};
+    auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
+      return (long)std::chrono::duration_cast<std::chrono::nanoseconds>(y - x).count();
+    };
+    t_sort += us(p0, p1);
+    t_kd += us(p1, p2);
+    t_dc += us(p2, p3);
+    t_out += us(p3, clk());
+    if (++calls % 100 == 0)
+      fprintf(stderr, "  ExactDelaunay (n > 3000, %d threads), mean us: sort %.0f, kd order %.0f, divide&conquer %.0f, output %.0f\n",
+              pool ? pool->size() : 1, t_sort / 1e3 / calls, t_kd / 1e3 / calls, t_dc / 1e3 / calls, t_out / 1e3 / calls);
   }
 }
 
@@ -750,11 +795,14 @@ void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vs
   const auto c1 = std::chrono::steady_clock::now();
   w.support.assign(n, 0);
   const float ftol = (float)p.outlier_flow_tolerance, dtol = (float)p.outlier_disp_tolerance;
-  const int32_t *tri = w.del.triangles();
   const float *fu = w.fu.data(), *fv = w.fv.data(), *dp = w.dp.data();
   int32_t *support = w.support.data();
-  for (int32_t t = 0; t < w.del.num_triangles(); t++) {
-    const int32_t q[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+  const ExactDelaunay &del = w.del;
+  // (support is a plain sum over triangle edges: the slot order is as good as Triangle's output order)
+  const int32_t slots = del.num_slots();
+  for (int32_t t = 0; t < slots; t++) {
+    int32_t q[3];
+    if (!del.slot_vertices(t, q)) continue;
     static const int E[3][2] = {{0, 1}, {1, 2}, {0, 2}};
     for (int e = 0; e < 3; e++) {
       const int32_t a = q[E[e][0]], b = q[E[e][1]];

@@ -104,8 +104,26 @@ class ExactDelaunay {
  public:
   // points are (x[i], y[i]); after run(), triangles() lists vertex triples by input index
   void run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool = nullptr);
-  int32_t num_triangles() const { return ntri_out_; }
-  const int32_t *triangles() const { return tri_out_.data(); }
+  // the triangle list as vertex triples (built on first use; removeOutliers walks the slots instead)
+  int32_t num_triangles() {
+    list_triangles();
+    return ntri_out_;
+  }
+  const int32_t *triangles() {
+    list_triangles();
+    return tri_out_.data();
+  }
+  // slot view: slots 0 .. num_slots()-1; a slot holds a triangle if slot_vertices() returns true
+  // (vertex triple by input index, same orientation as triangles())
+  int32_t num_slots() const { return 2 * m_; }
+  inline bool slot_vertices(int32_t t, int32_t *q) const {
+    const int32_t *v = &tri_[(size_t)t * 8 + 4];
+    if ((v[0] | v[1] | v[2]) < 0) return false;
+    q[0] = id_[v[1]];
+    q[1] = id_[v[2]];
+    q[2] = id_[v[0]];
+    return true;
+  }
 
  private:
   struct OTri {
@@ -123,12 +141,14 @@ class ExactDelaunay {
   std::vector<int32_t> id_;           // by sorted position: input index
   std::vector<int32_t> tri_, tri_out_;
   std::vector<Node> nodes_;
-  int32_t ntri_out_ = 0;
+  int32_t ntri_out_ = 0, m_ = 0;
+  bool listed_ = true;
+  void list_triangles();
   uint64_t seed_ = 1;
 
   uint32_t rnd(uint32_t choices);
   void vertex_sort(uint64_t *a, int32_t n);
-  void kd_order(int32_t m);
+  void kd_order(int32_t m, VsmForkJoin *pool);
   void recurse(int32_t off, int32_t n, int axis, int32_t &tcur, OTri &farleft, OTri &farright);
   void merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis, int32_t &tcur);
   int32_t build_tree(int32_t off, int32_t n, int axis, int32_t tbase, int depth);
