@@ -214,6 +214,17 @@ static inline uint64_t key_yx(uint64_t k) { return (((k >> 20) & 0x3fffu) << 14)
 
 uint32_t ExactDelaunay::rnd(uint32_t choices) {  // randomnation, :4046
   seed_ = (seed_ * 1366u + 150889u) % 714025u;
+  // seed / (714025 / choices + 1): most calls come from small sub-arrays, whose divisor and its
+  // 64-bit reciprocal are tabulated ((seed * magic) >> 64 is the exact quotient for 32-bit operands)
+  struct Recip {
+    uint64_t magic[256];
+    Recip() {
+      magic[0] = 0;
+      for (uint32_t c = 1; c < 256; c++) magic[c] = UINT64_MAX / (714025u / c + 1) + 1;
+    }
+  };
+  static const Recip table;
+  if (choices < 256) return (uint32_t)(((__uint128_t)seed_ * table.magic[choices]) >> 64);
   return (uint32_t)(seed_ / (714025u / choices + 1));
 }
 
@@ -232,7 +243,7 @@ void ExactDelaunay::vertex_sort(uint64_t *a, int32_t n) {
   }
   const uint64_t pv = KXY(a[rnd((uint32_t)n)]);
   int32_t left = -1, right = n;
-  if (n >= 64) {
+  if (n >= 8) {
     uint32_t *L = stop_.data(), *R = stop_.data() + n;
     int32_t nl = 0, nr = 0;
     for (int32_t i = 0; i < n; i++) {
