@@ -156,6 +156,7 @@ def main():
     elapsed = time.perf_counter() - t0
     total_pairs, elapsed, _ = shard.aggregate(dmod, torch, nf * args.steps, elapsed, comm_dev)
     value = total_pairs / elapsed
+    seq_t = m.sequence_timings()          # phase split of the last timed step (rank-local)
 
     # ---- the same sequence through the per-frame (drop-in) entry points ---------------------
     per_frame_value = None
@@ -294,7 +295,8 @@ def main():
         "cpu_baseline": cpu,
         "kernel_ms_per_frame": {k: round(v[0] / nf, 5) for k, v in stats.items() if v[1]},
         "kernel_avg_launch_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in stats.items() if v[1]},
-        "sequence_timings_us": m.sequence_timings(),
+        "sequence_timings_us": seq_t,
+        "gpu_phases_only_frame_pairs_per_s": round(nf / (seq_t["gpu_us"] * 1e-6), 1),
         "host_threads": int(os.environ["VSM_HOST_THREADS"]),
         "step_ms_rank0": step_ms,
         "match_timings_us_last_frame": m.timings(),
