@@ -444,3 +444,45 @@ def test_road_scene_golden(vm, synth):
     """street scene with real depth structure: the live stereo VO loop and the mono VO loop (success on
     every frame pair) against the all-reference run, frame by frame"""
     G.replay_road(_load_golden("road_1242x375"), synth, vm.VisualOdometryStereo, vm.VisualOdometryMono, vm.vo_sampler_seed)
+
+
+@pytest.mark.parametrize("seed", [20240607, 7, 424242])
+def test_randomised_configurations_vs_oracle(vm, B, synth, seed):
+    """seeded sweep over image sizes, parameters, methods and scene generators: every stage of the
+    HIP path equals the oracle's (catches tile-border, bin-border and tie-break mistakes that fixed
+    cases can miss)"""
+    rs = np.random.RandomState(seed)
+    pyr = synth.road_pyramid(77, levels=8, size=1024)
+    for case in range(40):
+        w = int(rs.randint(70, 700))
+        h = int(rs.randint(60, 300))
+        params = dict(nms_n=int(rs.choice([1, 2, 3, 3, 4, 5])), nms_tau=int(rs.choice([20, 50, 90])),
+                      match_binsize=int(rs.choice([17, 32, 50, 64])), match_radius=int(rs.choice([40, 100, 200])),
+                      match_disp_tolerance=int(rs.choice([1, 2, 3])), multi_stage=int(rs.choice([0, 1, 1])),
+                      half_resolution=int(rs.choice([0, 1, 1])), refinement=int(rs.choice([0, 1, 1, 2])),
+                      outlier_flow_tolerance=int(rs.choice([3, 5])), outlier_disp_tolerance=int(rs.choice([3, 5])))
+        method = int(rs.choice([0, 1, 2, 2]))
+        if rs.randint(2):
+            seq = synth.stereo_sequence(int(rs.randint(1, 10000)), w, h, 3, disparity=int(rs.randint(2, 25)),
+                                        ramp=(int(rs.randint(0, 3)), int(rs.randint(8, 30))))
+        else:
+            seq = [synth.road_stereo_frame(pyr, f, w, h, step_mm=int(rs.choice([150, 400])), base_mm=300) for f in range(3)]
+        use_tr = method == 2 and rs.randint(2) == 1
+        Tr = np.eye(4)
+        Tr[2, 3] = -0.3
+        g, c = vm.Matcher(stage_capture=True, **params), B.CpuMatcher("oracle", **params)
+        intr = (400.0, w / 2.0, h / 2.0, 0.3)
+        g.set_intrinsics(*intr)
+        c.set_intrinsics(*intr)
+        for f, (l, r) in enumerate(seq):
+            rep = f == 2 and rs.randint(3) == 0
+            g.push_back(l, r if method else None, replace=rep)
+            c.push_back(l, r if method else None, replace=rep)
+            for s in ("1c1", "1c2"):
+                assert _same(g.features(s), c.features(s)), (case, params, f, s)
+            t = Tr if (use_tr and f >= 1) else None
+            assert g.match(method, t) == c.match(method, t), (case, params, f)
+            for s in range(5):
+                assert _same(g.stage(s), c.stage(s)), (case, w, h, params, method, f, s)
+        g.close()
+        c.close()
