@@ -162,6 +162,12 @@ void vsm_get_kernel_stats(vsm_handle *h, double *total_ms, int64_t *launches);
  * of triangles; tris gets vertex triples by input index. */
 int32_t vsm_host_delaunay(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap, int32_t threads);
 
+/* the same triangulation computed in three steps -- prepare (sort, kd order, tree), independent
+ * sub-trees of at most max_task_points points, merges above them -- the form in which the look-ahead
+ * path shares the work between host and GPU; must equal vsm_host_delaunay() for every split */
+int32_t vsm_host_delaunay_split(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
+                                int32_t max_task_points);
+
 /* ---- stereo visual odometry on top of the matcher ----
  * class VisualOdometryStereo, viso/viso_stereo.h:28-88 + viso/viso.h:28-131: process() =
  * pushBack + matchFeatures(2, Tr_delta if valid) + bucketFeatures + getMatches + updateMotion

@@ -1012,6 +1012,19 @@ int32_t vsm_host_delaunay(const int32_t *x, const int32_t *y, int32_t n, int32_t
   return nt;
 }
 
+int32_t vsm_host_delaunay_split(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
+                                int32_t max_task_points) {
+  ExactDelaunay d;
+  if (d.prepare(x, y, n, max_task_points)) {
+    d.solve_tasks();
+    d.finish();
+  }
+  const int32_t nt = d.num_triangles();
+  for (int32_t i = 0; i < nt && i < cap; i++)
+    for (int k = 0; k < 3; k++) tris[i * 3 + k] = d.triangles()[i * 3 + k];
+  return nt;
+}
+
 void vsm_get_counters(vsm_handle *h, int64_t *out5) { memcpy(out5, h->counters, sizeof(h->counters)); }
 void vsm_get_timings(vsm_handle *h, double *out5) { memcpy(out5, h->timings, sizeof(h->timings)); }
 

@@ -209,7 +209,7 @@ void VsmForkJoin::run(int ntasks, const std::function<void(int)> &fn) {
 // contiguous slice of pt_.  tri_[t*8+o] = neighbour handle t2*4+o2, tri_[t*8+4+o] = vertex
 // position or -1 for the ghost ("NULL") corner of a bounding triangle.
 // =======================================================================================
-#define KXY(k) ((k) >> 20)
+#define KXY(k) VSM_KXY(k)
 static inline uint64_t key_yx(uint64_t k) { return (((k >> 20) & 0x3fffu) << 14) | (k >> 34); }
 
 uint32_t ExactDelaunay::rnd(uint32_t choices) {  // randomnation, :4046
@@ -388,282 +388,13 @@ void ExactDelaunay::kd_order(int32_t m, VsmForkJoin *pool) {
   key_.swap(k2_);
 }
 
-void ExactDelaunay::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis,
-                                int32_t &tcur) {
-  int32_t ildest = dest(innerleft), ilapex = apex(innerleft);
-  int32_t irorg = org(innerright), irapex = apex(innerright);
-  if (axis == 1) {  // horizontal cut: handles move to the bottom-/top-most hull vertices (:5666)
-    int32_t flpt = org(farleft), flapex = apex(farleft);
-    int32_t frpt = dest(farright);
-    while (py(flapex) < py(flpt)) {
-      farleft = sym(lnext(farleft));
-      flpt = flapex;
-      flapex = apex(farleft);
-    }
-    OTri chk = sym(innerleft);
-    int32_t cv = apex(chk);
-    while (py(cv) > py(ildest)) {
-      innerleft = lnext(chk);
-      ilapex = ildest;
-      ildest = cv;
-      chk = sym(innerleft);
-      cv = apex(chk);
-    }
-    while (py(irapex) < py(irorg)) {
-      innerright = sym(lnext(innerright));
-      irorg = irapex;
-      irapex = apex(innerright);
-    }
-    chk = sym(farright);
-    cv = apex(chk);
-    while (py(cv) > py(frpt)) {
-      farright = lnext(chk);
-      frpt = cv;
-      chk = sym(farright);
-      cv = apex(chk);
-    }
-  }
-  bool changed;
-  do {  // lower common tangent (:5704)
-    changed = false;
-    if (ccw(ildest, ilapex, irorg) > 0) {
-      innerleft = sym(lprev(innerleft));
-      ildest = ilapex;
-      ilapex = apex(innerleft);
-      changed = true;
-    }
-    if (ccw(irapex, irorg, ildest) > 0) {
-      innerright = sym(lnext(innerright));
-      irorg = irapex;
-      irapex = apex(innerright);
-      changed = true;
-    }
-  } while (changed);
-  OTri leftcand = sym(innerleft), rightcand = sym(innerright);
-  OTri base = make(tcur);
-  bond(base, innerleft);
-  base = lnext(base);
-  bond(base, innerright);
-  base = lnext(base);
-  set_org(base, irorg);
-  set_dest(base, ildest);
-  if (ildest == org(farleft)) farleft = lnext(base);
-  if (irorg == dest(farright)) farright = lprev(base);
-  int32_t ll = ildest, lr = irorg;
-  int32_t ul = apex(leftcand), ur = apex(rightcand);
-  for (;;) {
-    const bool lfin = ccw(ul, ll, lr) <= 0, rfin = ccw(ur, ll, lr) <= 0;
-    if (lfin && rfin) {  // close the seam with the top bounding triangle (:5771)
-      OTri top = make(tcur);
-      set_org(top, ll);
-      set_dest(top, lr);
-      bond(top, base);
-      top = lnext(top);
-      bond(top, rightcand);
-      top = lnext(top);
-      bond(top, leftcand);
-      if (axis == 1) {  // handles back to the left-/right-most vertices
-        int32_t flpt = org(farleft), frpt = dest(farright), frapex = apex(farright);
-        OTri chk = sym(farleft);
-        int32_t cv = apex(chk);
-        while (px(cv) < px(flpt)) {
-          farleft = lprev(chk);
-          flpt = cv;
-          chk = sym(farleft);
-          cv = apex(chk);
-        }
-        while (px(frapex) > px(frpt)) {
-          farright = sym(lprev(farright));
-          frpt = frapex;
-          frapex = apex(farright);
-        }
-      }
-      return;
-    }
-    if (!lfin) {  // dissolve non-Delaunay edges on the left (:5814)
-      OTri ne = sym(lprev(leftcand));
-      int32_t na = apex(ne);
-      if (na >= 0) {
-        bool bad = incircle(ll, lr, ul, na) > 0;
-        while (bad) {
-          ne = lnext(ne);
-          OTri topc = sym(ne);
-          ne = lnext(ne);
-          OTri sidec = sym(ne);
-          bond(ne, topc);
-          bond(leftcand, sidec);
-          leftcand = lnext(leftcand);
-          OTri outerc = sym(leftcand);
-          ne = lprev(ne);
-          bond(ne, outerc);
-          set_org(leftcand, ll);
-          set_dest(leftcand, -1);
-          set_apex(leftcand, na);
-          set_org(ne, -1);
-          set_dest(ne, ul);
-          set_apex(ne, na);
-          ul = na;
-          ne = sidec;
-          na = apex(ne);
-          bad = na >= 0 && incircle(ll, lr, ul, na) > 0;
-        }
-      }
-    }
-    if (!rfin) {  // ... and on the right (:5862)
-      OTri ne = sym(lnext(rightcand));
-      int32_t na = apex(ne);
-      if (na >= 0) {
-        bool bad = incircle(ll, lr, ur, na) > 0;
-        while (bad) {
-          ne = lprev(ne);
-          OTri topc = sym(ne);
-          ne = lprev(ne);
-          OTri sidec = sym(ne);
-          bond(ne, topc);
-          bond(rightcand, sidec);
-          rightcand = lprev(rightcand);
-          OTri outerc = sym(rightcand);
-          ne = lnext(ne);
-          bond(ne, outerc);
-          set_org(rightcand, -1);
-          set_dest(rightcand, lr);
-          set_apex(rightcand, na);
-          set_org(ne, ur);
-          set_dest(ne, -1);
-          set_apex(ne, na);
-          ur = na;
-          ne = sidec;
-          na = apex(ne);
-          bad = na >= 0 && incircle(ll, lr, ur, na) > 0;
-        }
-      }
-    }
-    if (lfin || (!rfin && incircle(ul, ll, lr, ur) > 0)) {  // new cross edge ll--ur (:5911)
-      bond(base, rightcand);
-      base = lprev(rightcand);
-      set_dest(base, ll);
-      lr = ur;
-      rightcand = sym(base);
-      ur = apex(rightcand);
-    } else {  // new cross edge ul--lr (:5920)
-      bond(base, leftcand);
-      base = lnext(leftcand);
-      set_org(base, lr);
-      ll = ul;
-      leftcand = sym(base);
-      ul = apex(leftcand);
-    }
-  }
-}
-
-// one sub-problem: positions [off, off+n).  Selection (alternateaxes) and triangulation
-// (divconqrecurse) share one recursion; the caller has already brought the right keys into
-// this slice.  Triangle slots: leaves use 2*off.., the merge at boundary b uses 2b-2, 2b-1.
-void ExactDelaunay::recurse(int32_t off, int32_t n, int axis, int32_t &tcur_unused, OTri &farleft, OTri &farright) {
-  (void)tcur_unused;
-  uint64_t *a = key_.data() + off;
-  if (n <= 3) {  // leaf: always ordered by x (then y), :5596-5600
-    if (KXY(a[0]) > KXY(a[1])) std::swap(a[0], a[1]);
-    if (n == 3) {
-      if (KXY(a[1]) > KXY(a[2])) std::swap(a[1], a[2]);
-      if (KXY(a[0]) > KXY(a[1])) std::swap(a[0], a[1]);
-    }
-    for (int32_t i = 0; i < n; i++) {
-      pt_[off + i] = (uint32_t)(a[i] >> 34) | ((uint32_t)((a[i] >> 20) & 0x3fff) << 16);
-      id_[off + i] = (int32_t)(a[i] & 0xfffff);
-    }
-    int32_t tcur = 2 * off;
-    const int32_t p0 = off, p1 = off + 1, p2 = off + 2;
-    if (n == 2) {  // one edge = two ghost triangles (:5978)
-      farleft = make(tcur);
-      set_org(farleft, p0);
-      set_dest(farleft, p1);
-      farright = make(tcur);
-      set_org(farright, p1);
-      set_dest(farright, p0);
-      bond(farleft, farright);
-      farleft = lprev(farleft);
-      farright = lnext(farright);
-      bond(farleft, farright);
-      farleft = lprev(farleft);
-      farright = lnext(farright);
-      bond(farleft, farright);
-      farleft = lprev(farright);
-      return;
-    }
-    OTri mid = make(tcur), t1 = make(tcur), t2 = make(tcur), t3 = make(tcur);  // (:6006)
-    const int32_t area = ccw(p0, p1, p2);
-    if (area == 0) {
-      set_org(mid, p0);
-      set_dest(mid, p1);
-      set_org(t1, p1);
-      set_dest(t1, p0);
-      set_org(t2, p2);
-      set_dest(t2, p1);
-      set_org(t3, p1);
-      set_dest(t3, p2);
-      bond(mid, t1);
-      bond(t2, t3);
-      mid = lnext(mid);
-      t1 = lprev(t1);
-      t2 = lnext(t2);
-      t3 = lprev(t3);
-      bond(mid, t3);
-      bond(t1, t2);
-      mid = lnext(mid);
-      t1 = lprev(t1);
-      t2 = lnext(t2);
-      t3 = lprev(t3);
-      bond(mid, t1);
-      bond(t2, t3);
-      farleft = t1;
-      farright = t2;
-    } else {
-      const int32_t b = area > 0 ? p1 : p2, c = area > 0 ? p2 : p1;
-      set_org(mid, p0);
-      set_dest(t1, p0);
-      set_org(t3, p0);
-      set_dest(mid, b);
-      set_org(t1, b);
-      set_dest(t2, b);
-      set_apex(mid, c);
-      set_org(t2, c);
-      set_dest(t3, c);
-      bond(mid, t1);
-      mid = lnext(mid);
-      bond(mid, t2);
-      mid = lnext(mid);
-      bond(mid, t3);
-      t1 = lprev(t1);
-      t2 = lnext(t2);
-      bond(t1, t2);
-      t1 = lprev(t1);
-      t3 = lprev(t3);
-      bond(t1, t3);
-      t2 = lnext(t2);
-      t3 = lprev(t3);
-      bond(t2, t3);
-      farleft = t1;
-      farright = area > 0 ? t2 : lnext(farleft);
-    }
-    return;
-  }
-  const int32_t divider = n >> 1;  // kd_order() has already arranged both halves
-  OTri innerleft, innerright;
-  int32_t dummy = 0;
-  recurse(off, divider, 1 - axis, dummy, farleft, innerleft);
-  recurse(off + divider, n - divider, 1 - axis, dummy, innerright, farright);
-  int32_t tcur = 2 * (off + divider) - 2;
-  merge_hulls(farleft, innerleft, innerright, farright, axis, tcur);
-}
-
-int32_t ExactDelaunay::build_tree(int32_t off, int32_t n, int axis, int32_t tbase, int depth) {
+int32_t ExactDelaunay::build_tree(int32_t off, int32_t n, int axis, int32_t max_task_points) {
   const int32_t me = (int32_t)nodes_.size();
-  nodes_.push_back(Node{off, n, axis, tbase, -1, -1, {0, 0}, {0, 0}});
-  if (depth > 0 && n >= 64) {
+  nodes_.push_back(Node{off, n, axis, 0, -1, -1, {0, 0}, {0, 0}});
+  if (n > max_task_points && n > 3) {
     const int32_t divider = n >> 1;
-    const int32_t l = build_tree(off, divider, 1 - axis, 0, depth - 1);
-    const int32_t r = build_tree(off + divider, n - divider, 1 - axis, 0, depth - 1);
+    const int32_t l = build_tree(off, divider, 1 - axis, max_task_points);
+    const int32_t r = build_tree(off + divider, n - divider, 1 - axis, max_task_points);
     nodes_[me].left = l;
     nodes_[me].right = r;
   }
@@ -679,18 +410,23 @@ void ExactDelaunay::list_triangles() {
     if (slot_vertices(t, &tri_out_[(size_t)ntri_out_ * 3])) ntri_out_++;
 }
 
-void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool) {
+bool ExactDelaunay::prepare(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, VsmForkJoin *pool) {
   ntri_out_ = 0;
   m_ = 0;
   listed_ = true;
+  tasks_.clear();
+  levels_.clear();
+  nodes_.clear();
   seed_ = 1;  // triangleinit(), :4031
-  if (n < 2) return;
+  if (n < 2) return false;
   key_.resize(n);
   stop_.resize((size_t)2 * n);
   for (int32_t i = 0; i < n; i++) key_[i] = ((uint64_t)(uint32_t)x[i] << 34) | ((uint64_t)(uint32_t)y[i] << 20) | (uint32_t)i;
   uint64_t *a = key_.data();
-  static const bool dbg = getenv("VSM_DEBUG_TIMING") != nullptr;
   auto clk = [] { return std::chrono::steady_clock::now(); };
+  auto ns = [](std::chrono::steady_clock::time_point u, std::chrono::steady_clock::time_point v) {
+    return (long)std::chrono::duration_cast<std::chrono::nanoseconds>(v - u).count();
+  };
   const auto p0 = clk();
   vertex_sort(a, n);
   const auto p1 = clk();
@@ -698,7 +434,7 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
   for (int32_t j = 1; j < n; j++)
     if (KXY(a[m]) != KXY(a[j])) a[++m] = a[j];
   m++;
-  if (m < 2) return;
+  if (m < 2) return false;
   if ((size_t)m * 16 > tri_.size()) tri_.resize((size_t)m * 16);
   pt_.resize(m);
   id_.resize(m);
@@ -706,71 +442,87 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
     for (int k = 0; k < 3; k++) tri_[(size_t)t * 8 + 4 + k] = -1;
   key_.resize(m);
   kd_order(m, pool);
-  const auto p2 = clk();
-  a = key_.data();
-  OTri hl, hr;
-  int32_t dummy = 0;
-  const int nthreads = pool ? pool->size() : 1;
-  int depth = 0;
-  while ((1 << depth) < nthreads) depth++;
-  if (nthreads <= 1 || m < 256) {
-    // root: the x-sorted array is cut in the middle; its halves are ordered by recurse()
-    recurse(0, m, 0, dummy, hl, hr);
-  } else {
-    nodes_.clear();
-    build_tree(0, m, 0, 0, depth);
-    // level order lists of internal nodes and the leaf tasks
-    std::vector<std::vector<int32_t>> levels;
-    std::vector<int32_t> tasks, cur{0};
-    while (!cur.empty()) {
-      std::vector<int32_t> next, internal;
-      for (int32_t q : cur) {
-        if (nodes_[q].left < 0) {
-          tasks.push_back(q);
-        } else {
-          internal.push_back(q);
-          next.push_back(nodes_[q].left);
-          next.push_back(nodes_[q].right);
-        }
-      }
-      if (!internal.empty()) levels.push_back(internal);
-      cur.swap(next);
-    }
-    // the sub-trees below the task nodes: sequential, one per task
-    pool->run((int)tasks.size(), [&](int t) {
-      Node &nd = nodes_[tasks[t]];
-      int32_t d2 = 0;
-      recurse(nd.off, nd.n, nd.axis, d2, nd.fl, nd.fr);
-    });
-    // bottom-up merges
-    for (int li = (int)levels.size() - 1; li >= 0; li--) {
-      const auto &lv = levels[li];
-      pool->run((int)lv.size(), [&](int t) {
-        Node &nd = nodes_[lv[t]];
-        Node &l = nodes_[nd.left], &r = nodes_[nd.right];
-        nd.fl = l.fl;
-        nd.fr = r.fr;
-        OTri il = l.fr, ir = r.fl;
-        int32_t tcur = 2 * (nd.off + (nd.n >> 1)) - 2;
-        merge_hulls(nd.fl, il, ir, nd.fr, nd.axis, tcur);
-      });
-    }
-  }
-  const auto p3 = clk();
+  t_sort_ = ns(p0, p1);
+  t_kd_ = ns(p1, clk());
   m_ = m;
   listed_ = false;
+  // tree layout: the x-sorted array is cut in the middle, the halves alternate their cut axis;
+  // nodes small enough become tasks, the rest is listed level by level for finish()
+  build_tree(0, m, 0, max_task_points < 2 ? 2 : max_task_points);
+  std::vector<int32_t> cur{0};
+  while (!cur.empty()) {
+    std::vector<int32_t> next, internal;
+    for (int32_t q : cur) {
+      if (nodes_[q].left < 0) {
+        tasks_.push_back(Task{nodes_[q].off, nodes_[q].n, nodes_[q].axis, q});
+      } else {
+        internal.push_back(q);
+        next.push_back(nodes_[q].left);
+        next.push_back(nodes_[q].right);
+      }
+    }
+    if (!internal.empty()) levels_.push_back(internal);
+    cur.swap(next);
+  }
+  return true;
+}
+
+void ExactDelaunay::solve_tasks(VsmForkJoin *pool) {
+  const DcMesh mesh = this->mesh();
+  auto one = [&](int t) {
+    Node &nd = nodes_[tasks_[t].node];
+    mesh.recurse(nd.off, nd.n, nd.axis, nd.fl, nd.fr);
+  };
+  if (pool && pool->size() > 1 && tasks_.size() > 1) {
+    pool->run((int)tasks_.size(), one);
+  } else {
+    for (int t = 0; t < (int)tasks_.size(); t++) one(t);
+  }
+}
+
+void ExactDelaunay::finish(VsmForkJoin *pool) {
+  const DcMesh mesh = this->mesh();
+  auto merge_node = [&](int32_t q) {
+    Node &nd = nodes_[q];
+    Node &l = nodes_[nd.left], &r = nodes_[nd.right];
+    nd.fl = l.fl;
+    nd.fr = r.fr;
+    OTri il = l.fr, ir = r.fl;
+    int32_t tcur = 2 * (nd.off + (nd.n >> 1)) - 2;
+    mesh.merge_hulls(nd.fl, il, ir, nd.fr, nd.axis, tcur);
+  };
+  for (int li = (int)levels_.size() - 1; li >= 0; li--) {  // bottom-up
+    const auto &lv = levels_[li];
+    if (pool && pool->size() > 1 && lv.size() > 1) {
+      pool->run((int)lv.size(), [&](int t) { merge_node(lv[t]); });
+    } else {
+      for (int32_t q : lv) merge_node(q);
+    }
+  }
+}
+
+void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool) {
+  static const bool dbg = getenv("VSM_DEBUG_TIMING") != nullptr;
+  const int nthreads = pool ? pool->size() : 1;
+  // one task (the whole array) when single-threaded, about one sub-tree per thread otherwise
+  int32_t max_task = n;
+  if (nthreads > 1 && n >= 256) {
+    int depth = 0;
+    while ((1 << depth) < nthreads) depth++;
+    max_task = std::max(63, (n >> depth) + 1);
+  }
+  if (!prepare(x, y, n, max_task, pool)) return;
+  const auto p2 = std::chrono::steady_clock::now();
+  solve_tasks(pool);
+  finish(pool);
   if (dbg && n > 3000) {
-    static std::atomic<long> calls{0}, t_sort{0}, t_kd{0}, t_dc{0}, t_out{0};
-    auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
-      return (long)std::chrono::duration_cast<std::chrono::nanoseconds>(y - x).count();
-    };
-    t_sort += us(p0, p1);
-    t_kd += us(p1, p2);
-    t_dc += us(p2, p3);
-    t_out += us(p3, clk());
+    static std::atomic<long> calls{0}, t_sort{0}, t_kd{0}, t_dc{0};
+    t_sort += t_sort_;
+    t_kd += t_kd_;
+    t_dc += (long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - p2).count();
     if (++calls % 100 == 0)
-      fprintf(stderr, "  ExactDelaunay (n > 3000, %d threads), mean us: sort %.0f, kd order %.0f, divide&conquer %.0f, output %.0f\n",
-              pool ? pool->size() : 1, t_sort / 1e3 / calls, t_kd / 1e3 / calls, t_dc / 1e3 / calls, t_out / 1e3 / calls);
+      fprintf(stderr, "  ExactDelaunay (n > 3000, %d threads), mean us: sort %.0f, kd order %.0f, divide&conquer %.0f\n",
+              nthreads, t_sort / 1e3 / calls, t_kd / 1e3 / calls, t_dc / 1e3 / calls);
   }
 }
 

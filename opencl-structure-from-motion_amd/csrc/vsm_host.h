@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "visomatch.h"
+#include "vsm_dc_mesh.h"
 
 // Small task pool for the host stages (Delaunay sub-problems / frame pairs are independent).
 // Work arrives as batches of n index tasks; batches are served FIFO.  run() is fork-join (the
@@ -102,8 +103,31 @@ class VsmForkJoin {
 // and solves the independent sub-problems of the top recursion levels on several host threads.
 class ExactDelaunay {
  public:
+  typedef DcMesh::OTri OTri;
   // points are (x[i], y[i]); after run(), triangles() lists vertex triples by input index
   void run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool = nullptr);
+
+  // The same in three steps, so that the independent sub-trees can be triangulated elsewhere (the
+  // look-ahead path hands them to the GPU, csrc/vsm_dc.hip):
+  //   prepare()  emulated vertex sort, duplicate removal, kd order, tree layout; sub-trees of at
+  //              most max_task_points points become tasks.  false: fewer than 2 distinct points.
+  //   tasks()    slices [off, off+n) with their cut axis; a solver runs DcMesh::recurse on each and
+  //              reports the two hull handles with set_task_hull() (solve_tasks() does it here)
+  //   finish()   the merges above the tasks, bottom-up.
+  struct Task {
+    int32_t off, n, axis, node;
+  };
+  bool prepare(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, VsmForkJoin *pool = nullptr);
+  const std::vector<Task> &tasks() const { return tasks_; }
+  void solve_tasks(VsmForkJoin *pool = nullptr);
+  void set_task_hull(int32_t task, OTri farleft, OTri farright) {
+    nodes_[tasks_[task].node].fl = farleft;
+    nodes_[tasks_[task].node].fr = farright;
+  }
+  void finish(VsmForkJoin *pool = nullptr);
+  int32_t points() const { return m_; }  // distinct points = sorted positions
+  DcMesh mesh() { return DcMesh{tri_.data(), pt_.data(), id_.data(), key_.data()}; }
+
   // the triangle list as vertex triples (built on first use; removeOutliers walks the slots instead)
   int32_t num_triangles() {
     list_triangles();
@@ -126,9 +150,6 @@ class ExactDelaunay {
   }
 
  private:
-  struct OTri {
-    int32_t t, o;
-  };
   struct Node {  // one sub-problem of the divide-and-conquer tree
     int32_t off, n, axis, tbase, left, right;
     OTri fl, fr;
@@ -141,62 +162,18 @@ class ExactDelaunay {
   std::vector<int32_t> id_;           // by sorted position: input index
   std::vector<int32_t> tri_, tri_out_;
   std::vector<Node> nodes_;
+  std::vector<Task> tasks_;
+  std::vector<std::vector<int32_t>> levels_;  // internal nodes above the tasks, root level first
   int32_t ntri_out_ = 0, m_ = 0;
   bool listed_ = true;
   void list_triangles();
   uint64_t seed_ = 1;
+  long t_sort_ = 0, t_kd_ = 0;  // ns, VSM_DEBUG_TIMING
 
   uint32_t rnd(uint32_t choices);
   void vertex_sort(uint64_t *a, int32_t n);
   void kd_order(int32_t m, VsmForkJoin *pool);
-  void recurse(int32_t off, int32_t n, int axis, int32_t &tcur, OTri &farleft, OTri &farright);
-  void merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis, int32_t &tcur);
-  int32_t build_tree(int32_t off, int32_t n, int axis, int32_t tbase, int depth);
-
-  // one 32-byte record per triangle: tri_[t*8 + o] = neighbour handle across edge o,
-  // tri_[t*8 + 4 + o] = vertex o (-1 = ghost corner); pt_[p] = x | y << 16
-  inline OTri make(int32_t &tcur) {
-    const int32_t t = tcur++;
-    int32_t *r = &tri_[(size_t)t * 8];
-    r[0] = r[1] = r[2] = -1;
-    r[4] = r[5] = r[6] = -1;
-    return OTri{t, 0};
-  }
-  inline OTri sym(OTri a) const {
-    int32_t e = tri_[(size_t)a.t * 8 + a.o];
-    return OTri{e >> 2, e & 3};
-  }
-  static inline OTri lnext(OTri a) { return OTri{a.t, a.o == 2 ? 0 : a.o + 1}; }
-  static inline OTri lprev(OTri a) { return OTri{a.t, a.o == 0 ? 2 : a.o - 1}; }
-  inline int32_t org(OTri a) const { return tri_[(size_t)a.t * 8 + 4 + (a.o == 2 ? 0 : a.o + 1)]; }
-  inline int32_t dest(OTri a) const { return tri_[(size_t)a.t * 8 + 4 + (a.o == 0 ? 2 : a.o - 1)]; }
-  inline int32_t apex(OTri a) const { return tri_[(size_t)a.t * 8 + 4 + a.o]; }
-  inline void set_org(OTri a, int32_t v) { tri_[(size_t)a.t * 8 + 4 + (a.o == 2 ? 0 : a.o + 1)] = v; }
-  inline void set_dest(OTri a, int32_t v) { tri_[(size_t)a.t * 8 + 4 + (a.o == 0 ? 2 : a.o - 1)] = v; }
-  inline void set_apex(OTri a, int32_t v) { tri_[(size_t)a.t * 8 + 4 + a.o] = v; }
-  inline void bond(OTri a, OTri b) {
-    tri_[(size_t)a.t * 8 + a.o] = b.t * 4 + b.o;
-    tri_[(size_t)b.t * 8 + b.o] = a.t * 4 + a.o;
-  }
-  inline int32_t px(int32_t p) const { return (int32_t)(pt_[p] & 0xffffu); }
-  inline int32_t py(int32_t p) const { return (int32_t)(pt_[p] >> 16); }
-  // coordinates < 2^14: the orientation determinant fits int32, the in-circle one int64
-  inline int32_t ccw(int32_t a, int32_t b, int32_t c) const {
-    const uint32_t pa = pt_[a], pb = pt_[b], pc = pt_[c];
-    const int32_t cx = (int32_t)(pc & 0xffffu), cy = (int32_t)(pc >> 16);
-    return ((int32_t)(pa & 0xffffu) - cx) * ((int32_t)(pb >> 16) - cy) -
-           ((int32_t)(pa >> 16) - cy) * ((int32_t)(pb & 0xffffu) - cx);
-  }
-  inline int64_t incircle(int32_t a, int32_t b, int32_t c, int32_t d) const {
-    const uint32_t pa = pt_[a], pb = pt_[b], pc = pt_[c], pd = pt_[d];
-    const int32_t dx = (int32_t)(pd & 0xffffu), dy = (int32_t)(pd >> 16);
-    const int32_t adx = (int32_t)(pa & 0xffffu) - dx, ady = (int32_t)(pa >> 16) - dy;
-    const int32_t bdx = (int32_t)(pb & 0xffffu) - dx, bdy = (int32_t)(pb >> 16) - dy;
-    const int32_t cdx = (int32_t)(pc & 0xffffu) - dx, cdy = (int32_t)(pc >> 16) - dy;
-    return (int64_t)(adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) +
-           (int64_t)(bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) +
-           (int64_t)(cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
-  }
+  int32_t build_tree(int32_t off, int32_t n, int axis, int32_t max_task_points);
 };
 
 struct VsmHostWork {

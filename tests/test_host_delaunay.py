@@ -38,3 +38,29 @@ def test_product_delaunay_equals_reference(B):
     vm = pkg("visomatch")
     for pts in _cases(11):
         assert _tri_set(vm.host_delaunay(pts, threads=4)) == _tri_set(B.delaunay("ref", pts.astype(np.float32)))
+
+
+def test_split_form_equals_whole(B):
+    """prepare / independent sub-trees / merges (the form shared between host and GPU in the look-ahead
+    path) gives the same triangle set as the one-piece run for every sub-tree size, duplicates and
+    degenerate layouts included"""
+    vm = pkg("visomatch")
+    rs = np.random.RandomState(11)
+
+    def canon(t):
+        t = np.sort(np.asarray(t), axis=1)
+        return t[np.lexsort(t.T[::-1])]
+
+    cases = []
+    for n in (2, 3, 5, 17, 64, 300, 2500):
+        p = np.stack([rs.randint(0, 120, n) * 2, rs.randint(0, 50, n) * 2], 1)
+        cases.append(p)
+    g = np.stack(np.meshgrid(np.arange(0, 40, 2), np.arange(0, 24, 2)), -1).reshape(-1, 2)   # lattice: all co-circular
+    cases.append(g)
+    cases.append(np.concatenate([g, g[::3]]))                                                    # + duplicates
+    cases.append(np.stack([np.arange(0, 200, 2), np.full(100, 8)], 1))                            # collinear
+    for p in cases:
+        whole = vm.host_delaunay(p, 1)
+        for leaf in (2, 3, 4, 7, 14, 56, 100000):
+            part = vm.host_delaunay_split(p, leaf)
+            assert np.array_equal(canon(whole), canon(part)), (len(p), leaf)
