@@ -168,6 +168,10 @@ int32_t vsm_host_delaunay(const int32_t *x, const int32_t *y, int32_t n, int32_t
 int32_t vsm_host_delaunay_split(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
                                 int32_t max_task_points);
 
+/* test hook for the shared form: sub-trees on the GPU (one thread each), the rest on the host; -1 on a HIP error */
+int32_t vsm_debug_delaunay_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
+                               int32_t max_task_points);
+
 /* ---- stereo visual odometry on top of the matcher ----
  * class VisualOdometryStereo, viso/viso_stereo.h:28-88 + viso/viso.h:28-131: process() =
  * pushBack + matchFeatures(2, Tr_delta if valid) + bucketFeatures + getMatches + updateMotion

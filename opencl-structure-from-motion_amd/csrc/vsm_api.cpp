@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "vsm_host.h"
+#include "vsm_dc_gpu.h"
 #include "vsm_internal.h"
 
 #define HIPCHK(expr)                                                                              \
@@ -1023,6 +1024,58 @@ int32_t vsm_host_delaunay_split(const int32_t *x, const int32_t *y, int32_t n, i
   for (int32_t i = 0; i < nt && i < cap; i++)
     for (int k = 0; k < 3; k++) tris[i * 3 + k] = d.triangles()[i * 3 + k];
   return nt;
+}
+
+// test hook: prepare on the host, sub-trees on the GPU (vsm_dc.hip), merges above them on the host
+int32_t vsm_debug_delaunay_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
+                               int32_t max_task_points) {
+  ExactDelaunay d;
+  if (d.prepare(x, y, n, max_task_points)) {
+    const int32_t m = d.points();
+    const DcMesh mesh = d.mesh();
+    const std::vector<ExactDelaunay::Task> &tasks = d.tasks();
+    const int nt = (int)tasks.size();
+    VsmDcJob job;
+    VsmDcTask *d_tasks = nullptr;
+    VsmDcJob *d_job = nullptr;
+    std::vector<VsmDcHull> hulls(nt);
+    const size_t tri_bytes = (size_t)m * 2 * 8 * sizeof(int32_t);
+    bool ok = hipMalloc((void **)&job.key, (size_t)m * 8) == hipSuccess && hipMalloc((void **)&job.pt, (size_t)m * 4) == hipSuccess &&
+              hipMalloc((void **)&job.id, (size_t)m * 4) == hipSuccess && hipMalloc((void **)&job.tri, tri_bytes) == hipSuccess &&
+              hipMalloc((void **)&d_tasks, sizeof(VsmDcTask) * nt) == hipSuccess &&
+              hipMalloc((void **)&job.hulls, sizeof(VsmDcHull) * nt) == hipSuccess &&
+              hipMalloc((void **)&d_job, sizeof(VsmDcJob)) == hipSuccess;
+    if (!ok) return -1;
+    job.tasks = d_tasks;
+    job.ntasks = nt;
+    job.m = m;
+    static_assert(sizeof(VsmDcTask) == sizeof(ExactDelaunay::Task), "task layout");
+    (void)hipMemcpy(job.key, mesh.key, (size_t)m * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_tasks, tasks.data(), sizeof(VsmDcTask) * nt, hipMemcpyHostToDevice);
+    (void)hipMemset(job.tri, 0xff, tri_bytes);
+    (void)hipMemcpy(d_job, &job, sizeof(job), hipMemcpyHostToDevice);
+    vsm_dc_launch_subtrees(nullptr, d_job, 1, nt);
+    ok = hipDeviceSynchronize() == hipSuccess;
+    (void)hipMemcpy(mesh.tri, job.tri, tri_bytes, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(mesh.pt, job.pt, (size_t)m * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(mesh.id, job.id, (size_t)m * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hulls.data(), job.hulls, sizeof(VsmDcHull) * nt, hipMemcpyDeviceToHost);
+    (void)hipFree(job.key);
+    (void)hipFree(job.pt);
+    (void)hipFree(job.id);
+    (void)hipFree(job.tri);
+    (void)hipFree(d_tasks);
+    (void)hipFree(job.hulls);
+    (void)hipFree(d_job);
+    if (!ok) return -1;
+    for (int t = 0; t < nt; t++)
+      d.set_task_hull(t, ExactDelaunay::OTri{hulls[t].fl_t, hulls[t].fl_o}, ExactDelaunay::OTri{hulls[t].fr_t, hulls[t].fr_o});
+    d.finish();
+  }
+  const int32_t ntri = d.num_triangles();
+  for (int32_t i = 0; i < ntri && i < cap; i++)
+    for (int k = 0; k < 3; k++) tris[i * 3 + k] = d.triangles()[i * 3 + k];
+  return ntri;
 }
 
 void vsm_get_counters(vsm_handle *h, int64_t *out5) { memcpy(out5, h->counters, sizeof(h->counters)); }

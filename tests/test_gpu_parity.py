@@ -486,3 +486,22 @@ def test_randomised_configurations_vs_oracle(vm, B, synth, seed):
                 assert _same(g.stage(s), c.stage(s)), (case, w, h, params, method, f, s)
         g.close()
         c.close()
+
+
+def test_delaunay_subtrees_on_gpu(vm):
+    """the shared form of the exact Delaunay: sub-trees triangulated by GPU threads (vsm_dc.hip), the
+    host continues on the same arrays; triangle sets equal the host-only run for every split"""
+    import time
+    rs = np.random.RandomState(3)
+
+    def canon(t):
+        t = np.sort(np.asarray(t), axis=1)
+        return t[np.lexsort(t.T[::-1])]
+
+    cases = [np.stack([rs.randint(0, 620, n) * 2, rs.randint(0, 187, n) * 2], 1) for n in (5, 64, 700, 7400)]
+    g = np.stack(np.meshgrid(np.arange(0, 60, 2), np.arange(0, 40, 2)), -1).reshape(-1, 2)
+    cases += [g, np.concatenate([g, g[::3]]), np.stack([np.arange(0, 300, 2), np.full(150, 8)], 1)]
+    for p in cases:
+        whole = canon(vm.host_delaunay(p, 1))
+        for leaf in (3, 14, 56, 500):
+            assert np.array_equal(whole, canon(vm.delaunay_gpu_split(p, leaf))), (len(p), leaf)
