@@ -172,6 +172,9 @@ int32_t vsm_host_delaunay_split(const int32_t *x, const int32_t *y, int32_t n, i
 int32_t vsm_debug_delaunay_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
                                int32_t max_task_points);
 
+double vsm_debug_dc_bench(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, int32_t njobs,
+                          int32_t reps);   /* kernel microseconds per launch of njobs triangulations */
+
 /* ---- stereo visual odometry on top of the matcher ----
  * class VisualOdometryStereo, viso/viso_stereo.h:28-88 + viso/viso.h:28-131: process() =
  * pushBack + matchFeatures(2, Tr_delta if valid) + bucketFeatures + getMatches + updateMotion

@@ -281,12 +281,73 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
   return VSM_OK;
 }
 
+// Look-ahead final stage, shared between host and GPU (vsm_dc.hip): per pair bank the pinned / device
+// slabs that carry the prepared keys and task lists to the GPU and the triangle records back.
+struct DcBank {
+  int npairs = 0, stride_pts = 0, stride_tasks = 0;
+  uint64_t *d_key = nullptr, *h_key = nullptr;
+  uint32_t *d_pt = nullptr, *h_pt = nullptr;
+  int32_t *d_id = nullptr, *h_id = nullptr, *d_tri = nullptr, *h_tri = nullptr;
+  VsmDcTask *d_tasks = nullptr, *h_tasks = nullptr;
+  VsmDcHull *d_hulls = nullptr, *h_hulls = nullptr;
+  VsmDcJob *d_jobs = nullptr, *h_jobs = nullptr;
+  std::vector<int32_t> m, nt;  // per pair: distinct points and tasks (nt < 0: the host solves the sub-trees)
+  hipEvent_t done = nullptr;
+  void release() {
+    (void)hipFree(d_key);
+    (void)hipFree(d_pt);
+    (void)hipFree(d_id);
+    (void)hipFree(d_tri);
+    (void)hipFree(d_tasks);
+    (void)hipFree(d_hulls);
+    (void)hipFree(d_jobs);
+    (void)hipHostFree(h_key);
+    (void)hipHostFree(h_pt);
+    (void)hipHostFree(h_id);
+    (void)hipHostFree(h_tri);
+    (void)hipHostFree(h_tasks);
+    (void)hipHostFree(h_hulls);
+    (void)hipHostFree(h_jobs);
+    if (done) (void)hipEventDestroy(done);
+    *this = DcBank();
+  }
+  bool reserve(int pairs, int pts, int tasks) {
+    if (pairs <= npairs && pts <= stride_pts && tasks <= stride_tasks) return true;
+    release();
+    npairs = pairs;
+    stride_pts = pts;
+    stride_tasks = tasks;
+    const size_t P = (size_t)pairs * pts, T = (size_t)pairs * tasks;
+    bool ok = hipMalloc((void **)&d_key, P * 8) == hipSuccess && hipMalloc((void **)&d_pt, P * 4) == hipSuccess &&
+              hipMalloc((void **)&d_id, P * 4) == hipSuccess && hipMalloc((void **)&d_tri, P * 64) == hipSuccess &&
+              hipMalloc((void **)&d_tasks, T * sizeof(VsmDcTask)) == hipSuccess &&
+              hipMalloc((void **)&d_hulls, T * sizeof(VsmDcHull)) == hipSuccess &&
+              hipMalloc((void **)&d_jobs, pairs * sizeof(VsmDcJob)) == hipSuccess &&
+              hipHostMalloc((void **)&h_key, P * 8, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&h_pt, P * 4, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&h_id, P * 4, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&h_tri, P * 64, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&h_tasks, T * sizeof(VsmDcTask), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&h_hulls, T * sizeof(VsmDcHull), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&h_jobs, pairs * sizeof(VsmDcJob), hipHostMallocDefault) == hipSuccess &&
+              hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess;
+    m.assign(pairs, 0);
+    nt.assign(pairs, 0);
+    if (!ok) release();
+    return ok;
+  }
+};
+
 // ---------------------------------------------------------------------------------------
 struct vsm_handle {
   vsm_params param;  // match_radius already halved for half_resolution (viso/matcher.cpp:59-60)
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t idle_wait = nullptr;  // blocking-sync event: the look-ahead caller yields its CPU to the host pool
+  static constexpr int kDcBanks = 4;  // chunks whose final stage may be in flight at once
+  struct DcBank *dc_bank[kDcBanks] = {nullptr, nullptr, nullptr, nullptr};  // look-ahead: GPU share of the exact Delaunay
+  hipStream_t dc_stream = nullptr;
+  std::vector<VsmHostWork> seq_work;               // per pair of every Delaunay bank: state between the two host halves
   VsmCtx ring;  // streaming ring buffer: 2 frame slots, 1 pair
   VsmCtx seq;   // look-ahead sequences: 2 banks of C frame slots, C pairs
   int seq_chunk = 0;
@@ -374,6 +435,11 @@ vsm_handle *vsm_create(const vsm_params *p) {
     h->fj = new VsmForkJoin(nt < 8 ? nt : 8);
     h->work.pool = h->fj;
   }
+  // k_dc_subtrees (vsm_dc.hip) recurses a few levels deep: make sure every thread has the stack for it
+  {
+    size_t cur = 0;
+    if (hipDeviceGetLimit(&cur, hipLimitStackSize) == hipSuccess && cur < 4096) (void)hipDeviceSetLimit(hipLimitStackSize, 4096);
+  }
   if (hipGetDevice(&h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->idle_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
     fprintf(stderr, "visomatch: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
@@ -398,6 +464,12 @@ void vsm_destroy(vsm_handle *h) {
   ctx_destroy(h->ring);
   ctx_destroy(h->seq);
   if (h->stage_host) (void)hipHostFree(h->stage_host);
+  for (int b = 0; b < vsm_handle::kDcBanks; b++)
+    if (h->dc_bank[b]) {
+      h->dc_bank[b]->release();
+      delete h->dc_bank[b];
+    }
+  if (h->dc_stream) (void)hipStreamDestroy(h->dc_stream);
   if (h->idle_wait) (void)hipEventDestroy(h->idle_wait);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h->pool;
@@ -675,6 +747,148 @@ float vsm_gain(vsm_handle *h, const int32_t *inliers, int32_t n) {
   return vsm_host_gain(h->gainI[0].data(), h->gainI[1].data(), h->dims_p, h->dims_c, h->matched, inliers, n);
 }
 
+// ---------------------------------------------------------------------------------------
+// Final stage of a look-ahead chunk (exact Delaunay support test), shared between host and GPU:
+//   A  host pool, per pair: copy the exported list, per-match arrays, ExactDelaunay::prepare (emulated
+//      sort, kd order, tree); keys and sub-tree tasks go to the bank's pinned slab
+//   G  GPU, second stream: all sub-trees of all pairs in one launch (vsm_dc.hip), records back
+//   B  host pool, per pair: adopt the records, the merges above the sub-trees, support, survivors
+// The stages hand over to each other without the caller's thread: the last A task to finish enqueues
+// G, a host function at the end of G submits B.  VSM_DC_GPU=0 keeps everything on the host.
+// ---------------------------------------------------------------------------------------
+struct DcChunk {
+  vsm_handle *h = nullptr;
+  VsmCtx *ctx = nullptr;
+  vsm_params p;
+  int method = 0, leaf = 32;
+  int bank = 0, n = 0, f0 = 0, first_pair = 0, work0 = 0;
+  std::shared_ptr<std::vector<char>> valid;
+  std::atomic<int> a_left{0};
+  std::atomic<int> stage{0};  // 0: A running, 1: G enqueued, 2: B submitted
+  VsmPool::Ticket a, b;
+};
+
+static void dc_submit_b(DcChunk *ch) {
+  vsm_handle *h = ch->h;
+  ch->b = h->pool->submit(ch->n, [ch](int i) {
+    if (!(*ch->valid)[i]) return;
+    vsm_handle *h = ch->h;
+    VsmHostWork &wk = h->seq_work[ch->work0 + i];
+    std::vector<vsm_p_match> &out = h->seq_matches[ch->f0 + i];
+    const int32_t nl = (int32_t)wk.tmp_list.size();
+    if (nl <= 3) {  // the reference leaves short lists alone (:1210)
+      out.assign(wk.tmp_list.begin(), wk.tmp_list.end());
+      return;
+    }
+    const DcBank &B = *h->dc_bank[ch->bank];
+    const int32_t m = B.m[i], nt = B.nt[i];
+    if (m >= 2) {
+      if (nt > 0) {  // adopt what the GPU built
+        const DcMesh mesh = wk.del.mesh();
+        memcpy(mesh.tri, B.h_tri + (size_t)i * B.stride_pts * 16, (size_t)m * 16 * sizeof(int32_t));
+        memcpy(mesh.pt, B.h_pt + (size_t)i * B.stride_pts, (size_t)m * 4);
+        memcpy(mesh.id, B.h_id + (size_t)i * B.stride_pts, (size_t)m * 4);
+        const VsmDcHull *hu = B.h_hulls + (size_t)i * B.stride_tasks;
+        for (int t = 0; t < nt; t++)
+          wk.del.set_task_hull(t, ExactDelaunay::OTri{hu[t].fl_t, hu[t].fl_o}, ExactDelaunay::OTri{hu[t].fr_t, hu[t].fr_o});
+      } else {
+        wk.del.solve_tasks();
+      }
+      wk.del.finish();
+    }
+    vsm_host_outliers_end(wk, ch->p, wk.tmp_list.data(), nl, ch->method, out);
+  });
+  ch->stage.store(2, std::memory_order_release);
+}
+
+static void dc_after_gpu(void *arg) { dc_submit_b((DcChunk *)arg); }  // runs on a HIP runtime thread: no HIP calls
+
+static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished the chunk's last A task
+  vsm_handle *h = ch->h;
+  (void)hipSetDevice(h->device);
+  DcBank &B = *h->dc_bank[ch->bank];
+  int maxt = 0, maxm = 0;
+  for (int i = 0; i < ch->n; i++) {
+    VsmDcJob &jb = B.h_jobs[i];
+    jb.key = B.d_key + (size_t)i * B.stride_pts;
+    jb.pt = B.d_pt + (size_t)i * B.stride_pts;
+    jb.id = B.d_id + (size_t)i * B.stride_pts;
+    jb.tri = B.d_tri + (size_t)i * B.stride_pts * 16;
+    jb.tasks = B.d_tasks + (size_t)i * B.stride_tasks;
+    jb.hulls = B.d_hulls + (size_t)i * B.stride_tasks;
+    jb.ntasks = std::max(B.nt[i], 0);
+    jb.m = B.m[i];
+    maxt = std::max(maxt, jb.ntasks);
+    if (B.nt[i] > 0) maxm = std::max(maxm, B.m[i]);
+  }
+  // only the used part of every pair's slab row travels: rows of maxm points / maxt tasks
+  const size_t sp = (size_t)B.stride_pts, st = (size_t)B.stride_tasks, rows = (size_t)ch->n;
+  hipStream_t s2 = h->dc_stream;
+  bool ok = true;
+  if (maxt > 0) {
+    ok = hipMemcpy2DAsync(B.d_key, sp * 8, B.h_key, sp * 8, (size_t)maxm * 8, rows, hipMemcpyHostToDevice, s2) == hipSuccess &&
+         hipMemcpy2DAsync(B.d_tasks, st * sizeof(VsmDcTask), B.h_tasks, st * sizeof(VsmDcTask), (size_t)maxt * sizeof(VsmDcTask), rows,
+                          hipMemcpyHostToDevice, s2) == hipSuccess &&
+         hipMemcpyAsync(B.d_jobs, B.h_jobs, ch->n * sizeof(VsmDcJob), hipMemcpyHostToDevice, s2) == hipSuccess &&
+         hipMemset2DAsync(B.d_tri, sp * 64, 0xff, (size_t)maxm * 64, rows, s2) == hipSuccess;
+    if (ok) {
+      vsm_dc_launch_subtrees(s2, B.d_jobs, ch->n, maxt);
+      ok = hipMemcpy2DAsync(B.h_tri, sp * 64, B.d_tri, sp * 64, (size_t)maxm * 64, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
+           hipMemcpy2DAsync(B.h_pt, sp * 4, B.d_pt, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
+           hipMemcpy2DAsync(B.h_id, sp * 4, B.d_id, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
+           hipMemcpy2DAsync(B.h_hulls, st * sizeof(VsmDcHull), B.d_hulls, st * sizeof(VsmDcHull), (size_t)maxt * sizeof(VsmDcHull), rows,
+                            hipMemcpyDeviceToHost, s2) == hipSuccess;
+    }
+  }
+  ch->stage.store(1, std::memory_order_release);
+  if (ok && maxt > 0 && hipLaunchHostFunc(s2, dc_after_gpu, ch) == hipSuccess) return;
+  // nothing for the GPU, or it could not be used: the host solves the sub-trees too
+  if (maxt > 0) {
+    (void)hipStreamSynchronize(s2);
+    for (int i = 0; i < ch->n; i++)
+      if (B.nt[i] > 0) B.nt[i] = -1;
+  }
+  dc_submit_b(ch);
+}
+
+static void dc_submit_a(DcChunk *ch) {
+  ch->a_left.store(ch->n, std::memory_order_relaxed);
+  ch->a = ch->h->pool->submit(ch->n, [ch](int i) {
+    vsm_handle *h = ch->h;
+    VsmHostWork &wk = h->seq_work[ch->work0 + i];
+    DcBank &B = *h->dc_bank[ch->bank];
+    B.m[i] = 0;
+    B.nt[i] = 0;
+    wk.tmp_list.clear();
+    if ((*ch->valid)[i]) {
+      const int pj = ch->first_pair + i;
+      // one wide copy out of the host-mapped export, then cache-resident work
+      wk.tmp_list.assign(ch->ctx->hm_list2[pj], ch->ctx->hm_list2[pj] + ch->ctx->hm_lcount[2 * pj + 1]);
+      const int32_t nl = (int32_t)wk.tmp_list.size();
+      if (nl > 3) {
+        vsm_host_outliers_begin(wk, wk.tmp_list.data(), nl, ch->method);
+        if (wk.del.prepare(wk.x.data(), wk.y.data(), nl, ch->leaf)) {
+          const int32_t m = wk.del.points(), nt = (int32_t)wk.del.tasks().size();
+          B.m[i] = m;
+          if (m > B.stride_pts || nt > B.stride_tasks) {
+            B.nt[i] = -1;  // does not fit the slab: this pair stays on the host
+          } else {
+            memcpy(B.h_key + (size_t)i * B.stride_pts, wk.del.mesh().key, (size_t)m * 8);
+            memcpy(B.h_tasks + (size_t)i * B.stride_tasks, wk.del.tasks().data(), (size_t)nt * sizeof(VsmDcTask));
+            B.nt[i] = nt;
+          }
+        }
+      }
+    }
+    if (ch->a_left.fetch_sub(1, std::memory_order_acq_rel) == 1) dc_enqueue_gpu(ch);  // the last one hands over
+  });
+}
+
+static void dc_wait(DcChunk *ch) {  // until the chunk's final lists are in seq_matches
+  while (ch->stage.load(std::memory_order_acquire) < 2) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  ch->h->pool->wait(ch->b);
+}
+
 // stream sync that puts the calling thread to sleep (the per-frame path keeps the spinning
 // hipStreamSynchronize: there a wake-up latency of tens of microseconds matters, here the CPU does)
 static hipError_t sync_sleeping(vsm_handle *h) {
@@ -738,6 +952,23 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   // Software pipeline over chunks: while the pool works on the final host stage of chunk k (it
   // reads pair bank k&1 in host-mapped memory), the GPU already runs chunk k+1 on the other bank.
   std::vector<VsmPool::Ticket> tickets;
+  // final stage: see DcChunk above
+  static const bool dc_env = !(getenv("VSM_DC_GPU") && atoi(getenv("VSM_DC_GPU")) == 0);
+  static const int dc_leaf = getenv("VSM_DC_LEAF") ? std::max(3, atoi(getenv("VSM_DC_LEAF"))) : 64;
+  bool dc_gpu = dc_env;
+  if (dc_gpu && !h->dc_stream) dc_gpu = hipStreamCreateWithFlags(&h->dc_stream, hipStreamNonBlocking) == hipSuccess;
+  if (dc_gpu) {
+    for (int b = 0; b < vsm_handle::kDcBanks; b++)
+      if (!h->dc_bank[b]) h->dc_bank[b] = new DcBank();
+    if ((int)h->seq_work.size() < vsm_handle::kDcBanks * C) h->seq_work.resize((size_t)vsm_handle::kDcBanks * C);
+  }
+  std::vector<std::unique_ptr<DcChunk>> chunks;
+  struct Drain {  // whatever way this function is left, nothing of it may still be running
+    std::vector<std::unique_ptr<DcChunk>> &c;
+    ~Drain() {
+      for (auto &ch : c) dc_wait(ch.get());
+    }
+  } drain{chunks};
   const int32_t dims_c[3] = {w, hh, c.dims.bpl};
   int32_t nprev[2][2] = {{0, 0}, {0, 0}};  // feature counts [side][set] of the previous chunk's last frame
   double tg = 0, thost = 0;
@@ -847,7 +1078,12 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     }
     // the export below overwrites this pair bank's host lists: chunk k-2 must be done with them
     const double tw0 = now_us();
-    if (k >= 2) h->pool->wait(tickets[k - 2]);
+    if (dc_gpu) {
+      if (k >= 2 && k - 2 < (int)chunks.size()) h->pool->wait(chunks[k - 2]->a);  // it copied the lists out first thing
+      if (k >= vsm_handle::kDcBanks && k - vsm_handle::kDcBanks < (int)chunks.size()) dc_wait(chunks[k - vsm_handle::kDcBanks].get());
+    } else if (k >= 2) {
+      h->pool->wait(tickets[k - 2]);
+    }
     if (vsm_debug_timing() && now_us() - tw0 > 2000) fprintf(stderr, "  chunk %d: waited %.0f us for chunk %d's final stage\n", k, now_us() - tw0, k - 2);
     cfg.sparse = 0;
     cfg.use_prior = p.multi_stage ? 1 : 0;
@@ -862,28 +1098,47 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     h->prof.resolve();
     if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass2 launch %.0f us sync %.0f us\n", k, tl2 - ta, now_us() - tl2);
     tg += now_us() - ta;
-    // final host stage of this chunk: asynchronous, overlapped with the next chunk's GPU work
+    // final stage of this chunk: asynchronous, overlapped with the next chunk's GPU work
     VsmCtx *cp = &c;
-    const vsm_params pcopy = p;
-    tickets.push_back(h->pool->submit(n, [h, cp, pcopy, validp, f0, first_pair, method](int i) {
-      if (!(*validp)[i]) return;
-      static thread_local VsmHostWork tw;
-      const int pj = first_pair + i;
-      std::vector<vsm_p_match> &out = h->seq_matches[f0 + i];
-      const double q0 = vsm_debug_timing() ? now_us() : 0;
-      // one wide copy out of the host-mapped export, then cache-resident work
-      tw.tmp_list.assign(cp->hm_list2[pj], cp->hm_list2[pj] + cp->hm_lcount[2 * pj + 1]);
-      vsm_host_remove_outliers_from(tw, pcopy, tw.tmp_list.data(), (int32_t)tw.tmp_list.size(), method, out);
-      if (vsm_debug_timing()) {
-        static std::atomic<long> n_done{0}, us_all{0};
-        us_all += (long)(now_us() - q0);
-        if (++n_done % 199 == 0)
-          fprintf(stderr, "  final host stage, mean per pair: %.1f us\n", (double)us_all / n_done);
+    if (dc_gpu) {
+      // slab sizes from this chunk's longest possible list (every pair's list is at most max_nq[1] long)
+      const int pts = ((max_nq[1] + 63) / 64) * 64 + 64, tsk = 2 * pts / std::max(dc_leaf, 2) + 16;
+      if (!h->dc_bank[k % vsm_handle::kDcBanks]->reserve(C, pts, tsk)) {
+        fprintf(stderr, "visomatch: no memory for the GPU share of the Delaunay stage, staying on the host\n");
+        dc_gpu = false;
       }
-    }));
+    }
+    if (dc_gpu) {
+      chunks.emplace_back(new DcChunk());
+      DcChunk *ch = chunks.back().get();
+      ch->h = h;
+      ch->ctx = cp;
+      ch->p = p;
+      ch->method = method;
+      ch->leaf = dc_leaf;
+      ch->bank = k % vsm_handle::kDcBanks;
+      ch->n = n;
+      ch->f0 = f0;
+      ch->first_pair = first_pair;
+      ch->work0 = ch->bank * C;
+      ch->valid = validp;
+      dc_submit_a(ch);
+    } else {
+      const vsm_params pcopy = p;
+      tickets.push_back(h->pool->submit(n, [h, cp, pcopy, validp, f0, first_pair, method](int i) {
+        if (!(*validp)[i]) return;
+        static thread_local VsmHostWork tw;
+        const int pj = first_pair + i;
+        std::vector<vsm_p_match> &out = h->seq_matches[f0 + i];
+        // one wide copy out of the host-mapped export, then cache-resident work
+        tw.tmp_list.assign(cp->hm_list2[pj], cp->hm_list2[pj] + cp->hm_lcount[2 * pj + 1]);
+        vsm_host_remove_outliers_from(tw, pcopy, tw.tmp_list.data(), (int32_t)tw.tmp_list.size(), method, out);
+      }));
+    }
   }
   {
     const double tb = now_us();
+    for (auto &ch : chunks) dc_wait(ch.get());
     for (auto &t : tickets) h->pool->wait(t);
     thost += now_us() - tb;
   }
@@ -1076,6 +1331,61 @@ int32_t vsm_debug_delaunay_gpu(const int32_t *x, const int32_t *y, int32_t n, in
   for (int32_t i = 0; i < ntri && i < cap; i++)
     for (int k = 0; k < 3; k++) tris[i * 3 + k] = d.triangles()[i * 3 + k];
   return ntri;
+}
+
+// micro-benchmark of the GPU sub-tree kernel: `njobs` copies of one prepared triangulation per launch;
+// returns microseconds per launch (kernel only, HIP events), -1 on error
+double vsm_debug_dc_bench(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, int32_t njobs,
+                          int32_t reps) {
+  ExactDelaunay d;
+  if (!d.prepare(x, y, n, max_task_points)) return -1;
+  const int32_t m = d.points();
+  const DcMesh mesh = d.mesh();
+  const int nt = (int)d.tasks().size();
+  const size_t tri_bytes = (size_t)m * 2 * 8 * sizeof(int32_t);
+  std::vector<VsmDcJob> jobs(njobs);
+  VsmDcTask *d_tasks = nullptr;
+  VsmDcJob *d_jobs = nullptr;
+  if (hipMalloc((void **)&d_tasks, sizeof(VsmDcTask) * nt) != hipSuccess) return -1;
+  (void)hipMemcpy(d_tasks, d.tasks().data(), sizeof(VsmDcTask) * nt, hipMemcpyHostToDevice);
+  for (auto &job : jobs) {
+    if (hipMalloc((void **)&job.key, (size_t)m * 8) != hipSuccess || hipMalloc((void **)&job.pt, (size_t)m * 4) != hipSuccess ||
+        hipMalloc((void **)&job.id, (size_t)m * 4) != hipSuccess || hipMalloc((void **)&job.tri, tri_bytes) != hipSuccess ||
+        hipMalloc((void **)&job.hulls, sizeof(VsmDcHull) * nt) != hipSuccess)
+      return -1;
+    job.tasks = d_tasks;
+    job.ntasks = nt;
+    job.m = m;
+  }
+  if (hipMalloc((void **)&d_jobs, sizeof(VsmDcJob) * njobs) != hipSuccess) return -1;
+  (void)hipMemcpy(d_jobs, jobs.data(), sizeof(VsmDcJob) * njobs, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  double total = 0;
+  for (int r = 0; r < reps + 1; r++) {
+    for (auto &job : jobs) {
+      (void)hipMemcpyAsync(job.key, mesh.key, (size_t)m * 8, hipMemcpyHostToDevice, nullptr);
+      (void)hipMemsetAsync(job.tri, 0xff, tri_bytes, nullptr);
+    }
+    (void)hipEventRecord(e0, nullptr);
+    vsm_dc_launch_subtrees(nullptr, d_jobs, njobs, nt);
+    (void)hipEventRecord(e1, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (r > 0) total += ms * 1e3;
+  }
+  for (auto &job : jobs) {
+    (void)hipFree(job.key);
+    (void)hipFree(job.pt);
+    (void)hipFree(job.id);
+    (void)hipFree(job.tri);
+    (void)hipFree(job.hulls);
+  }
+  (void)hipFree(d_tasks);
+  (void)hipFree(d_jobs);
+  return total / reps;
 }
 
 void vsm_get_counters(vsm_handle *h, int64_t *out5) { memcpy(out5, h->counters, sizeof(h->counters)); }

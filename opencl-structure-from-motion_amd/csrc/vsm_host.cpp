@@ -533,12 +533,7 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
 // only the survivors are copied.  The per-match quantities the support test compares (flow and
 // disparity, :1290-1340) are gathered into compact arrays first, so the triangle loop touches
 // 12 bytes per vertex instead of a 48-byte record.
-void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,
-                                   std::vector<vsm_p_match> &out) {
-  if (n <= 3) {  // the reference leaves short lists alone (:1210)
-    out.assign(in, in + std::max(n, 0));
-    return;
-  }
+void vsm_host_outliers_begin(VsmHostWork &w, const vsm_p_match *in, int32_t n, int method) {
   w.x.resize(n);
   w.y.resize(n);
   w.fu.resize(n);
@@ -552,10 +547,11 @@ void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vs
     w.fv[i] = a.v1c - a.v1p;
     w.dp[i] = method == 1 ? a.u1c - a.u2c : a.u1p - a.u2p;
   }
-  static const bool dbg = getenv("VSM_DEBUG_TIMING") != nullptr;
-  const auto c0 = std::chrono::steady_clock::now();
-  w.del.run(w.x.data(), w.y.data(), n, w.pool);
-  const auto c1 = std::chrono::steady_clock::now();
+}
+
+// support of every match from the triangulation in w.del, survivors (support >= 4) to `out`
+void vsm_host_outliers_end(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,
+                           std::vector<vsm_p_match> &out) {
   w.support.assign(n, 0);
   const float ftol = (float)p.outlier_flow_tolerance, dtol = (float)p.outlier_disp_tolerance;
   const float *fu = w.fu.data(), *fv = w.fv.data(), *dp = w.dp.data();
@@ -582,6 +578,20 @@ void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vs
   out.reserve((size_t)n);
   for (int32_t i = 0; i < n; i++)
     if (support[i] >= 4) out.push_back(in[i]);
+}
+
+void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,
+                                   std::vector<vsm_p_match> &out) {
+  if (n <= 3) {  // the reference leaves short lists alone (:1210)
+    out.assign(in, in + std::max(n, 0));
+    return;
+  }
+  vsm_host_outliers_begin(w, in, n, method);
+  static const bool dbg = getenv("VSM_DEBUG_TIMING") != nullptr;
+  const auto c0 = std::chrono::steady_clock::now();
+  w.del.run(w.x.data(), w.y.data(), n, w.pool);
+  const auto c1 = std::chrono::steady_clock::now();
+  vsm_host_outliers_end(w, p, in, n, method, out);
   if (dbg && n > 3000) {
     static std::atomic<long> calls{0}, us_del{0}, us_rest{0};
     const auto c2 = std::chrono::steady_clock::now();

@@ -186,6 +186,11 @@ struct VsmHostWork {
 
 // Matcher::removeOutliers, viso/matcher.cpp:1207-1377 (in place; order preserved)
 void vsm_host_remove_outliers(VsmHostWork &w, const vsm_params &p, std::vector<vsm_p_match> &m, int method);
+// the two ends of it, for callers that run the triangulation (w.del) themselves: the per-match
+// arrays (coordinates, flow, disparity), then support counting + survivors
+void vsm_host_outliers_begin(VsmHostWork &w, const vsm_p_match *in, int32_t n, int method);
+void vsm_host_outliers_end(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,
+                           std::vector<vsm_p_match> &out);
 // the same from a read-only list (e.g. the host-mapped export of the GPU) into `out`
 void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,
                                    std::vector<vsm_p_match> &out);
