@@ -344,6 +344,7 @@ struct vsm_handle {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t idle_wait = nullptr;  // blocking-sync event: the look-ahead caller yields its CPU to the host pool
+  hipEvent_t seq_ev[2] = {nullptr, nullptr};  // look-ahead markers: features done / pass 1 done (blocking sync too)
   static constexpr int kDcBanks = 4;  // chunks whose final stage may be in flight at once
   struct DcBank *dc_bank[kDcBanks] = {nullptr, nullptr, nullptr, nullptr};  // look-ahead: GPU share of the exact Delaunay
   hipStream_t dc_stream = nullptr;
@@ -441,7 +442,9 @@ vsm_handle *vsm_create(const vsm_params *p) {
     if (hipDeviceGetLimit(&cur, hipLimitStackSize) == hipSuccess && cur < 4096) (void)hipDeviceSetLimit(hipLimitStackSize, 4096);
   }
   if (hipGetDevice(&h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&h->idle_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&h->idle_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->seq_ev[0], hipEventBlockingSync | hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->seq_ev[1], hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
     fprintf(stderr, "visomatch: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
     delete h->pool;
     delete h->fj;
@@ -471,6 +474,8 @@ void vsm_destroy(vsm_handle *h) {
     }
   if (h->dc_stream) (void)hipStreamDestroy(h->dc_stream);
   if (h->idle_wait) (void)hipEventDestroy(h->idle_wait);
+  for (hipEvent_t e : h->seq_ev)
+    if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h->pool;
   delete h->fj;
@@ -766,11 +771,26 @@ struct DcChunk {
   std::atomic<int> a_left{0};
   std::atomic<int> stage{0};  // 0: A running, 1: G enqueued, 2: B submitted
   VsmPool::Ticket a, b;
+  // VSM_DEBUG_TIMING: when the stages changed hands, and the task time summed over the pool
+  double t_a0 = 0, t_g0 = 0, t_g1 = 0, t_b0 = 0, t_b1 = 0;
+  std::atomic<long long> a_ns{0}, b_ns{0};
+  std::atomic<int> b_left{0};
 };
 
 static void dc_submit_b(DcChunk *ch) {
   vsm_handle *h = ch->h;
+  ch->t_b0 = vsm_now_us();
+  ch->b_left.store(ch->n, std::memory_order_relaxed);
   ch->b = h->pool->submit(ch->n, [ch](int i) {
+    const double t0 = vsm_now_us();
+    struct Done {
+      DcChunk *ch;
+      double t0;
+      ~Done() {
+        ch->b_ns.fetch_add((long long)((vsm_now_us() - t0) * 1e3), std::memory_order_relaxed);
+        if (ch->b_left.fetch_sub(1, std::memory_order_acq_rel) == 1) ch->t_b1 = vsm_now_us();
+      }
+    } done{ch, t0};
     if (!(*ch->valid)[i]) return;
     vsm_handle *h = ch->h;
     VsmHostWork &wk = h->seq_work[ch->work0 + i];
@@ -784,6 +804,8 @@ static void dc_submit_b(DcChunk *ch) {
     const int32_t m = B.m[i], nt = B.nt[i];
     if (m >= 2) {
       if (nt > 0) {  // adopt what the GPU built
+        // (copied, not used in place: the merges and the support test chase pointers through these arrays, and
+        // on the pinned slab - small pages, no prefetch-friendly order - that cost 25 % of the whole run)
         const DcMesh mesh = wk.del.mesh();
         memcpy(mesh.tri, B.h_tri + (size_t)i * B.stride_pts * 16, (size_t)m * 16 * sizeof(int32_t));
         memcpy(mesh.pt, B.h_pt + (size_t)i * B.stride_pts, (size_t)m * 4);
@@ -801,11 +823,15 @@ static void dc_submit_b(DcChunk *ch) {
   ch->stage.store(2, std::memory_order_release);
 }
 
-static void dc_after_gpu(void *arg) { dc_submit_b((DcChunk *)arg); }  // runs on a HIP runtime thread: no HIP calls
+static void dc_after_gpu(void *arg) {
+  ((DcChunk *)arg)->t_g1 = vsm_now_us();
+  dc_submit_b((DcChunk *)arg);
+}  // runs on a HIP runtime thread: no HIP calls
 
 static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished the chunk's last A task
   vsm_handle *h = ch->h;
   (void)hipSetDevice(h->device);
+  ch->t_g0 = vsm_now_us();
   DcBank &B = *h->dc_bank[ch->bank];
   int maxt = 0, maxm = 0;
   for (int i = 0; i < ch->n; i++) {
@@ -853,7 +879,9 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
 
 static void dc_submit_a(DcChunk *ch) {
   ch->a_left.store(ch->n, std::memory_order_relaxed);
+  ch->t_a0 = vsm_now_us();
   ch->a = ch->h->pool->submit(ch->n, [ch](int i) {
+    const double t0 = vsm_now_us();
     vsm_handle *h = ch->h;
     VsmHostWork &wk = h->seq_work[ch->work0 + i];
     DcBank &B = *h->dc_bank[ch->bank];
@@ -880,6 +908,7 @@ static void dc_submit_a(DcChunk *ch) {
         }
       }
     }
+    ch->a_ns.fetch_add((long long)((vsm_now_us() - t0) * 1e3), std::memory_order_relaxed);
     if (ch->a_left.fetch_sub(1, std::memory_order_acq_rel) == 1) dc_enqueue_gpu(ch);  // the last one hands over
   });
 }
@@ -945,12 +974,16 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   VsmCtx &c = h->seq;
   if (!c.ready || c.dims.w != w || c.dims.h != hh || h->seq_chunk != C) {
     (void)hipStreamSynchronize(h->stream);
-    int rc = ctx_create(c, p, w, hh, 2 * C, 2 * C, h->stream);  // two banks of frames and of pairs
+    int rc = ctx_create(c, p, w, hh, 3 * C, 2 * C, h->stream);  // three banks of frames, two of pairs
     if (rc != VSM_OK) return rc;
     h->seq_chunk = C;
   }
-  // Software pipeline over chunks: while the pool works on the final host stage of chunk k (it
-  // reads pair bank k&1 in host-mapped memory), the GPU already runs chunk k+1 on the other bank.
+  // Software pipeline over chunks.  GPU order: pass 1 of chunk k, features of chunk k+1, pass 2 of
+  // chunk k - so the GPU has the next chunk's features to compute while the pool does chunk k's
+  // prior statistics, and the caller's thread never waits for features.  Frames live in three banks
+  // (chunk k+1's features must not overwrite the last frame of chunk k-1, which chunk k's first pair
+  // reads); pairs in two (the final host stage of chunk k reads pair bank k&1 in host-mapped memory
+  // while the GPU runs chunk k+1 on the other).
   std::vector<VsmPool::Ticket> tickets;
   // final stage: see DcChunk above
   static const bool dc_env = !(getenv("VSM_DC_GPU") && atoi(getenv("VSM_DC_GPU")) == 0);
@@ -973,29 +1006,38 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   int32_t nprev[2][2] = {{0, 0}, {0, 0}};  // feature counts [side][set] of the previous chunk's last frame
   double tg = 0, thost = 0;
   const double tstart = now_us();
-  for (int32_t f0 = 0, k = 0; f0 < n_frames; f0 += C, k++) {
+  const int nchunks = (n_frames + C - 1) / C;
+  auto launch_features_of = [&](int k) -> hipError_t {  // ingest + all feature kernels of chunk k, then the marker
+    const int32_t f0 = k * C;
     const int n = std::min<int32_t>(C, n_frames - f0);
-    const int bank = k & 1, first_img = 2 * bank * C, first_pair = bank * C;
-    const VsmPair *d_pairs = c.d_pairs + first_pair;
-    double ta = now_us();
-    // ---- features of the chunk's frames: one launch per kernel ----
+    const int first_img = 2 * (k % 3) * C;
     if (on_device) {
       vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first_img, left + (size_t)f0 * frame_stride,
                         right + (size_t)f0 * frame_stride, (size_t)frame_stride, bpl, n, c.dims);
     } else {
       for (int i = 0; i < n; i++) {
-        HIPCHK(hipMemcpy2DAsync(c.h_imgs[first_img + 2 * i].img, c.dims.bpl, left + (size_t)(f0 + i) * frame_stride, bpl, w,
-                                hh, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpy2DAsync(c.h_imgs[first_img + 2 * i + 1].img, c.dims.bpl, right + (size_t)(f0 + i) * frame_stride, bpl,
-                                w, hh, hipMemcpyHostToDevice, h->stream));
+        hipError_t e = hipMemcpy2DAsync(c.h_imgs[first_img + 2 * i].img, c.dims.bpl, left + (size_t)(f0 + i) * frame_stride, bpl, w, hh,
+                                        hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess)
+          e = hipMemcpy2DAsync(c.h_imgs[first_img + 2 * i + 1].img, c.dims.bpl, right + (size_t)(f0 + i) * frame_stride, bpl, w, hh,
+                               hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) return e;
       }
     }
     vsm_launch_features(h->stream, h->prof, c.d_imgs, first_img, 2 * n, c.dims, c.f1, c.f2, c.f_stride, p.nms_tau,
                         p.multi_stage, p.half_resolution, p.match_binsize, c.h_imgs.data());
-    const double tl0 = now_us();
-    HIPCHK(sync_sleeping(h));
+    return hipEventRecord(h->seq_ev[0], h->stream);
+  };
+  HIPCHK(launch_features_of(0));
+  for (int32_t f0 = 0, k = 0; f0 < n_frames; f0 += C, k++) {
+    const int n = std::min<int32_t>(C, n_frames - f0);
+    const int bank = k & 1, first_img = 2 * (k % 3) * C, first_pair = bank * C;
+    const VsmPair *d_pairs = c.d_pairs + first_pair;
+    double ta = now_us();
+    const double tl0 = ta;
+    HIPCHK(hipEventSynchronize(h->seq_ev[0]));  // the chunk's feature counts are in host-mapped memory
     HIPCHK(hipGetLastError());
-    if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: launch %.0f us, feature sync %.0f us\n", k, tl0 - ta, now_us() - tl0);
+    if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: feature wait %.0f us\n", k, now_us() - tl0);
     // ---- one job per frame of the chunk ----
     int max_nq[2] = {0, 0};
     std::shared_ptr<std::vector<char>> validp = std::make_shared<std::vector<char>>(n, 0);
@@ -1020,8 +1062,8 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
           cnt[0][s] = c.hm_counts[img_p * 2 + s];
           cnt[1][s] = c.hm_counts[(img_p + 1) * 2 + s];
         }
-      } else {  // the previous frame is the last one of the other bank
-        img_p = 2 * (1 - bank) * C + 2 * (C - 1);
+      } else {  // the previous frame is the last one of the previous chunk's bank
+        img_p = 2 * ((k + 2) % 3) * C + 2 * (C - 1);
         for (int s = 0; s < 2; s++) {
           cnt[0][s] = f > 0 ? nprev[0][s] : 0;
           cnt[1][s] = f > 0 ? nprev[1][s] : 0;
@@ -1055,8 +1097,10 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       cfg.use_prior = 0;
       vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, cfg, max_nq[0]);
       vsm_launch_export(h->stream, h->prof, d_pairs, n, 0, max_nq[0]);
+      HIPCHK(hipEventRecord(h->seq_ev[1], h->stream));
+      if (k + 1 < nchunks) HIPCHK(launch_features_of(k + 1));  // the GPU's work while the pool has the prior statistics
       const double tl1 = now_us();
-      HIPCHK(sync_sleeping(h));
+      HIPCHK(hipEventSynchronize(h->seq_ev[1]));
       double tb = now_us();
       if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass1 sync %.0f us\n", k, tb - tl1);
       tg += tb - ta;
@@ -1093,9 +1137,15 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
                         max_nq[1]);
     vsm_launch_export(h->stream, h->prof, d_pairs, n, 1, max_nq[1]);
     const double tl2 = now_us();
-    HIPCHK(sync_sleeping(h));
+    if (!p.multi_stage && k + 1 < nchunks) {  // single pass: the next features go behind this chunk's matching
+      HIPCHK(hipEventRecord(h->seq_ev[1], h->stream));
+      HIPCHK(launch_features_of(k + 1));
+      HIPCHK(hipEventSynchronize(h->seq_ev[1]));
+    } else {
+      HIPCHK(sync_sleeping(h));
+    }
     HIPCHK(hipGetLastError());
-    h->prof.resolve();
+    if (p.multi_stage || k + 1 >= nchunks) h->prof.resolve();
     if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass2 launch %.0f us sync %.0f us\n", k, tl2 - ta, now_us() - tl2);
     tg += now_us() - ta;
     // final stage of this chunk: asynchronous, overlapped with the next chunk's GPU work
@@ -1139,6 +1189,11 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   {
     const double tb = now_us();
     for (auto &ch : chunks) dc_wait(ch.get());
+    if (vsm_debug_timing())
+      for (auto &ch : chunks)
+        fprintf(stderr, "  final stage of %d pairs: A %.0f..%.0f us (tasks %.0f us), G ..%.0f, B %.0f..%.0f (tasks %.0f us)\n", ch->n,
+                ch->t_a0 - tstart, ch->t_g0 - tstart, ch->a_ns.load() * 1e-3, ch->t_g1 - tstart, ch->t_b0 - tstart, ch->t_b1 - tstart,
+                ch->b_ns.load() * 1e-3);
     for (auto &t : tickets) h->pool->wait(t);
     thost += now_us() - tb;
   }
