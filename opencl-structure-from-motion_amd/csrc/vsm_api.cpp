@@ -289,9 +289,10 @@ struct DcBank {
   uint32_t *d_pt = nullptr, *h_pt = nullptr;
   int32_t *d_id = nullptr, *h_id = nullptr, *d_tri = nullptr, *h_tri = nullptr;
   VsmDcTask *d_tasks = nullptr, *h_tasks = nullptr;
-  VsmDcHull *d_hulls = nullptr, *h_hulls = nullptr;
+  VsmDcMerge *d_merges = nullptr, *h_merges = nullptr;  // stride_tasks per pair (a binary tree has fewer internal nodes than leaves)
+  VsmDcHull *d_hulls = nullptr, *h_hulls = nullptr;    // by node number: 2 * stride_tasks per pair
   VsmDcJob *d_jobs = nullptr, *h_jobs = nullptr;
-  std::vector<int32_t> m, nt;  // per pair: distinct points and tasks (nt < 0: the host solves the sub-trees)
+  std::vector<int32_t> m, nt, nn;  // per pair: distinct points, tasks (nt < 0: the host solves the sub-trees), tree nodes
   hipEvent_t done = nullptr;
   void release() {
     (void)hipFree(d_key);
@@ -299,6 +300,7 @@ struct DcBank {
     (void)hipFree(d_id);
     (void)hipFree(d_tri);
     (void)hipFree(d_tasks);
+    (void)hipFree(d_merges);
     (void)hipFree(d_hulls);
     (void)hipFree(d_jobs);
     (void)hipHostFree(h_key);
@@ -306,6 +308,7 @@ struct DcBank {
     (void)hipHostFree(h_id);
     (void)hipHostFree(h_tri);
     (void)hipHostFree(h_tasks);
+    (void)hipHostFree(h_merges);
     (void)hipHostFree(h_hulls);
     (void)hipHostFree(h_jobs);
     if (done) (void)hipEventDestroy(done);
@@ -321,18 +324,21 @@ struct DcBank {
     bool ok = hipMalloc((void **)&d_key, P * 8) == hipSuccess && hipMalloc((void **)&d_pt, P * 4) == hipSuccess &&
               hipMalloc((void **)&d_id, P * 4) == hipSuccess && hipMalloc((void **)&d_tri, P * 64) == hipSuccess &&
               hipMalloc((void **)&d_tasks, T * sizeof(VsmDcTask)) == hipSuccess &&
-              hipMalloc((void **)&d_hulls, T * sizeof(VsmDcHull)) == hipSuccess &&
+              hipMalloc((void **)&d_merges, T * sizeof(VsmDcMerge)) == hipSuccess &&
+              hipMalloc((void **)&d_hulls, 2 * T * sizeof(VsmDcHull)) == hipSuccess &&
               hipMalloc((void **)&d_jobs, pairs * sizeof(VsmDcJob)) == hipSuccess &&
               hipHostMalloc((void **)&h_key, P * 8, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_pt, P * 4, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_id, P * 4, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_tri, P * 64, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_tasks, T * sizeof(VsmDcTask), hipHostMallocDefault) == hipSuccess &&
-              hipHostMalloc((void **)&h_hulls, T * sizeof(VsmDcHull), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&h_merges, T * sizeof(VsmDcMerge), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&h_hulls, 2 * T * sizeof(VsmDcHull), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_jobs, pairs * sizeof(VsmDcJob), hipHostMallocDefault) == hipSuccess &&
               hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess;
     m.assign(pairs, 0);
     nt.assign(pairs, 0);
+    nn.assign(pairs, 0);
     if (!ok) release();
     return ok;
   }
@@ -347,7 +353,7 @@ struct vsm_handle {
   hipEvent_t seq_ev[2] = {nullptr, nullptr};  // look-ahead markers: features done / pass 1 done (blocking sync too)
   static constexpr int kDcBanks = 4;  // chunks whose final stage may be in flight at once
   struct DcBank *dc_bank[kDcBanks] = {nullptr, nullptr, nullptr, nullptr};  // look-ahead: GPU share of the exact Delaunay
-  hipStream_t dc_stream = nullptr;
+  hipStream_t dc_stream[2] = {nullptr, nullptr};  // alternate per chunk: one chunk's records travel while the next one's kernels run
   std::vector<VsmHostWork> seq_work;               // per pair of every Delaunay bank: state between the two host halves
   VsmCtx ring;  // streaming ring buffer: 2 frame slots, 1 pair
   VsmCtx seq;   // look-ahead sequences: 2 banks of C frame slots, C pairs
@@ -472,7 +478,8 @@ void vsm_destroy(vsm_handle *h) {
       h->dc_bank[b]->release();
       delete h->dc_bank[b];
     }
-  if (h->dc_stream) (void)hipStreamDestroy(h->dc_stream);
+  for (hipStream_t st : h->dc_stream)
+    if (st) (void)hipStreamDestroy(st);
   if (h->idle_wait) (void)hipEventDestroy(h->idle_wait);
   for (hipEvent_t e : h->seq_ev)
     if (e) (void)hipEventDestroy(e);
@@ -765,7 +772,7 @@ struct DcChunk {
   vsm_handle *h = nullptr;
   VsmCtx *ctx = nullptr;
   vsm_params p;
-  int method = 0, leaf = 32;
+  int method = 0, leaf = 16, top = 240;
   int bank = 0, n = 0, f0 = 0, first_pair = 0, work0 = 0;
   std::shared_ptr<std::vector<char>> valid;
   std::atomic<int> a_left{0};
@@ -773,7 +780,7 @@ struct DcChunk {
   VsmPool::Ticket a, b;
   // VSM_DEBUG_TIMING: when the stages changed hands, and the task time summed over the pool
   double t_a0 = 0, t_g0 = 0, t_g1 = 0, t_b0 = 0, t_b1 = 0;
-  std::atomic<long long> a_ns{0}, b_ns{0};
+  std::atomic<long long> a_ns{0}, b_ns{0}, part_ns[8] = {};  // A: copy, arrays, prepare, slab; B: records, merges, support
   std::atomic<int> b_left{0};
 };
 
@@ -810,15 +817,22 @@ static void dc_submit_b(DcChunk *ch) {
         memcpy(mesh.tri, B.h_tri + (size_t)i * B.stride_pts * 16, (size_t)m * 16 * sizeof(int32_t));
         memcpy(mesh.pt, B.h_pt + (size_t)i * B.stride_pts, (size_t)m * 4);
         memcpy(mesh.id, B.h_id + (size_t)i * B.stride_pts, (size_t)m * 4);
-        const VsmDcHull *hu = B.h_hulls + (size_t)i * B.stride_tasks;
-        for (int t = 0; t < nt; t++)
-          wk.del.set_task_hull(t, ExactDelaunay::OTri{hu[t].fl_t, hu[t].fl_o}, ExactDelaunay::OTri{hu[t].fr_t, hu[t].fr_o});
+        const VsmDcHull *hu = B.h_hulls + (size_t)i * 2 * B.stride_tasks;
+        auto take = [&](int32_t q) { wk.del.set_node_hull(q, ExactDelaunay::OTri{hu[q].fl_t, hu[q].fl_o}, ExactDelaunay::OTri{hu[q].fr_t, hu[q].fr_o}); };
+        for (const ExactDelaunay::Task &tk : wk.del.tasks()) take(tk.node);
+        for (const ExactDelaunay::Merge &mg : wk.del.device_merges()) take(mg.node);
       } else {
         wk.del.solve_tasks();
+        wk.del.solve_merges();
       }
+      const double t1 = vsm_now_us();
+      ch->part_ns[4].fetch_add((long long)((t1 - t0) * 1e3), std::memory_order_relaxed);
       wk.del.finish();
+      ch->part_ns[5].fetch_add((long long)((vsm_now_us() - t1) * 1e3), std::memory_order_relaxed);
     }
+    const double t2 = vsm_now_us();
     vsm_host_outliers_end(wk, ch->p, wk.tmp_list.data(), nl, ch->method, out);
+    ch->part_ns[6].fetch_add((long long)((vsm_now_us() - t2) * 1e3), std::memory_order_relaxed);
   });
   ch->stage.store(2, std::memory_order_release);
 }
@@ -833,37 +847,49 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
   (void)hipSetDevice(h->device);
   ch->t_g0 = vsm_now_us();
   DcBank &B = *h->dc_bank[ch->bank];
-  int maxt = 0, maxm = 0;
+  int maxt = 0, maxm = 0, maxn = 0, maxlev = 0, maxg = 0, lev_nodes[VSM_DC_MAX_LEVELS] = {0};
   for (int i = 0; i < ch->n; i++) {
-    VsmDcJob &jb = B.h_jobs[i];
+    VsmDcJob &jb = B.h_jobs[i];  // (the A task left the level table in it)
     jb.key = B.d_key + (size_t)i * B.stride_pts;
     jb.pt = B.d_pt + (size_t)i * B.stride_pts;
     jb.id = B.d_id + (size_t)i * B.stride_pts;
     jb.tri = B.d_tri + (size_t)i * B.stride_pts * 16;
     jb.tasks = B.d_tasks + (size_t)i * B.stride_tasks;
-    jb.hulls = B.d_hulls + (size_t)i * B.stride_tasks;
+    jb.merges = B.d_merges + (size_t)i * B.stride_tasks;
+    jb.hulls = B.d_hulls + (size_t)i * 2 * B.stride_tasks;
     jb.ntasks = std::max(B.nt[i], 0);
     jb.m = B.m[i];
     maxt = std::max(maxt, jb.ntasks);
-    if (B.nt[i] > 0) maxm = std::max(maxm, B.m[i]);
+    if (B.nt[i] > 0) {
+      maxm = std::max(maxm, B.m[i]);
+      maxn = std::max(maxn, B.nn[i]);
+      maxlev = std::max(maxlev, jb.nlevels);
+      maxg = std::max(maxg, jb.level_off[jb.nlevels]);
+      for (int l = 0; l < jb.nlevels; l++) lev_nodes[l] = std::max(lev_nodes[l], jb.level_off[l + 1] - jb.level_off[l]);
+    } else {
+      jb.nlevels = 0;
+    }
   }
   // only the used part of every pair's slab row travels: rows of maxm points / maxt tasks
   const size_t sp = (size_t)B.stride_pts, st = (size_t)B.stride_tasks, rows = (size_t)ch->n;
-  hipStream_t s2 = h->dc_stream;
+  hipStream_t s2 = h->dc_stream[ch->bank & 1];
   bool ok = true;
   if (maxt > 0) {
     ok = hipMemcpy2DAsync(B.d_key, sp * 8, B.h_key, sp * 8, (size_t)maxm * 8, rows, hipMemcpyHostToDevice, s2) == hipSuccess &&
          hipMemcpy2DAsync(B.d_tasks, st * sizeof(VsmDcTask), B.h_tasks, st * sizeof(VsmDcTask), (size_t)maxt * sizeof(VsmDcTask), rows,
                           hipMemcpyHostToDevice, s2) == hipSuccess &&
+         (maxg == 0 || hipMemcpy2DAsync(B.d_merges, st * sizeof(VsmDcMerge), B.h_merges, st * sizeof(VsmDcMerge),
+                                        (size_t)maxg * sizeof(VsmDcMerge), rows, hipMemcpyHostToDevice, s2) == hipSuccess) &&
          hipMemcpyAsync(B.d_jobs, B.h_jobs, ch->n * sizeof(VsmDcJob), hipMemcpyHostToDevice, s2) == hipSuccess &&
          hipMemset2DAsync(B.d_tri, sp * 64, 0xff, (size_t)maxm * 64, rows, s2) == hipSuccess;
     if (ok) {
       vsm_dc_launch_subtrees(s2, B.d_jobs, ch->n, maxt);
+      for (int l = 0; l < maxlev; l++) vsm_dc_launch_merge_level(s2, B.d_jobs, ch->n, l, lev_nodes[l]);
       ok = hipMemcpy2DAsync(B.h_tri, sp * 64, B.d_tri, sp * 64, (size_t)maxm * 64, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
            hipMemcpy2DAsync(B.h_pt, sp * 4, B.d_pt, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
            hipMemcpy2DAsync(B.h_id, sp * 4, B.d_id, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
-           hipMemcpy2DAsync(B.h_hulls, st * sizeof(VsmDcHull), B.d_hulls, st * sizeof(VsmDcHull), (size_t)maxt * sizeof(VsmDcHull), rows,
-                            hipMemcpyDeviceToHost, s2) == hipSuccess;
+           hipMemcpy2DAsync(B.h_hulls, 2 * st * sizeof(VsmDcHull), B.d_hulls, 2 * st * sizeof(VsmDcHull), (size_t)maxn * sizeof(VsmDcHull),
+                            rows, hipMemcpyDeviceToHost, s2) == hipSuccess;
     }
   }
   ch->stage.store(1, std::memory_order_release);
@@ -893,16 +919,31 @@ static void dc_submit_a(DcChunk *ch) {
       // one wide copy out of the host-mapped export, then cache-resident work
       wk.tmp_list.assign(ch->ctx->hm_list2[pj], ch->ctx->hm_list2[pj] + ch->ctx->hm_lcount[2 * pj + 1]);
       const int32_t nl = (int32_t)wk.tmp_list.size();
+      const double t1 = vsm_now_us();
+      ch->part_ns[0].fetch_add((long long)((t1 - t0) * 1e3), std::memory_order_relaxed);
       if (nl > 3) {
         vsm_host_outliers_begin(wk, wk.tmp_list.data(), nl, ch->method);
-        if (wk.del.prepare(wk.x.data(), wk.y.data(), nl, ch->leaf)) {
-          const int32_t m = wk.del.points(), nt = (int32_t)wk.del.tasks().size();
+        const double t2 = vsm_now_us();
+        ch->part_ns[1].fetch_add((long long)((t2 - t1) * 1e3), std::memory_order_relaxed);
+        const bool prepared = wk.del.prepare(wk.x.data(), wk.y.data(), nl, ch->leaf, nullptr, ch->top);
+        ch->part_ns[2].fetch_add((long long)((vsm_now_us() - t2) * 1e3), std::memory_order_relaxed);
+        if (prepared) {
+          const int32_t m = wk.del.points(), nt = (int32_t)wk.del.tasks().size(), ng = (int32_t)wk.del.device_merges().size();
+          const std::vector<int32_t> &lv = wk.del.device_levels();
           B.m[i] = m;
-          if (m > B.stride_pts || nt > B.stride_tasks) {
+          B.nn[i] = wk.del.num_nodes();
+          if (m < nl) ch->part_ns[7].fetch_add(1, std::memory_order_relaxed);  // pairs with duplicate points
+          if (m > B.stride_pts || nt > B.stride_tasks || ng > B.stride_tasks || B.nn[i] > 2 * B.stride_tasks ||
+              (int)lv.size() > VSM_DC_MAX_LEVELS) {
             B.nt[i] = -1;  // does not fit the slab: this pair stays on the host
           } else {
             memcpy(B.h_key + (size_t)i * B.stride_pts, wk.del.mesh().key, (size_t)m * 8);
             memcpy(B.h_tasks + (size_t)i * B.stride_tasks, wk.del.tasks().data(), (size_t)nt * sizeof(VsmDcTask));
+            memcpy(B.h_merges + (size_t)i * B.stride_tasks, wk.del.device_merges().data(), (size_t)ng * sizeof(VsmDcMerge));
+            VsmDcJob &jb = B.h_jobs[i];
+            jb.nlevels = (int32_t)lv.size();
+            jb.level_off[0] = 0;
+            for (int l = 0; l < jb.nlevels; l++) jb.level_off[l + 1] = jb.level_off[l] + lv[l];
             B.nt[i] = nt;
           }
         }
@@ -987,9 +1028,11 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   std::vector<VsmPool::Ticket> tickets;
   // final stage: see DcChunk above
   static const bool dc_env = !(getenv("VSM_DC_GPU") && atoi(getenv("VSM_DC_GPU")) == 0);
-  static const int dc_leaf = getenv("VSM_DC_LEAF") ? std::max(3, atoi(getenv("VSM_DC_LEAF"))) : 64;
+  static const int dc_leaf = getenv("VSM_DC_LEAF") ? std::max(3, atoi(getenv("VSM_DC_LEAF"))) : 16;
+  static const int dc_top = getenv("VSM_DC_TOP") ? atoi(getenv("VSM_DC_TOP")) : 240;  // merge nodes up to this size follow on the GPU
   bool dc_gpu = dc_env;
-  if (dc_gpu && !h->dc_stream) dc_gpu = hipStreamCreateWithFlags(&h->dc_stream, hipStreamNonBlocking) == hipSuccess;
+  for (hipStream_t &st : h->dc_stream)
+    if (dc_gpu && !st) dc_gpu = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
   if (dc_gpu) {
     for (int b = 0; b < vsm_handle::kDcBanks; b++)
       if (!h->dc_bank[b]) h->dc_bank[b] = new DcBank();
@@ -1005,6 +1048,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   const int32_t dims_c[3] = {w, hh, c.dims.bpl};
   int32_t nprev[2][2] = {{0, 0}, {0, 0}};  // feature counts [side][set] of the previous chunk's last frame
   double tg = 0, thost = 0;
+  std::atomic<long long> mid_ns[2] = {};  // VSM_DEBUG_TIMING: pass-1 outlier removal, prior statistics (task time)
   const double tstart = now_us();
   const int nchunks = (n_frames + C - 1) / C;
   auto launch_features_of = [&](int k) -> hipError_t {  // ingest + all feature kernels of chunk k, then the marker
@@ -1109,11 +1153,15 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
         static thread_local std::vector<float> rg;
         static thread_local std::vector<vsm_p_match> m1;
         const int pj = first_pair + i;
+        const double t0 = now_us();
         m1.clear();
         if (valid[i]) m1.assign(c.hm_list1[pj], c.hm_list1[pj] + c.hm_lcount[2 * pj]);
         vsm_host_remove_outliers(tw, p, m1, method);
+        const double t1 = now_us();
         vsm_host_prior_statistics(p, dims_c, m1, method, rg);
         ranges_to_device_layout(c.h_ranges + (size_t)pj * c.ranges_stride, rg.data(), rg.size());
+        mid_ns[0].fetch_add((long long)((t1 - t0) * 1e3), std::memory_order_relaxed);
+        mid_ns[1].fetch_add((long long)((now_us() - t1) * 1e3), std::memory_order_relaxed);
       });
       ta = now_us();
       thost += ta - tb;
@@ -1166,6 +1214,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       ch->p = p;
       ch->method = method;
       ch->leaf = dc_leaf;
+      ch->top = dc_top;
       ch->bank = k % vsm_handle::kDcBanks;
       ch->n = n;
       ch->f0 = f0;
@@ -1194,6 +1243,13 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
         fprintf(stderr, "  final stage of %d pairs: A %.0f..%.0f us (tasks %.0f us), G ..%.0f, B %.0f..%.0f (tasks %.0f us)\n", ch->n,
                 ch->t_a0 - tstart, ch->t_g0 - tstart, ch->a_ns.load() * 1e-3, ch->t_g1 - tstart, ch->t_b0 - tstart, ch->t_b1 - tstart,
                 ch->b_ns.load() * 1e-3);
+    if (vsm_debug_timing() && !chunks.empty()) {
+      double part[8] = {0};
+      for (auto &ch : chunks)
+        for (int q = 0; q < 8; q++) part[q] += ch->part_ns[q].load() * 1e-3 / n_frames;
+      fprintf(stderr, "  per pair, us: pass-1 outliers %.0f prior statistics %.0f | A copy %.0f arrays %.0f prepare %.0f | B records %.0f merges %.0f support+survivors %.0f; pairs with duplicate points: %.0f\n",
+              mid_ns[0].load() * 1e-3 / n_frames, mid_ns[1].load() * 1e-3 / n_frames, part[0], part[1], part[2], part[4], part[5], part[6], part[7] * n_frames * 1e3);
+    }
     for (auto &t : tickets) h->pool->wait(t);
     thost += now_us() - tb;
   }
@@ -1324,10 +1380,11 @@ int32_t vsm_host_delaunay(const int32_t *x, const int32_t *y, int32_t n, int32_t
 }
 
 int32_t vsm_host_delaunay_split(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
-                                int32_t max_task_points) {
+                                int32_t max_task_points, int32_t device_top_points) {
   ExactDelaunay d;
-  if (d.prepare(x, y, n, max_task_points)) {
+  if (d.prepare(x, y, n, max_task_points, nullptr, device_top_points)) {
     d.solve_tasks();
+    d.solve_merges();
     d.finish();
   }
   const int32_t nt = d.num_triangles();
@@ -1336,50 +1393,97 @@ int32_t vsm_host_delaunay_split(const int32_t *x, const int32_t *y, int32_t n, i
   return nt;
 }
 
-// test hook: prepare on the host, sub-trees on the GPU (vsm_dc.hip), merges above them on the host
-int32_t vsm_debug_delaunay_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
-                               int32_t max_task_points) {
-  ExactDelaunay d;
-  if (d.prepare(x, y, n, max_task_points)) {
-    const int32_t m = d.points();
-    const DcMesh mesh = d.mesh();
-    const std::vector<ExactDelaunay::Task> &tasks = d.tasks();
-    const int nt = (int)tasks.size();
-    VsmDcJob job;
-    VsmDcTask *d_tasks = nullptr;
-    VsmDcJob *d_job = nullptr;
-    std::vector<VsmDcHull> hulls(nt);
-    const size_t tri_bytes = (size_t)m * 2 * 8 * sizeof(int32_t);
-    bool ok = hipMalloc((void **)&job.key, (size_t)m * 8) == hipSuccess && hipMalloc((void **)&job.pt, (size_t)m * 4) == hipSuccess &&
-              hipMalloc((void **)&job.id, (size_t)m * 4) == hipSuccess && hipMalloc((void **)&job.tri, tri_bytes) == hipSuccess &&
-              hipMalloc((void **)&d_tasks, sizeof(VsmDcTask) * nt) == hipSuccess &&
-              hipMalloc((void **)&job.hulls, sizeof(VsmDcHull) * nt) == hipSuccess &&
-              hipMalloc((void **)&d_job, sizeof(VsmDcJob)) == hipSuccess;
-    if (!ok) return -1;
-    job.tasks = d_tasks;
-    job.ntasks = nt;
-    job.m = m;
+// One prepared triangulation on the device, `copies` times (test hook and micro-benchmark below)
+namespace {
+struct DcDeviceCopy {
+  std::vector<VsmDcJob> jobs;
+  VsmDcTask *d_tasks = nullptr;
+  VsmDcMerge *d_merges = nullptr;
+  VsmDcJob *d_jobs = nullptr;
+  int nt = 0, nn = 0, m = 0, nlev = 0, lev_nodes[VSM_DC_MAX_LEVELS] = {0};
+  size_t tri_bytes = 0;
+  bool create(ExactDelaunay &d, int copies) {
     static_assert(sizeof(VsmDcTask) == sizeof(ExactDelaunay::Task), "task layout");
-    (void)hipMemcpy(job.key, mesh.key, (size_t)m * 8, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_tasks, tasks.data(), sizeof(VsmDcTask) * nt, hipMemcpyHostToDevice);
-    (void)hipMemset(job.tri, 0xff, tri_bytes);
-    (void)hipMemcpy(d_job, &job, sizeof(job), hipMemcpyHostToDevice);
-    vsm_dc_launch_subtrees(nullptr, d_job, 1, nt);
-    ok = hipDeviceSynchronize() == hipSuccess;
-    (void)hipMemcpy(mesh.tri, job.tri, tri_bytes, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(mesh.pt, job.pt, (size_t)m * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(mesh.id, job.id, (size_t)m * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(hulls.data(), job.hulls, sizeof(VsmDcHull) * nt, hipMemcpyDeviceToHost);
-    (void)hipFree(job.key);
-    (void)hipFree(job.pt);
-    (void)hipFree(job.id);
-    (void)hipFree(job.tri);
+    static_assert(sizeof(VsmDcMerge) == sizeof(ExactDelaunay::Merge), "merge layout");
+    m = d.points();
+    nt = (int)d.tasks().size();
+    nn = d.num_nodes();
+    const int ng = (int)d.device_merges().size();
+    nlev = (int)d.device_levels().size();
+    if (nlev > VSM_DC_MAX_LEVELS) return false;
+    tri_bytes = (size_t)m * 2 * 8 * sizeof(int32_t);
+    jobs.assign(copies, VsmDcJob());
+    if (hipMalloc((void **)&d_tasks, sizeof(VsmDcTask) * nt) != hipSuccess ||
+        hipMalloc((void **)&d_merges, sizeof(VsmDcMerge) * std::max(ng, 1)) != hipSuccess ||
+        hipMalloc((void **)&d_jobs, sizeof(VsmDcJob) * copies) != hipSuccess)
+      return false;
+    (void)hipMemcpy(d_tasks, d.tasks().data(), sizeof(VsmDcTask) * nt, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_merges, d.device_merges().data(), sizeof(VsmDcMerge) * ng, hipMemcpyHostToDevice);
+    for (VsmDcJob &job : jobs) {
+      if (hipMalloc((void **)&job.key, (size_t)m * 8) != hipSuccess || hipMalloc((void **)&job.pt, (size_t)m * 4) != hipSuccess ||
+          hipMalloc((void **)&job.id, (size_t)m * 4) != hipSuccess || hipMalloc((void **)&job.tri, tri_bytes) != hipSuccess ||
+          hipMalloc((void **)&job.hulls, sizeof(VsmDcHull) * nn) != hipSuccess)
+        return false;
+      job.tasks = d_tasks;
+      job.merges = d_merges;
+      job.ntasks = nt;
+      job.m = m;
+      job.nlevels = nlev;
+      job.level_off[0] = 0;
+      for (int l = 0; l < nlev; l++) {
+        job.level_off[l + 1] = job.level_off[l] + d.device_levels()[l];
+        lev_nodes[l] = d.device_levels()[l];
+      }
+    }
+    return hipMemcpy(d_jobs, jobs.data(), sizeof(VsmDcJob) * copies, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  void load(const DcMesh &mesh, hipStream_t s) {
+    for (VsmDcJob &job : jobs) {
+      (void)hipMemcpyAsync(job.key, mesh.key, (size_t)m * 8, hipMemcpyHostToDevice, s);
+      (void)hipMemsetAsync(job.tri, 0xff, tri_bytes, s);
+    }
+  }
+  void launch(hipStream_t s) {
+    vsm_dc_launch_subtrees(s, d_jobs, (int)jobs.size(), nt);
+    for (int l = 0; l < nlev; l++) vsm_dc_launch_merge_level(s, d_jobs, (int)jobs.size(), l, lev_nodes[l]);
+  }
+  ~DcDeviceCopy() {
+    for (VsmDcJob &job : jobs) {
+      (void)hipFree(job.key);
+      (void)hipFree(job.pt);
+      (void)hipFree(job.id);
+      (void)hipFree(job.tri);
+      (void)hipFree(job.hulls);
+    }
     (void)hipFree(d_tasks);
-    (void)hipFree(job.hulls);
-    (void)hipFree(d_job);
-    if (!ok) return -1;
-    for (int t = 0; t < nt; t++)
-      d.set_task_hull(t, ExactDelaunay::OTri{hulls[t].fl_t, hulls[t].fl_o}, ExactDelaunay::OTri{hulls[t].fr_t, hulls[t].fr_o});
+    (void)hipFree(d_merges);
+    (void)hipFree(d_jobs);
+  }
+};
+}  // namespace
+
+// test hook: prepare on the host; sub-trees and the merge nodes of at most device_top_points points on
+// the GPU (vsm_dc.hip); the merges above them on the host
+int32_t vsm_debug_delaunay_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
+                               int32_t max_task_points, int32_t device_top_points) {
+  ExactDelaunay d;
+  if (d.prepare(x, y, n, max_task_points, nullptr, device_top_points)) {
+    const DcMesh mesh = d.mesh();
+    DcDeviceCopy dev;
+    if (!dev.create(d, 1)) return -1;
+    dev.load(mesh, nullptr);
+    dev.launch(nullptr);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    std::vector<VsmDcHull> hulls(dev.nn);
+    (void)hipMemcpy(mesh.tri, dev.jobs[0].tri, dev.tri_bytes, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(mesh.pt, dev.jobs[0].pt, (size_t)dev.m * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(mesh.id, dev.jobs[0].id, (size_t)dev.m * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hulls.data(), dev.jobs[0].hulls, sizeof(VsmDcHull) * dev.nn, hipMemcpyDeviceToHost);
+    auto take = [&](int32_t q) {
+      d.set_node_hull(q, ExactDelaunay::OTri{hulls[q].fl_t, hulls[q].fl_o}, ExactDelaunay::OTri{hulls[q].fr_t, hulls[q].fr_o});
+    };
+    for (const ExactDelaunay::Task &tk : d.tasks()) take(tk.node);
+    for (const ExactDelaunay::Merge &mg : d.device_merges()) take(mg.node);
     d.finish();
   }
   const int32_t ntri = d.num_triangles();
@@ -1388,58 +1492,32 @@ int32_t vsm_debug_delaunay_gpu(const int32_t *x, const int32_t *y, int32_t n, in
   return ntri;
 }
 
-// micro-benchmark of the GPU sub-tree kernel: `njobs` copies of one prepared triangulation per launch;
-// returns microseconds per launch (kernel only, HIP events), -1 on error
-double vsm_debug_dc_bench(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, int32_t njobs,
-                          int32_t reps) {
+// micro-benchmark of the GPU side of the Delaunay stage: `njobs` copies of one prepared triangulation per
+// launch sequence (sub-trees, then the merge levels up to device_top_points); returns microseconds per
+// sequence (kernels only, HIP events), -1 on error
+double vsm_debug_dc_bench(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, int32_t device_top_points,
+                          int32_t njobs, int32_t reps) {
   ExactDelaunay d;
-  if (!d.prepare(x, y, n, max_task_points)) return -1;
-  const int32_t m = d.points();
+  if (!d.prepare(x, y, n, max_task_points, nullptr, device_top_points)) return -1;
   const DcMesh mesh = d.mesh();
-  const int nt = (int)d.tasks().size();
-  const size_t tri_bytes = (size_t)m * 2 * 8 * sizeof(int32_t);
-  std::vector<VsmDcJob> jobs(njobs);
-  VsmDcTask *d_tasks = nullptr;
-  VsmDcJob *d_jobs = nullptr;
-  if (hipMalloc((void **)&d_tasks, sizeof(VsmDcTask) * nt) != hipSuccess) return -1;
-  (void)hipMemcpy(d_tasks, d.tasks().data(), sizeof(VsmDcTask) * nt, hipMemcpyHostToDevice);
-  for (auto &job : jobs) {
-    if (hipMalloc((void **)&job.key, (size_t)m * 8) != hipSuccess || hipMalloc((void **)&job.pt, (size_t)m * 4) != hipSuccess ||
-        hipMalloc((void **)&job.id, (size_t)m * 4) != hipSuccess || hipMalloc((void **)&job.tri, tri_bytes) != hipSuccess ||
-        hipMalloc((void **)&job.hulls, sizeof(VsmDcHull) * nt) != hipSuccess)
-      return -1;
-    job.tasks = d_tasks;
-    job.ntasks = nt;
-    job.m = m;
-  }
-  if (hipMalloc((void **)&d_jobs, sizeof(VsmDcJob) * njobs) != hipSuccess) return -1;
-  (void)hipMemcpy(d_jobs, jobs.data(), sizeof(VsmDcJob) * njobs, hipMemcpyHostToDevice);
+  DcDeviceCopy dev;
+  if (!dev.create(d, njobs)) return -1;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   double total = 0;
   for (int r = 0; r < reps + 1; r++) {
-    for (auto &job : jobs) {
-      (void)hipMemcpyAsync(job.key, mesh.key, (size_t)m * 8, hipMemcpyHostToDevice, nullptr);
-      (void)hipMemsetAsync(job.tri, 0xff, tri_bytes, nullptr);
-    }
+    dev.load(mesh, nullptr);
     (void)hipEventRecord(e0, nullptr);
-    vsm_dc_launch_subtrees(nullptr, d_jobs, njobs, nt);
+    dev.launch(nullptr);
     (void)hipEventRecord(e1, nullptr);
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     if (r > 0) total += ms * 1e3;
   }
-  for (auto &job : jobs) {
-    (void)hipFree(job.key);
-    (void)hipFree(job.pt);
-    (void)hipFree(job.id);
-    (void)hipFree(job.tri);
-    (void)hipFree(job.hulls);
-  }
-  (void)hipFree(d_tasks);
-  (void)hipFree(d_jobs);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return total / reps;
 }
 

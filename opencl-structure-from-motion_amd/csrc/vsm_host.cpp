@@ -7,6 +7,9 @@
 
 #include <algorithm>
 #include <chrono>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 // =======================================================================================
 // VsmPool
@@ -228,51 +231,107 @@ uint32_t ExactDelaunay::rnd(uint32_t choices) {  // randomnation, :4046
   return (uint32_t)(seed_ / (714025u / choices + 1));
 }
 
-// vertexsort (:5447) on packed (x,y) keys.  The Hoare partition is reproduced exactly, but for
-// large ranges its data-dependent scan loops (a coin-flip branch per element) are replaced by two
-// branch-free passes: the left scan can only stop at the positions L[0] < L[1] < ... holding keys
-// >= pivot, the right scan at R[0] > R[1] > ... holding keys <= pivot, and the reference swaps
-// exactly the pairs (L[t], R[t]) while L[t] < R[t] (the region between two swapped positions is
-// untouched, so later stoppers are the original ones).  After those swaps the scalar loop resumes
-// from (left, right) = (L[K-1], R[K-1]) and finishes the partition, so `left`/`right` and the
-// element order are bit-identical to the reference's.
+// vertexsort (:5447) on packed (x,y) keys.  The Hoare partition is reproduced exactly, but without
+// its data-dependent scan loops (a coin-flip branch per element).  Where the scans can stop is known
+// up front: the left scan at keys >= pivot, the right scan at keys <= pivot, and the keys strictly
+// between the two scan positions are always the original ones (swaps happen at the scan positions
+// only).  So one branch-free pass writes two bit masks (GE, LE; eight keys per instruction where the
+// CPU has AVX-512) and the partition becomes a loop over set bits:
+//   left scan from `left`:   first GE bit in (left, right), else it stops at `right` itself (the key
+//                            swapped in there is >= pivot; before the first swap the pivot is inside)
+//   right scan from `right`: last LE bit in (left', right), else it stops at left' if that key equals
+//                            the pivot, else at left' - 1 (the `left <= right` test of the reference)
+//   swap while left' < right'.
+// `left`, `right` and the element order after every step are those of the reference.
+namespace {
+inline void stop_masks_plain(const uint64_t *a, int32_t n, uint64_t ge_key, uint64_t lt_key, uint64_t *GE, uint64_t *LE) {
+  for (int32_t w = 0; w * 64 < n; w++) {
+    const int32_t cnt = std::min(64, n - w * 64);
+    uint64_t g = 0, l = 0;
+    for (int32_t i = 0; i < cnt; i++) {
+      const uint64_t k = a[w * 64 + i];
+      g |= (uint64_t)(k >= ge_key) << i;
+      l |= (uint64_t)(k < lt_key) << i;
+    }
+    GE[w] = g;
+    LE[w] = l;
+  }
+}
+#if defined(__x86_64__)
+__attribute__((target("avx512f"))) void stop_masks_avx512(const uint64_t *a, int32_t n, uint64_t ge_key, uint64_t lt_key, uint64_t *GE,
+                                                          uint64_t *LE) {
+  const __m512i vg = _mm512_set1_epi64((long long)ge_key), vl = _mm512_set1_epi64((long long)lt_key);
+  for (int32_t w = 0; w * 64 < n; w++) {
+    const int32_t cnt = std::min(64, n - w * 64);
+    uint64_t g = 0, l = 0;
+    for (int32_t i = 0; i < cnt; i += 8) {
+      const __mmask8 valid = cnt - i >= 8 ? (__mmask8)0xff : (__mmask8)((1u << (cnt - i)) - 1);
+      const __m512i v = _mm512_maskz_loadu_epi64(valid, (const void *)(a + w * 64 + i));
+      g |= (uint64_t)_mm512_mask_cmpge_epu64_mask(valid, v, vg) << i;
+      l |= (uint64_t)_mm512_mask_cmplt_epu64_mask(valid, v, vl) << i;
+    }
+    GE[w] = g;
+    LE[w] = l;
+  }
+}
+const bool kHaveAvx512 = __builtin_cpu_supports("avx512f") && !(getenv("VSM_NO_AVX512") && atoi(getenv("VSM_NO_AVX512")) != 0);
+#else
+void stop_masks_avx512(const uint64_t *, int32_t, uint64_t, uint64_t, uint64_t *, uint64_t *) {}
+const bool kHaveAvx512 = false;
+#endif
+
+// first set bit at a position >= from, or n
+inline int32_t next_bit(const uint64_t *m, int32_t from, int32_t n) {
+  if (from >= n) return n;
+  int32_t w = from >> 6;
+  uint64_t x = m[w] & (~0ull << (from & 63));
+  const int32_t nw = (n + 63) >> 6;
+  while (!x) {
+    if (++w >= nw) return n;
+    x = m[w];
+  }
+  return w * 64 + __builtin_ctzll(x);
+}
+// last set bit at a position <= from, or -1
+inline int32_t prev_bit(const uint64_t *m, int32_t from) {
+  if (from < 0) return -1;
+  int32_t w = from >> 6;
+  uint64_t x = m[w] & (~0ull >> (63 - (from & 63)));
+  while (!x) {
+    if (--w < 0) return -1;
+    x = m[w];
+  }
+  return w * 64 + 63 - __builtin_clzll(x);
+}
+}  // namespace
+
 void ExactDelaunay::vertex_sort(uint64_t *a, int32_t n) {
   if (n == 2) {
     if (KXY(a[0]) > KXY(a[1])) std::swap(a[0], a[1]);
     return;
   }
   const uint64_t pv = KXY(a[rnd((uint32_t)n)]);
+  // KXY(k) >= pv  <=>  k >= pv << 20;  KXY(k) <= pv  <=>  k < (pv + 1) << 20
+  const int32_t nw = (n + 63) >> 6;
+  uint64_t *GE = stop_.data(), *LE = stop_.data() + nw;  // dead before the recursive calls
+  if (kHaveAvx512)
+    stop_masks_avx512(a, n, pv << 20, (pv + 1) << 20, GE, LE);
+  else
+    stop_masks_plain(a, n, pv << 20, (pv + 1) << 20, GE, LE);
   int32_t left = -1, right = n;
-  if (n >= 8) {
-    uint32_t *L = stop_.data(), *R = stop_.data() + n;
-    int32_t nl = 0, nr = 0;
-    for (int32_t i = 0; i < n; i++) {
-      L[nl] = (uint32_t)i;
-      nl += KXY(a[i]) >= pv;
+  for (;;) {
+    const int32_t l = std::min(next_bit(GE, left + 1, n), right);
+    if (l == right) {  // ran into the key it swapped there itself: the right scan gives up at once
+      left = l;
+      right = l - 1;
+      break;
     }
-    for (int32_t j = n - 1; j >= 0; j--) {
-      R[nr] = (uint32_t)j;
-      nr += KXY(a[j]) <= pv;
-    }
-    const int32_t lim = nl < nr ? nl : nr;
-    int32_t k = 0;
-    while (k < lim && L[k] < R[k]) {
-      std::swap(a[L[k]], a[R[k]]);
-      k++;
-    }
-    if (k > 0) {
-      left = (int32_t)L[k - 1];
-      right = (int32_t)R[k - 1];
-    }
-  }
-  while (left < right) {
-    do {
-      left++;
-    } while (left <= right && KXY(a[left]) < pv);
-    do {
-      right--;
-    } while (left <= right && KXY(a[right]) > pv);
-    if (left < right) std::swap(a[left], a[right]);
+    int32_t r = prev_bit(LE, right - 1);
+    if (r <= l) r = ((LE[l >> 6] >> (l & 63)) & 1) ? l : l - 1;
+    left = l;
+    right = r;
+    if (l >= r) break;
+    std::swap(a[l], a[r]);
   }
   if (left > 1) vertex_sort(a, left);
   if (right < n - 2) vertex_sort(a + right + 1, n - right - 1);
@@ -388,15 +447,23 @@ void ExactDelaunay::kd_order(int32_t m, VsmForkJoin *pool) {
   key_.swap(k2_);
 }
 
-int32_t ExactDelaunay::build_tree(int32_t off, int32_t n, int axis, int32_t max_task_points) {
+// tree layout: the x-sorted array is cut in the middle, the halves alternate their cut axis.  Nodes small
+// enough become tasks; the internal nodes are listed by depth (left to right), those of at most
+// device_top_points points apart
+int32_t ExactDelaunay::build_tree(int32_t off, int32_t n, int axis, int32_t depth) {
   const int32_t me = (int32_t)nodes_.size();
   nodes_.push_back(Node{off, n, axis, 0, -1, -1, {0, 0}, {0, 0}});
-  if (n > max_task_points && n > 3) {
+  if (n > max_task_ && n > 3) {
+    std::vector<std::vector<int32_t>> &lists = n <= device_top_ ? dev_levels_ : levels_;
+    if ((int32_t)lists.size() <= depth) lists.resize(depth + 1);
+    lists[depth].push_back(me);
     const int32_t divider = n >> 1;
-    const int32_t l = build_tree(off, divider, 1 - axis, max_task_points);
-    const int32_t r = build_tree(off + divider, n - divider, 1 - axis, max_task_points);
+    const int32_t l = build_tree(off, divider, 1 - axis, depth + 1);
+    const int32_t r = build_tree(off + divider, n - divider, 1 - axis, depth + 1);
     nodes_[me].left = l;
     nodes_[me].right = r;
+  } else {
+    tasks_.push_back(Task{off, n, axis, me});
   }
   return me;
 }
@@ -410,17 +477,21 @@ void ExactDelaunay::list_triangles() {
     if (slot_vertices(t, &tri_out_[(size_t)ntri_out_ * 3])) ntri_out_++;
 }
 
-bool ExactDelaunay::prepare(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, VsmForkJoin *pool) {
+bool ExactDelaunay::prepare(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, VsmForkJoin *pool,
+                            int32_t device_top_points) {
   ntri_out_ = 0;
   m_ = 0;
   listed_ = true;
   tasks_.clear();
-  levels_.clear();
+  dmerges_.clear();
+  dlevels_.clear();
+  for (auto &lv : levels_) lv.clear();  // (the lists keep their memory)
+  for (auto &lv : dev_levels_) lv.clear();
   nodes_.clear();
   seed_ = 1;  // triangleinit(), :4031
   if (n < 2) return false;
   key_.resize(n);
-  stop_.resize((size_t)2 * n);
+  stop_.resize(2 * ((size_t)n / 64 + 2));
   for (int32_t i = 0; i < n; i++) key_[i] = ((uint64_t)(uint32_t)x[i] << 34) | ((uint64_t)(uint32_t)y[i] << 20) | (uint32_t)i;
   uint64_t *a = key_.data();
   auto clk = [] { return std::chrono::steady_clock::now(); };
@@ -446,25 +517,31 @@ bool ExactDelaunay::prepare(const int32_t *x, const int32_t *y, int32_t n, int32
   t_kd_ = ns(p1, clk());
   m_ = m;
   listed_ = false;
-  // tree layout: the x-sorted array is cut in the middle, the halves alternate their cut axis;
-  // nodes small enough become tasks, the rest is listed level by level for finish()
-  build_tree(0, m, 0, max_task_points < 2 ? 2 : max_task_points);
-  std::vector<int32_t> cur{0};
-  while (!cur.empty()) {
-    std::vector<int32_t> next, internal;
-    for (int32_t q : cur) {
-      if (nodes_[q].left < 0) {
-        tasks_.push_back(Task{nodes_[q].off, nodes_[q].n, nodes_[q].axis, q});
-      } else {
-        internal.push_back(q);
-        next.push_back(nodes_[q].left);
-        next.push_back(nodes_[q].right);
-      }
-    }
-    if (!internal.empty()) levels_.push_back(internal);
-    cur.swap(next);
+  max_task_ = max_task_points < 2 ? 2 : max_task_points;
+  device_top_ = device_top_points;
+  build_tree(0, m, 0, 0);
+  for (int d = (int)dev_levels_.size() - 1; d >= 0; d--) {
+    if (dev_levels_[d].empty()) continue;
+    dlevels_.push_back((int32_t)dev_levels_[d].size());
+    for (int32_t q : dev_levels_[d]) dmerges_.push_back(Merge{nodes_[q].off, nodes_[q].n, nodes_[q].axis, q, nodes_[q].left, nodes_[q].right});
   }
   return true;
+}
+
+// one internal node: what divconqrecurse does after its two recursive calls (viso/triangle.cpp, see DcMesh::recurse)
+void ExactDelaunay::merge_node(int32_t q) {
+  const DcMesh mesh = this->mesh();
+  Node &nd = nodes_[q];
+  Node &l = nodes_[nd.left], &r = nodes_[nd.right];
+  nd.fl = l.fl;
+  nd.fr = r.fr;
+  OTri il = l.fr, ir = r.fl;
+  int32_t tcur = 2 * (nd.off + (nd.n >> 1)) - 2;
+  mesh.merge_hulls(nd.fl, il, ir, nd.fr, nd.axis, tcur);
+}
+
+void ExactDelaunay::solve_merges() {
+  for (const Merge &mg : dmerges_) merge_node(mg.node);  // deepest level first
 }
 
 void ExactDelaunay::solve_tasks(VsmForkJoin *pool) {
@@ -481,16 +558,6 @@ void ExactDelaunay::solve_tasks(VsmForkJoin *pool) {
 }
 
 void ExactDelaunay::finish(VsmForkJoin *pool) {
-  const DcMesh mesh = this->mesh();
-  auto merge_node = [&](int32_t q) {
-    Node &nd = nodes_[q];
-    Node &l = nodes_[nd.left], &r = nodes_[nd.right];
-    nd.fl = l.fl;
-    nd.fr = r.fr;
-    OTri il = l.fr, ir = r.fl;
-    int32_t tcur = 2 * (nd.off + (nd.n >> 1)) - 2;
-    mesh.merge_hulls(nd.fl, il, ir, nd.fr, nd.axis, tcur);
-  };
   for (int li = (int)levels_.size() - 1; li >= 0; li--) {  // bottom-up
     const auto &lv = levels_[li];
     if (pool && pool->size() > 1 && lv.size() > 1) {

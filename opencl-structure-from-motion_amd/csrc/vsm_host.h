@@ -107,23 +107,37 @@ class ExactDelaunay {
   // points are (x[i], y[i]); after run(), triangles() lists vertex triples by input index
   void run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool = nullptr);
 
-  // The same in three steps, so that the independent sub-trees can be triangulated elsewhere (the
-  // look-ahead path hands them to the GPU, csrc/vsm_dc.hip):
+  // The same in steps, so that the lower part of the tree can be triangulated elsewhere (the
+  // look-ahead path hands it to the GPU, csrc/vsm_dc.hip):
   //   prepare()  emulated vertex sort, duplicate removal, kd order, tree layout; sub-trees of at
-  //              most max_task_points points become tasks.  false: fewer than 2 distinct points.
+  //              most max_task_points points become tasks, the merge nodes above them with at most
+  //              device_top_points points are listed apart (deepest level first).
+  //              false: fewer than 2 distinct points.
   //   tasks()    slices [off, off+n) with their cut axis; a solver runs DcMesh::recurse on each and
-  //              reports the two hull handles with set_task_hull() (solve_tasks() does it here)
-  //   finish()   the merges above the tasks, bottom-up.
+  //              reports the two hull handles with set_node_hull() (solve_tasks() does it here)
+  //   device_merges()  {slice, axis, node, children}: DcMesh::merge_hulls on the children's handles,
+  //              level by level (device_levels(): nodes per level), again reported with
+  //              set_node_hull() (solve_merges() does it here)
+  //   finish()   the remaining merges, bottom-up.
   struct Task {
     int32_t off, n, axis, node;
   };
-  bool prepare(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, VsmForkJoin *pool = nullptr);
+  struct Merge {
+    int32_t off, n, axis, node, left, right;
+  };
+  bool prepare(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, VsmForkJoin *pool = nullptr,
+               int32_t device_top_points = 0);
   const std::vector<Task> &tasks() const { return tasks_; }
+  const std::vector<Merge> &device_merges() const { return dmerges_; }
+  const std::vector<int32_t> &device_levels() const { return dlevels_; }
+  int32_t num_nodes() const { return (int32_t)nodes_.size(); }
   void solve_tasks(VsmForkJoin *pool = nullptr);
-  void set_task_hull(int32_t task, OTri farleft, OTri farright) {
-    nodes_[tasks_[task].node].fl = farleft;
-    nodes_[tasks_[task].node].fr = farright;
+  void solve_merges();
+  void set_node_hull(int32_t node, OTri farleft, OTri farright) {
+    nodes_[node].fl = farleft;
+    nodes_[node].fr = farright;
   }
+  void set_task_hull(int32_t task, OTri farleft, OTri farright) { set_node_hull(tasks_[task].node, farleft, farright); }
   void finish(VsmForkJoin *pool = nullptr);
   int32_t points() const { return m_; }  // distinct points = sorted positions
   DcMesh mesh() { return DcMesh{tri_.data(), pt_.data(), id_.data(), key_.data()}; }
@@ -155,7 +169,7 @@ class ExactDelaunay {
     OTri fl, fr;
   };
   std::vector<uint64_t> key_;         // (x << 34) | (y << 20) | input index
-  std::vector<uint32_t> stop_;        // scratch of the branch-free partition
+  std::vector<uint64_t> stop_;        // scratch of the branch-free partition: two bit masks
   std::vector<uint32_t> xl_, yl_, yr_, tmp_, ord_;  // kd_order(): presorted lists, y-ranks
   std::vector<uint64_t> ybuf0_, ybuf1_, k2_;
   std::vector<uint32_t> pt_;          // by sorted position: x | y << 16
@@ -163,7 +177,11 @@ class ExactDelaunay {
   std::vector<int32_t> tri_, tri_out_;
   std::vector<Node> nodes_;
   std::vector<Task> tasks_;
-  std::vector<std::vector<int32_t>> levels_;  // internal nodes above the tasks, root level first
+  std::vector<Merge> dmerges_;    // merge nodes left to the sub-tree solver's side, deepest level first
+  std::vector<int32_t> dlevels_;  // their number per level
+  std::vector<std::vector<int32_t>> levels_, dev_levels_;  // internal nodes by depth: the host's, the sub-tree solver's
+  int32_t max_task_ = 2, device_top_ = 0;
+  void merge_node(int32_t q);
   int32_t ntri_out_ = 0, m_ = 0;
   bool listed_ = true;
   void list_triangles();
@@ -173,7 +191,7 @@ class ExactDelaunay {
   uint32_t rnd(uint32_t choices);
   void vertex_sort(uint64_t *a, int32_t n);
   void kd_order(int32_t m, VsmForkJoin *pool);
-  int32_t build_tree(int32_t off, int32_t n, int axis, int32_t max_task_points);
+  int32_t build_tree(int32_t off, int32_t n, int axis, int32_t depth);
 };
 
 struct VsmHostWork {
