@@ -168,13 +168,15 @@ int32_t vsm_host_delaunay(const int32_t *x, const int32_t *y, int32_t n, int32_t
 int32_t vsm_host_delaunay_split(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
                                 int32_t max_task_points, int32_t device_top_points);
 
-/* test hook for the shared form: sub-trees (at most max_task_points points) on the GPU, one thread each, then
- * the merge nodes of at most device_top_points points level by level, the rest on the host; -1 on a HIP error */
+/* test hook for the shared form: (device_kd != 0: the kd order of the sorted keys,) sub-trees (at most
+ * max_task_points points) on the GPU, one thread each, then the merge nodes of at most device_top_points points
+ * level by level (device_top_points < 0: one wave per sub-tree inside LDS instead, any max_task_points), the rest
+ * on the host; -1 on a HIP error */
 int32_t vsm_debug_delaunay_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
-                               int32_t max_task_points, int32_t device_top_points);
+                               int32_t max_task_points, int32_t device_top_points, int32_t device_kd);
 
 double vsm_debug_dc_bench(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, int32_t device_top_points,
-                          int32_t njobs, int32_t reps);   /* kernel microseconds for njobs triangulations at once */
+                          int32_t device_kd, int32_t njobs, int32_t reps);   /* kernel microseconds for njobs triangulations at once */
 
 /* ---- stereo visual odometry on top of the matcher ----
  * class VisualOdometryStereo, viso/viso_stereo.h:28-88 + viso/viso.h:28-131: process() =

@@ -285,7 +285,8 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
 // slabs that carry the prepared keys and task lists to the GPU and the triangle records back.
 struct DcBank {
   int npairs = 0, stride_pts = 0, stride_tasks = 0;
-  uint64_t *d_key = nullptr, *h_key = nullptr;
+  uint64_t *d_key = nullptr, *h_key = nullptr, *d_key_sorted = nullptr;  // h_key: (x,y) order if the GPU orders them, else kd order
+  uint32_t *d_kd = nullptr;  // scratch of k_dc_kd_order
   uint32_t *d_pt = nullptr, *h_pt = nullptr;
   int32_t *d_id = nullptr, *h_id = nullptr, *d_tri = nullptr, *h_tri = nullptr;
   VsmDcTask *d_tasks = nullptr, *h_tasks = nullptr;
@@ -296,6 +297,8 @@ struct DcBank {
   hipEvent_t done = nullptr;
   void release() {
     (void)hipFree(d_key);
+    (void)hipFree(d_key_sorted);
+    (void)hipFree(d_kd);
     (void)hipFree(d_pt);
     (void)hipFree(d_id);
     (void)hipFree(d_tri);
@@ -321,7 +324,8 @@ struct DcBank {
     stride_pts = pts;
     stride_tasks = tasks;
     const size_t P = (size_t)pairs * pts, T = (size_t)pairs * tasks;
-    bool ok = hipMalloc((void **)&d_key, P * 8) == hipSuccess && hipMalloc((void **)&d_pt, P * 4) == hipSuccess &&
+    bool ok = hipMalloc((void **)&d_key, P * 8) == hipSuccess && hipMalloc((void **)&d_key_sorted, P * 8) == hipSuccess &&
+              hipMalloc((void **)&d_kd, P * 4 * VSM_DC_KD_SCRATCH) == hipSuccess && hipMalloc((void **)&d_pt, P * 4) == hipSuccess &&
               hipMalloc((void **)&d_id, P * 4) == hipSuccess && hipMalloc((void **)&d_tri, P * 64) == hipSuccess &&
               hipMalloc((void **)&d_tasks, T * sizeof(VsmDcTask)) == hipSuccess &&
               hipMalloc((void **)&d_merges, T * sizeof(VsmDcMerge)) == hipSuccess &&
@@ -773,6 +777,8 @@ struct DcChunk {
   VsmCtx *ctx = nullptr;
   vsm_params p;
   int method = 0, leaf = 16, top = 240;
+  bool device_kd = true;  // the GPU orders the keys (k_dc_kd_order); else ExactDelaunay::prepare does
+  bool block = true;      // sub-trees of <= VSM_DC_BLOCK_POINTS points, one wave each inside LDS (k_dc_block); else leaf / top
   int bank = 0, n = 0, f0 = 0, first_pair = 0, work0 = 0;
   std::shared_ptr<std::vector<char>> valid;
   std::atomic<int> a_left{0};
@@ -822,6 +828,7 @@ static void dc_submit_b(DcChunk *ch) {
         for (const ExactDelaunay::Task &tk : wk.del.tasks()) take(tk.node);
         for (const ExactDelaunay::Merge &mg : wk.del.device_merges()) take(mg.node);
       } else {
+        wk.del.order_keys();
         wk.del.solve_tasks();
         wk.del.solve_merges();
       }
@@ -851,6 +858,9 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
   for (int i = 0; i < ch->n; i++) {
     VsmDcJob &jb = B.h_jobs[i];  // (the A task left the level table in it)
     jb.key = B.d_key + (size_t)i * B.stride_pts;
+    jb.key_sorted = ch->device_kd && B.nt[i] > 0 ? B.d_key_sorted + (size_t)i * B.stride_pts : nullptr;
+    jb.kd_scratch = B.d_kd + (size_t)i * B.stride_pts * VSM_DC_KD_SCRATCH;
+    jb.kd_stride = B.stride_pts;
     jb.pt = B.d_pt + (size_t)i * B.stride_pts;
     jb.id = B.d_id + (size_t)i * B.stride_pts;
     jb.tri = B.d_tri + (size_t)i * B.stride_pts * 16;
@@ -875,7 +885,8 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
   hipStream_t s2 = h->dc_stream[ch->bank & 1];
   bool ok = true;
   if (maxt > 0) {
-    ok = hipMemcpy2DAsync(B.d_key, sp * 8, B.h_key, sp * 8, (size_t)maxm * 8, rows, hipMemcpyHostToDevice, s2) == hipSuccess &&
+    ok = hipMemcpy2DAsync(ch->device_kd ? B.d_key_sorted : B.d_key, sp * 8, B.h_key, sp * 8, (size_t)maxm * 8, rows, hipMemcpyHostToDevice,
+                          s2) == hipSuccess &&
          hipMemcpy2DAsync(B.d_tasks, st * sizeof(VsmDcTask), B.h_tasks, st * sizeof(VsmDcTask), (size_t)maxt * sizeof(VsmDcTask), rows,
                           hipMemcpyHostToDevice, s2) == hipSuccess &&
          (maxg == 0 || hipMemcpy2DAsync(B.d_merges, st * sizeof(VsmDcMerge), B.h_merges, st * sizeof(VsmDcMerge),
@@ -883,8 +894,13 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
          hipMemcpyAsync(B.d_jobs, B.h_jobs, ch->n * sizeof(VsmDcJob), hipMemcpyHostToDevice, s2) == hipSuccess &&
          hipMemset2DAsync(B.d_tri, sp * 64, 0xff, (size_t)maxm * 64, rows, s2) == hipSuccess;
     if (ok) {
-      vsm_dc_launch_subtrees(s2, B.d_jobs, ch->n, maxt);
-      for (int l = 0; l < maxlev; l++) vsm_dc_launch_merge_level(s2, B.d_jobs, ch->n, l, lev_nodes[l]);
+      if (ch->device_kd) vsm_dc_launch_kd_order(s2, B.d_jobs, ch->n);
+      if (ch->block) {
+        vsm_dc_launch_blocks(s2, B.d_jobs, ch->n, maxt);
+      } else {
+        vsm_dc_launch_subtrees(s2, B.d_jobs, ch->n, maxt);
+        for (int l = 0; l < maxlev; l++) vsm_dc_launch_merge_level(s2, B.d_jobs, ch->n, l, lev_nodes[l]);
+      }
       ok = hipMemcpy2DAsync(B.h_tri, sp * 64, B.d_tri, sp * 64, (size_t)maxm * 64, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
            hipMemcpy2DAsync(B.h_pt, sp * 4, B.d_pt, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
            hipMemcpy2DAsync(B.h_id, sp * 4, B.d_id, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
@@ -925,7 +941,8 @@ static void dc_submit_a(DcChunk *ch) {
         vsm_host_outliers_begin(wk, wk.tmp_list.data(), nl, ch->method);
         const double t2 = vsm_now_us();
         ch->part_ns[1].fetch_add((long long)((t2 - t1) * 1e3), std::memory_order_relaxed);
-        const bool prepared = wk.del.prepare(wk.x.data(), wk.y.data(), nl, ch->leaf, nullptr, ch->top);
+        const bool prepared = ch->block ? wk.del.prepare(wk.x.data(), wk.y.data(), nl, VSM_DC_BLOCK_POINTS, nullptr, 0, ch->device_kd)
+                                        : wk.del.prepare(wk.x.data(), wk.y.data(), nl, ch->leaf, nullptr, ch->top, ch->device_kd);
         ch->part_ns[2].fetch_add((long long)((vsm_now_us() - t2) * 1e3), std::memory_order_relaxed);
         if (prepared) {
           const int32_t m = wk.del.points(), nt = (int32_t)wk.del.tasks().size(), ng = (int32_t)wk.del.device_merges().size();
@@ -934,7 +951,7 @@ static void dc_submit_a(DcChunk *ch) {
           B.nn[i] = wk.del.num_nodes();
           if (m < nl) ch->part_ns[7].fetch_add(1, std::memory_order_relaxed);  // pairs with duplicate points
           if (m > B.stride_pts || nt > B.stride_tasks || ng > B.stride_tasks || B.nn[i] > 2 * B.stride_tasks ||
-              (int)lv.size() > VSM_DC_MAX_LEVELS) {
+              (int)lv.size() > VSM_DC_MAX_LEVELS || (ch->device_kd && m > VSM_DC_KD_MAX_POINTS)) {
             B.nt[i] = -1;  // does not fit the slab: this pair stays on the host
           } else {
             memcpy(B.h_key + (size_t)i * B.stride_pts, wk.del.mesh().key, (size_t)m * 8);
@@ -1029,6 +1046,8 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   // final stage: see DcChunk above
   static const bool dc_env = !(getenv("VSM_DC_GPU") && atoi(getenv("VSM_DC_GPU")) == 0);
   static const int dc_leaf = getenv("VSM_DC_LEAF") ? std::max(3, atoi(getenv("VSM_DC_LEAF"))) : 16;
+  static const bool dc_kd = !(getenv("VSM_DC_KD") && atoi(getenv("VSM_DC_KD")) == 0);  // kd order of the keys on the GPU too
+  static const bool dc_block = !(getenv("VSM_DC_BLOCK") && atoi(getenv("VSM_DC_BLOCK")) == 0);  // k_dc_block instead of leaf / top
   static const int dc_top = getenv("VSM_DC_TOP") ? atoi(getenv("VSM_DC_TOP")) : 240;  // merge nodes up to this size follow on the GPU
   bool dc_gpu = dc_env;
   for (hipStream_t &st : h->dc_stream)
@@ -1215,6 +1234,8 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       ch->method = method;
       ch->leaf = dc_leaf;
       ch->top = dc_top;
+      ch->device_kd = dc_kd;
+      ch->block = dc_block;
       ch->bank = k % vsm_handle::kDcBanks;
       ch->n = n;
       ch->f0 = f0;
@@ -1402,6 +1423,8 @@ struct DcDeviceCopy {
   VsmDcJob *d_jobs = nullptr;
   int nt = 0, nn = 0, m = 0, nlev = 0, lev_nodes[VSM_DC_MAX_LEVELS] = {0};
   size_t tri_bytes = 0;
+  bool device_kd = false;  // the keys arrive in (x,y) order and k_dc_kd_order runs first
+  bool block = false;      // k_dc_block instead of k_dc_subtrees + k_dc_merge_level
   bool create(ExactDelaunay &d, int copies) {
     static_assert(sizeof(VsmDcTask) == sizeof(ExactDelaunay::Task), "task layout");
     static_assert(sizeof(VsmDcMerge) == sizeof(ExactDelaunay::Merge), "merge layout");
@@ -1424,6 +1447,10 @@ struct DcDeviceCopy {
           hipMalloc((void **)&job.id, (size_t)m * 4) != hipSuccess || hipMalloc((void **)&job.tri, tri_bytes) != hipSuccess ||
           hipMalloc((void **)&job.hulls, sizeof(VsmDcHull) * nn) != hipSuccess)
         return false;
+      if (device_kd && (hipMalloc((void **)&job.key_sorted, (size_t)m * 8) != hipSuccess ||
+                        hipMalloc((void **)&job.kd_scratch, (size_t)m * 4 * VSM_DC_KD_SCRATCH) != hipSuccess))
+        return false;
+      job.kd_stride = m;
       job.tasks = d_tasks;
       job.merges = d_merges;
       job.ntasks = nt;
@@ -1439,11 +1466,16 @@ struct DcDeviceCopy {
   }
   void load(const DcMesh &mesh, hipStream_t s) {
     for (VsmDcJob &job : jobs) {
-      (void)hipMemcpyAsync(job.key, mesh.key, (size_t)m * 8, hipMemcpyHostToDevice, s);
+      (void)hipMemcpyAsync(device_kd ? (void *)job.key_sorted : (void *)job.key, mesh.key, (size_t)m * 8, hipMemcpyHostToDevice, s);
       (void)hipMemsetAsync(job.tri, 0xff, tri_bytes, s);
     }
   }
   void launch(hipStream_t s) {
+    if (device_kd) vsm_dc_launch_kd_order(s, d_jobs, (int)jobs.size());
+    if (block) {
+      vsm_dc_launch_blocks(s, d_jobs, (int)jobs.size(), nt);
+      return;
+    }
     vsm_dc_launch_subtrees(s, d_jobs, (int)jobs.size(), nt);
     for (int l = 0; l < nlev; l++) vsm_dc_launch_merge_level(s, d_jobs, (int)jobs.size(), l, lev_nodes[l]);
   }
@@ -1454,6 +1486,8 @@ struct DcDeviceCopy {
       (void)hipFree(job.id);
       (void)hipFree(job.tri);
       (void)hipFree(job.hulls);
+      (void)hipFree((void *)job.key_sorted);
+      (void)hipFree(job.kd_scratch);
     }
     (void)hipFree(d_tasks);
     (void)hipFree(d_merges);
@@ -1465,11 +1499,14 @@ struct DcDeviceCopy {
 // test hook: prepare on the host; sub-trees and the merge nodes of at most device_top_points points on
 // the GPU (vsm_dc.hip); the merges above them on the host
 int32_t vsm_debug_delaunay_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
-                               int32_t max_task_points, int32_t device_top_points) {
+                               int32_t max_task_points, int32_t device_top_points, int32_t device_kd) {
   ExactDelaunay d;
-  if (d.prepare(x, y, n, max_task_points, nullptr, device_top_points)) {
+  if (d.prepare(x, y, n, max_task_points, nullptr, std::max(device_top_points, 0), device_kd != 0)) {
+    if (d.points() > VSM_DC_KD_MAX_POINTS) return -1;
     const DcMesh mesh = d.mesh();
     DcDeviceCopy dev;
+    dev.device_kd = device_kd != 0;
+    dev.block = device_top_points < 0;
     if (!dev.create(d, 1)) return -1;
     dev.load(mesh, nullptr);
     dev.launch(nullptr);
@@ -1496,11 +1533,13 @@ int32_t vsm_debug_delaunay_gpu(const int32_t *x, const int32_t *y, int32_t n, in
 // launch sequence (sub-trees, then the merge levels up to device_top_points); returns microseconds per
 // sequence (kernels only, HIP events), -1 on error
 double vsm_debug_dc_bench(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, int32_t device_top_points,
-                          int32_t njobs, int32_t reps) {
+                          int32_t device_kd, int32_t njobs, int32_t reps) {
   ExactDelaunay d;
-  if (!d.prepare(x, y, n, max_task_points, nullptr, device_top_points)) return -1;
+  if (!d.prepare(x, y, n, max_task_points, nullptr, std::max(device_top_points, 0), device_kd != 0)) return -1;
   const DcMesh mesh = d.mesh();
   DcDeviceCopy dev;
+  dev.device_kd = device_kd != 0;
+  dev.block = device_top_points < 0;
   if (!dev.create(d, njobs)) return -1;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);

@@ -15,7 +15,12 @@ struct VsmDcHull {  // the two hull handles a node hands to the merge above it
   int32_t fl_t, fl_o, fr_t, fr_o;
 };
 #define VSM_DC_MAX_LEVELS 6
+#define VSM_DC_KD_MAX_POINTS 16384  // k_dc_kd_order keeps 16-bit counters in LDS
+#define VSM_DC_KD_SCRATCH 7        // uint32 arrays of m entries it needs per job
 struct VsmDcJob {  // one triangulation; all pointers are device pointers
+  const uint64_t *key_sorted;  // [m] distinct packed keys in (x,y) order, or null: `key` arrives in kd order
+  uint32_t *kd_scratch;        // [VSM_DC_KD_SCRATCH][kd_stride]
+  int32_t kd_stride, pad_;
   uint64_t *key;   // [m]  packed keys in kd order (leaves reorder their 2-3 keys by x)
   uint32_t *pt;    // [m]  out: x | y << 16 by sorted position
   int32_t *id;     // [m]  out: input index by sorted position
@@ -27,7 +32,13 @@ struct VsmDcJob {  // one triangulation; all pointers are device pointers
   int32_t nlevels, level_off[VSM_DC_MAX_LEVELS + 1];  // merges[level_off[l] .. level_off[l+1]) is level l
 };
 
+// kd order of the jobs that bring key_sorted: one workgroup per job (ExactDelaunay::kd_order on the device)
+void vsm_dc_launch_kd_order(hipStream_t s, const VsmDcJob *d_jobs, int njobs);
 // one thread per sub-tree, blockIdx.y = job; max_tasks >= every job's ntasks
 void vsm_dc_launch_subtrees(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int max_tasks);
+// one wave per sub-tree of at most VSM_DC_BLOCK_POINTS points, triangulated inside LDS (leaves of <= 14 points
+// one per lane, then the merge levels); blockIdx.y = job; max_tasks >= every job's ntasks
+#define VSM_DC_BLOCK_POINTS 480
+void vsm_dc_launch_blocks(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int max_tasks);
 // one thread per merge node of level `level`; max_nodes >= every job's node count on that level
 void vsm_dc_launch_merge_level(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int level, int max_nodes);

@@ -478,7 +478,7 @@ void ExactDelaunay::list_triangles() {
 }
 
 bool ExactDelaunay::prepare(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, VsmForkJoin *pool,
-                            int32_t device_top_points) {
+                            int32_t device_top_points, bool defer_order) {
   ntri_out_ = 0;
   m_ = 0;
   listed_ = true;
@@ -512,7 +512,8 @@ bool ExactDelaunay::prepare(const int32_t *x, const int32_t *y, int32_t n, int32
   for (int t = 2 * m - 2; t < 2 * m; t++)  // the two unused slots
     for (int k = 0; k < 3; k++) tri_[(size_t)t * 8 + 4 + k] = -1;
   key_.resize(m);
-  kd_order(m, pool);
+  ordered_ = !defer_order;
+  if (!defer_order) kd_order(m, pool);
   t_sort_ = ns(p0, p1);
   t_kd_ = ns(p1, clk());
   m_ = m;

@@ -125,8 +125,14 @@ class ExactDelaunay {
   struct Merge {
     int32_t off, n, axis, node, left, right;
   };
+  //   (defer_order: prepare() stops before the kd order - mesh().key stays in (x,y) order - for a
+  //   solver that orders the keys itself; order_keys() does it here later if it turns out to be needed)
   bool prepare(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, VsmForkJoin *pool = nullptr,
-               int32_t device_top_points = 0);
+               int32_t device_top_points = 0, bool defer_order = false);
+  void order_keys(VsmForkJoin *pool = nullptr) {
+    if (!ordered_) kd_order(m_, pool);
+    ordered_ = true;
+  }
   const std::vector<Task> &tasks() const { return tasks_; }
   const std::vector<Merge> &device_merges() const { return dmerges_; }
   const std::vector<int32_t> &device_levels() const { return dlevels_; }
@@ -183,7 +189,7 @@ class ExactDelaunay {
   int32_t max_task_ = 2, device_top_ = 0;
   void merge_node(int32_t q);
   int32_t ntri_out_ = 0, m_ = 0;
-  bool listed_ = true;
+  bool listed_ = true, ordered_ = true;
   void list_triangles();
   uint64_t seed_ = 1;
   long t_sort_ = 0, t_kd_ = 0;  // ns, VSM_DEBUG_TIMING

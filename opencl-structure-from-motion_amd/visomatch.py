@@ -115,8 +115,8 @@ def lib():
         L.vsm_get_kernel_stats.argtypes = [vp, vp, vp]
         L.vsm_host_delaunay.argtypes = [vp, vp, i32, vp, i32, i32]
         L.vsm_host_delaunay_split.argtypes = [vp, vp, i32, vp, i32, i32, i32]
-        L.vsm_debug_delaunay_gpu.argtypes = [vp, vp, i32, vp, i32, i32, i32]
-        L.vsm_debug_dc_bench.argtypes = [vp, vp, i32, i32, i32, i32, i32]
+        L.vsm_debug_delaunay_gpu.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32]
+        L.vsm_debug_dc_bench.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32]
         L.vsm_debug_dc_bench.restype = C.c_double
         L.vsm_sequence_run.argtypes = [vp, vp, vp, C.c_int64, C.c_int, i32, i32, i32, i32, i32, vp, vp]
         L.vsm_sequence_num_matches.argtypes = [vp, i32]
@@ -261,16 +261,16 @@ def host_delaunay_split(pts, max_task_points, device_top_points=0):
     return tris[:k]
 
 
-def delaunay_gpu_split(pts, max_task_points, device_top_points=0):
+def delaunay_gpu_split(pts, max_task_points, device_top_points=0, device_kd=False):
     """test hook: sub-trees of the exact Delaunay and the merge nodes of at most device_top_points points on
-    the GPU, preparation and the remaining merges on the host"""
+    the GPU (device_kd: the kd order of the keys too), preparation and the remaining merges on the host"""
     pts = np.asarray(pts).reshape(-1, 2)
     x = np.ascontiguousarray(pts[:, 0], dtype=np.int32)
     y = np.ascontiguousarray(pts[:, 1], dtype=np.int32)
     cap = 2 * len(x) + 16
     tris = np.zeros((cap, 3), dtype=np.int32)
     k = lib().vsm_debug_delaunay_gpu(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), len(x),
-                                     tris.ctypes.data_as(C.c_void_p), cap, max_task_points, device_top_points)
+                                     tris.ctypes.data_as(C.c_void_p), cap, max_task_points, device_top_points, int(device_kd))
     if k < 0:
         raise VisoMatchError("vsm_debug_delaunay_gpu: HIP error")
     return tris[:k]

@@ -503,5 +503,7 @@ def test_delaunay_subtrees_on_gpu(vm):
     cases += [g, np.concatenate([g, g[::3]]), np.stack([np.arange(0, 300, 2), np.full(150, 8)], 1)]
     for p in cases:
         whole = canon(vm.host_delaunay(p, 1))
-        for leaf, top in ((3, 0), (14, 0), (56, 0), (500, 0), (3, 12), (14, 120), (16, 240), (56, 480), (30, 900)):
-            assert np.array_equal(whole, canon(vm.delaunay_gpu_split(p, leaf, top))), (len(p), leaf, top)
+        for leaf, top in ((3, 0), (14, 0), (56, 0), (500, 0), (3, 12), (14, 120), (16, 240), (56, 480), (30, 900),
+                          (480, -1), (100, -1), (14, -1), (5000, -1)):
+            for kd in (False, True):
+                assert np.array_equal(whole, canon(vm.delaunay_gpu_split(p, leaf, top, kd))), (len(p), leaf, top, kd)
