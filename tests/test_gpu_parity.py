@@ -207,9 +207,12 @@ def test_sequence_api_equals_frame_by_frame(vm, B, synth, monkeypatch, method, c
     g.close()
 
 
-def test_sequence_api_golden_feedback_and_device_inputs(vm, synth):
-    """config 2 through the look-ahead API: 60 frames resident in HBM, replayed Tr_delta"""
+@pytest.mark.parametrize("chunk", ["50", "16", "17"])
+def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, chunk):
+    """config 2 through the look-ahead API: 60 frames resident in HBM, replayed Tr_delta; chunk 16 / 17 make
+    it a sequence of four chunks (three frame banks, two pair banks and the slab banks all come round)"""
     import torch
+    monkeypatch.setenv("VSM_SEQ_CHUNK", chunk)
     g = G.load("cfg2_seq200_tr")
     w, h, nf = int(g["w"]), int(g["h"]), 60
     cv = synth.canvas(int(g["seed"]), w, h)
