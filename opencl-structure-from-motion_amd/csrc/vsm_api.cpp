@@ -1044,11 +1044,11 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   // while the GPU runs chunk k+1 on the other).
   std::vector<VsmPool::Ticket> tickets;
   // final stage: see DcChunk above
-  static const bool dc_env = !(getenv("VSM_DC_GPU") && atoi(getenv("VSM_DC_GPU")) == 0);
-  static const int dc_leaf = getenv("VSM_DC_LEAF") ? std::max(3, atoi(getenv("VSM_DC_LEAF"))) : 16;
-  static const bool dc_kd = !(getenv("VSM_DC_KD") && atoi(getenv("VSM_DC_KD")) == 0);  // kd order of the keys on the GPU too
-  static const bool dc_block = !(getenv("VSM_DC_BLOCK") && atoi(getenv("VSM_DC_BLOCK")) == 0);  // k_dc_block instead of leaf / top
-  static const int dc_top = getenv("VSM_DC_TOP") ? atoi(getenv("VSM_DC_TOP")) : 240;  // merge nodes up to this size follow on the GPU
+  const bool dc_env = !(getenv("VSM_DC_GPU") && atoi(getenv("VSM_DC_GPU")) == 0);
+  const int dc_leaf = getenv("VSM_DC_LEAF") ? std::max(3, atoi(getenv("VSM_DC_LEAF"))) : 16;
+  const bool dc_kd = !(getenv("VSM_DC_KD") && atoi(getenv("VSM_DC_KD")) == 0);  // kd order of the keys on the GPU too
+  const bool dc_block = !(getenv("VSM_DC_BLOCK") && atoi(getenv("VSM_DC_BLOCK")) == 0);  // k_dc_block instead of leaf / top
+  const int dc_top = getenv("VSM_DC_TOP") ? atoi(getenv("VSM_DC_TOP")) : 240;  // merge nodes up to this size follow on the GPU
   bool dc_gpu = dc_env;
   for (hipStream_t &st : h->dc_stream)
     if (dc_gpu && !st) dc_gpu = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;

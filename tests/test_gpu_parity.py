@@ -227,6 +227,31 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
     m.close()
 
 
+@pytest.mark.parametrize("env", [{"VSM_DC_GPU": "0"}, {"VSM_DC_BLOCK": "0"}, {"VSM_DC_BLOCK": "0", "VSM_DC_KD": "0"},
+                                 {"VSM_DC_KD": "0"}, {"VSM_DC_BLOCK": "0", "VSM_DC_LEAF": "64", "VSM_DC_TOP": "0"},
+                                 {"VSM_DC_BLOCK": "0", "VSM_DC_LEAF": "5", "VSM_DC_TOP": "100000"}])
+def test_sequence_api_final_stage_variants(vm, synth, monkeypatch, env):
+    """the ways the exact Delaunay of the look-ahead final stage can be shared between host and GPU (host only;
+    sub-trees per thread + merge levels; kd order on either side; the last one overflows the level table and
+    falls back to the host pair by pair) all give the reference's lists"""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = G.load("cfg2_seq200_tr")
+    w, h, nf = int(g["w"]), int(g["h"]), 24
+    cv = synth.canvas(int(g["seed"]), w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
+    left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
+    right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
+    monkeypatch.setenv("VSM_SEQ_CHUNK", "10")
+    m = vm.Matcher()
+    m.set_intrinsics(*[float(x) for x in g["intr"]])
+    got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
+    for f in range(nf):
+        assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), (env, f)
+    m.close()
+
+
 def test_sequence_api_fallbacks(vm, B, synth):
     seq = synth.stereo_sequence(8, 320, 128, 4)
     left = np.stack([l for l, _ in seq])
