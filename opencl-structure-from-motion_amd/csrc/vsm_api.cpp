@@ -287,6 +287,8 @@ struct DcBank {
   int npairs = 0, stride_pts = 0, stride_tasks = 0;
   uint64_t *d_key = nullptr, *h_key = nullptr, *d_key_sorted = nullptr;  // h_key: (x,y) order if the GPU orders them, else kd order
   uint32_t *d_kd = nullptr;  // scratch of k_dc_kd_order
+  float *d_flow = nullptr, *h_flow = nullptr;          // per pair [3][stride_pts]: flow u, flow v, disparity of every match
+  int32_t *d_support = nullptr, *h_support = nullptr;  // per pair [stride_pts]: support count of every match
   uint32_t *d_pt = nullptr, *h_pt = nullptr;
   int32_t *d_id = nullptr, *h_id = nullptr, *d_tri = nullptr, *h_tri = nullptr;
   VsmDcTask *d_tasks = nullptr, *h_tasks = nullptr;
@@ -299,6 +301,10 @@ struct DcBank {
     (void)hipFree(d_key);
     (void)hipFree(d_key_sorted);
     (void)hipFree(d_kd);
+    (void)hipFree(d_flow);
+    (void)hipFree(d_support);
+    (void)hipHostFree(h_flow);
+    (void)hipHostFree(h_support);
     (void)hipFree(d_pt);
     (void)hipFree(d_id);
     (void)hipFree(d_tri);
@@ -326,6 +332,9 @@ struct DcBank {
     const size_t P = (size_t)pairs * pts, T = (size_t)pairs * tasks;
     bool ok = hipMalloc((void **)&d_key, P * 8) == hipSuccess && hipMalloc((void **)&d_key_sorted, P * 8) == hipSuccess &&
               hipMalloc((void **)&d_kd, P * 4 * VSM_DC_KD_SCRATCH) == hipSuccess && hipMalloc((void **)&d_pt, P * 4) == hipSuccess &&
+              hipMalloc((void **)&d_flow, P * 12) == hipSuccess && hipMalloc((void **)&d_support, P * 4) == hipSuccess &&
+              hipHostMalloc((void **)&h_flow, P * 12, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&h_support, P * 4, hipHostMallocDefault) == hipSuccess &&
               hipMalloc((void **)&d_id, P * 4) == hipSuccess && hipMalloc((void **)&d_tri, P * 64) == hipSuccess &&
               hipMalloc((void **)&d_tasks, T * sizeof(VsmDcTask)) == hipSuccess &&
               hipMalloc((void **)&d_merges, T * sizeof(VsmDcMerge)) == hipSuccess &&
@@ -779,6 +788,7 @@ struct DcChunk {
   int method = 0, leaf = 16, top = 240;
   bool device_kd = true;  // the GPU orders the keys (k_dc_kd_order); else ExactDelaunay::prepare does
   bool block = true;      // sub-trees of <= VSM_DC_BLOCK_POINTS points, one wave each inside LDS (k_dc_block); else leaf / top
+  bool full = true;       // (with block) all merge levels and the support test on the GPU too: only the counts come back
   int bank = 0, n = 0, f0 = 0, first_pair = 0, work0 = 0;
   std::shared_ptr<std::vector<char>> valid;
   std::atomic<int> a_left{0};
@@ -815,6 +825,13 @@ static void dc_submit_b(DcChunk *ch) {
     }
     const DcBank &B = *h->dc_bank[ch->bank];
     const int32_t m = B.m[i], nt = B.nt[i];
+    if (ch->block && ch->full && nt > 0) {  // the GPU went all the way: keep the matches with support >= 4 (:1369)
+      const double t1 = vsm_now_us();
+      const int32_t *support = B.h_support + (size_t)i * B.stride_pts;
+      vsm_host_keep_supported(wk.tmp_list.data(), support, nl, out);
+      ch->part_ns[6].fetch_add((long long)((vsm_now_us() - t1) * 1e3), std::memory_order_relaxed);
+      return;
+    }
     if (m >= 2) {
       if (nt > 0) {  // adopt what the GPU built
         // (copied, not used in place: the merges and the support test chase pointers through these arrays, and
@@ -854,7 +871,7 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
   (void)hipSetDevice(h->device);
   ch->t_g0 = vsm_now_us();
   DcBank &B = *h->dc_bank[ch->bank];
-  int maxt = 0, maxm = 0, maxn = 0, maxlev = 0, maxg = 0, lev_nodes[VSM_DC_MAX_LEVELS] = {0};
+  int maxt = 0, maxm = 0, maxin = 0, maxn = 0, maxlev = 0, maxg = 0, lev_nodes[VSM_DC_MAX_LEVELS] = {0};
   for (int i = 0; i < ch->n; i++) {
     VsmDcJob &jb = B.h_jobs[i];  // (the A task left the level table in it)
     jb.key = B.d_key + (size_t)i * B.stride_pts;
@@ -867,11 +884,16 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
     jb.tasks = B.d_tasks + (size_t)i * B.stride_tasks;
     jb.merges = B.d_merges + (size_t)i * B.stride_tasks;
     jb.hulls = B.d_hulls + (size_t)i * 2 * B.stride_tasks;
+    jb.flow_u = B.d_flow + (size_t)i * 3 * B.stride_pts;
+    jb.flow_v = jb.flow_u + B.stride_pts;
+    jb.disp = jb.flow_v + B.stride_pts;
+    jb.support = ch->full ? B.d_support + (size_t)i * B.stride_pts : nullptr;
     jb.ntasks = std::max(B.nt[i], 0);
     jb.m = B.m[i];
     maxt = std::max(maxt, jb.ntasks);
     if (B.nt[i] > 0) {
       maxm = std::max(maxm, B.m[i]);
+      maxin = std::max(maxin, jb.n_in);
       maxn = std::max(maxn, B.nn[i]);
       maxlev = std::max(maxlev, jb.nlevels);
       maxg = std::max(maxg, jb.level_off[jb.nlevels]);
@@ -899,13 +921,23 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
         vsm_dc_launch_blocks(s2, B.d_jobs, ch->n, maxt);
       } else {
         vsm_dc_launch_subtrees(s2, B.d_jobs, ch->n, maxt);
-        for (int l = 0; l < maxlev; l++) vsm_dc_launch_merge_level(s2, B.d_jobs, ch->n, l, lev_nodes[l]);
       }
-      ok = hipMemcpy2DAsync(B.h_tri, sp * 64, B.d_tri, sp * 64, (size_t)maxm * 64, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
-           hipMemcpy2DAsync(B.h_pt, sp * 4, B.d_pt, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
-           hipMemcpy2DAsync(B.h_id, sp * 4, B.d_id, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
-           hipMemcpy2DAsync(B.h_hulls, 2 * st * sizeof(VsmDcHull), B.d_hulls, 2 * st * sizeof(VsmDcHull), (size_t)maxn * sizeof(VsmDcHull),
-                            rows, hipMemcpyDeviceToHost, s2) == hipSuccess;
+      for (int l = 0; l < maxlev; l++) vsm_dc_launch_merge_level(s2, B.d_jobs, ch->n, l, lev_nodes[l]);
+      if (ch->block && ch->full) {
+        // the triangulations are complete on the device: count the support there, only the counts travel
+        ok = hipMemcpy2DAsync(B.d_flow, sp * 12, B.h_flow, sp * 12, sp * 12, rows, hipMemcpyHostToDevice, s2) == hipSuccess &&
+             hipMemset2DAsync(B.d_support, sp * 4, 0, (size_t)maxin * 4, rows, s2) == hipSuccess;
+        if (ok) {
+          vsm_dc_launch_support(s2, B.d_jobs, ch->n, maxm, ch->method, (float)ch->p.outlier_flow_tolerance, (float)ch->p.outlier_disp_tolerance);
+          ok = hipMemcpy2DAsync(B.h_support, sp * 4, B.d_support, sp * 4, (size_t)maxin * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess;
+        }
+      } else {
+        ok = hipMemcpy2DAsync(B.h_tri, sp * 64, B.d_tri, sp * 64, (size_t)maxm * 64, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
+             hipMemcpy2DAsync(B.h_pt, sp * 4, B.d_pt, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
+             hipMemcpy2DAsync(B.h_id, sp * 4, B.d_id, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
+             hipMemcpy2DAsync(B.h_hulls, 2 * st * sizeof(VsmDcHull), B.d_hulls, 2 * st * sizeof(VsmDcHull), (size_t)maxn * sizeof(VsmDcHull),
+                              rows, hipMemcpyDeviceToHost, s2) == hipSuccess;
+      }
     }
   }
   ch->stage.store(1, std::memory_order_release);
@@ -941,7 +973,7 @@ static void dc_submit_a(DcChunk *ch) {
         vsm_host_outliers_begin(wk, wk.tmp_list.data(), nl, ch->method);
         const double t2 = vsm_now_us();
         ch->part_ns[1].fetch_add((long long)((t2 - t1) * 1e3), std::memory_order_relaxed);
-        const bool prepared = ch->block ? wk.del.prepare(wk.x.data(), wk.y.data(), nl, VSM_DC_BLOCK_POINTS, nullptr, 0, ch->device_kd)
+        const bool prepared = ch->block ? wk.del.prepare(wk.x.data(), wk.y.data(), nl, VSM_DC_BLOCK_POINTS, nullptr, ch->full ? INT32_MAX : 0, ch->device_kd)
                                         : wk.del.prepare(wk.x.data(), wk.y.data(), nl, ch->leaf, nullptr, ch->top, ch->device_kd);
         ch->part_ns[2].fetch_add((long long)((vsm_now_us() - t2) * 1e3), std::memory_order_relaxed);
         if (prepared) {
@@ -950,14 +982,21 @@ static void dc_submit_a(DcChunk *ch) {
           B.m[i] = m;
           B.nn[i] = wk.del.num_nodes();
           if (m < nl) ch->part_ns[7].fetch_add(1, std::memory_order_relaxed);  // pairs with duplicate points
-          if (m > B.stride_pts || nt > B.stride_tasks || ng > B.stride_tasks || B.nn[i] > 2 * B.stride_tasks ||
+          if (m > B.stride_pts || nl > B.stride_pts || nt > B.stride_tasks || ng > B.stride_tasks || B.nn[i] > 2 * B.stride_tasks ||
               (int)lv.size() > VSM_DC_MAX_LEVELS || (ch->device_kd && m > VSM_DC_KD_MAX_POINTS)) {
             B.nt[i] = -1;  // does not fit the slab: this pair stays on the host
           } else {
             memcpy(B.h_key + (size_t)i * B.stride_pts, wk.del.mesh().key, (size_t)m * 8);
             memcpy(B.h_tasks + (size_t)i * B.stride_tasks, wk.del.tasks().data(), (size_t)nt * sizeof(VsmDcTask));
             memcpy(B.h_merges + (size_t)i * B.stride_tasks, wk.del.device_merges().data(), (size_t)ng * sizeof(VsmDcMerge));
+            if (ch->full) {
+              float *fl = B.h_flow + (size_t)i * 3 * B.stride_pts;
+              memcpy(fl, wk.fu.data(), (size_t)nl * 4);
+              memcpy(fl + B.stride_pts, wk.fv.data(), (size_t)nl * 4);
+              memcpy(fl + 2 * (size_t)B.stride_pts, wk.dp.data(), (size_t)nl * 4);
+            }
             VsmDcJob &jb = B.h_jobs[i];
+            jb.n_in = nl;
             jb.nlevels = (int32_t)lv.size();
             jb.level_off[0] = 0;
             for (int l = 0; l < jb.nlevels; l++) jb.level_off[l + 1] = jb.level_off[l] + lv[l];
@@ -1048,6 +1087,11 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   const int dc_leaf = getenv("VSM_DC_LEAF") ? std::max(3, atoi(getenv("VSM_DC_LEAF"))) : 16;
   const bool dc_kd = !(getenv("VSM_DC_KD") && atoi(getenv("VSM_DC_KD")) == 0);  // kd order of the keys on the GPU too
   const bool dc_block = !(getenv("VSM_DC_BLOCK") && atoi(getenv("VSM_DC_BLOCK")) == 0);  // k_dc_block instead of leaf / top
+  // (with block) the merges above the sub-trees and the support test on the GPU too: a third less host work per
+  // pair, but the large merges are slow there (a dependent L2 round trip per step), so it pays when the host has
+  // few cores for this rank (200 frames 1242x375, ms: 16 threads 9.1 shared / 14.2 full, 8: 12.9 / 14.9, 4: 21.5 / 18.6,
+  // 2: 33.1 / 25.8; host only: 14.0, 25.3, 43.4, 70.8); VSM_DC_FULL=0/1 decides otherwise
+  const bool dc_full = getenv("VSM_DC_FULL") ? atoi(getenv("VSM_DC_FULL")) != 0 : h->pool->size() <= 6;
   const int dc_top = getenv("VSM_DC_TOP") ? atoi(getenv("VSM_DC_TOP")) : 240;  // merge nodes up to this size follow on the GPU
   bool dc_gpu = dc_env;
   for (hipStream_t &st : h->dc_stream)
@@ -1236,6 +1280,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       ch->top = dc_top;
       ch->device_kd = dc_kd;
       ch->block = dc_block;
+      ch->full = dc_full;
       ch->bank = k % vsm_handle::kDcBanks;
       ch->n = n;
       ch->f0 = f0;

@@ -333,3 +333,44 @@ void vsm_dc_launch_blocks(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int 
   if (njobs <= 0 || max_tasks <= 0) return;
   hipLaunchKernelGGL(k_dc_block, dim3(max_tasks, njobs), dim3(64), 0, s, d_jobs, njobs);
 }
+
+// The support test of removeOutliers (viso/matcher.cpp:1266-1364; vsm_host_outliers_end is the host form):
+// every triangle gives each of its three edges a vote for both end points if the two matches agree in flow
+// and / or disparity.  Differences, absolute values, one sum and a compare in float: the same values on
+// either side; the counts are integer sums, so their order does not matter.
+__global__ void __launch_bounds__(256) k_dc_support(const VsmDcJob *__restrict__ jobs, int njobs, int method, float ftol, float dtol) {
+  const int j = blockIdx.y;
+  if (j >= njobs) return;
+  const VsmDcJob jb = jobs[j];
+  if (!jb.support || jb.ntasks <= 0) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * jb.m) return;
+  const int32_t *v = jb.tri + (size_t)t * 8 + 4;
+  const int32_t v0 = v[0], v1 = v[1], v2 = v[2];
+  if ((v0 | v1 | v2) < 0) return;
+  const int32_t q[3] = {jb.id[v1], jb.id[v2], jb.id[v0]};
+  float fu[3], fv[3], dp[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    fu[k] = jb.flow_u[q[k]];
+    fv[k] = jb.flow_v[q[k]];
+    dp[k] = jb.disp[q[k]];
+  }
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    const int a = e == 2 ? 0 : e, b = e == 0 ? 1 : 2;  // (0,1) (1,2) (0,2)
+    const bool flow_ok = fabsf(fu[a] - fu[b]) + fabsf(fv[a] - fv[b]) < ftol;
+    const bool disp_ok = fabsf(dp[a] - dp[b]) < dtol;
+    const bool ok = method == 0 ? flow_ok : (method == 1 ? disp_ok : (disp_ok && flow_ok));
+    if (ok) {
+      atomicAdd(&jb.support[q[a]], 1);
+      atomicAdd(&jb.support[q[b]], 1);
+    }
+  }
+}
+
+void vsm_dc_launch_support(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int max_points, int method, float flow_tol,
+                           float disp_tol) {
+  if (njobs <= 0 || max_points <= 0) return;
+  hipLaunchKernelGGL(k_dc_support, dim3((2 * max_points + 255) / 256, njobs), dim3(256), 0, s, d_jobs, njobs, method, flow_tol, disp_tol);
+}

@@ -14,7 +14,7 @@ struct VsmDcMerge {  // == ExactDelaunay::Merge: an internal node, children by n
 struct VsmDcHull {  // the two hull handles a node hands to the merge above it
   int32_t fl_t, fl_o, fr_t, fr_o;
 };
-#define VSM_DC_MAX_LEVELS 6
+#define VSM_DC_MAX_LEVELS 8
 #define VSM_DC_KD_MAX_POINTS 16384  // k_dc_kd_order keeps 16-bit counters in LDS
 #define VSM_DC_KD_SCRATCH 7        // uint32 arrays of m entries it needs per job
 struct VsmDcJob {  // one triangulation; all pointers are device pointers
@@ -30,6 +30,10 @@ struct VsmDcJob {  // one triangulation; all pointers are device pointers
   VsmDcHull *hulls;          // by node number
   int32_t ntasks, m;
   int32_t nlevels, level_off[VSM_DC_MAX_LEVELS + 1];  // merges[level_off[l] .. level_off[l+1]) is level l
+  // support test of removeOutliers on the finished triangulation (k_dc_support): per input match
+  const float *flow_u, *flow_v, *disp;  // [n_in] u1c-u1p, v1c-v1p, disparity (vsm_host_outliers_begin)
+  int32_t *support;                     // [n_in] out
+  int32_t n_in, pad2_;
 };
 
 // kd order of the jobs that bring key_sorted: one workgroup per job (ExactDelaunay::kd_order on the device)
@@ -40,5 +44,9 @@ void vsm_dc_launch_subtrees(hipStream_t s, const VsmDcJob *d_jobs, int njobs, in
 // one per lane, then the merge levels); blockIdx.y = job; max_tasks >= every job's ntasks
 #define VSM_DC_BLOCK_POINTS 480
 void vsm_dc_launch_blocks(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int max_tasks);
+// removeOutliers' support count (viso/matcher.cpp:1266-1364) over the triangle slots of finished triangulations:
+// thread per slot, blockIdx.y = job; max_points >= every job's m.  method: 0 flow, 1 stereo, 2 quad
+void vsm_dc_launch_support(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int max_points, int method, float flow_tol,
+                           float disp_tol);
 // one thread per merge node of level `level`; max_nodes >= every job's node count on that level
 void vsm_dc_launch_merge_level(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int level, int max_nodes);

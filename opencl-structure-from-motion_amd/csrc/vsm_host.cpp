@@ -642,10 +642,26 @@ void vsm_host_outliers_end(VsmHostWork &w, const vsm_params &p, const vsm_p_matc
       }
     }
   }
-  out.clear();
-  out.reserve((size_t)n);
-  for (int32_t i = 0; i < n; i++)
-    if (support[i] >= 4) out.push_back(in[i]);
+  vsm_host_keep_supported(in, support, n, out);
+}
+
+// survivors of the support test (support >= 4, viso/matcher.cpp:1369-1371), in list order; almost all matches
+// survive, so they are copied run by run
+void vsm_host_keep_supported(const vsm_p_match *in, const int32_t *support, int32_t n, std::vector<vsm_p_match> &out) {
+  out.resize((size_t)std::max(n, 0));
+  vsm_p_match *dst = out.data();
+  int32_t i = 0;
+  while (i < n) {
+    while (i < n && support[i] < 4) i++;
+    int32_t j = i;
+    while (j < n && support[j] >= 4) j++;
+    if (j > i) {
+      memcpy((void *)dst, (const void *)(in + i), (size_t)(j - i) * sizeof(vsm_p_match));
+      dst += j - i;
+    }
+    i = j;
+  }
+  out.resize((size_t)(dst - out.data()));
 }
 
 void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,

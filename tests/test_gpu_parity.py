@@ -227,13 +227,14 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
     m.close()
 
 
-@pytest.mark.parametrize("env", [{"VSM_DC_GPU": "0"}, {"VSM_DC_BLOCK": "0"}, {"VSM_DC_BLOCK": "0", "VSM_DC_KD": "0"},
+@pytest.mark.parametrize("env", [{"VSM_DC_GPU": "0"}, {"VSM_DC_FULL": "1"}, {"VSM_DC_FULL": "0"}, {"VSM_DC_FULL": "1", "VSM_DC_KD": "0"},
+                                 {"VSM_DC_BLOCK": "0"}, {"VSM_DC_BLOCK": "0", "VSM_DC_KD": "0"},
                                  {"VSM_DC_KD": "0"}, {"VSM_DC_BLOCK": "0", "VSM_DC_LEAF": "64", "VSM_DC_TOP": "0"},
                                  {"VSM_DC_BLOCK": "0", "VSM_DC_LEAF": "5", "VSM_DC_TOP": "100000"}])
 def test_sequence_api_final_stage_variants(vm, synth, monkeypatch, env):
     """the ways the exact Delaunay of the look-ahead final stage can be shared between host and GPU (host only;
-    sub-trees per thread + merge levels; kd order on either side; the last one overflows the level table and
-    falls back to the host pair by pair) all give the reference's lists"""
+    everything after the sort on the GPU; sub-trees per thread + merge levels; kd order on either side; the last
+    one overflows the level table and falls back to the host pair by pair) all give the reference's lists"""
     import torch
     for k, v in env.items():
         monkeypatch.setenv(k, v)
