@@ -792,6 +792,8 @@ struct DcChunk {
   int bank = 0, n = 0, f0 = 0, first_pair = 0, work0 = 0;
   std::shared_ptr<std::vector<char>> valid;
   std::atomic<int> a_left{0};
+  int chunk = 0;           // the look-ahead chunk it belongs to
+  bool a_waited = false;   // (caller's thread only)
   std::atomic<int> stage{0};  // 0: A running, 1: G enqueued, 2: B submitted
   VsmPool::Ticket a, b;
   // VSM_DEBUG_TIMING: when the stages changed hands, and the task time summed over the pool
@@ -1081,9 +1083,11 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   // (chunk k+1's features must not overwrite the last frame of chunk k-1, which chunk k's first pair
   // reads); pairs in two (the final host stage of chunk k reads pair bank k&1 in host-mapped memory
   // while the GPU runs chunk k+1 on the other).
-  std::vector<VsmPool::Ticket> tickets;
+  std::vector<VsmPool::Ticket> tickets;  // final stages that stay on the host ...
+  std::vector<int> ticket_chunk;         // ... and the chunk each belongs to
   // final stage: see DcChunk above
   const bool dc_env = !(getenv("VSM_DC_GPU") && atoi(getenv("VSM_DC_GPU")) == 0);
+  const bool dc_forced = getenv("VSM_DC_GPU") && atoi(getenv("VSM_DC_GPU")) != 0;
   const int dc_leaf = getenv("VSM_DC_LEAF") ? std::max(3, atoi(getenv("VSM_DC_LEAF"))) : 16;
   const bool dc_kd = !(getenv("VSM_DC_KD") && atoi(getenv("VSM_DC_KD")) == 0);  // kd order of the keys on the GPU too
   const bool dc_block = !(getenv("VSM_DC_BLOCK") && atoi(getenv("VSM_DC_BLOCK")) == 0);  // k_dc_block instead of leaf / top
@@ -1233,12 +1237,16 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     }
     // the export below overwrites this pair bank's host lists: chunk k-2 must be done with them
     const double tw0 = now_us();
-    if (dc_gpu) {
-      if (k >= 2 && k - 2 < (int)chunks.size()) h->pool->wait(chunks[k - 2]->a);  // it copied the lists out first thing
-      if (k >= vsm_handle::kDcBanks && k - vsm_handle::kDcBanks < (int)chunks.size()) dc_wait(chunks[k - vsm_handle::kDcBanks].get());
-    } else if (k >= 2) {
-      h->pool->wait(tickets[k - 2]);
-    }
+    for (auto &ch : chunks)  // (they copied the lists out first thing)
+      if (ch->chunk <= k - 2 && !ch->a_waited) {
+        h->pool->wait(ch->a);
+        ch->a_waited = true;
+      }
+    for (size_t q = 0; q < tickets.size(); q++)
+      if (ticket_chunk[q] <= k - 2 && tickets[q]) {
+        h->pool->wait(tickets[q]);
+        tickets[q].reset();
+      }
     if (vsm_debug_timing() && now_us() - tw0 > 2000) fprintf(stderr, "  chunk %d: waited %.0f us for chunk %d's final stage\n", k, now_us() - tw0, k - 2);
     cfg.sparse = 0;
     cfg.use_prior = p.multi_stage ? 1 : 0;
@@ -1261,15 +1269,20 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     tg += now_us() - ta;
     // final stage of this chunk: asynchronous, overlapped with the next chunk's GPU work
     VsmCtx *cp = &c;
-    if (dc_gpu) {
+    // The GPU share pays when the pool has other pairs to work on while the GPU has this chunk's (its part is
+    // latency-bound): a chunk with fewer pairs than pool threads stays on the host, unless VSM_DC_GPU=1 insists
+    bool use_dc = dc_gpu && (dc_forced || n >= h->pool->size());
+    const int dc_q = (int)chunks.size(), dc_b = dc_q % vsm_handle::kDcBanks;
+    if (use_dc) {
+      if (dc_q >= vsm_handle::kDcBanks) dc_wait(chunks[dc_q - vsm_handle::kDcBanks].get());  // its slabs are reused now
       // slab sizes from this chunk's longest possible list (every pair's list is at most max_nq[1] long)
       const int pts = ((max_nq[1] + 63) / 64) * 64 + 64, tsk = 2 * pts / std::max(dc_leaf, 2) + 16;
-      if (!h->dc_bank[k % vsm_handle::kDcBanks]->reserve(C, pts, tsk)) {
+      if (!h->dc_bank[dc_b]->reserve(C, pts, tsk)) {
         fprintf(stderr, "visomatch: no memory for the GPU share of the Delaunay stage, staying on the host\n");
-        dc_gpu = false;
+        dc_gpu = use_dc = false;
       }
     }
-    if (dc_gpu) {
+    if (use_dc) {
       chunks.emplace_back(new DcChunk());
       DcChunk *ch = chunks.back().get();
       ch->h = h;
@@ -1281,7 +1294,8 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       ch->device_kd = dc_kd;
       ch->block = dc_block;
       ch->full = dc_full;
-      ch->bank = k % vsm_handle::kDcBanks;
+      ch->chunk = k;
+      ch->bank = dc_b;
       ch->n = n;
       ch->f0 = f0;
       ch->first_pair = first_pair;
@@ -1290,6 +1304,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       dc_submit_a(ch);
     } else {
       const vsm_params pcopy = p;
+      ticket_chunk.push_back(k);
       tickets.push_back(h->pool->submit(n, [h, cp, pcopy, validp, f0, first_pair, method](int i) {
         if (!(*validp)[i]) return;
         static thread_local VsmHostWork tw;
@@ -1316,7 +1331,8 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       fprintf(stderr, "  per pair, us: pass-1 outliers %.0f prior statistics %.0f | A copy %.0f arrays %.0f prepare %.0f | B records %.0f merges %.0f support+survivors %.0f; pairs with duplicate points: %.0f\n",
               mid_ns[0].load() * 1e-3 / n_frames, mid_ns[1].load() * 1e-3 / n_frames, part[0], part[1], part[2], part[4], part[5], part[6], part[7] * n_frames * 1e3);
     }
-    for (auto &t : tickets) h->pool->wait(t);
+    for (auto &t : tickets)
+      if (t) h->pool->wait(t);
     thost += now_us() - tb;
   }
   h->seq_timings[0] = tg;

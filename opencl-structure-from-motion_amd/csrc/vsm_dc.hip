@@ -70,7 +70,7 @@ __device__ inline void kd_node_at(int32_t q, int depth, int32_t m, int32_t &off,
 }
 
 __global__ void __launch_bounds__(KD_THREADS) k_dc_kd_order(const VsmDcJob *__restrict__ jobs, int njobs) {
-  __shared__ uint16_t hist[KD_DIGITS * KD_CHUNKS];
+  __shared__ uint32_t hist[KD_DIGITS * KD_CHUNKS];
   __shared__ uint32_t tot[KD_THREADS / 64 + 1];
   const VsmDcJob jb = jobs[blockIdx.x];
   const int32_t m = jb.m;
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc_kd_order(const VsmDcJob *__re
       uint32_t run = kd_block_scan(sum, tot);
       for (int i = 0; i < per; i++) {
         const uint32_t c = hist[t * per + i];
-        hist[t * per + i] = (uint16_t)run;
+        hist[t * per + i] = run;
         run += c;
       }
     }

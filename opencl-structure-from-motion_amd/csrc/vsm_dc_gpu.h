@@ -15,7 +15,7 @@ struct VsmDcHull {  // the two hull handles a node hands to the merge above it
   int32_t fl_t, fl_o, fr_t, fr_o;
 };
 #define VSM_DC_MAX_LEVELS 8
-#define VSM_DC_KD_MAX_POINTS 16384  // k_dc_kd_order keeps 16-bit counters in LDS
+#define VSM_DC_KD_MAX_POINTS 65536  // sizes k_dc_kd_order was written for (32-bit counters in 128 KB of LDS)
 #define VSM_DC_KD_SCRATCH 7        // uint32 arrays of m entries it needs per job
 struct VsmDcJob {  // one triangulation; all pointers are device pointers
   const uint64_t *key_sorted;  // [m] distinct packed keys in (x,y) order, or null: `key` arrives in kd order

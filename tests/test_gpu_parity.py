@@ -213,6 +213,7 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
     it a sequence of four chunks (three frame banks, two pair banks and the slab banks all come round)"""
     import torch
     monkeypatch.setenv("VSM_SEQ_CHUNK", chunk)
+    monkeypatch.setenv("VSM_DC_GPU", "1")   # (chunks with fewer pairs than host threads would stay on the host)
     g = G.load("cfg2_seq200_tr")
     w, h, nf = int(g["w"]), int(g["h"]), 60
     cv = synth.canvas(int(g["seed"]), w, h)
@@ -236,6 +237,7 @@ def test_sequence_api_final_stage_variants(vm, synth, monkeypatch, env):
     everything after the sort on the GPU; sub-trees per thread + merge levels; kd order on either side; the last
     one overflows the level table and falls back to the host pair by pair) all give the reference's lists"""
     import torch
+    monkeypatch.setenv("VSM_DC_GPU", "1")   # (chunks with fewer pairs than host threads would stay on the host)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     g = G.load("cfg2_seq200_tr")
@@ -530,6 +532,8 @@ def test_delaunay_subtrees_on_gpu(vm):
     cases = [np.stack([rs.randint(0, 620, n) * 2, rs.randint(0, 187, n) * 2], 1) for n in (5, 64, 700, 7400)]
     g = np.stack(np.meshgrid(np.arange(0, 60, 2), np.arange(0, 40, 2)), -1).reshape(-1, 2)
     cases += [g, np.concatenate([g, g[::3]]), np.stack([np.arange(0, 300, 2), np.full(150, 8)], 1)]
+    big = np.stack([rs.randint(0, 1024, 20000) * 2, rs.randint(0, 512, 20000) * 2], 1)   # > 16384 distinct points
+    assert np.array_equal(canon(vm.host_delaunay(big, 1)), canon(vm.delaunay_gpu_split(big, 480, -1, True)))
     for p in cases:
         whole = canon(vm.host_delaunay(p, 1))
         for leaf, top in ((3, 0), (14, 0), (56, 0), (500, 0), (3, 12), (14, 120), (16, 240), (56, 480), (30, 900),
