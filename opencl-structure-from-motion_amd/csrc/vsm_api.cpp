@@ -296,7 +296,6 @@ struct DcBank {
   VsmDcHull *d_hulls = nullptr, *h_hulls = nullptr;    // by node number: 2 * stride_tasks per pair
   VsmDcJob *d_jobs = nullptr, *h_jobs = nullptr;
   std::vector<int32_t> m, nt, nn;  // per pair: distinct points, tasks (nt < 0: the host solves the sub-trees), tree nodes
-  hipEvent_t done = nullptr;
   void release() {
     (void)hipFree(d_key);
     (void)hipFree(d_key_sorted);
@@ -320,7 +319,6 @@ struct DcBank {
     (void)hipHostFree(h_merges);
     (void)hipHostFree(h_hulls);
     (void)hipHostFree(h_jobs);
-    if (done) (void)hipEventDestroy(done);
     *this = DcBank();
   }
   bool reserve(int pairs, int pts, int tasks) {
@@ -347,8 +345,7 @@ struct DcBank {
               hipHostMalloc((void **)&h_tasks, T * sizeof(VsmDcTask), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_merges, T * sizeof(VsmDcMerge), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_hulls, 2 * T * sizeof(VsmDcHull), hipHostMallocDefault) == hipSuccess &&
-              hipHostMalloc((void **)&h_jobs, pairs * sizeof(VsmDcJob), hipHostMallocDefault) == hipSuccess &&
-              hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess;
+              hipHostMalloc((void **)&h_jobs, pairs * sizeof(VsmDcJob), hipHostMallocDefault) == hipSuccess;
     m.assign(pairs, 0);
     nt.assign(pairs, 0);
     nn.assign(pairs, 0);
@@ -1099,7 +1096,11 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   const int dc_top = getenv("VSM_DC_TOP") ? atoi(getenv("VSM_DC_TOP")) : 240;  // merge nodes up to this size follow on the GPU
   bool dc_gpu = dc_env;
   for (hipStream_t &st : h->dc_stream)
-    if (dc_gpu && !st) dc_gpu = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    if (dc_gpu && !st) {  // lowest priority: these kernels are long and latency-bound, the main stream's come first
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      dc_gpu = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) == hipSuccess;
+    }
   if (dc_gpu) {
     for (int b = 0; b < vsm_handle::kDcBanks; b++)
       if (!h->dc_bank[b]) h->dc_bank[b] = new DcBank();

@@ -1,7 +1,6 @@
 # A/B runs of the look-ahead path under environment switches, interleaved so that box-to-box variance cancels
-run() { echo -n "$1: "; timeout -k 10 200 python tools/thread_cpu.py 100 2>/dev/null | grep -h "wall\|total" | tr '\n' ' '; echo; }
-for t in 16 8 4 2; do
-  VSM_HOST_THREADS=$t VSM_DC_FULL=1 run "threads$t full"
-  VSM_HOST_THREADS=$t VSM_DC_FULL=0 run "threads$t shared"
-  VSM_HOST_THREADS=$t VSM_DC_GPU=0 run "threads$t host-only"
+run() { echo -n "$1: "; timeout -k 10 200 python tools/thread_cpu.py 150 2>/dev/null | grep -h "wall\|total" | tr '\n' ' '; echo; }
+for i in 1 2 3; do
+  run "default"
 done
+timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-per-frame 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline'])"
