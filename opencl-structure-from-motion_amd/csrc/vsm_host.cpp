@@ -305,36 +305,63 @@ inline int32_t prev_bit(const uint64_t *m, int32_t from) {
 }
 }  // namespace
 
-void ExactDelaunay::vertex_sort(uint64_t *a, int32_t n) {
-  if (n == 2) {
-    if (KXY(a[0]) > KXY(a[1])) std::swap(a[0], a[1]);
+// The recursion itself is an explicit stack in the reference's depth-first order (left part first: the
+// random numbers are drawn in that order).  Two-element parts draw no number, so they are settled on the
+// spot, without a branch; parts of three or more are pushed, again without a branch (the slot is written
+// either way, the stack pointer moves by the condition): what is left to mispredict per partition is the
+// exit of the bit loop.
+void ExactDelaunay::vertex_sort(uint64_t *a0, int32_t n0) {
+  if (n0 < 2) return;
+  if (n0 == 2) {
+    if (KXY(a0[0]) > KXY(a0[1])) std::swap(a0[0], a0[1]);
     return;
   }
-  const uint64_t pv = KXY(a[rnd((uint32_t)n)]);
-  // KXY(k) >= pv  <=>  k >= pv << 20;  KXY(k) <= pv  <=>  k < (pv + 1) << 20
-  const int32_t nw = (n + 63) >> 6;
-  uint64_t *GE = stop_.data(), *LE = stop_.data() + nw;  // dead before the recursive calls
-  if (kHaveAvx512)
-    stop_masks_avx512(a, n, pv << 20, (pv + 1) << 20, GE, LE);
-  else
-    stop_masks_plain(a, n, pv << 20, (pv + 1) << 20, GE, LE);
-  int32_t left = -1, right = n;
-  for (;;) {
-    const int32_t l = std::min(next_bit(GE, left + 1, n), right);
-    if (l == right) {  // ran into the key it swapped there itself: the right scan gives up at once
+  sort_stack_.resize((size_t)n0 + 2);  // a pending right part per level of the recursion at most
+  uint64_t *stack = sort_stack_.data();
+  int32_t sp = 0;
+  stack[sp++] = (uint64_t)(uint32_t)n0 << 32;  // (offset, length)
+  auto settle_pair = [](uint64_t *p, bool is_pair) {  // vertexsort on two elements if is_pair, nothing otherwise
+    const uint64_t x = p[0], y = p[1];
+    const bool sw = is_pair & (KXY(x) > KXY(y));
+    p[0] = sw ? y : x;
+    p[1] = sw ? x : y;
+  };
+  while (sp > 0) {
+    const uint64_t top = stack[--sp];
+    const int32_t off = (int32_t)(uint32_t)top, n = (int32_t)(top >> 32);  // n >= 3
+    uint64_t *a = a0 + off;
+    const uint64_t pv = KXY(a[rnd((uint32_t)n)]);
+    // KXY(k) >= pv  <=>  k >= pv << 20;  KXY(k) <= pv  <=>  k < (pv + 1) << 20
+    const int32_t nw = (n + 63) >> 6;
+    uint64_t *GE = stop_.data(), *LE = stop_.data() + nw;
+    if (kHaveAvx512)
+      stop_masks_avx512(a, n, pv << 20, (pv + 1) << 20, GE, LE);
+    else
+      stop_masks_plain(a, n, pv << 20, (pv + 1) << 20, GE, LE);
+    int32_t left = -1, right = n;
+    for (;;) {
+      const int32_t l = std::min(next_bit(GE, left + 1, n), right);
+      if (l == right) {  // ran into the key it swapped there itself: the right scan gives up at once
+        left = l;
+        right = l - 1;
+        break;
+      }
+      int32_t r = prev_bit(LE, right - 1);
+      if (r <= l) r = ((LE[l >> 6] >> (l & 63)) & 1) ? l : l - 1;
       left = l;
-      right = l - 1;
-      break;
+      right = r;
+      if (l >= r) break;
+      std::swap(a[l], a[r]);
     }
-    int32_t r = prev_bit(LE, right - 1);
-    if (r <= l) r = ((LE[l >> 6] >> (l & 63)) & 1) ? l : l - 1;
-    left = l;
-    right = r;
-    if (l >= r) break;
-    std::swap(a[l], a[r]);
+    // the parts [0, left) and (right, n): `if (left > 1) vertexsort(...)`, `if (right < n - 2) vertexsort(...)`
+    const int32_t rn = n - right - 1;
+    settle_pair(a, left == 2);
+    settle_pair(rn == 2 ? a + right + 1 : a, rn == 2);  // (a[0], a[1] exist and are rewritten unchanged otherwise)
+    stack[sp] = (uint64_t)(uint32_t)(off + right + 1) | ((uint64_t)(uint32_t)rn << 32);
+    sp += rn > 2;
+    stack[sp] = (uint64_t)(uint32_t)off | ((uint64_t)(uint32_t)left << 32);
+    sp += left > 2;
   }
-  if (left > 1) vertex_sort(a, left);
-  if (right < n - 2) vertex_sort(a + right + 1, n - right - 1);
 }
 
 // alternateaxes (:5583) for the whole tree at once.  The reference re-partitions every node with a

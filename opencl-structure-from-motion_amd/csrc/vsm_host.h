@@ -176,6 +176,7 @@ class ExactDelaunay {
   };
   std::vector<uint64_t> key_;         // (x << 34) | (y << 20) | input index
   std::vector<uint64_t> stop_;        // scratch of the branch-free partition: two bit masks
+  std::vector<uint64_t> sort_stack_;  // pending parts of the emulated quicksort
   std::vector<uint32_t> xl_, yl_, yr_, tmp_, ord_;  // kd_order(): presorted lists, y-ranks
   std::vector<uint64_t> ybuf0_, ybuf1_, k2_;
   std::vector<uint32_t> pt_;          // by sorted position: x | y << 16

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Side measurements quoted in DESIGN.md / profiles/README.md (never bench.py's `value`):
   * per-frame API fed from pageable HOST buffers (PCIe-inclusive rate) at 1242x375,
+  * the look-ahead API on a 1000-frame sequence (the bench's 200 frames five times over, replayed Tr_delta): the
+    rate once the pipeline's fill and drain (4 of bench.py's 9 ms) no longer count,
   * config 5: 2048x1024 stereo, per-frame and look-ahead,
   * config 3: 640x480 mono, flow matching (per-frame API),
   * the street scene (synth.road_*, depth-dependent disparity/flow): whole VisualOdometryStereo::process
@@ -45,6 +47,24 @@ dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in seq]
 out["cfg2_device_buffers_per_frame_fps"] = round(per_frame(m, dev, 2), 2)
 out["cfg2_matches_last_frame"] = int(len(m.get_matches()))
 m.close()
+# 1b. long sequence through the look-ahead API
+g = np.load(os.path.join(ROOT, "tests", "golden", "cfg4_seq200_tr_8seeds.npz"))
+cvs = synth.canvas(1234, 1242, 375)
+fr = [synth.stereo_frame(cvs, f, 1242, 375) for f in range(200)]
+reps = 5
+L = torch.from_numpy(np.stack([l for l, _ in fr] * reps)).cuda()
+R = torch.from_numpy(np.stack([r for _, r in fr] * reps)).cuda()
+tr = np.ascontiguousarray(np.tile(g["s1234_tr_in"][:200].reshape(200, 16)[:, :12], (reps, 1)))
+trv = np.ascontiguousarray(np.tile(g["s1234_tr_valid"][:200].astype(np.uint8), reps))
+m = vm.Matcher()
+m.set_intrinsics(*[float(x) for x in g["intr"]])
+m.run_sequence(L, R, 2, tr, trv, fetch=False)
+t0 = time.perf_counter()
+for _ in range(3):
+    m.run_sequence(L, R, 2, tr, trv, fetch=False)
+out["cfg2_lookahead_1000_frames_fps"] = round(3 * 200 * reps / (time.perf_counter() - t0), 1)
+m.close()
+del L, R
 # 2. 2048x1024
 seq5 = synth.stereo_sequence(1234, 2048, 1024, 12)
 m = vm.Matcher()
