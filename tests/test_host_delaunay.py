@@ -40,6 +40,32 @@ def test_product_delaunay_equals_reference(B):
         assert _tri_set(vm.host_delaunay(pts, threads=4)) == _tri_set(B.delaunay("ref", pts.astype(np.float32)))
 
 
+def test_plain_mask_pass_of_the_sort(B):
+    """the emulated vertex sort writes its two bit masks with AVX-512 where the CPU has it; the plain loop
+    (VSM_NO_AVX512=1, read when the library is loaded, hence the child process) must make the same decisions"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from conftest import pkg\n"
+        "import test_host_delaunay as T\n"
+        "vm = pkg('visomatch')\n"
+        "np.save(sys.argv[1], np.array([vm.host_delaunay(p, threads=1) for p in T._cases(5)], dtype=object), allow_pickle=True)\n"
+    ) % os.path.dirname(os.path.abspath(__file__))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "t.npy")
+        env = dict(os.environ, VSM_NO_AVX512="1")
+        subprocess.check_call([sys.executable, "-c", code, out], env=env, timeout=300)
+        plain = np.load(out, allow_pickle=True)
+    vm = pkg("visomatch")
+    for pts, t in zip(_cases(5), plain):
+        assert _tri_set(vm.host_delaunay(pts, threads=1)) == _tri_set(t)
+        assert _tri_set(t) == _tri_set(B.delaunay("oracle", pts.astype(np.float32)))
+
+
 def test_split_form_equals_whole(B):
     """prepare / independent sub-trees / merges (the form shared between host and GPU in the look-ahead
     path) gives the same triangle set as the one-piece run for every sub-tree size, duplicates and
