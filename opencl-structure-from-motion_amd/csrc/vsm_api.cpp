@@ -1096,11 +1096,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   const int dc_top = getenv("VSM_DC_TOP") ? atoi(getenv("VSM_DC_TOP")) : 240;  // merge nodes up to this size follow on the GPU
   bool dc_gpu = dc_env;
   for (hipStream_t &st : h->dc_stream)
-    if (dc_gpu && !st) {  // lowest priority: these kernels are long and latency-bound, the main stream's come first
-      int least = 0, greatest = 0;
-      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      dc_gpu = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) == hipSuccess;
-    }
+    if (dc_gpu && !st) dc_gpu = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;  // (stream priorities make no measurable difference)
   if (dc_gpu) {
     for (int b = 0; b < vsm_handle::kDcBanks; b++)
       if (!h->dc_bank[b]) h->dc_bank[b] = new DcBank();
