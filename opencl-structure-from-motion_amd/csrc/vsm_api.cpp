@@ -913,7 +913,8 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
          (maxg == 0 || hipMemcpy2DAsync(B.d_merges, st * sizeof(VsmDcMerge), B.h_merges, st * sizeof(VsmDcMerge),
                                         (size_t)maxg * sizeof(VsmDcMerge), rows, hipMemcpyHostToDevice, s2) == hipSuccess) &&
          hipMemcpyAsync(B.d_jobs, B.h_jobs, ch->n * sizeof(VsmDcJob), hipMemcpyHostToDevice, s2) == hipSuccess &&
-         hipMemset2DAsync(B.d_tri, sp * 64, 0xff, (size_t)maxm * 64, rows, s2) == hipSuccess;
+         // (k_dc_block writes every slot of every sub-tree; the per-lane kernels rely on empty slots reading -1)
+         (ch->block || hipMemset2DAsync(B.d_tri, sp * 64, 0xff, (size_t)maxm * 64, rows, s2) == hipSuccess);
     if (ok) {
       if (ch->device_kd) vsm_dc_launch_kd_order(s2, B.d_jobs, ch->n);
       if (ch->block) {

@@ -215,6 +215,9 @@ __global__ void __launch_bounds__(64) k_dc_block(const VsmDcJob *__restrict__ jo
   const VsmDcTask tk = jb.tasks[blockIdx.x];
   const int lane = threadIdx.x;
   if (tk.n > VSM_DC_BLOCK_POINTS) {  // not expected (the host cuts tasks to fit): plain recursion in global memory
+    int32_t *gt = jb.tri + (size_t)2 * tk.off * 8;
+    for (int i = lane; i < 2 * tk.n * 8; i += 64) gt[i] = -1;
+    __syncthreads();
     if (lane == 0) {
       const DcMesh mesh{jb.tri, jb.pt, jb.id, jb.key};
       DcMesh::OTri fl, fr;
