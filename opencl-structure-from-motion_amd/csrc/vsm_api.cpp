@@ -827,7 +827,8 @@ static void dc_submit_b(DcChunk *ch) {
     if (ch->block && ch->full && nt > 0) {  // the GPU went all the way: keep the matches with support >= 4 (:1369)
       const double t1 = vsm_now_us();
       const int32_t *support = B.h_support + (size_t)i * B.stride_pts;
-      vsm_host_keep_supported(wk.tmp_list.data(), support, nl, out);
+      vsm_host_keep_supported(wk.tmp_list, support);  // in place, then the buffers change hands
+      out.swap(wk.tmp_list);
       ch->part_ns[6].fetch_add((long long)((vsm_now_us() - t1) * 1e3), std::memory_order_relaxed);
       return;
     }
@@ -854,7 +855,9 @@ static void dc_submit_b(DcChunk *ch) {
       ch->part_ns[5].fetch_add((long long)((vsm_now_us() - t1) * 1e3), std::memory_order_relaxed);
     }
     const double t2 = vsm_now_us();
-    vsm_host_outliers_end(wk, ch->p, wk.tmp_list.data(), nl, ch->method, out);
+    vsm_host_count_support(wk, ch->p, nl, ch->method);
+    vsm_host_keep_supported(wk.tmp_list, wk.support.data());  // in place, then the buffers change hands
+    out.swap(wk.tmp_list);
     ch->part_ns[6].fetch_add((long long)((vsm_now_us() - t2) * 1e3), std::memory_order_relaxed);
   });
   ch->stage.store(2, std::memory_order_release);

@@ -647,6 +647,11 @@ void vsm_host_outliers_begin(VsmHostWork &w, const vsm_p_match *in, int32_t n, i
 // support of every match from the triangulation in w.del, survivors (support >= 4) to `out`
 void vsm_host_outliers_end(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,
                            std::vector<vsm_p_match> &out) {
+  vsm_host_count_support(w, p, n, method);
+  vsm_host_keep_supported(in, w.support.data(), n, out);
+}
+
+void vsm_host_count_support(VsmHostWork &w, const vsm_params &p, int32_t n, int method) {
   w.support.assign(n, 0);
   const float ftol = (float)p.outlier_flow_tolerance, dtol = (float)p.outlier_disp_tolerance;
   const float *fu = w.fu.data(), *fv = w.fv.data(), *dp = w.dp.data();
@@ -669,26 +674,39 @@ void vsm_host_outliers_end(VsmHostWork &w, const vsm_params &p, const vsm_p_matc
       }
     }
   }
-  vsm_host_keep_supported(in, support, n, out);
 }
 
 // survivors of the support test (support >= 4, viso/matcher.cpp:1369-1371), in list order; almost all matches
 // survive, so they are copied run by run
 void vsm_host_keep_supported(const vsm_p_match *in, const int32_t *support, int32_t n, std::vector<vsm_p_match> &out) {
-  out.resize((size_t)std::max(n, 0));
-  vsm_p_match *dst = out.data();
+  out.clear();
+  out.reserve((size_t)std::max(n, 0));  // (no resize: that would write the whole list once for nothing)
+  int32_t i = 0;
+  while (i < n) {
+    while (i < n && support[i] < 4) i++;
+    int32_t j = i;
+    while (j < n && support[j] >= 4) j++;
+    if (j > i) out.insert(out.end(), in + i, in + j);
+    i = j;
+  }
+}
+
+// the same inside the list itself (the runs move down over the gaps)
+void vsm_host_keep_supported(std::vector<vsm_p_match> &list, const int32_t *support) {
+  const int32_t n = (int32_t)list.size();
+  vsm_p_match *base = list.data(), *dst = base;
   int32_t i = 0;
   while (i < n) {
     while (i < n && support[i] < 4) i++;
     int32_t j = i;
     while (j < n && support[j] >= 4) j++;
     if (j > i) {
-      memcpy((void *)dst, (const void *)(in + i), (size_t)(j - i) * sizeof(vsm_p_match));
+      if (dst != base + i) memmove((void *)dst, (const void *)(base + i), (size_t)(j - i) * sizeof(vsm_p_match));
       dst += j - i;
     }
     i = j;
   }
-  out.resize((size_t)(dst - out.data()));
+  list.resize((size_t)(dst - base));
 }
 
 void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,

@@ -214,7 +214,9 @@ void vsm_host_remove_outliers(VsmHostWork &w, const vsm_params &p, std::vector<v
 // the two ends of it, for callers that run the triangulation (w.del) themselves: the per-match
 // arrays (coordinates, flow, disparity), then support counting + survivors
 void vsm_host_outliers_begin(VsmHostWork &w, const vsm_p_match *in, int32_t n, int method);
+void vsm_host_count_support(VsmHostWork &w, const vsm_params &p, int32_t n, int method);  // -> w.support, from w.del
 void vsm_host_keep_supported(const vsm_p_match *in, const int32_t *support, int32_t n, std::vector<vsm_p_match> &out);
+void vsm_host_keep_supported(std::vector<vsm_p_match> &list, const int32_t *support);  // in place
 void vsm_host_outliers_end(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,
                            std::vector<vsm_p_match> &out);
 // the same from a read-only list (e.g. the host-mapped export of the GPU) into `out`
