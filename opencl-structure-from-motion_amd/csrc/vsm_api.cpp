@@ -449,8 +449,11 @@ vsm_handle *vsm_create(const vsm_params *p) {
     // (the look-ahead caller sleeps in a blocking event wait while the GPU works, so all nt budgeted
     // CPUs go to pool workers: nt workers + the caller's thread)
     h->pool = new VsmPool(nt + 1);
-    h->fj = new VsmForkJoin(nt < 8 ? nt : 8);
+    int fjt = nt < 8 ? nt : 8;
+    if (const char *e = getenv("VSM_FJ_THREADS")) fjt = std::max(1, std::min(atoi(e), nt));
+    h->fj = new VsmForkJoin(fjt);
     h->work.pool = h->fj;
+    h->work.async = h->pool;
   }
   // k_dc_subtrees (vsm_dc.hip) recurses a few levels deep: make sure every thread has the stack for it
   {
@@ -976,6 +979,8 @@ static void dc_submit_a(DcChunk *ch) {
         vsm_host_outliers_begin(wk, wk.tmp_list.data(), nl, ch->method);
         const double t2 = vsm_now_us();
         ch->part_ns[1].fetch_add((long long)((t2 - t1) * 1e3), std::memory_order_relaxed);
+        // (the emulated vertex sort first: set apart - ExactDelaunay::prepare's defer_ties - it would let the GPU start
+        // 0.1 ms per pair earlier, but costs a radix sort on top, and this path is bound by host time, not latency)
         const bool prepared = ch->block ? wk.del.prepare(wk.x.data(), wk.y.data(), nl, VSM_DC_BLOCK_POINTS, nullptr, ch->full ? INT32_MAX : 0, ch->device_kd)
                                         : wk.del.prepare(wk.x.data(), wk.y.data(), nl, ch->leaf, nullptr, ch->top, ch->device_kd);
         ch->part_ns[2].fetch_add((long long)((vsm_now_us() - t2) * 1e3), std::memory_order_relaxed);
@@ -1455,7 +1460,8 @@ void vsm_get_kernel_stats(vsm_handle *h, double *total_ms, int64_t *launches) {
 int32_t vsm_host_delaunay(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap, int32_t threads) {
   ExactDelaunay d;
   VsmForkJoin pool(threads);
-  d.run(x, y, n, threads > 1 ? &pool : nullptr);
+  VsmPool side(2);  // with more than one thread the emulated vertex sort runs next to the triangulation (as in a handle)
+  d.run(x, y, n, threads > 1 ? &pool : nullptr, threads > 1 ? &side : nullptr);
   const int32_t nt = d.num_triangles();
   for (int32_t i = 0; i < nt && i < cap; i++)
     for (int k = 0; k < 3; k++) tris[i * 3 + k] = d.triangles()[i * 3 + k];
@@ -1465,10 +1471,13 @@ int32_t vsm_host_delaunay(const int32_t *x, const int32_t *y, int32_t n, int32_t
 int32_t vsm_host_delaunay_split(const int32_t *x, const int32_t *y, int32_t n, int32_t *tris, int32_t cap,
                                 int32_t max_task_points, int32_t device_top_points) {
   ExactDelaunay d;
-  if (d.prepare(x, y, n, max_task_points, nullptr, device_top_points)) {
+  // (device_top_points < 0: additionally with the emulated vertex sort set apart, see ExactDelaunay::prepare)
+  if (d.prepare(x, y, n, max_task_points, nullptr, std::max(device_top_points, 0), false, device_top_points < 0)) {
     d.solve_tasks();
     d.solve_merges();
     d.finish();
+    d.resolve_ties();
+    d.apply_ties();
   }
   const int32_t nt = d.num_triangles();
   for (int32_t i = 0; i < nt && i < cap; i++)

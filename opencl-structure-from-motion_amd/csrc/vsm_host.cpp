@@ -505,7 +505,7 @@ void ExactDelaunay::list_triangles() {
 }
 
 bool ExactDelaunay::prepare(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, VsmForkJoin *pool,
-                            int32_t device_top_points, bool defer_order) {
+                            int32_t device_top_points, bool defer_order, bool defer_ties) {
   ntri_out_ = 0;
   m_ = 0;
   listed_ = true;
@@ -516,6 +516,10 @@ bool ExactDelaunay::prepare(const int32_t *x, const int32_t *y, int32_t n, int32
   for (auto &lv : dev_levels_) lv.clear();
   nodes_.clear();
   seed_ = 1;  // triangleinit(), :4031
+  has_ties_ = false;
+  ties_resolved_ = true;
+  patches_.clear();
+  n_in_ = n;
   if (n < 2) return false;
   key_.resize(n);
   stop_.resize(2 * ((size_t)n / 64 + 2));
@@ -526,12 +530,32 @@ bool ExactDelaunay::prepare(const int32_t *x, const int32_t *y, int32_t n, int32
     return (long)std::chrono::duration_cast<std::chrono::nanoseconds>(v - u).count();
   };
   const auto p0 = clk();
-  vertex_sort(a, n);
+  if (defer_ties) {
+    emu_.assign(key_.begin(), key_.end());
+    // stable LSD radix sort by (x, y) (28 bits): equal points stay in input order
+    rs_.resize(n);
+    uint64_t *src = a, *dst = rs_.data();
+    for (int pass = 0; pass < 3; pass++) {
+      const int sh = 20 + pass * 10;
+      uint32_t cnt[1025] = {0};
+      for (int32_t i = 0; i < n; i++) cnt[((src[i] >> sh) & 1023) + 1]++;
+      for (int b = 0; b < 1024; b++) cnt[b + 1] += cnt[b];
+      for (int32_t i = 0; i < n; i++) dst[cnt[(src[i] >> sh) & 1023]++] = src[i];
+      std::swap(src, dst);
+    }
+    if (src != a) memcpy(a, src, (size_t)n * sizeof(uint64_t));
+  } else {
+    vertex_sort(a, n);
+  }
   const auto p1 = clk();
   int32_t m = 0;  // duplicates: the first one in sorted order survives (:6183)
   for (int32_t j = 1; j < n; j++)
     if (KXY(a[m]) != KXY(a[j])) a[++m] = a[j];
   m++;
+  if (defer_ties && m < n) {
+    has_ties_ = true;
+    ties_resolved_ = false;
+  }
   if (m < 2) return false;
   if ((size_t)m * 16 > tri_.size()) tri_.resize((size_t)m * 16);
   pt_.resize(m);
@@ -596,7 +620,44 @@ void ExactDelaunay::finish(VsmForkJoin *pool) {
   }
 }
 
-void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool) {
+void ExactDelaunay::resolve_ties() {
+  if (ties_resolved_) return;
+  seed_ = 1;  // triangleinit(), :4031
+  uint64_t *e = emu_.data();
+  const int32_t n = n_in_;
+  vertex_sort(e, n);
+  for (int32_t i = 0; i < n;) {  // of equal points the first one in this order is the vertex (:6183)
+    int32_t j = i + 1;
+    while (j < n && KXY(e[j]) == KXY(e[i])) j++;
+    if (j - i > 1) {
+      int32_t rep = (int32_t)(e[i] & 0xfffffu);
+      for (int32_t k = i + 1; k < j; k++) rep = std::min(rep, (int32_t)(e[k] & 0xfffffu));
+      const int32_t first = (int32_t)(e[i] & 0xfffffu);
+      if (rep != first) patches_.push_back(std::make_pair(rep, first));
+    }
+    i = j;
+  }
+  ties_resolved_ = true;
+}
+
+void ExactDelaunay::apply_ties() {
+  if (!ties_resolved_) resolve_ties();
+  if (patches_.empty()) return;
+  tie_bits_.assign(((size_t)n_in_ + 63) / 64, 0);
+  for (const auto &pt : patches_) tie_bits_[pt.first >> 6] |= 1ull << (pt.first & 63);
+  for (int32_t pos = 0; pos < m_; pos++) {
+    const int32_t q = id_[pos];
+    if (!((tie_bits_[q >> 6] >> (q & 63)) & 1)) continue;
+    for (const auto &pt : patches_)
+      if (pt.first == q) {
+        id_[pos] = pt.second;
+        break;
+      }
+  }
+  patches_.clear();
+}
+
+void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool, VsmPool *async) {
   static const bool dbg = getenv("VSM_DEBUG_TIMING") != nullptr;
   const int nthreads = pool ? pool->size() : 1;
   // one task (the whole array) when single-threaded, about one sub-tree per thread otherwise
@@ -606,10 +667,18 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
     while ((1 << depth) < nthreads) depth++;
     max_task = std::max(63, (n >> depth) + 1);
   }
-  if (!prepare(x, y, n, max_task, pool)) return;
+  // with somebody to take it, the emulated vertex sort runs next to the triangulation instead of in front of it
+  const bool apart = async != nullptr && async->size() > 1 && n >= 1024;
+  if (!prepare(x, y, n, max_task, pool, 0, false, apart)) return;
+  VsmPool::Ticket ties;
+  if (has_ties_) ties = async->submit(1, [this](int) { resolve_ties(); }, true);
   const auto p2 = std::chrono::steady_clock::now();
   solve_tasks(pool);
   finish(pool);
+  if (ties) {
+    async->wait(ties);
+    apply_ties();
+  }
   if (dbg && n > 3000) {
     static std::atomic<long> calls{0}, t_sort{0}, t_kd{0}, t_dc{0};
     t_sort += t_sort_;
@@ -652,28 +721,51 @@ void vsm_host_outliers_end(VsmHostWork &w, const vsm_params &p, const vsm_p_matc
 }
 
 void vsm_host_count_support(VsmHostWork &w, const vsm_params &p, int32_t n, int method) {
-  w.support.assign(n, 0);
   const float ftol = (float)p.outlier_flow_tolerance, dtol = (float)p.outlier_disp_tolerance;
   const float *fu = w.fu.data(), *fv = w.fv.data(), *dp = w.dp.data();
-  int32_t *support = w.support.data();
   const ExactDelaunay &del = w.del;
-  // (support is a plain sum over triangle edges: the slot order is as good as Triangle's output order)
-  const int32_t slots = del.num_slots();
-  for (int32_t t = 0; t < slots; t++) {
-    int32_t q[3];
-    if (!del.slot_vertices(t, q)) continue;
-    static const int E[3][2] = {{0, 1}, {1, 2}, {0, 2}};
-    for (int e = 0; e < 3; e++) {
-      const int32_t a = q[E[e][0]], b = q[E[e][1]];
-      const bool flow_ok = fabsf(fu[a] - fu[b]) + fabsf(fv[a] - fv[b]) < ftol;
-      const bool disp_ok = fabsf(dp[a] - dp[b]) < dtol;
-      const bool ok = method == 0 ? flow_ok : (method == 1 ? disp_ok : (disp_ok && flow_ok));
-      if (ok) {
-        support[a]++;
-        support[b]++;
+  // (support is a plain sum over triangle edges: the slot order is as good as Triangle's output order,
+  // and so is any split of the slots over threads - integer sums)
+  auto votes_of = [&](int32_t t0, int32_t t1, int32_t *support) {
+    for (int32_t t = t0; t < t1; t++) {
+      int32_t q[3];
+      if (!del.slot_vertices(t, q)) continue;
+      static const int E[3][2] = {{0, 1}, {1, 2}, {0, 2}};
+      for (int e = 0; e < 3; e++) {
+        const int32_t a = q[E[e][0]], b = q[E[e][1]];
+        const bool flow_ok = fabsf(fu[a] - fu[b]) + fabsf(fv[a] - fv[b]) < ftol;
+        const bool disp_ok = fabsf(dp[a] - dp[b]) < dtol;
+        const bool ok = method == 0 ? flow_ok : (method == 1 ? disp_ok : (disp_ok && flow_ok));
+        if (ok) {
+          support[a]++;
+          support[b]++;
+        }
       }
     }
+  };
+  const int32_t slots = del.num_slots();
+  const int T = w.pool ? w.pool->size() : 1;
+  if (T > 1 && n >= 2048) {  // the per-frame path: every thread counts a range of slots into its own array
+    w.support.resize(n);
+    w.support_parts.resize((size_t)T * n);
+    w.pool->run(T, [&](int k) {
+      int32_t *mine = w.support_parts.data() + (size_t)k * n;
+      memset(mine, 0, (size_t)n * sizeof(int32_t));
+      votes_of((int32_t)((int64_t)slots * k / T), (int32_t)((int64_t)slots * (k + 1) / T), mine);
+    });
+    w.pool->run(T, [&](int k) {
+      const int32_t i0 = (int32_t)((int64_t)n * k / T), i1 = (int32_t)((int64_t)n * (k + 1) / T);
+      int32_t *sum = w.support.data();
+      for (int32_t i = i0; i < i1; i++) sum[i] = w.support_parts[i];
+      for (int q = 1; q < T; q++) {
+        const int32_t *part = w.support_parts.data() + (size_t)q * n;
+        for (int32_t i = i0; i < i1; i++) sum[i] += part[i];
+      }
+    });
+    return;
   }
+  w.support.assign(n, 0);
+  votes_of(0, slots, w.support.data());
 }
 
 // survivors of the support test (support >= 4, viso/matcher.cpp:1369-1371), in list order; almost all matches
@@ -718,7 +810,7 @@ void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vs
   vsm_host_outliers_begin(w, in, n, method);
   static const bool dbg = getenv("VSM_DEBUG_TIMING") != nullptr;
   const auto c0 = std::chrono::steady_clock::now();
-  w.del.run(w.x.data(), w.y.data(), n, w.pool);
+  w.del.run(w.x.data(), w.y.data(), n, w.pool, w.async);
   const auto c1 = std::chrono::steady_clock::now();
   vsm_host_outliers_end(w, p, in, n, method, out);
   if (dbg && n > 3000) {

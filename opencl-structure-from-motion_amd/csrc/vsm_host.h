@@ -105,7 +105,8 @@ class ExactDelaunay {
  public:
   typedef DcMesh::OTri OTri;
   // points are (x[i], y[i]); after run(), triangles() lists vertex triples by input index
-  void run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool = nullptr);
+  // (async: a pool that can take the emulated vertex sort while this thread and `pool` triangulate)
+  void run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool = nullptr, VsmPool *async = nullptr);
 
   // The same in steps, so that the lower part of the tree can be triangulated elsewhere (the
   // look-ahead path hands it to the GPU, csrc/vsm_dc.hip):
@@ -127,8 +128,18 @@ class ExactDelaunay {
   };
   //   (defer_order: prepare() stops before the kd order - mesh().key stays in (x,y) order - for a
   //   solver that orders the keys itself; order_keys() does it here later if it turns out to be needed)
+  //   (defer_ties: the triangulation itself does not depend on Triangle's randomised vertex sort - the sorted
+  //   distinct points and their kd order are what they are; the sort only decides which of several matches at
+  //   the SAME pixel stands for the point, i.e. which input index a position carries.  With defer_ties the keys
+  //   are ordered by a plain radix sort, every point carries the smallest of its input indices for the time
+  //   being, and the emulated sort runs apart - resolve_ties(), safe next to kd order / sub-trees / merges, and
+  //   nothing at all if no two matches share a pixel; apply_ties() then puts the right indices in place, after
+  //   the sub-trees have been solved and before anybody reads ids)
   bool prepare(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, VsmForkJoin *pool = nullptr,
-               int32_t device_top_points = 0, bool defer_order = false);
+               int32_t device_top_points = 0, bool defer_order = false, bool defer_ties = false);
+  bool has_ties() const { return has_ties_; }
+  void resolve_ties();
+  void apply_ties();
   void order_keys(VsmForkJoin *pool = nullptr) {
     if (!ordered_) kd_order(m_, pool);
     ordered_ = true;
@@ -177,6 +188,11 @@ class ExactDelaunay {
   std::vector<uint64_t> key_;         // (x << 34) | (y << 20) | input index
   std::vector<uint64_t> stop_;        // scratch of the branch-free partition: two bit masks
   std::vector<uint64_t> sort_stack_;  // pending parts of the emulated quicksort
+  std::vector<uint64_t> emu_, rs_;    // defer_ties: the keys in input order for the emulated sort; radix scratch
+  std::vector<uint64_t> tie_bits_;
+  std::vector<std::pair<int32_t, int32_t>> patches_;  // (index a point carries, index it should carry)
+  int32_t n_in_ = 0;
+  bool has_ties_ = false, ties_resolved_ = true;
   std::vector<uint32_t> xl_, yl_, yr_, tmp_, ord_;  // kd_order(): presorted lists, y-ranks
   std::vector<uint64_t> ybuf0_, ybuf1_, k2_;
   std::vector<uint32_t> pt_;          // by sorted position: x | y << 16
@@ -202,8 +218,9 @@ class ExactDelaunay {
 };
 
 struct VsmHostWork {
+  VsmPool *async = nullptr;  // may take the emulated vertex sort of a triangulation (ExactDelaunay::run)
   ExactDelaunay del;
-  std::vector<int32_t> x, y, support;
+  std::vector<int32_t> x, y, support, support_parts;
   std::vector<float> fu, fv, dp;        // per match: flow and disparity, what the support test compares
   std::vector<vsm_p_match> tmp_list;
   VsmForkJoin *pool = nullptr;  // optional: threads for the sub-problems of one triangulation

@@ -88,6 +88,6 @@ def test_split_form_equals_whole(B):
     for p in cases:
         whole = vm.host_delaunay(p, 1)
         for leaf in (2, 3, 4, 7, 14, 56, 100000):
-            for top in (0, 4 * leaf, 100000):
+            for top in (0, 4 * leaf, 100000, -1):
                 part = vm.host_delaunay_split(p, leaf, top)
                 assert np.array_equal(canon(whole), canon(part)), (len(p), leaf, top)
