@@ -178,6 +178,13 @@ int32_t vsm_debug_delaunay_gpu(const int32_t *x, const int32_t *y, int32_t n, in
 double vsm_debug_dc_bench(const int32_t *x, const int32_t *y, int32_t n, int32_t max_task_points, int32_t device_top_points,
                           int32_t device_kd, int32_t njobs, int32_t reps);   /* kernel microseconds for njobs triangulations at once */
 
+/* test hooks: which of several matches at one pixel stands for the point in the exact Delaunay (Triangle's
+ * randomised vertex sort decides, viso/triangle.cpp:5447 + :6183): (index of the smallest-index match, index of the
+ * one the sort puts first) for every pixel where they differ - from the host emulation and from the GPU's
+ * (k_dc_ties, one wave; kernel_us may be null); return the count, -1 where the GPU declines (list too long) */
+int32_t vsm_host_ties(const int32_t *x, const int32_t *y, int32_t n, int32_t *pairs, int32_t cap);
+int32_t vsm_debug_ties_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_t *pairs, int32_t cap, double *kernel_us);
+
 /* ---- stereo visual odometry on top of the matcher ----
  * class VisualOdometryStereo, viso/viso_stereo.h:28-88 + viso/viso.h:28-131: process() =
  * pushBack + matchFeatures(2, Tr_delta if valid) + bucketFeatures + getMatches + updateMotion

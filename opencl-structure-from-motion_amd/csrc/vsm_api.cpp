@@ -287,6 +287,8 @@ struct DcBank {
   int npairs = 0, stride_pts = 0, stride_tasks = 0;
   uint64_t *d_key = nullptr, *h_key = nullptr, *d_key_sorted = nullptr;  // h_key: (x,y) order if the GPU orders them, else kd order
   uint32_t *d_kd = nullptr;  // scratch of k_dc_kd_order
+  uint64_t *d_tie_keys = nullptr;  // per pair [stride_pts]: keys of the pass-2 list in list order (k_dc_tie_keys)
+  int32_t *d_tie_n = nullptr;      // per pair: list length
   float *d_flow = nullptr, *h_flow = nullptr;          // per pair [3][stride_pts]: flow u, flow v, disparity of every match
   int32_t *d_support = nullptr, *h_support = nullptr;  // per pair [stride_pts]: support count of every match
   uint32_t *d_pt = nullptr, *h_pt = nullptr;
@@ -300,6 +302,8 @@ struct DcBank {
     (void)hipFree(d_key);
     (void)hipFree(d_key_sorted);
     (void)hipFree(d_kd);
+    (void)hipFree(d_tie_keys);
+    (void)hipFree(d_tie_n);
     (void)hipFree(d_flow);
     (void)hipFree(d_support);
     (void)hipHostFree(h_flow);
@@ -331,6 +335,7 @@ struct DcBank {
     bool ok = hipMalloc((void **)&d_key, P * 8) == hipSuccess && hipMalloc((void **)&d_key_sorted, P * 8) == hipSuccess &&
               hipMalloc((void **)&d_kd, P * 4 * VSM_DC_KD_SCRATCH) == hipSuccess && hipMalloc((void **)&d_pt, P * 4) == hipSuccess &&
               hipMalloc((void **)&d_flow, P * 12) == hipSuccess && hipMalloc((void **)&d_support, P * 4) == hipSuccess &&
+              hipMalloc((void **)&d_tie_keys, P * 8) == hipSuccess && hipMalloc((void **)&d_tie_n, (size_t)pairs * 4) == hipSuccess &&
               hipHostMalloc((void **)&h_flow, P * 12, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_support, P * 4, hipHostMallocDefault) == hipSuccess &&
               hipMalloc((void **)&d_id, P * 4) == hipSuccess && hipMalloc((void **)&d_tri, P * 64) == hipSuccess &&
@@ -363,6 +368,12 @@ struct vsm_handle {
   hipEvent_t seq_ev[2] = {nullptr, nullptr};  // look-ahead markers: features done / pass 1 done (blocking sync too)
   static constexpr int kDcBanks = 4;  // chunks whose final stage may be in flight at once
   struct DcBank *dc_bank[kDcBanks] = {nullptr, nullptr, nullptr, nullptr};  // look-ahead: GPU share of the exact Delaunay
+  hipStream_t tie_stream[2] = {nullptr, nullptr};  // the emulated vertex sorts of a chunk's pairs (k_dc_ties_of_lists), alternating
+  hipEvent_t tie_ev = nullptr;                     // pass-2 lists compacted
+  hipEvent_t tie_copied[2] = {nullptr, nullptr};   // per pair bank: its lists' keys have been copied out
+  bool tie_copied_set[2] = {false, false};
+  int32_t *hm_ties = nullptr, *d_ties = nullptr;   // host-mapped verdicts [kDcBanks][chunk][VSM_DC_TIE_OUT_INTS]
+  int ties_chunk = 0;
   hipStream_t dc_stream[2] = {nullptr, nullptr};  // alternate per chunk: one chunk's records travel while the next one's kernels run
   std::vector<VsmHostWork> seq_work;               // per pair of every Delaunay bank: state between the two host halves
   VsmCtx ring;  // streaming ring buffer: 2 frame slots, 1 pair
@@ -493,6 +504,12 @@ void vsm_destroy(vsm_handle *h) {
     }
   for (hipStream_t st : h->dc_stream)
     if (st) (void)hipStreamDestroy(st);
+  for (hipStream_t st : h->tie_stream)
+    if (st) (void)hipStreamDestroy(st);
+  if (h->tie_ev) (void)hipEventDestroy(h->tie_ev);
+  for (hipEvent_t e : h->tie_copied)
+    if (e) (void)hipEventDestroy(e);
+  if (h->hm_ties) (void)hipHostFree(h->hm_ties);
   if (h->idle_wait) (void)hipEventDestroy(h->idle_wait);
   for (hipEvent_t e : h->seq_ev)
     if (e) (void)hipEventDestroy(e);
@@ -789,10 +806,14 @@ struct DcChunk {
   bool device_kd = true;  // the GPU orders the keys (k_dc_kd_order); else ExactDelaunay::prepare does
   bool block = true;      // sub-trees of <= VSM_DC_BLOCK_POINTS points, one wave each inside LDS (k_dc_block); else leaf / top
   bool full = true;       // (with block) all merge levels and the support test on the GPU too: only the counts come back
+  bool ties_gpu = false;  // Triangle's randomised vertex sort runs on the GPU (k_dc_ties_of_lists), beside everything else
+  const int32_t *ties = nullptr;   // its verdicts, [n][VSM_DC_TIE_OUT_INTS] (host-mapped)
+  std::atomic<int> ties_done{1};
   int bank = 0, n = 0, f0 = 0, first_pair = 0, work0 = 0;
   std::shared_ptr<std::vector<char>> valid;
   std::atomic<int> a_left{0};
   int chunk = 0;           // the look-ahead chunk it belongs to
+  bool submitted = false;  // dc_submit_a() has run (caller's thread only)
   bool a_waited = false;   // (caller's thread only)
   std::atomic<int> stage{0};  // 0: A running, 1: G enqueued, 2: B submitted
   VsmPool::Ticket a, b;
@@ -851,6 +872,12 @@ static void dc_submit_b(DcChunk *ch) {
         wk.del.order_keys();
         wk.del.solve_tasks();
         wk.del.solve_merges();
+      }
+      if (ch->ties_gpu) {  // which match stands for a shared pixel: the GPU's verdict (or, where it declined, the host's)
+        while (!ch->ties_done.load(std::memory_order_acquire)) std::this_thread::yield();
+        const int32_t *row = ch->ties + (size_t)i * VSM_DC_TIE_OUT_INTS;
+        if (row[0] >= 0 && row[0] <= VSM_DC_TIE_PATCHES) wk.del.set_ties(row + 1, row[0]);
+        wk.del.apply_ties();
       }
       const double t1 = vsm_now_us();
       ch->part_ns[4].fetch_add((long long)((t1 - t0) * 1e3), std::memory_order_relaxed);
@@ -958,6 +985,7 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
 }
 
 static void dc_submit_a(DcChunk *ch) {
+  ch->submitted = true;
   ch->a_left.store(ch->n, std::memory_order_relaxed);
   ch->t_a0 = vsm_now_us();
   ch->a = ch->h->pool->submit(ch->n, [ch](int i) {
@@ -979,10 +1007,11 @@ static void dc_submit_a(DcChunk *ch) {
         vsm_host_outliers_begin(wk, wk.tmp_list.data(), nl, ch->method);
         const double t2 = vsm_now_us();
         ch->part_ns[1].fetch_add((long long)((t2 - t1) * 1e3), std::memory_order_relaxed);
-        // (the emulated vertex sort first: set apart - ExactDelaunay::prepare's defer_ties - it would let the GPU start
-        // 0.1 ms per pair earlier, but costs a radix sort on top, and this path is bound by host time, not latency)
-        const bool prepared = ch->block ? wk.del.prepare(wk.x.data(), wk.y.data(), nl, VSM_DC_BLOCK_POINTS, nullptr, ch->full ? INT32_MAX : 0, ch->device_kd)
-                                        : wk.del.prepare(wk.x.data(), wk.y.data(), nl, ch->leaf, nullptr, ch->top, ch->device_kd);
+        // (ties_gpu: the emulated vertex sort is the GPU's, ExactDelaunay::prepare's defer_ties; on the host it would only
+        // move 150 us per pair from in front of the GPU's part to beside it, and cost a radix sort on top)
+        const bool prepared = ch->block ? wk.del.prepare(wk.x.data(), wk.y.data(), nl, VSM_DC_BLOCK_POINTS, nullptr, ch->full ? INT32_MAX : 0,
+                                                         ch->device_kd, ch->ties_gpu)
+                                        : wk.del.prepare(wk.x.data(), wk.y.data(), nl, ch->leaf, nullptr, ch->top, ch->device_kd, ch->ties_gpu);
         ch->part_ns[2].fetch_add((long long)((vsm_now_us() - t2) * 1e3), std::memory_order_relaxed);
         if (prepared) {
           const int32_t m = wk.del.points(), nt = (int32_t)wk.del.tasks().size(), ng = (int32_t)wk.del.device_merges().size();
@@ -1019,6 +1048,10 @@ static void dc_submit_a(DcChunk *ch) {
 }
 
 static void dc_wait(DcChunk *ch) {  // until the chunk's final lists are in seq_matches
+  if (!ch->submitted) {  // (left early, between setting it up and submitting it: only its vertex sorts may be in flight)
+    while (!ch->ties_done.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    return;
+  }
   while (ch->stage.load(std::memory_order_acquire) < 2) std::this_thread::sleep_for(std::chrono::microseconds(50));
   ch->h->pool->wait(ch->b);
 }
@@ -1106,6 +1139,31 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   bool dc_gpu = dc_env;
   for (hipStream_t &st : h->dc_stream)
     if (dc_gpu && !st) dc_gpu = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;  // (stream priorities make no measurable difference)
+  // VSM_DC_TIES=1: Triangle's randomised vertex sort on the GPU too (k_dc_ties_of_keys, one wave per pair, started right
+  // behind the pass-2 compaction).  Exact, and it takes 150 us per pair off the host, but one wave needs 3.2 ms for a
+  // 7.4 k list (0.65 us per partition, all dependent scalar work) - longer than everything else of a chunk together, so
+  // the B stage ends up waiting for it: 13.4 ms per 200 frames against 9.0.  Off unless asked for.
+  const bool dc_ties = dc_gpu && getenv("VSM_DC_TIES") && atoi(getenv("VSM_DC_TIES")) != 0;
+  if (dc_ties) {
+    bool ok = true;
+    for (hipStream_t &st : h->tie_stream)
+      if (ok && !st) ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    if (ok && !h->tie_ev) ok = hipEventCreateWithFlags(&h->tie_ev, hipEventDisableTiming) == hipSuccess;
+    for (hipEvent_t &e : h->tie_copied)
+      if (ok && !e) ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    h->tie_copied_set[0] = h->tie_copied_set[1] = false;
+    if (ok && (!h->hm_ties || h->ties_chunk < C)) {
+      if (h->hm_ties) (void)hipHostFree(h->hm_ties);
+      h->hm_ties = nullptr;
+      ok = hipHostMalloc((void **)&h->hm_ties, (size_t)vsm_handle::kDcBanks * C * VSM_DC_TIE_OUT_INTS * sizeof(int32_t), hipHostMallocMapped) == hipSuccess &&
+           hipHostGetDevicePointer((void **)&h->d_ties, h->hm_ties, 0) == hipSuccess;
+      h->ties_chunk = C;
+    }
+    if (!ok && h->hm_ties) {
+      (void)hipHostFree(h->hm_ties);
+      h->hm_ties = nullptr;
+    }
+  }
   if (dc_gpu) {
     for (int b = 0; b < vsm_handle::kDcBanks; b++)
       if (!h->dc_bank[b]) h->dc_bank[b] = new DcBank();
@@ -1254,26 +1312,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
         tickets[q].reset();
       }
     if (vsm_debug_timing() && now_us() - tw0 > 2000) fprintf(stderr, "  chunk %d: waited %.0f us for chunk %d's final stage\n", k, now_us() - tw0, k - 2);
-    cfg.sparse = 0;
-    cfg.use_prior = p.multi_stage ? 1 : 0;
-    vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, cfg, max_nq[1]);
-    if (p.refinement > 0)
-      vsm_launch_refine(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, c.dims, method, p.refinement,
-                        max_nq[1]);
-    vsm_launch_export(h->stream, h->prof, d_pairs, n, 1, max_nq[1]);
-    const double tl2 = now_us();
-    if (!p.multi_stage && k + 1 < nchunks) {  // single pass: the next features go behind this chunk's matching
-      HIPCHK(hipEventRecord(h->seq_ev[1], h->stream));
-      HIPCHK(launch_features_of(k + 1));
-      HIPCHK(hipEventSynchronize(h->seq_ev[1]));
-    } else {
-      HIPCHK(sync_sleeping(h));
-    }
-    HIPCHK(hipGetLastError());
-    if (p.multi_stage || k + 1 >= nchunks) h->prof.resolve();
-    if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass2 launch %.0f us sync %.0f us\n", k, tl2 - ta, now_us() - tl2);
-    tg += now_us() - ta;
-    // final stage of this chunk: asynchronous, overlapped with the next chunk's GPU work
+    // the chunk's final stage is set up here already: the GPU's emulated vertex sorts start right behind the compaction
     VsmCtx *cp = &c;
     // The GPU share pays when the pool has other pairs to work on while the GPU has this chunk's (its part is
     // latency-bound): a chunk with fewer pairs than pool threads stays on the host, unless VSM_DC_GPU=1 insists
@@ -1306,6 +1345,56 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       ch->f0 = f0;
       ch->first_pair = first_pair;
       ch->work0 = ch->bank * C;
+      ch->valid = validp;
+      ch->ties_gpu = dc_ties && ch->block && !ch->full && h->hm_ties != nullptr;
+      ch->ties = h->hm_ties + (size_t)dc_b * h->ties_chunk * VSM_DC_TIE_OUT_INTS;
+    }
+    // (this pair bank's pass-2 lists are about to be rewritten: the copy of chunk k-2's keys out of them comes first)
+    if (h->tie_copied_set[bank]) HIPCHK(hipStreamWaitEvent(h->stream, h->tie_copied[bank], 0));
+    cfg.sparse = 0;
+    cfg.use_prior = p.multi_stage ? 1 : 0;
+    vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, cfg, max_nq[1]);
+    if (use_dc && chunks.back()->ties_gpu) {
+      DcChunk *ch = chunks.back().get();
+      hipStream_t ts = h->tie_stream[dc_b & 1];
+      ch->ties_done.store(0, std::memory_order_relaxed);
+      DcBank &B = *h->dc_bank[dc_b];
+      bool ok = hipEventRecord(h->tie_ev, h->stream) == hipSuccess && hipStreamWaitEvent(ts, h->tie_ev, 0) == hipSuccess;
+      if (ok) {
+        vsm_dc_launch_tie_keys(ts, d_pairs, n, max_nq[1], B.d_tie_keys, B.stride_pts, B.d_tie_n);
+        ok = hipEventRecord(h->tie_copied[bank], ts) == hipSuccess;
+        h->tie_copied_set[bank] = ok;
+      }
+      if (ok) {
+        vsm_dc_launch_ties_of_keys(ts, n, B.d_tie_keys, B.stride_pts, B.d_tie_n, h->d_ties + (size_t)dc_b * h->ties_chunk * VSM_DC_TIE_OUT_INTS,
+                                   VSM_DC_TIE_OUT_INTS);
+        ok = hipLaunchHostFunc(ts, [](void *arg) { ((DcChunk *)arg)->ties_done.store(1, std::memory_order_release); }, ch) == hipSuccess;
+      }
+      if (!ok) {  // the host does it then (in A, as without this)
+        (void)hipStreamSynchronize(ts);
+        ch->ties_gpu = false;
+        ch->ties_done.store(1, std::memory_order_relaxed);
+      }
+    }
+    if (p.refinement > 0)
+      vsm_launch_refine(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, c.dims, method, p.refinement,
+                        max_nq[1]);
+    vsm_launch_export(h->stream, h->prof, d_pairs, n, 1, max_nq[1]);
+    const double tl2 = now_us();
+    if (!p.multi_stage && k + 1 < nchunks) {  // single pass: the next features go behind this chunk's matching
+      HIPCHK(hipEventRecord(h->seq_ev[1], h->stream));
+      HIPCHK(launch_features_of(k + 1));
+      HIPCHK(hipEventSynchronize(h->seq_ev[1]));
+    } else {
+      HIPCHK(sync_sleeping(h));
+    }
+    HIPCHK(hipGetLastError());
+    if (p.multi_stage || k + 1 >= nchunks) h->prof.resolve();
+    if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass2 launch %.0f us sync %.0f us\n", k, tl2 - ta, now_us() - tl2);
+    tg += now_us() - ta;
+    // final stage of this chunk: asynchronous, overlapped with the next chunk's GPU work
+    if (use_dc) {
+      DcChunk *ch = chunks.back().get();
       ch->valid = validp;
       dc_submit_a(ch);
     } else {
@@ -1629,6 +1718,62 @@ double vsm_debug_dc_bench(const int32_t *x, const int32_t *y, int32_t n, int32_t
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return total / reps;
+}
+
+// test hooks: which matches at shared pixels stand for their points, (index the radix-sorted keys carry, index
+// Triangle's randomised vertex sort puts first) pairs - from the host emulation and from k_dc_ties; -1: not done
+int32_t vsm_host_ties(const int32_t *x, const int32_t *y, int32_t n, int32_t *pairs, int32_t cap) {
+  ExactDelaunay d;
+  d.prepare(x, y, n, n, nullptr, 0, true, true);
+  d.resolve_ties();
+  const auto &t = d.ties();
+  for (size_t k = 0; k < t.size() && (int32_t)k < cap; k++) {
+    pairs[2 * k] = t[k].first;
+    pairs[2 * k + 1] = t[k].second;
+  }
+  return (int32_t)t.size();
+}
+
+int32_t vsm_debug_ties_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_t *pairs, int32_t cap, double *kernel_us) {
+  ExactDelaunay d;
+  d.prepare(x, y, n, n, nullptr, 0, true, true);
+  VsmDcJob job;
+  memset(&job, 0, sizeof(job));
+  VsmDcJob *d_job = nullptr;
+  uint64_t *d_keys = nullptr;
+  int32_t *d_out = nullptr;
+  std::vector<int32_t> out(1 + 2 * VSM_DC_TIE_PATCHES, 0);
+  if (hipMalloc((void **)&d_keys, (size_t)std::max(n, 1) * 8) != hipSuccess || hipMalloc((void **)&d_out, out.size() * 4) != hipSuccess ||
+      hipMalloc((void **)&d_job, sizeof(job)) != hipSuccess)
+    return -2;
+  (void)hipMemcpy(d_keys, d.tie_keys(), (size_t)n * 8, hipMemcpyHostToDevice);
+  (void)hipMemset(d_out, 0, out.size() * 4);
+  job.tie_keys = d_keys;
+  job.tie_out = d_out;
+  job.n_in = n;
+  (void)hipMemcpy(d_job, &job, sizeof(job), hipMemcpyHostToDevice);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, nullptr);
+  vsm_dc_launch_ties(nullptr, d_job, 1);
+  (void)hipEventRecord(e1, nullptr);
+  const bool ok = hipDeviceSynchronize() == hipSuccess;
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  if (kernel_us) *kernel_us = ms * 1e3;
+  (void)hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d_keys);
+  (void)hipFree(d_out);
+  (void)hipFree(d_job);
+  if (!ok) return -2;
+  for (int32_t k = 0; k < out[0] && k < cap; k++) {
+    pairs[2 * k] = out[1 + 2 * k];
+    pairs[2 * k + 1] = out[2 + 2 * k];
+  }
+  return out[0];
 }
 
 void vsm_get_counters(vsm_handle *h, int64_t *out5) { memcpy(out5, h->counters, sizeof(h->counters)); }

@@ -12,8 +12,11 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <algorithm>
+
 #include "vsm_dc_gpu.h"
 #include "vsm_dc_mesh.h"
+#include "vsm_internal.h"
 
 // ---------------------------------------------------------------------------------------
 // kd order (ExactDelaunay::kd_order, vsm_host.cpp; Triangle's alternateaxes, viso/triangle.cpp:5583):
@@ -337,6 +340,334 @@ void vsm_dc_launch_blocks(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int 
   hipLaunchKernelGGL(k_dc_block, dim3(max_tasks, njobs), dim3(64), 0, s, d_jobs, njobs);
 }
 
+// ---------------------------------------------------------------------------------------
+// Triangle's vertexsort (viso/triangle.cpp:5447; host form: ExactDelaunay::vertex_sort) on one wave.
+// The triangulation does not depend on it (ExactDelaunay::prepare, defer_ties) - only which of several
+// matches at one pixel stands for the point does - but it is the largest piece of host time per frame pair
+// and strictly serial: ~4900 partitions, each needing the random number after the previous one's.  A wave
+// does it in LDS with the same decisions: the Hoare partition from two ballot masks (left scan stops at
+// keys >= pivot, right scan at keys <= pivot), sub-arrays of <= 64 elements entirely in registers (one
+// element per lane, pivot by readlane, swaps by writelane) together with everything below them in the
+// recursion, larger ones through stopper lists in LDS whose swaps are independent and run one per lane.
+// ---------------------------------------------------------------------------------------
+#define TIE_STACK 2048
+
+__device__ inline uint32_t tie_rnd(uint32_t &seed, uint32_t choices) {  // randomnation, :4046
+  seed = (seed * 1366u + 150889u) % 714025u;
+  const uint32_t d = 714025u / choices + 1;
+  uint32_t q = (uint32_t)((float)seed * (1.0f / (float)d));  // seed < 2^20: off by one at most
+  if (q * d > seed) q--;
+  if ((q + 1) * d <= seed) q++;
+  return q;
+}
+// the same with the divisor and its reciprocal looked up (lane c of the two table registers holds them for c choices)
+__device__ inline uint32_t tie_rnd_small(uint32_t &seed, int choices, uint32_t dtab, float rtab) {
+  seed = (seed * 1366u + 150889u) % 714025u;
+  const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)dtab, choices);
+  const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rtab), choices));
+  uint32_t q = (uint32_t)((float)seed * r);
+  if (q * d > seed) q--;
+  if ((q + 1) * d <= seed) q++;
+  return q;
+}
+
+__device__ inline uint32_t tie_readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ inline uint32_t tie_writelane(uint32_t val, int lane, uint32_t old) {  // (no writelane builtin in this compiler)
+  return (int)threadIdx.x == lane ? val : old;
+}
+
+// Hoare loop of the reference on two masks over positions 0..n-1 of one 64-bit word (n <= 64): calls swap(l, r)
+// for every exchanged pair, returns the final (left, right)
+template <typename Swap>
+__device__ inline void tie_hoare64(uint64_t GE, uint64_t LE, int n, int &left, int &right, Swap swap) {
+  left = -1;
+  right = n;
+  for (;;) {
+    const uint64_t above = left + 1 >= 64 ? 0ull : (~0ull << (left + 1));
+    const uint64_t g = GE & above;
+    int l = g ? __builtin_ctzll(g) : 64;
+    if (l > right) l = right;
+    if (l == right) {
+      left = l;
+      right = l - 1;
+      return;
+    }
+    const uint64_t below = right >= 64 ? ~0ull : ((1ull << right) - 1);
+    const uint64_t e = LE & below;
+    int r = e ? 63 - __builtin_clzll(e) : -1;
+    if (r <= l) r = ((LE >> l) & 1) ? l : l - 1;
+    left = l;
+    right = r;
+    if (l >= r) return;
+    swap(l, r);
+  }
+}
+
+// the keys of a match list as ExactDelaunay packs them (x, y = u1c, v1c truncated, vsm_host_outliers_begin)
+struct TieFromKeys {
+  const uint64_t *keys;
+  __device__ inline uint32_t kxy(int i) const { return (uint32_t)(keys[i] >> 20); }
+  __device__ inline uint32_t idx(int i) const { return (uint32_t)(keys[i] & 0xfffffu); }
+};
+
+template <typename Src>
+__device__ inline void tie_sort(const Src src, const int n0, int32_t *__restrict__ tie_out) {
+  __shared__ uint32_t s_k[VSM_DC_TIE_POINTS], s_i[VSM_DC_TIE_POINTS];
+  __shared__ uint16_t s_L[VSM_DC_TIE_POINTS], s_R[VSM_DC_TIE_POINTS];
+  __shared__ uint64_t s_ge[VSM_DC_TIE_POINTS / 64], s_le[VSM_DC_TIE_POINTS / 64];
+  __shared__ uint32_t s_stack[TIE_STACK * 2];
+  const int lane = threadIdx.x;
+  if (n0 > VSM_DC_TIE_POINTS) {
+    if (lane == 0) tie_out[0] = -1;
+    return;
+  }
+  for (int i = lane; i < n0; i += 64) {
+    s_k[i] = src.kxy(i);
+    s_i[i] = src.idx(i);
+  }
+  __syncthreads();
+  uint32_t seed = 1;  // triangleinit(), :4031
+  const uint32_t dtab = lane > 0 ? 714025u / (uint32_t)lane + 1 : 1u;  // randomnation's divisor for `lane` choices
+  const float rtab = 1.0f / (float)dtab;
+  int sp = 0;
+  bool overflow = false;
+  auto push = [&](int off, int n) {
+    if (sp >= TIE_STACK) {
+      overflow = true;
+      return;
+    }
+    if (lane == 0) {
+      s_stack[2 * sp] = (uint32_t)off;
+      s_stack[2 * sp + 1] = (uint32_t)n;
+    }
+    sp++;
+  };
+  // two elements: vertexsort's n == 2 case, no random number
+  auto settle_pair_lds = [&](int at) {
+    if (lane == 0) {
+      const uint32_t a = s_k[at], b = s_k[at + 1];
+      if (a > b) {
+        s_k[at] = b;
+        s_k[at + 1] = a;
+        const uint32_t t = s_i[at];
+        s_i[at] = s_i[at + 1];
+        s_i[at + 1] = t;
+      }
+    }
+  };
+  if (n0 == 2) settle_pair_lds(0);
+  if (n0 > 2) push(0, n0);
+  __syncthreads();
+  while (sp > 0 && !overflow) {
+    sp--;
+    const int off = (int)__builtin_amdgcn_readfirstlane((int)s_stack[2 * sp]);
+    const int n = (int)__builtin_amdgcn_readfirstlane((int)s_stack[2 * sp + 1]);
+    if (n <= 64) {
+      // ---- this part and all parts below it: in registers, lane = position - off; the pending parts too
+      // (lane j of `stk` holds entry j: lo | m << 8) ----
+      uint32_t k = lane < n ? s_k[off + lane] : 0, ix = lane < n ? s_i[off + lane] : 0, stk = 0;
+      int lsp = 0;
+      int lo = 0, m = n;  // current part: lanes [lo, lo + m)
+      for (;;) {
+        const int pl = lo + (int)(m < 64 ? tie_rnd_small(seed, m, dtab, rtab) : tie_rnd(seed, 64u));
+        const uint32_t pv = tie_readlane(k, pl);
+        const bool in = lane >= lo && lane < lo + m;
+        const uint64_t GE = __ballot(in && k >= pv) >> lo, LE = __ballot(in && k <= pv) >> lo;
+        int left, right;
+        tie_hoare64(GE, LE, m, left, right, [&](int l, int r) {
+          const uint32_t ka = tie_readlane(k, lo + l), kb = tie_readlane(k, lo + r);
+          const uint32_t ia = tie_readlane(ix, lo + l), ib = tie_readlane(ix, lo + r);
+          k = tie_writelane(kb, lo + l, k);
+          k = tie_writelane(ka, lo + r, k);
+          ix = tie_writelane(ib, lo + l, ix);
+          ix = tie_writelane(ia, lo + r, ix);
+        });
+        const int rn = m - right - 1, ro = lo + right + 1;
+        auto settle_pair = [&](int at) {
+          const uint32_t ka = tie_readlane(k, at), kb = tie_readlane(k, at + 1);
+          if (ka > kb) {
+            const uint32_t ia = tie_readlane(ix, at), ib = tie_readlane(ix, at + 1);
+            k = tie_writelane(kb, at, k);
+            k = tie_writelane(ka, at + 1, k);
+            ix = tie_writelane(ib, at, ix);
+            ix = tie_writelane(ia, at + 1, ix);
+          }
+        };
+        if (left == 2) settle_pair(lo);
+        if (rn == 2) settle_pair(ro);
+        // depth first, left part first: the right one waits (at most one pending part per level, < 64 levels)
+        if (rn > 2) {
+          stk = tie_writelane((uint32_t)ro | ((uint32_t)rn << 8), lsp, stk);
+          lsp++;
+        }
+        if (left > 2) {
+          m = left;  // lo stays
+          continue;
+        }
+        if (lsp > 0) {
+          lsp--;
+          const uint32_t e = tie_readlane(stk, lsp);
+          lo = (int)(e & 0xffu);
+          m = (int)(e >> 8);
+          continue;
+        }
+        break;
+      }
+      if (lane < n) {
+        s_k[off + lane] = k;
+        s_i[off + lane] = ix;
+      }
+      continue;
+    }
+    // ---- a part of more than 64 elements: masks and stopper lists in LDS ----
+    const uint32_t pv = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_k[off + (int)tie_rnd(seed, (uint32_t)n)]);
+    const int nw = (n + 63) >> 6;
+    int nl = 0;
+    for (int w = 0; w < nw; w++) {  // left stoppers, ascending
+      const int p = w * 64 + lane;
+      const bool ge = p < n && s_k[off + p] >= pv, le = p < n && s_k[off + p] <= pv;
+      const uint64_t bg = __ballot(ge), bl = __ballot(le);
+      if (ge) s_L[nl + __builtin_popcountll(bg & ((1ull << lane) - 1))] = (uint16_t)p;
+      if (lane == 0) {
+        s_ge[w] = bg;
+        s_le[w] = bl;
+      }
+      nl += __builtin_popcountll(bg);
+    }
+    int nr = 0;
+    for (int w = nw - 1; w >= 0; w--) {  // right stoppers, descending
+      const int p = w * 64 + lane;
+      const bool le = p < n && s_k[off + p] <= pv;
+      const uint64_t bl = __ballot(le);
+      if (le) s_R[nr + __builtin_popcountll(bl & ~((2ull << lane) - 1))] = (uint16_t)p;
+      nr += __builtin_popcountll(bl);
+    }
+    __syncthreads();
+    // the reference swaps (L[t], R[t]) while L[t] < R[t]; L ascends and R descends, so that is a prefix
+    const int lim = nl < nr ? nl : nr;
+    int K = 0;
+    for (int t0 = 0; t0 < lim; t0 += 64) {
+      const int t = t0 + lane;
+      const bool go = t < lim && s_L[t] < s_R[t];
+      const uint64_t b = __ballot(go);
+      if (go) {
+        const int a = off + s_L[t], c = off + s_R[t];
+        const uint32_t ka = s_k[a], ia = s_i[a];
+        s_k[a] = s_k[c];
+        s_i[a] = s_i[c];
+        s_k[c] = ka;
+        s_i[c] = ia;
+      }
+      K += __builtin_popcountll(b);
+      if (b != ~0ull) break;
+    }
+    __syncthreads();
+    // the scans after the last swap (no further swap can follow): on the masks, which still describe everything
+    // strictly between the two positions
+    int left = K > 0 ? (int)__builtin_amdgcn_readfirstlane((int)s_L[K - 1]) : -1;
+    int right = K > 0 ? (int)__builtin_amdgcn_readfirstlane((int)s_R[K - 1]) : n;
+    {
+      int l = n;  // first GE bit at a position > left
+      for (int p = left + 1; p < n;) {
+        const uint64_t word = s_ge[p >> 6] & (~0ull << (p & 63));
+        if (word) {
+          l = (p & ~63) + __builtin_ctzll(word);
+          break;
+        }
+        p = (p & ~63) + 64;
+      }
+      if (l > right) l = right;
+      if (l == right) {
+        left = l;
+        right = l - 1;
+      } else {
+        int r = -1;  // last LE bit at a position < right
+        for (int p = right - 1; p >= 0;) {
+          const uint64_t word = s_le[p >> 6] & (~0ull >> (63 - (p & 63)));
+          if (word) {
+            r = (p & ~63) + 63 - __builtin_clzll(word);
+            break;
+          }
+          p = (p & ~63) - 1;
+        }
+        if (r <= l) r = ((s_le[l >> 6] >> (l & 63)) & 1) ? l : l - 1;
+        left = l;
+        right = r;
+        // (l < r here would be one more swap: cannot happen, (L[K], R[K]) was the next candidate pair and failed)
+      }
+    }
+    const int rn = n - right - 1;
+    if (left == 2) settle_pair_lds(off);
+    if (rn == 2) settle_pair_lds(off + right + 1);
+    __syncthreads();
+    if (rn > 2) push(off + right + 1, rn);
+    if (left > 2) push(off, left);
+    __syncthreads();
+  }
+  __syncthreads();
+  if (overflow) {
+    if (lane == 0) tie_out[0] = -1;
+    return;
+  }
+  // of equal points the first one in this order is the vertex (:6183); the triangulation carries the smallest index
+  int np = 0;
+  for (int i0 = 0; i0 < n0 && np <= VSM_DC_TIE_PATCHES; i0 += 64) {
+    const int i = i0 + lane;
+    const bool start = i < n0 && (i == 0 || s_k[i - 1] != s_k[i]) && i + 1 < n0 && s_k[i + 1] == s_k[i];
+    uint64_t b = __ballot(start);
+    while (b && np <= VSM_DC_TIE_PATCHES) {
+      const int j = i0 + __builtin_ctzll(b);
+      b &= b - 1;
+      if (lane == 0) {
+        const uint32_t key = s_k[j];
+        uint32_t rep = s_i[j];
+        for (int q = j + 1; q < n0 && s_k[q] == key; q++) rep = min(rep, s_i[q]);
+        if (rep != s_i[j] && np < VSM_DC_TIE_PATCHES) {
+          tie_out[1 + 2 * np] = (int32_t)rep;
+          tie_out[2 + 2 * np] = (int32_t)s_i[j];
+        }
+        s_stack[0] = rep != s_i[j];
+      }
+      __syncthreads();
+      np += (int)__builtin_amdgcn_readfirstlane((int)s_stack[0]);
+      __syncthreads();
+    }
+  }
+  if (lane == 0) tie_out[0] = np > VSM_DC_TIE_PATCHES ? -1 : np;
+}
+
+__global__ void __launch_bounds__(64) k_dc_ties(const VsmDcJob *__restrict__ jobs, int njobs) {
+  const VsmDcJob jb = jobs[blockIdx.x];
+  if (!jb.tie_keys || !jb.tie_out) return;
+  tie_sort(TieFromKeys{jb.tie_keys}, jb.n_in, jb.tie_out);
+}
+
+// The same for the pairs of a look-ahead chunk, as soon as their compacted pass-2 lists exist (refinement does
+// not move u1c, v1c).  Two kernels: the keys are copied out of the pair buffers first (those are overwritten two
+// chunks later, the caller orders that behind this copy), then one wave per pair sorts its private copy.
+__global__ void __launch_bounds__(256) k_dc_tie_keys(const VsmPair *__restrict__ pairs, int npairs, uint64_t *__restrict__ keys, int stride,
+                                                     int32_t *__restrict__ counts) {
+  const VsmPair pr = pairs[blockIdx.y];
+  const int n = pr.count[1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[blockIdx.y] = n;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && i < stride) {
+    const vsm_p_match a = pr.list2[i];
+    keys[(size_t)blockIdx.y * stride + i] = ((uint64_t)(uint32_t)(int32_t)a.u1c << 34) | ((uint64_t)(uint32_t)(int32_t)a.v1c << 20) | (uint32_t)i;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_dc_ties_of_keys(const uint64_t *__restrict__ keys, int stride, const int32_t *__restrict__ counts,
+                                                        int32_t *__restrict__ tie_out, int out_stride) {
+  int32_t *out = tie_out + (size_t)blockIdx.x * out_stride;
+  const int n = counts[blockIdx.x];
+  if (n < 2 || n > stride) {
+    if (threadIdx.x == 0) out[0] = n < 2 ? 0 : -1;
+    return;
+  }
+  tie_sort(TieFromKeys{keys + (size_t)blockIdx.x * stride}, n, out);
+}
+
 // The support test of removeOutliers (viso/matcher.cpp:1266-1364; vsm_host_outliers_end is the host form):
 // every triangle gives each of its three edges a vote for both end points if the two matches agree in flow
 // and / or disparity.  Differences, absolute values, one sum and a compare in float: the same values on
@@ -376,4 +707,19 @@ void vsm_dc_launch_support(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int
                            float disp_tol) {
   if (njobs <= 0 || max_points <= 0) return;
   hipLaunchKernelGGL(k_dc_support, dim3((2 * max_points + 255) / 256, njobs), dim3(256), 0, s, d_jobs, njobs, method, flow_tol, disp_tol);
+}
+
+void vsm_dc_launch_ties(hipStream_t s, const VsmDcJob *d_jobs, int njobs) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(k_dc_ties, dim3(njobs), dim3(64), 0, s, d_jobs, njobs);
+}
+
+void vsm_dc_launch_tie_keys(hipStream_t s, const VsmPair *d_pairs, int npairs, int max_list, uint64_t *keys, int stride, int32_t *counts) {
+  if (npairs <= 0) return;
+  hipLaunchKernelGGL(k_dc_tie_keys, dim3((std::max(max_list, 1) + 255) / 256, npairs), dim3(256), 0, s, d_pairs, npairs, keys, stride, counts);
+}
+void vsm_dc_launch_ties_of_keys(hipStream_t s, int npairs, const uint64_t *keys, int stride, const int32_t *counts, int32_t *tie_out,
+                                int out_stride) {
+  if (npairs <= 0) return;
+  hipLaunchKernelGGL(k_dc_ties_of_keys, dim3(npairs), dim3(64), 0, s, keys, stride, counts, tie_out, out_stride);
 }

@@ -34,7 +34,13 @@ struct VsmDcJob {  // one triangulation; all pointers are device pointers
   const float *flow_u, *flow_v, *disp;  // [n_in] u1c-u1p, v1c-v1p, disparity (vsm_host_outliers_begin)
   int32_t *support;                     // [n_in] out
   int32_t n_in, pad2_;
+  // Triangle's randomised vertex sort, emulated on the device (k_dc_ties): which match stands for a pixel that
+  // several matches share
+  const uint64_t *tie_keys;  // [n_in] packed keys in input order, or null
+  int32_t *tie_out;          // [1 + 2 * VSM_DC_TIE_PATCHES]: count (-1: not done here), then (index carried, index it should be)
 };
+#define VSM_DC_TIE_POINTS 8192   // lists up to this length are sorted inside LDS
+#define VSM_DC_TIE_PATCHES 255
 
 // kd order of the jobs that bring key_sorted: one workgroup per job (ExactDelaunay::kd_order on the device)
 void vsm_dc_launch_kd_order(hipStream_t s, const VsmDcJob *d_jobs, int njobs);
@@ -48,5 +54,14 @@ void vsm_dc_launch_blocks(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int 
 // thread per slot, blockIdx.y = job; max_points >= every job's m.  method: 0 flow, 1 stereo, 2 quad
 void vsm_dc_launch_support(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int max_points, int method, float flow_tol,
                            float disp_tol);
+// one wave per job: the emulated vertex sort of the jobs that bring tie_keys
+void vsm_dc_launch_ties(hipStream_t s, const VsmDcJob *d_jobs, int njobs);
+// ... for the pairs of a chunk: the keys of their compacted pass-2 lists into keys[pair * stride ..] (lengths into
+// counts), then one wave per pair on that copy; tie_out (device-visible) + pair * out_stride gets the verdict
+struct VsmPair;
+void vsm_dc_launch_tie_keys(hipStream_t s, const VsmPair *d_pairs, int npairs, int max_list, uint64_t *keys, int stride, int32_t *counts);
+void vsm_dc_launch_ties_of_keys(hipStream_t s, int npairs, const uint64_t *keys, int stride, const int32_t *counts, int32_t *tie_out,
+                                int out_stride);
+#define VSM_DC_TIE_OUT_INTS 512
 // one thread per merge node of level `level`; max_nodes >= every job's node count on that level
 void vsm_dc_launch_merge_level(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int level, int max_nodes);

@@ -140,6 +140,15 @@ class ExactDelaunay {
   bool has_ties() const { return has_ties_; }
   void resolve_ties();
   void apply_ties();
+  // for a solver that runs the emulated sort elsewhere (k_dc_ties): the keys in input order, and its verdict
+  const uint64_t *tie_keys() const { return emu_.data(); }
+  int32_t tie_count() const { return n_in_; }
+  void set_ties(const int32_t *pairs, int32_t count) {  // (index a point carries, index it should carry) x count
+    patches_.clear();
+    for (int32_t k = 0; k < count; k++) patches_.push_back(std::make_pair(pairs[2 * k], pairs[2 * k + 1]));
+    ties_resolved_ = true;
+  }
+  const std::vector<std::pair<int32_t, int32_t>> &ties() const { return patches_; }
   void order_keys(VsmForkJoin *pool = nullptr) {
     if (!ordered_) kd_order(m_, pool);
     ordered_ = true;

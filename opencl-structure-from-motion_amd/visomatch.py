@@ -28,7 +28,7 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_num_features", "vsm_get_features", "vsm_set_stage_capture", "vsm_stage_size", "vsm_stage_get",
            "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
            "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
-           "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
+           "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
            "vsm_sequence_get_timings", "vsm_version",
            "vsm_vo_stereo_default_params", "vsm_vo_stereo_create", "vsm_vo_stereo_destroy", "vsm_vo_stereo_process",
            "vsm_vo_stereo_process_device", "vsm_vo_stereo_process_matches", "vsm_vo_stereo_get_motion",
@@ -118,6 +118,8 @@ def lib():
         L.vsm_debug_delaunay_gpu.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32]
         L.vsm_debug_dc_bench.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32]
         L.vsm_debug_dc_bench.restype = C.c_double
+        L.vsm_host_ties.argtypes = [vp, vp, i32, vp, i32]
+        L.vsm_debug_ties_gpu.argtypes = [vp, vp, i32, vp, i32, vp]
         L.vsm_sequence_run.argtypes = [vp, vp, vp, C.c_int64, C.c_int, i32, i32, i32, i32, i32, vp, vp]
         L.vsm_sequence_num_matches.argtypes = [vp, i32]
         L.vsm_sequence_get_matches.argtypes = [vp, i32, vp, i32]
@@ -274,6 +276,26 @@ def delaunay_gpu_split(pts, max_task_points, device_top_points=0, device_kd=Fals
     if k < 0:
         raise VisoMatchError("vsm_debug_delaunay_gpu: HIP error")
     return tris[:k]
+
+
+def ties(pts, gpu=False):
+    """which matches at shared pixels stand for their points: sorted (carried index, right index) pairs where they
+    differ, from the host emulation of Triangle's vertex sort or from the GPU's; (pairs, kernel microseconds)"""
+    pts = np.asarray(pts).reshape(-1, 2)
+    x = np.ascontiguousarray(pts[:, 0], dtype=np.int32)
+    y = np.ascontiguousarray(pts[:, 1], dtype=np.int32)
+    cap = 4096
+    out = np.zeros((cap, 2), dtype=np.int32)
+    us = C.c_double(0)
+    if gpu:
+        k = lib().vsm_debug_ties_gpu(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), len(x), out.ctypes.data_as(C.c_void_p), cap,
+                                     C.byref(us))
+    else:
+        k = lib().vsm_host_ties(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), len(x), out.ctypes.data_as(C.c_void_p), cap)
+    if k < 0:
+        return None, us.value
+    o = out[:k]
+    return o[np.lexsort(o.T[::-1])], us.value
 
 
 def default_params():

@@ -228,7 +228,7 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
     m.close()
 
 
-@pytest.mark.parametrize("env", [{"VSM_DC_GPU": "0"}, {"VSM_DC_FULL": "1"}, {"VSM_DC_FULL": "0"}, {"VSM_DC_FULL": "1", "VSM_DC_KD": "0"},
+@pytest.mark.parametrize("env", [{"VSM_DC_GPU": "0"}, {"VSM_DC_FULL": "1"}, {"VSM_DC_FULL": "0"}, {"VSM_DC_FULL": "0", "VSM_DC_TIES": "1"}, {"VSM_DC_FULL": "1", "VSM_DC_KD": "0"},
                                  {"VSM_DC_BLOCK": "0"}, {"VSM_DC_BLOCK": "0", "VSM_DC_KD": "0"},
                                  {"VSM_DC_KD": "0"}, {"VSM_DC_BLOCK": "0", "VSM_DC_LEAF": "64", "VSM_DC_TOP": "0"},
                                  {"VSM_DC_BLOCK": "0", "VSM_DC_LEAF": "5", "VSM_DC_TOP": "100000"}])
@@ -517,6 +517,28 @@ def test_randomised_configurations_vs_oracle(vm, B, synth, seed):
                 assert _same(g.stage(s), c.stage(s)), (case, w, h, params, method, f, s)
         g.close()
         c.close()
+
+
+def test_emulated_vertex_sort_on_gpu(vm):
+    """k_dc_ties (Triangle's randomised vertex sort on one wave, in LDS) names the same match for every shared pixel
+    as the host emulation: sizes around the 64-lane boundary, heavy duplication, all points equal"""
+    rs = np.random.RandomState(7)
+    cases = []
+    for n in (2, 3, 5, 8, 33, 63, 64, 65, 66, 129, 500, 2048, 7400, 8192):
+        for span in (2, 30, 400):
+            cases.append(np.stack([rs.randint(0, span * 2 + 1, n) * 2, rs.randint(0, span + 1, n) * 2], 1))
+    g = np.stack(np.meshgrid(np.arange(0, 60, 2), np.arange(0, 40, 2)), -1).reshape(-1, 2)
+    cases += [np.concatenate([g, g[::3]]), np.zeros((70, 2), dtype=np.int64)]
+    checked = 0
+    for p in cases:
+        host, _ = vm.ties(p, gpu=False)
+        dev, _ = vm.ties(p, gpu=True)
+        if dev is None:          # more shared pixels than the kernel reports (255): it declines, the host decides
+            assert len(host) > 255, len(p)
+            continue
+        assert np.array_equal(host, dev), len(p)
+        checked += 1
+    assert checked > 30
 
 
 def test_delaunay_subtrees_on_gpu(vm):
