@@ -364,7 +364,7 @@ struct vsm_handle {
   vsm_params param;  // match_radius already halved for half_resolution (viso/matcher.cpp:59-60)
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t idle_wait = nullptr;  // blocking-sync event: the look-ahead caller yields its CPU to the host pool
+  hipEvent_t idle_wait = nullptr;  // blocking-sync event (pass 2 of a chunk done): the look-ahead caller sleeps on it, its CPU goes to the host pool
   hipEvent_t seq_ev[2] = {nullptr, nullptr};  // look-ahead markers: features done / pass 1 done (blocking sync too)
   static constexpr int kDcBanks = 4;  // chunks whose final stage may be in flight at once
   struct DcBank *dc_bank[kDcBanks] = {nullptr, nullptr, nullptr, nullptr};  // look-ahead: GPU share of the exact Delaunay
@@ -1056,14 +1056,6 @@ static void dc_wait(DcChunk *ch) {  // until the chunk's final lists are in seq_
   ch->h->pool->wait(ch->b);
 }
 
-// stream sync that puts the calling thread to sleep (the per-frame path keeps the spinning
-// hipStreamSynchronize: there a wake-up latency of tens of microseconds matters, here the CPU does)
-static hipError_t sync_sleeping(vsm_handle *h) {
-  hipError_t e = hipEventRecord(h->idle_wait, h->stream);
-  if (e != hipSuccess) return e;
-  return hipEventSynchronize(h->idle_wait);
-}
-
 // ---------------------------------------------------------------------------------------
 // Look-ahead sequence API.  Semantics: exactly pushBack(frame f) + matchFeatures(method, Tr[f])
 // for f = 0..n-1 on a fresh matcher.  Frames are processed in chunks of C: every kernel runs once
@@ -1203,23 +1195,40 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
                         p.multi_stage, p.half_resolution, p.match_binsize, c.h_imgs.data());
     return hipEventRecord(h->seq_ev[0], h->stream);
   };
-  HIPCHK(launch_features_of(0));
-  for (int32_t f0 = 0, k = 0; f0 < n_frames; f0 += C, k++) {
-    const int n = std::min<int32_t>(C, n_frames - f0);
-    const int bank = k & 1, first_img = 2 * (k % 3) * C, first_pair = bank * C;
+  // what a chunk needs from one step to the next
+  struct SeqChunk {
+    int32_t f0 = 0;
+    int n = 0, bank = 0, first_img = 0, first_pair = 0;
+    int max_nq[2] = {0, 0};
+    std::shared_ptr<std::vector<char>> validp;
+  };
+  std::vector<SeqChunk> sc(nchunks);
+  // First step of chunk k: wait for its features, one job per frame, pass 1 (if there is one) and its export, then the
+  // features of chunk k+1.  For k > 0 this is issued right behind pass 2 of chunk k-1 - before the caller waits for that
+  // pass - so the GPU goes from one chunk into the next without the caller in between.
+  auto start_chunk = [&](int k) -> int {
+    SeqChunk &q = sc[k];
+    q.f0 = k * C;
+    q.n = std::min<int32_t>(C, n_frames - q.f0);
+    q.bank = k & 1;
+    q.first_img = 2 * (k % 3) * C;
+    q.first_pair = q.bank * C;
+    const int32_t f0 = q.f0;
+    const int n = q.n, first_img = q.first_img, first_pair = q.first_pair;
     const VsmPair *d_pairs = c.d_pairs + first_pair;
-    double ta = now_us();
-    const double tl0 = ta;
+    VsmJob *h_jobs = c.h_jobs + first_pair, *d_jobs = c.d_jobs + first_pair;
+    int *max_nq = q.max_nq;
+    const double tl0 = now_us();
     HIPCHK(hipEventSynchronize(h->seq_ev[0]));  // the chunk's feature counts are in host-mapped memory
     HIPCHK(hipGetLastError());
     if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: feature wait %.0f us\n", k, now_us() - tl0);
     // ---- one job per frame of the chunk ----
-    int max_nq[2] = {0, 0};
-    std::shared_ptr<std::vector<char>> validp = std::make_shared<std::vector<char>>(n, 0);
-    std::vector<char> &valid = *validp;
+    max_nq[0] = max_nq[1] = 0;
+    q.validp = std::make_shared<std::vector<char>>(n, 0);
+    std::vector<char> &valid = *q.validp;
     for (int i = 0; i < n; i++) {
       const int32_t f = f0 + i;
-      VsmJob &jb = c.h_jobs[i];
+      VsmJob &jb = h_jobs[i];
       memset(&jb, 0, sizeof(jb));
       const int img_c = first_img + 2 * i;
       int img_p;
@@ -1263,17 +1272,39 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       nprev[0][s] = c.hm_counts[(first_img + 2 * (n - 1)) * 2 + s];
       nprev[1][s] = c.hm_counts[(first_img + 2 * (n - 1) + 1) * 2 + s];
     }
-    HIPCHK(hipMemcpyAsync(c.d_jobs, c.h_jobs, sizeof(VsmJob) * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_jobs, h_jobs, sizeof(VsmJob) * n, hipMemcpyHostToDevice, h->stream));
+    if (p.multi_stage) {
+      VsmMatchCfg cfg = make_cfg(p, method);
+      VsmJob dummy;
+      memset(&dummy, 0, sizeof(dummy));
+      cfg.sparse = 1;
+      cfg.use_prior = 0;
+      vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, d_jobs, dummy, n, c.dims, cfg, max_nq[0]);
+      vsm_launch_export(h->stream, h->prof, d_pairs, n, 0, max_nq[0]);
+      HIPCHK(hipEventRecord(h->seq_ev[1], h->stream));
+    }
+    if (k + 1 < nchunks) HIPCHK(launch_features_of(k + 1));  // the GPU's work while the pool has the prior statistics
+    return VSM_OK;
+  };
+  HIPCHK(launch_features_of(0));
+  {
+    const int rc = start_chunk(0);
+    if (rc != VSM_OK) return rc;
+  }
+  for (int32_t k = 0; k < nchunks; k++) {
+    const SeqChunk &q = sc[k];
+    const int32_t f0 = q.f0;
+    const int n = q.n, bank = q.bank, first_pair = q.first_pair;
+    const VsmPair *d_pairs = c.d_pairs + first_pair;
+    const VsmJob *d_jobs = c.d_jobs + first_pair;
+    const int *max_nq = q.max_nq;
+    const std::shared_ptr<std::vector<char>> validp = q.validp;
+    const std::vector<char> &valid = *validp;
     VsmMatchCfg cfg = make_cfg(p, method);
     VsmJob dummy;
     memset(&dummy, 0, sizeof(dummy));
+    double ta = now_us();
     if (p.multi_stage) {
-      cfg.sparse = 1;
-      cfg.use_prior = 0;
-      vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, cfg, max_nq[0]);
-      vsm_launch_export(h->stream, h->prof, d_pairs, n, 0, max_nq[0]);
-      HIPCHK(hipEventRecord(h->seq_ev[1], h->stream));
-      if (k + 1 < nchunks) HIPCHK(launch_features_of(k + 1));  // the GPU's work while the pool has the prior statistics
       const double tl1 = now_us();
       HIPCHK(hipEventSynchronize(h->seq_ev[1]));
       double tb = now_us();
@@ -1353,7 +1384,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     if (h->tie_copied_set[bank]) HIPCHK(hipStreamWaitEvent(h->stream, h->tie_copied[bank], 0));
     cfg.sparse = 0;
     cfg.use_prior = p.multi_stage ? 1 : 0;
-    vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, cfg, max_nq[1]);
+    vsm_launch_match(h->stream, h->prof, c.d_imgs, d_pairs, d_jobs, dummy, n, c.dims, cfg, max_nq[1]);
     if (use_dc && chunks.back()->ties_gpu) {
       DcChunk *ch = chunks.back().get();
       hipStream_t ts = h->tie_stream[dc_b & 1];
@@ -1377,19 +1408,21 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       }
     }
     if (p.refinement > 0)
-      vsm_launch_refine(h->stream, h->prof, c.d_imgs, d_pairs, c.d_jobs, dummy, n, c.dims, c.dims, method, p.refinement,
+      vsm_launch_refine(h->stream, h->prof, c.d_imgs, d_pairs, d_jobs, dummy, n, c.dims, c.dims, method, p.refinement,
                         max_nq[1]);
     vsm_launch_export(h->stream, h->prof, d_pairs, n, 1, max_nq[1]);
     const double tl2 = now_us();
-    if (!p.multi_stage && k + 1 < nchunks) {  // single pass: the next features go behind this chunk's matching
-      HIPCHK(hipEventRecord(h->seq_ev[1], h->stream));
-      HIPCHK(launch_features_of(k + 1));
-      HIPCHK(hipEventSynchronize(h->seq_ev[1]));
-    } else {
-      HIPCHK(sync_sleeping(h));
+    HIPCHK(hipEventRecord(h->idle_wait, h->stream));
+    if (k + 1 < nchunks) {  // the next chunk's pass 1 and the features after it go right behind this pass 2
+      const int rc = start_chunk(k + 1);
+      if (rc != VSM_OK) return rc;
     }
+    HIPCHK(hipEventSynchronize(h->idle_wait));
     HIPCHK(hipGetLastError());
-    if (p.multi_stage || k + 1 >= nchunks) h->prof.resolve();
+    if (h->prof.on) {  // (kernel timing: everything launched so far has to be over before the spans are read)
+      HIPCHK(hipStreamSynchronize(h->stream));
+      h->prof.resolve();
+    }
     if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass2 launch %.0f us sync %.0f us\n", k, tl2 - ta, now_us() - tl2);
     tg += now_us() - ta;
     // final stage of this chunk: asynchronous, overlapped with the next chunk's GPU work
