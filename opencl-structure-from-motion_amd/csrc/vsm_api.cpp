@@ -1201,12 +1201,15 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     int n = 0, bank = 0, first_img = 0, first_pair = 0;
     int max_nq[2] = {0, 0};
     std::shared_ptr<std::vector<char>> validp;
+    DcChunk *dc = nullptr;  // its final stage, if that is shared with the GPU
+    double t_pass2 = 0;
   };
   std::vector<SeqChunk> sc(nchunks);
-  // First step of chunk k: wait for its features, one job per frame, pass 1 (if there is one) and its export, then the
-  // features of chunk k+1.  For k > 0 this is issued right behind pass 2 of chunk k-1 - before the caller waits for that
-  // pass - so the GPU goes from one chunk into the next without the caller in between.
-  auto start_chunk = [&](int k) -> int {
+  // First step of chunk k: wait for its features, one job per frame, pass 1 (if there is one) and its export.
+  // Order on the stream: ... pass 2 of k-1, features of k+1, pass 1 of k+1, pass 2 of k, features of k+2 ...: while the
+  // pool computes chunk k's prior statistics the GPU has pass 2 of chunk k-1 and the features of chunk k+1 to do, and
+  // pass 1 of chunk k+1 is over before its prior statistics are wanted.
+  auto start_chunk = [&](int k, bool then_features) -> int {
     SeqChunk &q = sc[k];
     q.f0 = k * C;
     q.n = std::min<int32_t>(C, n_frames - q.f0);
@@ -1283,12 +1286,45 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       vsm_launch_export(h->stream, h->prof, d_pairs, n, 0, max_nq[0]);
       HIPCHK(hipEventRecord(h->seq_ev[1], h->stream));
     }
-    if (k + 1 < nchunks) HIPCHK(launch_features_of(k + 1));  // the GPU's work while the pool has the prior statistics
+    if (then_features && k + 1 < nchunks) HIPCHK(launch_features_of(k + 1));
+    return VSM_OK;
+  };
+  // Last step of chunk j: its pass 2 is over, the final stage goes to the pool (and from there to the GPU and back)
+  VsmCtx *cp = &c;
+  auto finalize = [&](int j) -> int {
+    const SeqChunk &q = sc[j];
+    const double t0 = now_us();
+    HIPCHK(hipEventSynchronize(h->idle_wait));
+    HIPCHK(hipGetLastError());
+    if (h->prof.on) {  // (kernel timing: everything launched so far has to be over before the spans are read)
+      HIPCHK(hipStreamSynchronize(h->stream));
+      h->prof.resolve();
+    }
+    if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass2 launched %.0f us ago, waited %.0f us for it\n", j, t0 - q.t_pass2, now_us() - t0);
+    tg += now_us() - t0;
+    if (q.dc) {
+      dc_submit_a(q.dc);
+    } else {
+      const vsm_params pcopy = p;
+      const std::shared_ptr<std::vector<char>> validp = q.validp;
+      const int32_t f0 = q.f0;
+      const int first_pair = q.first_pair;
+      ticket_chunk.push_back(j);
+      tickets.push_back(h->pool->submit(q.n, [h, cp, pcopy, validp, f0, first_pair, method](int i) {
+        if (!(*validp)[i]) return;
+        static thread_local VsmHostWork tw;
+        const int pj = first_pair + i;
+        std::vector<vsm_p_match> &out = h->seq_matches[f0 + i];
+        // one wide copy out of the host-mapped export, then cache-resident work
+        tw.tmp_list.assign(cp->hm_list2[pj], cp->hm_list2[pj] + cp->hm_lcount[2 * pj + 1]);
+        vsm_host_remove_outliers_from(tw, pcopy, tw.tmp_list.data(), (int32_t)tw.tmp_list.size(), method, out);
+      }));
+    }
     return VSM_OK;
   };
   HIPCHK(launch_features_of(0));
   {
-    const int rc = start_chunk(0);
+    const int rc = start_chunk(0, true);
     if (rc != VSM_OK) return rc;
   }
   for (int32_t k = 0; k < nchunks; k++) {
@@ -1330,6 +1366,15 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       HIPCHK(hipMemcpyAsync(c.d_ranges + (size_t)first_pair * c.ranges_stride, c.h_ranges + (size_t)first_pair * c.ranges_stride,
                             c.ranges_stride * 4 * n, hipMemcpyHostToDevice, h->stream));
     }
+    if (k > 0) {  // pass 2 of the previous chunk ran meanwhile
+      const int rc = finalize(k - 1);
+      if (rc != VSM_OK) return rc;
+    }
+    if (k + 1 < nchunks) {  // pass 1 of the next chunk goes in front of this chunk's pass 2
+      const int rc = start_chunk(k + 1, false);
+      if (rc != VSM_OK) return rc;
+    }
+    ta = now_us();
     // the export below overwrites this pair bank's host lists: chunk k-2 must be done with them
     const double tw0 = now_us();
     for (auto &ch : chunks)  // (they copied the lists out first thing)
@@ -1344,7 +1389,6 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       }
     if (vsm_debug_timing() && now_us() - tw0 > 2000) fprintf(stderr, "  chunk %d: waited %.0f us for chunk %d's final stage\n", k, now_us() - tw0, k - 2);
     // the chunk's final stage is set up here already: the GPU's emulated vertex sorts start right behind the compaction
-    VsmCtx *cp = &c;
     // The GPU share pays when the pool has other pairs to work on while the GPU has this chunk's (its part is
     // latency-bound): a chunk with fewer pairs than pool threads stays on the host, unless VSM_DC_GPU=1 insists
     bool use_dc = dc_gpu && (dc_forced || n >= h->pool->size());
@@ -1379,6 +1423,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       ch->valid = validp;
       ch->ties_gpu = dc_ties && ch->block && !ch->full && h->hm_ties != nullptr;
       ch->ties = h->hm_ties + (size_t)dc_b * h->ties_chunk * VSM_DC_TIE_OUT_INTS;
+      sc[k].dc = ch;
     }
     // (this pair bank's pass-2 lists are about to be rewritten: the copy of chunk k-2's keys out of them comes first)
     if (h->tie_copied_set[bank]) HIPCHK(hipStreamWaitEvent(h->stream, h->tie_copied[bank], 0));
@@ -1411,38 +1456,14 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       vsm_launch_refine(h->stream, h->prof, c.d_imgs, d_pairs, d_jobs, dummy, n, c.dims, c.dims, method, p.refinement,
                         max_nq[1]);
     vsm_launch_export(h->stream, h->prof, d_pairs, n, 1, max_nq[1]);
-    const double tl2 = now_us();
+    sc[k].t_pass2 = now_us();
     HIPCHK(hipEventRecord(h->idle_wait, h->stream));
-    if (k + 1 < nchunks) {  // the next chunk's pass 1 and the features after it go right behind this pass 2
-      const int rc = start_chunk(k + 1);
-      if (rc != VSM_OK) return rc;
-    }
-    HIPCHK(hipEventSynchronize(h->idle_wait));
-    HIPCHK(hipGetLastError());
-    if (h->prof.on) {  // (kernel timing: everything launched so far has to be over before the spans are read)
-      HIPCHK(hipStreamSynchronize(h->stream));
-      h->prof.resolve();
-    }
-    if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass2 launch %.0f us sync %.0f us\n", k, tl2 - ta, now_us() - tl2);
+    if (k + 2 < nchunks) HIPCHK(launch_features_of(k + 2));
     tg += now_us() - ta;
-    // final stage of this chunk: asynchronous, overlapped with the next chunk's GPU work
-    if (use_dc) {
-      DcChunk *ch = chunks.back().get();
-      ch->valid = validp;
-      dc_submit_a(ch);
-    } else {
-      const vsm_params pcopy = p;
-      ticket_chunk.push_back(k);
-      tickets.push_back(h->pool->submit(n, [h, cp, pcopy, validp, f0, first_pair, method](int i) {
-        if (!(*validp)[i]) return;
-        static thread_local VsmHostWork tw;
-        const int pj = first_pair + i;
-        std::vector<vsm_p_match> &out = h->seq_matches[f0 + i];
-        // one wide copy out of the host-mapped export, then cache-resident work
-        tw.tmp_list.assign(cp->hm_list2[pj], cp->hm_list2[pj] + cp->hm_lcount[2 * pj + 1]);
-        vsm_host_remove_outliers_from(tw, pcopy, tw.tmp_list.data(), (int32_t)tw.tmp_list.size(), method, out);
-      }));
-    }
+  }
+  if (nchunks > 0) {
+    const int rc = finalize(nchunks - 1);
+    if (rc != VSM_OK) return rc;
   }
   {
     const double tb = now_us();
