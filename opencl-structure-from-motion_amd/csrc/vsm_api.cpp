@@ -293,6 +293,7 @@ struct DcBank {
   int32_t *d_support = nullptr, *h_support = nullptr;  // per pair [stride_pts]: support count of every match
   uint32_t *d_pt = nullptr, *h_pt = nullptr;
   int32_t *d_id = nullptr, *h_id = nullptr, *d_tri = nullptr, *h_tri = nullptr;
+  uint32_t *d_trip = nullptr, *h_trip = nullptr;  // packed triangle records, [2 * stride_pts][3] per pair (VsmDcJob::tri_packed)
   VsmDcTask *d_tasks = nullptr, *h_tasks = nullptr;
   VsmDcMerge *d_merges = nullptr, *h_merges = nullptr;  // stride_tasks per pair (a binary tree has fewer internal nodes than leaves)
   VsmDcHull *d_hulls = nullptr, *h_hulls = nullptr;    // by node number: 2 * stride_tasks per pair
@@ -311,6 +312,8 @@ struct DcBank {
     (void)hipFree(d_pt);
     (void)hipFree(d_id);
     (void)hipFree(d_tri);
+    (void)hipFree(d_trip);
+    (void)hipHostFree(h_trip);
     (void)hipFree(d_tasks);
     (void)hipFree(d_merges);
     (void)hipFree(d_hulls);
@@ -339,6 +342,7 @@ struct DcBank {
               hipHostMalloc((void **)&h_flow, P * 12, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_support, P * 4, hipHostMallocDefault) == hipSuccess &&
               hipMalloc((void **)&d_id, P * 4) == hipSuccess && hipMalloc((void **)&d_tri, P * 64) == hipSuccess &&
+              hipMalloc((void **)&d_trip, P * 24) == hipSuccess && hipHostMalloc((void **)&h_trip, P * 24, hipHostMallocDefault) == hipSuccess &&
               hipMalloc((void **)&d_tasks, T * sizeof(VsmDcTask)) == hipSuccess &&
               hipMalloc((void **)&d_merges, T * sizeof(VsmDcMerge)) == hipSuccess &&
               hipMalloc((void **)&d_hulls, 2 * T * sizeof(VsmDcHull)) == hipSuccess &&
@@ -806,6 +810,7 @@ struct DcChunk {
   bool device_kd = true;  // the GPU orders the keys (k_dc_kd_order); else ExactDelaunay::prepare does
   bool block = true;      // sub-trees of <= VSM_DC_BLOCK_POINTS points, one wave each inside LDS (k_dc_block); else leaf / top
   bool full = true;       // (with block) all merge levels and the support test on the GPU too: only the counts come back
+  bool packed = false;    // (with block, not full) the triangle records come back as 12-byte packed words (set when G is enqueued)
   bool ties_gpu = false;  // Triangle's randomised vertex sort runs on the GPU (k_dc_ties_of_lists), beside everything else
   const int32_t *ties = nullptr;   // its verdicts, [n][VSM_DC_TIE_OUT_INTS] (host-mapped)
   std::atomic<int> ties_done{1};
@@ -861,7 +866,19 @@ static void dc_submit_b(DcChunk *ch) {
         // (copied, not used in place: the merges and the support test chase pointers through these arrays, and
         // on the pinned slab - small pages, no prefetch-friendly order - that cost 25 % of the whole run)
         const DcMesh mesh = wk.del.mesh();
-        memcpy(mesh.tri, B.h_tri + (size_t)i * B.stride_pts * 16, (size_t)m * 16 * sizeof(int32_t));
+        if (ch->packed) {
+          const uint32_t *src = B.h_trip + (size_t)i * B.stride_pts * 6;
+          int32_t *dst = mesh.tri;
+          for (int32_t t = 0; t < 2 * m; t++, src += 3, dst += 8) {
+            for (int o = 0; o < 3; o++) {
+              const uint32_t wv = src[o], nb = wv & 0x1ffffu, vx = wv >> 17;
+              dst[o] = nb == 0x1ffffu ? -1 : (int32_t)nb;
+              dst[4 + o] = vx == 0x7fffu ? -1 : (int32_t)vx;
+            }
+          }
+        } else {
+          memcpy(mesh.tri, B.h_tri + (size_t)i * B.stride_pts * 16, (size_t)m * 16 * sizeof(int32_t));
+        }
         memcpy(mesh.pt, B.h_pt + (size_t)i * B.stride_pts, (size_t)m * 4);
         memcpy(mesh.id, B.h_id + (size_t)i * B.stride_pts, (size_t)m * 4);
         const VsmDcHull *hu = B.h_hulls + (size_t)i * 2 * B.stride_tasks;
@@ -934,6 +951,8 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
       jb.nlevels = 0;
     }
   }
+  ch->packed = ch->block && !ch->full && maxm > 0 && maxm <= VSM_DC_PACKED_MAX_POINTS;
+  for (int i = 0; i < ch->n; i++) B.h_jobs[i].tri_packed = ch->packed ? B.d_trip + (size_t)i * B.stride_pts * 6 : nullptr;
   // only the used part of every pair's slab row travels: rows of maxm points / maxt tasks
   const size_t sp = (size_t)B.stride_pts, st = (size_t)B.stride_tasks, rows = (size_t)ch->n;
   hipStream_t s2 = h->dc_stream[ch->bank & 1];
@@ -965,7 +984,8 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
           ok = hipMemcpy2DAsync(B.h_support, sp * 4, B.d_support, sp * 4, (size_t)maxin * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess;
         }
       } else {
-        ok = hipMemcpy2DAsync(B.h_tri, sp * 64, B.d_tri, sp * 64, (size_t)maxm * 64, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
+        ok = (ch->packed ? hipMemcpy2DAsync(B.h_trip, sp * 24, B.d_trip, sp * 24, (size_t)maxm * 24, rows, hipMemcpyDeviceToHost, s2)
+                         : hipMemcpy2DAsync(B.h_tri, sp * 64, B.d_tri, sp * 64, (size_t)maxm * 64, rows, hipMemcpyDeviceToHost, s2)) == hipSuccess &&
              hipMemcpy2DAsync(B.h_pt, sp * 4, B.d_pt, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
              hipMemcpy2DAsync(B.h_id, sp * 4, B.d_id, sp * 4, (size_t)maxm * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess &&
              hipMemcpy2DAsync(B.h_hulls, 2 * st * sizeof(VsmDcHull), B.d_hulls, 2 * st * sizeof(VsmDcHull), (size_t)maxn * sizeof(VsmDcHull),

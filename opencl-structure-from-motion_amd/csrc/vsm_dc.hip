@@ -295,8 +295,16 @@ __global__ void __launch_bounds__(64) k_dc_block(const VsmDcJob *__restrict__ jo
     }
     __syncthreads();
   }
-  int32_t *gt = jb.tri + (size_t)2 * tk.off * 8;
-  for (int i = lane; i < 2 * tk.n * 8; i += 64) gt[i] = s_tri[i];
+  if (jb.tri_packed) {  // 12 bytes per triangle for the trip to the host
+    uint32_t *gp = jb.tri_packed + (size_t)2 * tk.off * 3;
+    for (int i = lane; i < 2 * tk.n * 3; i += 64) {
+      const int t = i / 3, o = i - 3 * t;
+      gp[i] = ((uint32_t)s_tri[t * 8 + o] & 0x1ffffu) | (((uint32_t)s_tri[t * 8 + 4 + o] & 0x7fffu) << 17);
+    }
+  } else {
+    int32_t *gt = jb.tri + (size_t)2 * tk.off * 8;
+    for (int i = lane; i < 2 * tk.n * 8; i += 64) gt[i] = s_tri[i];
+  }
   for (int i = lane; i < tk.n; i += 64) {
     jb.pt[tk.off + i] = s_pt[i];
     jb.id[tk.off + i] = s_id[i];

@@ -25,6 +25,9 @@ struct VsmDcJob {  // one triangulation; all pointers are device pointers
   uint32_t *pt;    // [m]  out: x | y << 16 by sorted position
   int32_t *id;     // [m]  out: input index by sorted position
   int32_t *tri;    // [2m][8] out: triangle records
+  uint32_t *tri_packed;  // or (k_dc_block): [2m][3] words, neighbour handle (17 bits, all ones = none) | vertex << 17 (15 bits,
+                         // all ones = none) per corner - what travels to the host instead of the 32-byte records
+#define VSM_DC_PACKED_MAX_POINTS 16000
   const VsmDcTask *tasks;
   const VsmDcMerge *merges;  // merge nodes of the levels above the tasks, deepest level first
   VsmDcHull *hulls;          // by node number
