@@ -1193,10 +1193,34 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   double tg = 0, thost = 0;
   std::atomic<long long> mid_ns[2] = {};  // VSM_DEBUG_TIMING: pass-1 outlier removal, prior statistics (task time)
   const double tstart = now_us();
-  const int nchunks = (n_frames + C - 1) / C;
+  // Chunk boundaries: chunks of C frames; a sequence of at least three chunks starts (and ends) with a half chunk - the
+  // host pool has nothing to do until the first chunk's lists exist, and nothing overlaps the last chunk's final stage
+  std::vector<int32_t> chunk_start;
+  {
+    const bool taper = !(getenv("VSM_SEQ_TAPER") && atoi(getenv("VSM_SEQ_TAPER")) == 0);
+    const int32_t half = C / 2;
+    int32_t f = 0;
+    if (taper && half >= 8 && n_frames >= 3 * C) {
+      chunk_start.push_back(0);
+      f = half;
+      while (n_frames - f > C + half) {
+        chunk_start.push_back(f);
+        f += C;
+      }
+      if (n_frames - f > C) {  // between C and 3C/2 frames left: a full chunk and a short one
+        chunk_start.push_back(f);
+        f = n_frames - std::min<int32_t>(half, n_frames - f - 1);
+      }
+      chunk_start.push_back(f);
+    } else {
+      for (; f < n_frames; f += C) chunk_start.push_back(f);
+    }
+    chunk_start.push_back(n_frames);
+  }
+  const int nchunks = (int)chunk_start.size() - 1;
   auto launch_features_of = [&](int k) -> hipError_t {  // ingest + all feature kernels of chunk k, then the marker
-    const int32_t f0 = k * C;
-    const int n = std::min<int32_t>(C, n_frames - f0);
+    const int32_t f0 = chunk_start[k];
+    const int n = chunk_start[k + 1] - f0;
     const int first_img = 2 * (k % 3) * C;
     if (on_device) {
       vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first_img, left + (size_t)f0 * frame_stride,
@@ -1231,8 +1255,8 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   // pass 1 of chunk k+1 is over before its prior statistics are wanted.
   auto start_chunk = [&](int k, bool then_features) -> int {
     SeqChunk &q = sc[k];
-    q.f0 = k * C;
-    q.n = std::min<int32_t>(C, n_frames - q.f0);
+    q.f0 = chunk_start[k];
+    q.n = chunk_start[k + 1] - q.f0;
     q.bank = k & 1;
     q.first_img = 2 * (k % 3) * C;
     q.first_pair = q.bank * C;
@@ -1270,7 +1294,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
           cnt[1][s] = c.hm_counts[(img_p + 1) * 2 + s];
         }
       } else {  // the previous frame is the last one of the previous chunk's bank
-        img_p = 2 * ((k + 2) % 3) * C + 2 * (C - 1);
+        img_p = 2 * ((k + 2) % 3) * C + 2 * ((k > 0 ? chunk_start[k] - chunk_start[k - 1] : 1) - 1);
         for (int s = 0; s < 2; s++) {
           cnt[0][s] = f > 0 ? nprev[0][s] : 0;
           cnt[1][s] = f > 0 ? nprev[1][s] : 0;
