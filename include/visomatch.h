@@ -113,8 +113,9 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
 /* getMatches() as it would read after frame `frame` */
 int32_t vsm_sequence_num_matches(vsm_handle *h, int32_t frame);
 int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out, int32_t cap);
-/* wall-clock split of the last vsm_sequence_run() in microseconds: {GPU phases incl. syncs, host
- * phases, total, chunk size} */
+/* wall-clock split of the last vsm_sequence_run() on the caller's thread, microseconds: {launching and waiting
+ * for the GPU, host stages it takes part in (prior statistics, final drain), total, chunk size} - the stages
+ * overlap, so the first two are not what the GPU / the host pool were busy for */
 void vsm_sequence_get_timings(vsm_handle *h, double *out4);
 
 /* ---- stage-level views for parity tests (the reference's private members) ---- */
