@@ -9,7 +9,7 @@
 //                   the host stages of the chunk's pairs run in parallel on the pool.
 //
 // A VsmCtx is the device-resident working set for F frame slots and P frame pairs; the streaming
-// ring buffer is the (F=2, P=1) instance, sequences use (F=2C, P=C).
+// ring buffer is the (F=2, P=1) instance, sequences use three banks of frame slots and two of pairs (F=6C images, P=2C).
 // There is no CPU fallback: without a usable HIP device vsm_create() returns NULL.
 #include <math.h>
 #include <stdio.h>
@@ -381,7 +381,7 @@ struct vsm_handle {
   hipStream_t dc_stream[2] = {nullptr, nullptr};  // alternate per chunk: one chunk's records travel while the next one's kernels run
   std::vector<VsmHostWork> seq_work;               // per pair of every Delaunay bank: state between the two host halves
   VsmCtx ring;  // streaming ring buffer: 2 frame slots, 1 pair
-  VsmCtx seq;   // look-ahead sequences: 2 banks of C frame slots, C pairs
+  VsmCtx seq;   // look-ahead sequences: 3 banks of C frame slots, 2 banks of C pairs
   int seq_chunk = 0;
 
   // ring buffer state (Matcher's prev/curr pointers, viso/matcher.cpp:108-155)
