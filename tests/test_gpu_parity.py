@@ -190,9 +190,15 @@ def test_reference_vo_runs_on_dropin_matcher(synth, tmp_path, binary):
 
 @pytest.mark.parametrize("chunk", ["1", "3", "50"])
 @pytest.mark.parametrize("method", [2, 0, 1])
-def test_sequence_api_equals_frame_by_frame(vm, B, synth, monkeypatch, method, chunk):
-    """look-ahead API == pushBack+matchFeatures per frame (oracle), across chunk boundaries"""
+@pytest.mark.parametrize("final_stage", ["as it comes", "shared with the GPU", "all on the GPU"])
+def test_sequence_api_equals_frame_by_frame(vm, B, synth, monkeypatch, method, chunk, final_stage):
+    """look-ahead API == pushBack+matchFeatures per frame (oracle), across chunk boundaries; with the final stage
+    (exact Delaunay support test) where the chunk size puts it - the host for these short chunks - and forced
+    through both forms of the GPU share, for flow, stereo and quad matching"""
     monkeypatch.setenv("VSM_SEQ_CHUNK", chunk)
+    if final_stage != "as it comes":
+        monkeypatch.setenv("VSM_DC_GPU", "1")
+        monkeypatch.setenv("VSM_DC_FULL", "1" if final_stage == "all on the GPU" else "0")
     seq = synth.stereo_sequence(31, 417, 163, 7, disparity=10, ramp=(1, 12))
     left = np.stack([l for l, _ in seq])
     right = np.stack([r for _, r in seq])
