@@ -73,6 +73,22 @@ def test_golden_cfg5_highres(vm, synth):
     G.replay_hashed(G.load("cfg5_2048x1024_quad"), synth, _gpu(vm))
 
 
+@pytest.mark.parametrize("full", ["0", "1"])
+def test_golden_cfg5_highres_lookahead_gpu_final_stage(vm, synth, monkeypatch, full):
+    """2048x1024 (33 k matches per pair: more points than the packed record form and the 16-bit paths take) through
+    the look-ahead API with the final stage forced onto the GPU share: the reference's final lists"""
+    g = G.load("cfg5_2048x1024_quad")
+    w, h, nf, method = int(g["w"]), int(g["h"]), int(g["n_frames"]), int(g["method"])
+    seq = synth.stereo_sequence(int(g["seed"]), w, h, nf, blur=int(g["blur"]))
+    monkeypatch.setenv("VSM_DC_GPU", "1")
+    monkeypatch.setenv("VSM_DC_FULL", full)
+    m = vm.Matcher()
+    got = m.run_sequence(np.stack([l for l, _ in seq]), np.stack([r for _, r in seq]), method)
+    for f in range(nf):
+        assert len(got[f]) == int(g["counts"][f][-1]) and G.sha(got[f]) == str(g["hashes"][f][-1]), f
+    m.close()
+
+
 def test_golden_cfg2_sequence_feedback(vm, synth):
     G.replay_vo_sequence(G.load("cfg2_seq200_tr"), synth, _gpu(vm), n_frames=40)
 
