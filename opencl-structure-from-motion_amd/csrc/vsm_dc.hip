@@ -72,6 +72,63 @@ __device__ inline void kd_node_at(int32_t q, int depth, int32_t m, int32_t &off,
   }
 }
 
+// the levels of the kd order on the lists X (x order), Y (y order) and their inverses PX, PY (element -> position);
+// T = uint16_t for lists that live in LDS (m <= KD_LDS_POINTS), uint32_t for the global scratch
+template <typename T>
+__device__ inline void kd_levels(T *X0, T *X1, T *Y0, T *Y1, T *PX, T *PY, uint32_t *P, const int32_t m, uint32_t *tot,
+                                 const uint64_t *__restrict__ ks, uint64_t *__restrict__ key_out) {
+  const int t = threadIdx.x;
+  T *X = X0, *Xn = X1, *Y = Y0, *Yn = Y1;
+  const int32_t per = (m + KD_THREADS - 1) / KD_THREADS;
+  for (int depth = 0; ((m + (1 << depth) - 1) >> depth) > 3; depth++) {
+    const bool cut_x = (depth & 1) == 0;
+    const T *S = cut_x ? Y : X;     // the list to partition
+    T *D = cut_x ? Yn : Xn;
+    const T *PO = cut_x ? PX : PY;  // position in the list that is cut in place
+    T *PS = cut_x ? PY : PX;
+    // flags + exclusive scan (thread = contiguous run of positions)
+    {
+      const int32_t q0 = t * per, q1 = min(m, q0 + per);
+      uint32_t sum = 0;
+      for (int32_t q = q0; q < q1; q++) {
+        int32_t off, n;
+        kd_node_at(q, depth, m, off, n);
+        const uint32_t left = n <= 3 || (int32_t)PO[S[q]] < off + (n >> 1);
+        P[q] = left;
+        sum += left;
+      }
+      uint32_t run = kd_block_scan(sum, tot);
+      for (int32_t q = q0; q < q1; q++) {
+        const uint32_t f = P[q];
+        P[q] = (run << 1) | f;  // flags before q, and q's own
+        run += f;
+      }
+    }
+    __syncthreads();
+    for (int32_t q = t; q < m; q += KD_THREADS) {
+      int32_t off, n;
+      kd_node_at(q, depth, m, off, n);
+      const uint32_t pq = P[q], before = (pq >> 1) - (P[off] >> 1), e = S[q];
+      const uint32_t np = (pq & 1) ? off + before : off + (n >> 1) + ((q - off) - before);
+      D[np] = (T)e;
+      PS[e] = (T)np;
+    }
+    __syncthreads();
+    if (cut_x) {
+      T *w = Y;
+      Y = Yn;
+      Yn = w;
+    } else {
+      T *w = X;
+      X = Xn;
+      Xn = w;
+    }
+  }
+  for (int32_t q = t; q < m; q += KD_THREADS) key_out[q] = ks[X[q]];
+}
+
+#define KD_LDS_POINTS 8192  // 6 uint16 lists + the uint32 scan fit where the histogram was
+
 __global__ void __launch_bounds__(KD_THREADS) k_dc_kd_order(const VsmDcJob *__restrict__ jobs, int njobs) {
   __shared__ uint32_t hist[KD_DIGITS * KD_CHUNKS];
   __shared__ uint32_t tot[KD_THREADS / 64 + 1];
@@ -123,61 +180,31 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc_kd_order(const VsmDcJob *__re
     }
     __syncthreads();
   }
+  if (m <= KD_LDS_POINTS) {
+    // the lists move into LDS, over the histogram (no longer needed): a dependent access there costs an LDS round
+    // trip instead of one through L2
+    uint16_t *l16 = (uint16_t *)hist;
+    uint16_t *lX0 = l16, *lX1 = lX0 + KD_LDS_POINTS, *lY0 = lX1 + KD_LDS_POINTS, *lY1 = lY0 + KD_LDS_POINTS;
+    uint16_t *lPX = lY1 + KD_LDS_POINTS, *lPY = lPX + KD_LDS_POINTS;
+    uint32_t *lP = hist + 3 * KD_LDS_POINTS;  // behind the six 16-bit lists
+    for (int32_t q = t; q < m; q += KD_THREADS) {
+      const uint32_t e = Y0[q];
+      lX0[q] = (uint16_t)q;
+      lPX[q] = (uint16_t)q;
+      lY0[q] = (uint16_t)e;
+      lPY[e] = (uint16_t)q;
+    }
+    __syncthreads();
+    kd_levels<uint16_t>(lX0, lX1, lY0, lY1, lPX, lPY, lP, m, tot, ks, jb.key);
+    return;
+  }
   for (int32_t q = t; q < m; q += KD_THREADS) {
     X0[q] = (uint32_t)q;
     PX[q] = (uint32_t)q;
     PY[Y0[q]] = (uint32_t)q;
   }
   __syncthreads();
-
-  // ---- the levels ----
-  uint32_t *X = X0, *Xn = X1, *Y = Y0, *Yn = Y1;
-  const int32_t per = (m + KD_THREADS - 1) / KD_THREADS;
-  for (int depth = 0; ((m + (1 << depth) - 1) >> depth) > 3; depth++) {
-    const bool cut_x = (depth & 1) == 0;
-    const uint32_t *S = cut_x ? Y : X;     // the list to partition
-    uint32_t *D = cut_x ? Yn : Xn;
-    const uint32_t *PO = cut_x ? PX : PY;  // position in the list that is cut in place
-    uint32_t *PS = cut_x ? PY : PX;
-    // flags + exclusive scan (thread = contiguous run of positions)
-    {
-      const int32_t q0 = t * per, q1 = min(m, q0 + per);
-      uint32_t sum = 0;
-      for (int32_t q = q0; q < q1; q++) {
-        int32_t off, n;
-        kd_node_at(q, depth, m, off, n);
-        const uint32_t left = n <= 3 || (int32_t)PO[S[q]] < off + (n >> 1);
-        P[q] = left;
-        sum += left;
-      }
-      uint32_t run = kd_block_scan(sum, tot);
-      for (int32_t q = q0; q < q1; q++) {
-        const uint32_t f = P[q];
-        P[q] = (run << 1) | f;  // flags before q, and q's own
-        run += f;
-      }
-    }
-    __syncthreads();
-    for (int32_t q = t; q < m; q += KD_THREADS) {
-      int32_t off, n;
-      kd_node_at(q, depth, m, off, n);
-      const uint32_t pq = P[q], before = (pq >> 1) - (P[off] >> 1), e = S[q];
-      const uint32_t np = (pq & 1) ? off + before : off + (n >> 1) + ((q - off) - before);
-      D[np] = e;
-      PS[e] = np;
-    }
-    __syncthreads();
-    if (cut_x) {
-      uint32_t *w = Y;
-      Y = Yn;
-      Yn = w;
-    } else {
-      uint32_t *w = X;
-      X = Xn;
-      Xn = w;
-    }
-  }
-  for (int32_t q = t; q < m; q += KD_THREADS) jb.key[q] = ks[X[q]];
+  kd_levels<uint32_t>(X0, X1, Y0, Y1, PX, PY, P, m, tot, ks, jb.key);
 }
 
 __global__ void __launch_bounds__(64) k_dc_subtrees(const VsmDcJob *__restrict__ jobs, int njobs) {
