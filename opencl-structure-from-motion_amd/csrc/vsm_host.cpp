@@ -764,6 +764,41 @@ void vsm_host_count_support(VsmHostWork &w, const vsm_params &p, int32_t n, int 
     });
     return;
   }
+  // One thread: the triangle slots follow the kd order of the points, so per-POSITION copies of what the test compares
+  // (16 bytes per point, one cache line for a triangle's corners more often than not) make the walk local; the counts
+  // go back to the matches through the ids at the end.
+  const int32_t m = del.points();
+  const int32_t *id = del.ids();
+  if (m >= 1024) {
+    struct Q {
+      float fu, fv, dp;
+      int32_t votes;
+    };
+    w.support_pos.resize((size_t)m * 4);
+    Q *qp = reinterpret_cast<Q *>(w.support_pos.data());
+    for (int32_t pos = 0; pos < m; pos++) {
+      const int32_t i = id[pos];
+      qp[pos] = Q{fu[i], fv[i], dp[i], 0};
+    }
+    for (int32_t t = 0; t < slots; t++) {
+      const int32_t *v = del.slot_record(t);
+      if ((v[0] | v[1] | v[2]) < 0) continue;
+      Q &a = qp[v[1]], &b = qp[v[2]], &c3 = qp[v[0]];
+      Q *const tri3[3] = {&a, &b, &c3};
+      static const int E[3][2] = {{0, 1}, {1, 2}, {0, 2}};
+      for (int e = 0; e < 3; e++) {
+        Q &x = *tri3[E[e][0]], &y = *tri3[E[e][1]];
+        const bool flow_ok = fabsf(x.fu - y.fu) + fabsf(x.fv - y.fv) < ftol;
+        const bool disp_ok = fabsf(x.dp - y.dp) < dtol;
+        const bool ok = method == 0 ? flow_ok : (method == 1 ? disp_ok : (disp_ok && flow_ok));
+        x.votes += ok;
+        y.votes += ok;
+      }
+    }
+    w.support.assign(n, 0);
+    for (int32_t pos = 0; pos < m; pos++) w.support[id[pos]] = qp[pos].votes;
+    return;
+  }
   w.support.assign(n, 0);
   votes_of(0, slots, w.support.data());
 }

@@ -180,6 +180,8 @@ class ExactDelaunay {
   // slot view: slots 0 .. num_slots()-1; a slot holds a triangle if slot_vertices() returns true
   // (vertex triple by input index, same orientation as triangles())
   int32_t num_slots() const { return 2 * m_; }
+  const int32_t *slot_record(int32_t t) const { return &tri_[(size_t)t * 8 + 4]; }  // its three vertices by position (-1: none)
+  const int32_t *ids() const { return id_.data(); }                                  // position -> input index
   inline bool slot_vertices(int32_t t, int32_t *q) const {
     const int32_t *v = &tri_[(size_t)t * 8 + 4];
     if ((v[0] | v[1] | v[2]) < 0) return false;
@@ -230,6 +232,7 @@ struct VsmHostWork {
   VsmPool *async = nullptr;  // may take the emulated vertex sort of a triangulation (ExactDelaunay::run)
   ExactDelaunay del;
   std::vector<int32_t> x, y, support, support_parts;
+  std::vector<float> support_pos;  // per sorted position: flow u, flow v, disparity, votes (vsm_host_count_support)
   std::vector<float> fu, fv, dp;        // per match: flow and disparity, what the support test compares
   std::vector<vsm_p_match> tmp_list;
   VsmForkJoin *pool = nullptr;  // optional: threads for the sub-problems of one triangulation
