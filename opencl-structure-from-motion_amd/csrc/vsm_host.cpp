@@ -274,10 +274,70 @@ __attribute__((target("avx512f"))) void stop_masks_avx512(const uint64_t *a, int
     LE[w] = l;
   }
 }
-const bool kHaveAvx512 = __builtin_cpu_supports("avx512f") && !(getenv("VSM_NO_AVX512") && atoi(getenv("VSM_NO_AVX512")) != 0);
+const bool kHaveAvx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") &&
+                         __builtin_cpu_supports("bmi2") && !(getenv("VSM_NO_AVX512") && atoi(getenv("VSM_NO_AVX512")) != 0);
 #else
 void stop_masks_avx512(const uint64_t *, int32_t, uint64_t, uint64_t, uint64_t *, uint64_t *) {}
 const bool kHaveAvx512 = false;
+#endif
+
+// Parts of 3 to kTinyMax keys - most partitions of a sort - straight from a table: what the Hoare loop does depends
+// only on which keys are below, equal to or above the pivot, i.e. on the two masks; the table (filled once by running
+// the reference loop on every combination) holds the resulting order and the final (left, right) in four bytes: eight
+// 3-bit source positions, left, right + 1.  With AVX-512 the keys are one register: masked load, two compares, a lookup,
+// one permute, masked store.
+struct TinyTable {
+  static constexpr int kMax = 7;
+  std::vector<uint32_t> e[kMax + 1];  // [n][GE | LE << n]
+  TinyTable() {
+    for (int n = 3; n <= kMax; n++) {
+      e[n].resize((size_t)1 << (2 * n));
+      for (int ge = 0; ge < (1 << n); ge++)
+        for (int le = 0; le < (1 << n); le++) {
+          int key[8], src[8];
+          for (int i = 0; i < 8; i++) {
+            src[i] = i;
+            const bool g = (ge >> i) & 1, l = (le >> i) & 1;
+            key[i] = g && l ? 1 : (g ? 2 : 0);  // pivot value 1 (a key neither >= nor <= does not occur)
+          }
+          int left = -1, right = n;  // vertexsort's loop (:5467-5487), bounds made safe for combinations that cannot occur
+          while (left < right) {
+            do {
+              left++;
+            } while (left <= right && left < n && key[left] < 1);
+            do {
+              right--;
+            } while (left <= right && right >= 0 && key[right] > 1);
+            if (left < right) {
+              std::swap(key[left], key[right]);
+              std::swap(src[left], src[right]);
+            }
+          }
+          uint32_t w = 0;
+          for (int i = 0; i < 8; i++) w |= (uint32_t)src[i] << (3 * i);
+          w |= (uint32_t)(left & 15) << 24;
+          w |= (uint32_t)((right + 1) & 15) << 28;
+          e[n][ge | (le << n)] = w;
+        }
+    }
+  }
+};
+constexpr int kTinyMax = TinyTable::kMax;
+#if defined(__x86_64__)
+__attribute__((target("avx512f,avx512bw,avx512vl,bmi2"))) inline void tiny_partition_avx512(uint64_t *a, int32_t n, uint64_t ge_key, uint64_t lt_key,
+                                                                                             const TinyTable &tab, int32_t &left, int32_t &right) {
+  const __mmask8 valid = (__mmask8)((1u << n) - 1);
+  const __m512i v = _mm512_maskz_loadu_epi64(valid, (const void *)a);
+  const unsigned ge = _mm512_mask_cmpge_epu64_mask(valid, v, _mm512_set1_epi64((long long)ge_key));
+  const unsigned le = _mm512_mask_cmplt_epu64_mask(valid, v, _mm512_set1_epi64((long long)lt_key));
+  const uint32_t w = tab.e[n][ge | (le << n)];
+  const __m512i idx = _mm512_cvtepu8_epi64(_mm_cvtsi64_si128((long long)_pdep_u64(w & 0xffffffu, 0x0707070707070707ull)));
+  _mm512_mask_storeu_epi64((void *)a, valid, _mm512_permutexvar_epi64(idx, v));
+  left = (int32_t)((w >> 24) & 15);
+  right = (int32_t)(w >> 28) - 1;
+}
+#else
+inline void tiny_partition_avx512(uint64_t *, int32_t, uint64_t, uint64_t, const TinyTable &, int32_t &, int32_t &) {}
 #endif
 
 // first set bit at a position >= from, or n
@@ -332,13 +392,17 @@ void ExactDelaunay::vertex_sort(uint64_t *a0, int32_t n0) {
     uint64_t *a = a0 + off;
     const uint64_t pv = KXY(a[rnd((uint32_t)n)]);
     // KXY(k) >= pv  <=>  k >= pv << 20;  KXY(k) <= pv  <=>  k < (pv + 1) << 20
+    int32_t left = -1, right = n;
+    if (n <= kTinyMax && kHaveAvx512) {
+      static const TinyTable *tiny = new TinyTable();
+      tiny_partition_avx512(a, n, pv << 20, (pv + 1) << 20, *tiny, left, right);
+    } else {
     const int32_t nw = (n + 63) >> 6;
     uint64_t *GE = stop_.data(), *LE = stop_.data() + nw;
     if (kHaveAvx512)
       stop_masks_avx512(a, n, pv << 20, (pv + 1) << 20, GE, LE);
     else
       stop_masks_plain(a, n, pv << 20, (pv + 1) << 20, GE, LE);
-    int32_t left = -1, right = n;
     for (;;) {
       const int32_t l = std::min(next_bit(GE, left + 1, n), right);
       if (l == right) {  // ran into the key it swapped there itself: the right scan gives up at once
@@ -352,6 +416,7 @@ void ExactDelaunay::vertex_sort(uint64_t *a0, int32_t n0) {
       right = r;
       if (l >= r) break;
       std::swap(a[l], a[r]);
+    }
     }
     // the parts [0, left) and (right, n): `if (left > 1) vertexsort(...)`, `if (right < n - 2) vertexsort(...)`
     const int32_t rn = n - right - 1;
