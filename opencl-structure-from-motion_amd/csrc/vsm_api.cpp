@@ -821,6 +821,7 @@ struct DcChunk {
   bool submitted = false;  // dc_submit_a() has run (caller's thread only)
   bool a_waited = false;   // (caller's thread only)
   std::atomic<int> stage{0};  // 0: A running, 1: G enqueued, 2: B submitted
+  std::atomic<bool> b_once{false};  // B is submitted by whoever comes first: the end of G, or dc_wait() giving up on it
   VsmPool::Ticket a, b;
   // VSM_DEBUG_TIMING: when the stages changed hands, and the task time summed over the pool
   double t_a0 = 0, t_g0 = 0, t_g1 = 0, t_b0 = 0, t_b1 = 0;
@@ -910,10 +911,11 @@ static void dc_submit_b(DcChunk *ch) {
   ch->stage.store(2, std::memory_order_release);
 }
 
-static void dc_after_gpu(void *arg) {
-  ((DcChunk *)arg)->t_g1 = vsm_now_us();
-  dc_submit_b((DcChunk *)arg);
-}  // runs on a HIP runtime thread: no HIP calls
+static void dc_after_gpu(void *arg) {  // runs on a HIP runtime thread: no HIP calls
+  DcChunk *ch = (DcChunk *)arg;
+  ch->t_g1 = vsm_now_us();
+  if (!ch->b_once.exchange(true)) dc_submit_b(ch);
+}
 
 static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished the chunk's last A task
   vsm_handle *h = ch->h;
@@ -1001,7 +1003,7 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
     for (int i = 0; i < ch->n; i++)
       if (B.nt[i] > 0) B.nt[i] = -1;
   }
-  dc_submit_b(ch);
+  if (!ch->b_once.exchange(true)) dc_submit_b(ch);
 }
 
 static void dc_submit_a(DcChunk *ch) {
@@ -1072,7 +1074,24 @@ static void dc_wait(DcChunk *ch) {  // until the chunk's final lists are in seq_
     while (!ch->ties_done.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
     return;
   }
-  while (ch->stage.load(std::memory_order_acquire) < 2) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  const double t0 = vsm_now_us();
+  while (ch->stage.load(std::memory_order_acquire) < 2) {
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+    // The GPU's part normally takes a millisecond or two.  If its end has not been reported after 20 s (a stream in an
+    // error state never runs its host function), the host does the pairs itself rather than wait forever.
+    if (ch->stage.load(std::memory_order_acquire) == 1 && vsm_now_us() - t0 > 20e6 && !ch->b_once.exchange(true)) {
+      fprintf(stderr, "visomatch: the GPU share of the Delaunay stage did not report back, finishing the chunk on the host\n");
+      DcBank &B = *ch->h->dc_bank[ch->bank];
+      for (int i = 0; i < ch->n; i++)
+        if (B.nt[i] > 0) B.nt[i] = -1;
+      ch->full = false;
+      if (ch->ties_gpu) {  // (its vertex sorts will not report either: the host's verdicts)
+        for (int i = 0; i < ch->n; i++) const_cast<int32_t *>(ch->ties)[(size_t)i * VSM_DC_TIE_OUT_INTS] = -1;
+        ch->ties_done.store(1, std::memory_order_release);
+      }
+      dc_submit_b(ch);
+    }
+  }
   ch->h->pool->wait(ch->b);
 }
 
