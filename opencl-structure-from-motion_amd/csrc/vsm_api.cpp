@@ -817,6 +817,10 @@ struct DcChunk {
   int bank = 0, n = 0, f0 = 0, first_pair = 0, work0 = 0;
   std::shared_ptr<std::vector<char>> valid;
   std::atomic<int> a_left{0};
+  DcBank *B = nullptr;         // its slabs
+  VsmHostWork *work = nullptr; // its per-pair host state [n]
+  int pass = 1;            // 1: the final stage (pass-2 lists -> seq_matches); 0: pass-1 lists, survivors stay in work[i].tmp_list
+  hipStream_t stream = nullptr;
   int chunk = 0;           // the look-ahead chunk it belongs to
   bool submitted = false;  // dc_submit_a() has run (caller's thread only)
   bool a_waited = false;   // (caller's thread only)
@@ -829,36 +833,27 @@ struct DcChunk {
   std::atomic<int> b_left{0};
 };
 
-static void dc_submit_b(DcChunk *ch) {
-  vsm_handle *h = ch->h;
-  ch->t_b0 = vsm_now_us();
-  ch->b_left.store(ch->n, std::memory_order_relaxed);
-  ch->b = h->pool->submit(ch->n, [ch](int i) {
+// B for pair i of the chunk: the GPU's records adopted, the merges above them, support test, survivors
+static void dc_task_b(DcChunk *ch, int i) {
+  {
     const double t0 = vsm_now_us();
-    struct Done {
-      DcChunk *ch;
-      double t0;
-      ~Done() {
-        ch->b_ns.fetch_add((long long)((vsm_now_us() - t0) * 1e3), std::memory_order_relaxed);
-        if (ch->b_left.fetch_sub(1, std::memory_order_acq_rel) == 1) ch->t_b1 = vsm_now_us();
-      }
-    } done{ch, t0};
     if (!(*ch->valid)[i]) return;
     vsm_handle *h = ch->h;
-    VsmHostWork &wk = h->seq_work[ch->work0 + i];
-    std::vector<vsm_p_match> &out = h->seq_matches[ch->f0 + i];
+    VsmHostWork &wk = ch->work[i];
+    std::vector<vsm_p_match> dummy_out;
+    std::vector<vsm_p_match> &out = ch->pass == 1 ? h->seq_matches[ch->f0 + i] : dummy_out;
     const int32_t nl = (int32_t)wk.tmp_list.size();
     if (nl <= 3) {  // the reference leaves short lists alone (:1210)
-      out.assign(wk.tmp_list.begin(), wk.tmp_list.end());
+      if (ch->pass == 1) out.assign(wk.tmp_list.begin(), wk.tmp_list.end());
       return;
     }
-    const DcBank &B = *h->dc_bank[ch->bank];
+    const DcBank &B = *ch->B;
     const int32_t m = B.m[i], nt = B.nt[i];
     if (ch->block && ch->full && nt > 0) {  // the GPU went all the way: keep the matches with support >= 4 (:1369)
       const double t1 = vsm_now_us();
       const int32_t *support = B.h_support + (size_t)i * B.stride_pts;
       vsm_host_keep_supported(wk.tmp_list, support);  // in place, then the buffers change hands
-      out.swap(wk.tmp_list);
+      if (ch->pass == 1) out.swap(wk.tmp_list);
       ch->part_ns[6].fetch_add((long long)((vsm_now_us() - t1) * 1e3), std::memory_order_relaxed);
       return;
     }
@@ -905,8 +900,20 @@ static void dc_submit_b(DcChunk *ch) {
     const double t2 = vsm_now_us();
     vsm_host_count_support(wk, ch->p, nl, ch->method);
     vsm_host_keep_supported(wk.tmp_list, wk.support.data());  // in place, then the buffers change hands
-    out.swap(wk.tmp_list);
+    if (ch->pass == 1) out.swap(wk.tmp_list);
     ch->part_ns[6].fetch_add((long long)((vsm_now_us() - t2) * 1e3), std::memory_order_relaxed);
+  }
+}
+
+static void dc_submit_b(DcChunk *ch) {
+  vsm_handle *h = ch->h;
+  ch->t_b0 = vsm_now_us();
+  ch->b_left.store(ch->n, std::memory_order_relaxed);
+  ch->b = h->pool->submit(ch->n, [ch](int i) {
+    const double t0 = vsm_now_us();
+    dc_task_b(ch, i);
+    ch->b_ns.fetch_add((long long)((vsm_now_us() - t0) * 1e3), std::memory_order_relaxed);
+    if (ch->b_left.fetch_sub(1, std::memory_order_acq_rel) == 1) ch->t_b1 = vsm_now_us();
   });
   ch->stage.store(2, std::memory_order_release);
 }
@@ -917,11 +924,13 @@ static void dc_after_gpu(void *arg) {  // runs on a HIP runtime thread: no HIP c
   if (!ch->b_once.exchange(true)) dc_submit_b(ch);
 }
 
-static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished the chunk's last A task
+// from the pool thread that finished the chunk's last A task; wait_here: from the caller's thread, which waits for the
+// GPU's part itself and submits nothing (pass 0)
+static void dc_enqueue_gpu(DcChunk *ch, bool wait_here = false) {
   vsm_handle *h = ch->h;
   (void)hipSetDevice(h->device);
   ch->t_g0 = vsm_now_us();
-  DcBank &B = *h->dc_bank[ch->bank];
+  DcBank &B = *ch->B;
   int maxt = 0, maxm = 0, maxin = 0, maxn = 0, maxlev = 0, maxg = 0, lev_nodes[VSM_DC_MAX_LEVELS] = {0};
   for (int i = 0; i < ch->n; i++) {
     VsmDcJob &jb = B.h_jobs[i];  // (the A task left the level table in it)
@@ -957,7 +966,7 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
   for (int i = 0; i < ch->n; i++) B.h_jobs[i].tri_packed = ch->packed ? B.d_trip + (size_t)i * B.stride_pts * 6 : nullptr;
   // only the used part of every pair's slab row travels: rows of maxm points / maxt tasks
   const size_t sp = (size_t)B.stride_pts, st = (size_t)B.stride_tasks, rows = (size_t)ch->n;
-  hipStream_t s2 = h->dc_stream[ch->bank & 1];
+  hipStream_t s2 = ch->stream;
   bool ok = true;
   if (maxt > 0) {
     ok = hipMemcpy2DAsync(ch->device_kd ? B.d_key_sorted : B.d_key, sp * 8, B.h_key, sp * 8, (size_t)maxm * 8, rows, hipMemcpyHostToDevice,
@@ -996,6 +1005,14 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
     }
   }
   ch->stage.store(1, std::memory_order_release);
+  if (wait_here) {
+    if (maxt > 0 && !(ok && hipStreamSynchronize(s2) == hipSuccess)) {
+      (void)hipStreamSynchronize(s2);
+      for (int i = 0; i < ch->n; i++)
+        if (B.nt[i] > 0) B.nt[i] = -1;
+    }
+    return;
+  }
   if (ok && maxt > 0 && hipLaunchHostFunc(s2, dc_after_gpu, ch) == hipSuccess) return;
   // nothing for the GPU, or it could not be used: the host solves the sub-trees too
   if (maxt > 0) {
@@ -1006,22 +1023,22 @@ static void dc_enqueue_gpu(DcChunk *ch) {  // from the pool thread that finished
   if (!ch->b_once.exchange(true)) dc_submit_b(ch);
 }
 
-static void dc_submit_a(DcChunk *ch) {
-  ch->submitted = true;
-  ch->a_left.store(ch->n, std::memory_order_relaxed);
-  ch->t_a0 = vsm_now_us();
-  ch->a = ch->h->pool->submit(ch->n, [ch](int i) {
+// A for pair i of the chunk: the list out of host-mapped memory, the per-match arrays, the host's part of the triangulation
+static void dc_task_a(DcChunk *ch, int i) {
+  {
     const double t0 = vsm_now_us();
-    vsm_handle *h = ch->h;
-    VsmHostWork &wk = h->seq_work[ch->work0 + i];
-    DcBank &B = *h->dc_bank[ch->bank];
+    VsmHostWork &wk = ch->work[i];
+    DcBank &B = *ch->B;
     B.m[i] = 0;
     B.nt[i] = 0;
     wk.tmp_list.clear();
     if ((*ch->valid)[i]) {
       const int pj = ch->first_pair + i;
       // one wide copy out of the host-mapped export, then cache-resident work
-      wk.tmp_list.assign(ch->ctx->hm_list2[pj], ch->ctx->hm_list2[pj] + ch->ctx->hm_lcount[2 * pj + 1]);
+      if (ch->pass == 1)
+        wk.tmp_list.assign(ch->ctx->hm_list2[pj], ch->ctx->hm_list2[pj] + ch->ctx->hm_lcount[2 * pj + 1]);
+      else
+        wk.tmp_list.assign(ch->ctx->hm_list1[pj], ch->ctx->hm_list1[pj] + ch->ctx->hm_lcount[2 * pj]);
       const int32_t nl = (int32_t)wk.tmp_list.size();
       const double t1 = vsm_now_us();
       ch->part_ns[0].fetch_add((long long)((t1 - t0) * 1e3), std::memory_order_relaxed);
@@ -1065,6 +1082,15 @@ static void dc_submit_a(DcChunk *ch) {
       }
     }
     ch->a_ns.fetch_add((long long)((vsm_now_us() - t0) * 1e3), std::memory_order_relaxed);
+  }
+}
+
+static void dc_submit_a(DcChunk *ch) {
+  ch->submitted = true;
+  ch->a_left.store(ch->n, std::memory_order_relaxed);
+  ch->t_a0 = vsm_now_us();
+  ch->a = ch->h->pool->submit(ch->n, [ch](int i) {
+    dc_task_a(ch, i);
     if (ch->a_left.fetch_sub(1, std::memory_order_acq_rel) == 1) dc_enqueue_gpu(ch);  // the last one hands over
   });
 }
@@ -1081,7 +1107,7 @@ static void dc_wait(DcChunk *ch) {  // until the chunk's final lists are in seq_
     // error state never runs its host function), the host does the pairs itself rather than wait forever.
     if (ch->stage.load(std::memory_order_acquire) == 1 && vsm_now_us() - t0 > 20e6 && !ch->b_once.exchange(true)) {
       fprintf(stderr, "visomatch: the GPU share of the Delaunay stage did not report back, finishing the chunk on the host\n");
-      DcBank &B = *ch->h->dc_bank[ch->bank];
+      DcBank &B = *ch->B;
       for (int i = 0; i < ch->n; i++)
         if (B.nt[i] > 0) B.nt[i] = -1;
       ch->full = false;
@@ -1485,6 +1511,9 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       ch->f0 = f0;
       ch->first_pair = first_pair;
       ch->work0 = ch->bank * C;
+      ch->B = h->dc_bank[dc_b];
+      ch->work = h->seq_work.data() + ch->work0;
+      ch->stream = h->dc_stream[dc_b & 1];
       ch->valid = validp;
       ch->ties_gpu = dc_ties && ch->block && !ch->full && h->hm_ties != nullptr;
       ch->ties = h->hm_ties + (size_t)dc_b * h->ties_chunk * VSM_DC_TIE_OUT_INTS;
