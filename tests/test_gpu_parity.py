@@ -277,6 +277,38 @@ def test_sequence_api_final_stage_variants(vm, synth, monkeypatch, env):
     m.close()
 
 
+def test_two_matchers_in_two_threads(vm, synth, monkeypatch):
+    """instances are independent (the reference's Triangle globals are gone): two look-ahead runs at the same time, each
+    with its own handle, host pool and streams, both with the final stage on the GPU share"""
+    import threading
+    import torch
+    monkeypatch.setenv("VSM_DC_GPU", "1")
+    monkeypatch.setenv("VSM_SEQ_CHUNK", "12")
+    g = G.load("cfg2_seq200_tr")
+    w, h, nf = int(g["w"]), int(g["h"]), 36
+    cv = synth.canvas(int(g["seed"]), w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
+    left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
+    right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
+    out = [None, None]
+
+    def work(k):
+        m = vm.Matcher()
+        m.set_intrinsics(*[float(x) for x in g["intr"]])
+        for _ in range(3):
+            out[k] = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
+        m.close()
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for k in range(2):
+        for f in range(nf):
+            assert len(out[k][f]) == int(g["counts"][f]) and G.sha(out[k][f]) == str(g["hashes"][f]), (k, f)
+
+
 def test_sequence_api_fallbacks(vm, B, synth):
     seq = synth.stereo_sequence(8, 320, 128, 4)
     left = np.stack([l for l, _ in seq])
