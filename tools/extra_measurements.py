@@ -2,7 +2,7 @@
 """Side measurements quoted in DESIGN.md / profiles/README.md (never bench.py's `value`):
   * per-frame API fed from pageable HOST buffers (PCIe-inclusive rate) at 1242x375,
   * the look-ahead API on a 1000-frame sequence (the bench's 200 frames five times over, replayed Tr_delta): the
-    rate once the pipeline's fill and drain (4 of bench.py's 9 ms) no longer count,
+    rate once the pipeline's fill and drain no longer count; two independent sequences at once on the one GPU,
   * config 5: 2048x1024 stereo, per-frame and look-ahead,
   * config 3: 640x480 mono, flow matching (per-frame API),
   * the street scene (synth.road_*, depth-dependent disparity/flow): whole VisualOdometryStereo::process
@@ -65,6 +65,34 @@ for _ in range(3):
 out["cfg2_lookahead_1000_frames_fps"] = round(3 * 200 * reps / (time.perf_counter() - t0), 1)
 m.close()
 del L, R
+# 1c. two independent 200-frame sequences at once on the one GPU (two handles, two caller threads, half the host threads
+#     each): one sequence's pipeline fills while the other's drains
+import threading
+nt_all = int(os.environ.get("VSM_HOST_THREADS", "16"))
+os.environ["VSM_HOST_THREADS"] = str(max(1, nt_all // 2))
+L2 = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
+R2 = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
+tr2 = np.ascontiguousarray(g["s1234_tr_in"][:200].reshape(200, 16)[:, :12])
+trv2 = np.ascontiguousarray(g["s1234_tr_valid"][:200].astype(np.uint8))
+ms = [vm.Matcher() for _ in range(2)]
+for mm in ms:
+    mm.set_intrinsics(*[float(x) for x in g["intr"]])
+    mm.run_sequence(L2, R2, 2, tr2, trv2, fetch=False)
+reps2 = 20
+def _loop(mm):
+    for _ in range(reps2):
+        mm.run_sequence(L2, R2, 2, tr2, trv2, fetch=False)
+ths = [threading.Thread(target=_loop, args=(mm,)) for mm in ms]
+t0 = time.perf_counter()
+for t in ths:
+    t.start()
+for t in ths:
+    t.join()
+out["cfg2_two_sequences_at_once_fps"] = round(2 * reps2 * 200 / (time.perf_counter() - t0), 1)
+for mm in ms:
+    mm.close()
+os.environ["VSM_HOST_THREADS"] = str(nt_all)
+del L2, R2
 # 2. 2048x1024
 seq5 = synth.stereo_sequence(1234, 2048, 1024, 12)
 m = vm.Matcher()
