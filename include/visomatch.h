@@ -117,6 +117,10 @@ int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out,
  * for the GPU, host stages it takes part in (prior statistics, final drain), total, chunk size} - the stages
  * overlap, so the first two are not what the GPU / the host pool were busy for */
 void vsm_sequence_get_timings(vsm_handle *h, double *out4);
+/* which form of the look-ahead path the last vsm_sequence_run took: 2 = GPU-resident (lists stay in HBM from the first
+ * matching pass to the survivors; the host only runs Triangle's vertex sort), 1 = host-shared (VSM_SEQ_V2=0, or a list
+ * the device chain declines) */
+int32_t vsm_sequence_path(vsm_handle *h);
 
 /* ---- stage-level views for parity tests (the reference's private members) ---- */
 
@@ -185,6 +189,19 @@ double vsm_debug_dc_bench(const int32_t *x, const int32_t *y, int32_t n, int32_t
  * (k_dc_ties, one wave; kernel_us may be null); return the count, -1 where the GPU declines (list too long) */
 int32_t vsm_host_ties(const int32_t *x, const int32_t *y, int32_t n, int32_t *pairs, int32_t cap);
 int32_t vsm_debug_ties_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_t *pairs, int32_t cap, double *kernel_us);
+
+/* Matcher::removeOutliers (viso/matcher.cpp:1207-1377) and Matcher::computePriorStatistics (:734-868) on a match
+ * list of the caller: the host code of the per-frame path, and the GPU-resident chain of the look-ahead path
+ * (keys, vertex sort - on the device if gpu_ties, else on the host -, kd order, block sub-trees, cached merge levels,
+ * support votes, survivors, prior statistics) run on `copies` identical jobs at once.  Test hooks: the two must
+ * agree byte for byte.  out gets the survivors, ranges (may be null) the prior boxes in the device layout of the
+ * match kernels ([bin][stage][u_min, u_max, v_min, v_max], p->match_radius as given); return the number of
+ * survivors, -1 on a HIP error, -2 if the device chain declines the list; kernel_us (may be null): microseconds of
+ * the device chain for all copies. */
+int32_t vsm_host_outliers_and_prior(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, vsm_p_match *out,
+                                    int32_t cap, float *ranges, int32_t w, int32_t h);
+int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, int32_t gpu_ties, int32_t copies,
+                      vsm_p_match *out, int32_t cap, float *ranges, int32_t w, int32_t h, double *kernel_us);
 
 /* ---- stereo visual odometry on top of the matcher ----
  * class VisualOdometryStereo, viso/viso_stereo.h:28-88 + viso/viso.h:28-131: process() =

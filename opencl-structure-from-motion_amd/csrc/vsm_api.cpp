@@ -407,6 +407,8 @@ struct vsm_handle {
   // results of the sequence API
   std::vector<std::vector<vsm_p_match>> seq_matches;
   double seq_timings[4] = {0, 0, 0, 0};
+  struct Seq2 *seq2 = nullptr;   // GPU-resident look-ahead path (vsm_seq2.inc): streams, slabs, result arena
+  int32_t seq_v2_frames = 0;     // > 0: the last sequence's results are in seq2's arena, not in seq_matches
 
   uint8_t *stage_host = nullptr;  // pinned staging for host images
   size_t stage_bytes = 0;
@@ -427,6 +429,7 @@ static void ranges_to_device_layout(float *dst, const float *src, size_t n_float
 VsmPool *vsm_pool_of(vsm_handle *h) { return h->pool; }
 VsmForkJoin *vsm_forkjoin_of(vsm_handle *h) { return h->fj; }
 double vsm_now_us() { return now_us(); }
+static void seq2_destroy(vsm_handle *h);  // vsm_seq2.inc
 
 extern "C" {
 
@@ -498,6 +501,7 @@ static void reset_ring_state(vsm_handle *h) {
 void vsm_destroy(vsm_handle *h) {
   if (!h) return;
   (void)hipStreamSynchronize(h->stream);
+  seq2_destroy(h);
   ctx_destroy(h->ring);
   ctx_destroy(h->seq);
   if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -1121,6 +1125,10 @@ static void dc_wait(DcChunk *ch) {  // until the chunk's final lists are in seq_
   ch->h->pool->wait(ch->b);
 }
 
+}  // extern "C"
+#include "vsm_seq2.inc"
+extern "C" {
+
 // ---------------------------------------------------------------------------------------
 // Look-ahead sequence API.  Semantics: exactly pushBack(frame f) + matchFeatures(method, Tr[f])
 // for f = 0..n-1 on a fresh matcher.  Frames are processed in chunks of C: every kernel runs once
@@ -1132,6 +1140,7 @@ static int sequence_fallback(vsm_handle *h, const uint8_t *left, const uint8_t *
                              const uint8_t *Tr_valid) {
   // rarely used configurations (mono input, refinement==2) go frame by frame on a fresh ring
   (void)hipStreamSynchronize(h->stream);
+  seq2_destroy(h);
   ctx_destroy(h->ring);
   reset_ring_state(h);
   h->matched.clear();
@@ -1162,12 +1171,20 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   if (!right || p.refinement == 2)
     return sequence_fallback(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
 
+  // The GPU-resident form (vsm_seq2.inc) takes the run unless VSM_SEQ_V2=0 asks for the host-shared form below, or
+  // it declines (lists beyond what its device-side vertex sort / kd order were written for).
+  h->seq_v2_frames = 0;
+  if (!(getenv("VSM_SEQ_V2") && atoi(getenv("VSM_SEQ_V2")) == 0)) {
+    const int rc = sequence_run_v2(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
+    if (rc != VSM_SEQ2_DECLINED) return rc;
+    h->seq_v2_frames = 0;
+  }
   int C = 50;
   if (const char *e = getenv("VSM_SEQ_CHUNK")) C = atoi(e);
   if (C < 1) C = 1;
   if (C > n_frames) C = n_frames;
   VsmCtx &c = h->seq;
-  if (!c.ready || c.dims.w != w || c.dims.h != hh || h->seq_chunk != C) {
+  if (!c.ready || c.dims.w != w || c.dims.h != hh || h->seq_chunk != C || c.npairs != 2 * C) {
     (void)hipStreamSynchronize(h->stream);
     int rc = ctx_create(c, p, w, hh, 3 * C, 2 * C, h->stream);  // three banks of frames, two of pairs
     if (rc != VSM_OK) return rc;
@@ -1589,10 +1606,18 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
 }
 
 int32_t vsm_sequence_num_matches(vsm_handle *h, int32_t frame) {
+  if (h->seq_v2_frames > 0) return (frame >= 0 && frame < h->seq_v2_frames) ? h->seq2->res_cnt[frame] : 0;
   return (frame >= 0 && frame < (int32_t)h->seq_matches.size()) ? (int32_t)h->seq_matches[frame].size() : 0;
 }
 
 int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out, int32_t cap) {
+  if (h->seq_v2_frames > 0) {
+    if (frame < 0 || frame >= h->seq_v2_frames) return 0;
+    int32_t n = h->seq2->res_cnt[frame];
+    if (n > cap) n = cap;
+    if (n > 0) memcpy(out, h->seq2->res + h->seq2->res_off[frame], (size_t)n * sizeof(vsm_p_match));
+    return n;
+  }
   if (frame < 0 || frame >= (int32_t)h->seq_matches.size()) return 0;
   int32_t n = (int32_t)h->seq_matches[frame].size();
   if (n > cap) n = cap;
@@ -1601,6 +1626,7 @@ int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out,
 }
 
 void vsm_sequence_get_timings(vsm_handle *h, double *out4) { memcpy(out4, h->seq_timings, sizeof(h->seq_timings)); }
+int32_t vsm_sequence_path(vsm_handle *h) { return h->seq_v2_frames > 0 ? 2 : 1; }
 
 // ---- stage-level views ----
 static bool which_set(vsm_handle *h, int32_t which, int &img, int &set, int32_t &n) {
@@ -1922,6 +1948,99 @@ int32_t vsm_debug_ties_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_
     pairs[2 * k + 1] = out[2 + 2 * k];
   }
   return out[0];
+}
+
+int32_t vsm_host_outliers_and_prior(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, vsm_p_match *out,
+                                    int32_t cap, float *ranges, int32_t w, int32_t hh) {
+  VsmHostWork wk;
+  std::vector<vsm_p_match> m(list, list + std::max(n, 0));
+  vsm_host_remove_outliers(wk, *p, m, method);
+  if (ranges) {
+    const int32_t dims[3] = {w, hh, w};
+    std::vector<float> rg;
+    vsm_host_prior_statistics(*p, dims, m, method, rg);
+    ranges_to_device_layout(ranges, rg.data(), rg.size());
+  }
+  for (size_t i = 0; i < m.size() && (int32_t)i < cap; i++) out[i] = m[i];
+  return (int32_t)m.size();
+}
+
+int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, int32_t gpu_ties, int32_t copies,
+                      vsm_p_match *out, int32_t cap, float *ranges, int32_t w, int32_t hh, double *kernel_us) {
+  if (copies < 1) copies = 1;
+  const int ub = (int)ceilf((float)w / (float)p->match_binsize), vb = (int)ceilf((float)hh / (float)p->match_binsize);
+  if (ranges && ub * vb > 1024) return -2;
+  Dc2Bank B;
+  if (!B.reserve(copies, std::max(n, 64), true)) return -1;
+  vsm_p_match *d_list = nullptr, *d_out = nullptr;
+  int32_t *d_cnt = nullptr;
+  float *d_ranges = nullptr;
+  const size_t lb = (size_t)std::max(n, 1) * sizeof(vsm_p_match), rb = (size_t)ub * vb * 16 * 4;
+  bool ok = hipMalloc((void **)&d_list, lb) == hipSuccess && hipMalloc((void **)&d_out, lb * copies) == hipSuccess &&
+            hipMalloc((void **)&d_cnt, 4) == hipSuccess && hipMalloc((void **)&d_ranges, rb * copies) == hipSuccess;
+  int32_t result = -1;
+  if (ok) {
+    (void)hipMemcpy(d_list, list, (size_t)n * sizeof(vsm_p_match), hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_cnt, &n, 4, hipMemcpyHostToDevice);
+    for (int i = 0; i < copies; i++)
+      B.fill_job(i, d_list, d_cnt, gpu_ties != 0, d_out + (size_t)i * std::max(n, 1), nullptr, d_ranges + (size_t)i * ub * vb * 16);
+    (void)hipMemcpy(B.d_jobs, B.h_jobs, sizeof(VsmDc2Job) * copies, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, nullptr);
+    dc2_enqueue_triangulation(nullptr, B, copies, n, gpu_ties != 0);
+    if (!gpu_ties) {  // the host's verdicts (the look-ahead path computes them while the device triangulates)
+      ok = hipDeviceSynchronize() == hipSuccess;
+      ExactDelaunay sorter;
+      for (int i = 0; i < copies && ok; i++) {
+        int32_t *o = B.host_ties_of(i);
+        const int32_t nn = B.h_n[i];
+        o[0] = nn > 3 ? sorter.sort_ties(B.host_keys(i), nn, o + 1, (B.ties_stride - 1) / 2) : 0;
+      }
+    }
+    dc2_enqueue_mesh(nullptr, B, copies, n);
+    vsm_dc2_launch_support(nullptr, B.d_jobs, copies, n, method, (float)p->outlier_flow_tolerance, (float)p->outlier_disp_tolerance);
+    vsm_dc2_launch_compact(nullptr, B.d_jobs, copies);
+    if (ranges) vsm_dc2_launch_prior(nullptr, B.d_jobs, copies, method, p->match_binsize, p->match_radius, w, hh, ub, vb);
+    (void)hipEventRecord(e1, nullptr);
+    ok = ok && hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (kernel_us) *kernel_us = ms * 1e3;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (ok && *B.h_error) {
+      result = -2;
+    } else if (ok) {
+      // every copy must have produced the same survivors
+      std::vector<int32_t> cnt(copies);
+      std::vector<vsm_p_match> first, other;
+      bool same = true;
+      for (int i = 0; i < copies && same; i++) {
+        (void)hipMemcpy(&cnt[i], B.pp[i].out_count, 4, hipMemcpyDeviceToHost);
+        same = cnt[i] == cnt[0] && cnt[i] >= 0 && cnt[i] <= n;
+        if (!same) break;
+        std::vector<vsm_p_match> &dst = i == 0 ? first : other;
+        dst.resize(cnt[i]);
+        if (cnt[i]) (void)hipMemcpy(dst.data(), d_out + (size_t)i * std::max(n, 1), (size_t)cnt[i] * sizeof(vsm_p_match), hipMemcpyDeviceToHost);
+        if (i > 0) same = memcmp(first.data(), other.data(), (size_t)cnt[0] * sizeof(vsm_p_match)) == 0;
+      }
+      if (same) {
+        result = cnt[0];
+        for (int32_t i = 0; i < result && i < cap; i++) out[i] = first[i];
+        if (ranges) (void)hipMemcpy(ranges, d_ranges + (size_t)(copies - 1) * ub * vb * 16, rb, hipMemcpyDeviceToHost);
+      } else {
+        result = -3;
+      }
+    }
+  }
+  (void)hipFree(d_list);
+  (void)hipFree(d_out);
+  (void)hipFree(d_cnt);
+  (void)hipFree(d_ranges);
+  B.release();
+  return result;
 }
 
 void vsm_get_counters(vsm_handle *h, int64_t *out5) { memcpy(out5, h->counters, sizeof(h->counters)); }

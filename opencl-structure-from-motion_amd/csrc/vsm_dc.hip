@@ -129,15 +129,13 @@ __device__ inline void kd_levels(T *X0, T *X1, T *Y0, T *Y1, T *PX, T *PY, uint3
 
 #define KD_LDS_POINTS 8192  // 6 uint16 lists + the uint32 scan fit where the histogram was
 
-__global__ void __launch_bounds__(KD_THREADS) k_dc_kd_order(const VsmDcJob *__restrict__ jobs, int njobs) {
-  __shared__ uint32_t hist[KD_DIGITS * KD_CHUNKS];
-  __shared__ uint32_t tot[KD_THREADS / 64 + 1];
-  const VsmDcJob jb = jobs[blockIdx.x];
-  const int32_t m = jb.m;
-  if (!jb.key_sorted || m < 2 || m > VSM_DC_KD_MAX_POINTS) return;  // (uniform for the block)
-  const uint64_t *ks = jb.key_sorted;
-  uint32_t *X0 = jb.kd_scratch, *X1 = X0 + jb.kd_stride, *Y0 = X1 + jb.kd_stride, *Y1 = Y0 + jb.kd_stride;
-  uint32_t *PX = Y1 + jb.kd_stride, *PY = PX + jb.kd_stride, *P = PY + jb.kd_stride;
+// the whole kd order of one triangulation by one workgroup of KD_THREADS threads: ks = distinct keys in (x,y) order,
+// scratch = VSM_DC_KD_SCRATCH arrays of `stride` uint32, hist / tot = the workgroup's LDS (KD_DIGITS * KD_CHUNKS and
+// KD_THREADS / 64 + 1 words); key_out gets the keys in kd order
+__device__ inline void kd_order_body(const uint64_t *__restrict__ ks, const int32_t m, uint32_t *scratch, const int32_t stride,
+                                     uint64_t *__restrict__ key_out, uint32_t *hist, uint32_t *tot) {
+  uint32_t *X0 = scratch, *X1 = X0 + stride, *Y0 = X1 + stride, *Y1 = Y0 + stride;
+  uint32_t *PX = Y1 + stride, *PY = PX + stride, *P = PY + stride;
   const int t = threadIdx.x;
 
   // ---- y order: stable LSD radix sort of the ranks by y (7 + 7 bits); every thread of the first
@@ -195,7 +193,7 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc_kd_order(const VsmDcJob *__re
       lPY[e] = (uint16_t)q;
     }
     __syncthreads();
-    kd_levels<uint16_t>(lX0, lX1, lY0, lY1, lPX, lPY, lP, m, tot, ks, jb.key);
+    kd_levels<uint16_t>(lX0, lX1, lY0, lY1, lPX, lPY, lP, m, tot, ks, key_out);
     return;
   }
   for (int32_t q = t; q < m; q += KD_THREADS) {
@@ -204,7 +202,16 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc_kd_order(const VsmDcJob *__re
     PY[Y0[q]] = (uint32_t)q;
   }
   __syncthreads();
-  kd_levels<uint32_t>(X0, X1, Y0, Y1, PX, PY, P, m, tot, ks, jb.key);
+  kd_levels<uint32_t>(X0, X1, Y0, Y1, PX, PY, P, m, tot, ks, key_out);
+}
+
+__global__ void __launch_bounds__(KD_THREADS) k_dc_kd_order(const VsmDcJob *__restrict__ jobs, int njobs) {
+  __shared__ uint32_t hist[KD_DIGITS * KD_CHUNKS];
+  __shared__ uint32_t tot[KD_THREADS / 64 + 1];
+  const VsmDcJob jb = jobs[blockIdx.x];
+  const int32_t m = jb.m;
+  if (!jb.key_sorted || m < 2 || m > VSM_DC_KD_MAX_POINTS) return;  // (uniform for the block)
+  kd_order_body(jb.key_sorted, m, jb.kd_scratch, jb.kd_stride, jb.key, hist, tot);
 }
 
 __global__ void __launch_bounds__(64) k_dc_subtrees(const VsmDcJob *__restrict__ jobs, int njobs) {
@@ -232,17 +239,14 @@ __global__ void __launch_bounds__(64) k_dc_subtrees(const VsmDcJob *__restrict__
 #define DCB_LEAF 14
 #define DCB_DEPTH 6  // ceil(480 / 2^6) <= 14
 
-__global__ void __launch_bounds__(64) k_dc_block(const VsmDcJob *__restrict__ jobs, int njobs) {
+// one sub-tree `tk` by the calling wave (64 threads = the whole workgroup); `jb` brings key, tri / tri_packed, pt, id;
+// the sub-tree's two hull handles go to *hull_out
+__device__ inline void dc_block_body(const VsmDcJob &jb, const VsmDcTask tk, VsmDcHull *hull_out) {
   __shared__ int32_t s_tri[2 * VSM_DC_BLOCK_POINTS * 8];
   __shared__ uint64_t s_key[VSM_DC_BLOCK_POINTS];
   __shared__ uint32_t s_pt[VSM_DC_BLOCK_POINTS];
   __shared__ int32_t s_id[VSM_DC_BLOCK_POINTS];
   __shared__ VsmDcHull s_hull[2 << DCB_DEPTH];
-  const int j = blockIdx.y;
-  if (j >= njobs) return;
-  const VsmDcJob jb = jobs[j];
-  if ((int)blockIdx.x >= jb.ntasks) return;
-  const VsmDcTask tk = jb.tasks[blockIdx.x];
   const int lane = threadIdx.x;
   if (tk.n > VSM_DC_BLOCK_POINTS) {  // not expected (the host cuts tasks to fit): plain recursion in global memory
     int32_t *gt = jb.tri + (size_t)2 * tk.off * 8;
@@ -252,7 +256,7 @@ __global__ void __launch_bounds__(64) k_dc_block(const VsmDcJob *__restrict__ jo
       const DcMesh mesh{jb.tri, jb.pt, jb.id, jb.key};
       DcMesh::OTri fl, fr;
       mesh.recurse(tk.off, tk.n, tk.axis, fl, fr);
-      jb.hulls[tk.node] = VsmDcHull{fl.t, fl.o, fr.t, fr.o};
+      *hull_out = VsmDcHull{fl.t, fl.o, fr.t, fr.o};
     }
     return;
   }
@@ -336,7 +340,16 @@ __global__ void __launch_bounds__(64) k_dc_block(const VsmDcJob *__restrict__ jo
     jb.pt[tk.off + i] = s_pt[i];
     jb.id[tk.off + i] = s_id[i];
   }
-  if (lane == 0) jb.hulls[tk.node] = s_hull[1];
+  if (lane == 0) *hull_out = s_hull[1];
+}
+
+__global__ void __launch_bounds__(64) k_dc_block(const VsmDcJob *__restrict__ jobs, int njobs) {
+  const int j = blockIdx.y;
+  if (j >= njobs) return;
+  const VsmDcJob jb = jobs[j];
+  if ((int)blockIdx.x >= jb.ntasks) return;
+  const VsmDcTask tk = jb.tasks[blockIdx.x];
+  dc_block_body(jb, tk, jb.hulls + tk.node);
 }
 
 __global__ void __launch_bounds__(64) k_dc_merge_level(const VsmDcJob *__restrict__ jobs, int njobs, int level) {
@@ -757,4 +770,580 @@ void vsm_dc_launch_ties_of_keys(hipStream_t s, int npairs, const uint64_t *keys,
                                 int out_stride) {
   if (npairs <= 0) return;
   hipLaunchKernelGGL(k_dc_ties_of_keys, dim3(npairs), dim3(64), 0, s, keys, stride, counts, tie_out, out_stride);
+}
+
+// =======================================================================================
+// GPU-resident removeOutliers (VsmDc2Job, vsm_dc_gpu.h): keys -> (x,y) sort + duplicate removal + kd order ->
+// block sub-trees -> merge levels through an LDS record cache -> tie patches, support votes -> survivors
+// (-> prior statistics for pass 1).  Every kernel finds its work from the list length / point count in device memory.
+// =======================================================================================
+#define DC2_AS3 __attribute__((address_space(3)))
+
+__global__ void __launch_bounds__(256) k_dc2_keys(const VsmDc2Job *__restrict__ jobs) {
+  const VsmDc2Job jb = jobs[blockIdx.y];
+  const int n = min(*jb.count, jb.cap);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && jb.h_n) *jb.h_n = n;
+  if (i >= n) return;
+  const vsm_p_match a = jb.list[i];
+  const uint64_t k = ((uint64_t)(uint32_t)(int32_t)a.u1c << 34) | ((uint64_t)(uint32_t)(int32_t)a.v1c << 20) | (uint32_t)i;
+  jb.keys_in[i] = k;
+  if (jb.h_keys) jb.h_keys[i] = k;
+  jb.remap[i] = i;
+  jb.support[i] = 0;
+}
+
+// one stable LSD pass (7 bits at `sh`) over n 64-bit keys; thread t < KD_CHUNKS owns a contiguous chunk and its own
+// histogram column, so the order inside a digit is the order of the source
+__device__ inline void dc2_radix_pass(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, const int32_t n, const int sh,
+                                      uint32_t *hist, uint32_t *tot) {
+  const int t = threadIdx.x;
+  const int32_t chunk = (n + KD_CHUNKS - 1) / KD_CHUNKS;
+  for (int i = t; i < KD_DIGITS * KD_CHUNKS; i += KD_THREADS) hist[i] = 0;
+  __syncthreads();
+  if (t < KD_CHUNKS) {
+    const int32_t i0 = t * chunk, i1 = min(n, i0 + chunk);
+    for (int32_t i = i0; i < i1; i++) hist[((src[i] >> sh) & (KD_DIGITS - 1)) * KD_CHUNKS + t]++;
+  }
+  __syncthreads();
+  {
+    const int per = KD_DIGITS * KD_CHUNKS / KD_THREADS;
+    uint32_t sum = 0;
+    for (int i = 0; i < per; i++) sum += hist[t * per + i];
+    uint32_t run = kd_block_scan(sum, tot);
+    for (int i = 0; i < per; i++) {
+      const uint32_t c = hist[t * per + i];
+      hist[t * per + i] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  if (t < KD_CHUNKS) {
+    const int32_t i0 = t * chunk, i1 = min(n, i0 + chunk);
+    for (int32_t i = i0; i < i1; i++) {
+      const uint64_t k = src[i];
+      dst[hist[((k >> sh) & (KD_DIGITS - 1)) * KD_CHUNKS + t]++] = k;
+    }
+  }
+  __syncthreads();
+}
+
+// ExactDelaunay::prepare(defer_ties) on the device: stable sort of the keys by (x, y), the first key of every pixel
+// stays (it carries the smallest input index; the vertex sort's verdict is patched in later), kd order.
+__global__ void __launch_bounds__(KD_THREADS) k_dc2_prepare(const VsmDc2Job *__restrict__ jobs) {
+  __shared__ uint32_t hist[KD_DIGITS * KD_CHUNKS];
+  __shared__ uint32_t tot[KD_THREADS / 64 + 1];
+  __shared__ int32_t s_m;
+  const VsmDc2Job jb = jobs[blockIdx.x];
+  const int t = threadIdx.x;
+  const int32_t nl = *jb.count;
+  int32_t n = min(nl, jb.cap), m = 0;
+  if (nl > jb.cap || nl > VSM_DC_KD_MAX_POINTS) {  // (not expected: the host sizes the slabs from the query counts)
+    if (t == 0) *jb.error = 1;
+    n = 0;
+  }
+  if (n > 3) {  // the reference leaves lists of up to three matches alone (viso/matcher.cpp:1210)
+    uint64_t *T0 = (uint64_t *)jb.kd_scratch, *T1 = T0 + jb.kd_stride;
+    dc2_radix_pass(jb.keys_in, T0, n, 20, hist, tot);
+    dc2_radix_pass(T0, T1, n, 27, hist, tot);
+    dc2_radix_pass(T1, T0, n, 34, hist, tot);
+    dc2_radix_pass(T0, T1, n, 41, hist, tot);
+    const int32_t per = (n + KD_THREADS - 1) / KD_THREADS;
+    const int32_t i0 = min(n, t * per), i1 = min(n, i0 + per);
+    uint32_t cnt = 0;
+    for (int32_t i = i0; i < i1; i++) cnt += (i == 0 || VSM_KXY(T1[i]) != VSM_KXY(T1[i - 1])) ? 1u : 0u;
+    uint32_t pos = kd_block_scan(cnt, tot);
+    for (int32_t i = i0; i < i1; i++)
+      if (i == 0 || VSM_KXY(T1[i]) != VSM_KXY(T1[i - 1])) jb.key_sorted[pos++] = T1[i];
+    if (t == KD_THREADS - 1) s_m = (int32_t)pos;
+    __syncthreads();
+    m = s_m;
+  }
+  if (t == 0) {
+    jb.mn[0] = m;
+    jb.mn[1] = n;
+  }
+  if (m >= 2) kd_order_body(jb.key_sorted, m, jb.kd_scratch, jb.kd_stride, jb.key, hist, tot);
+}
+
+// The divide-and-conquer tree is ExactDelaunay::build_tree's: [off, off+n) splits at n >> 1 while n > block points.
+// A node is named by its depth and path from the root (bit per level, most significant first) and has heap index
+// (1 << depth) | path.  Returns false if the path runs past a sub-tree that became a block earlier.
+__device__ inline bool dc2_walk(int32_t m, int depth, uint32_t path, int32_t &off, int32_t &n, int &axis) {
+  off = 0;
+  n = m;
+  axis = 0;
+  for (int b = depth - 1; b >= 0; b--) {
+    if (n <= VSM_DC_BLOCK_POINTS) return false;
+    const int32_t div = n >> 1;
+    if ((path >> b) & 1) {
+      off += div;
+      n -= div;
+    } else {
+      n = div;
+    }
+    axis = 1 - axis;
+  }
+  return true;
+}
+
+__global__ void __launch_bounds__(64) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
+  const VsmDc2Job j2 = jobs[blockIdx.y];
+  const int32_t m = j2.mn[0];
+  if (m < 2) return;
+  // the block at the end of path p (depth bits); a sub-tree that fits a block at a smaller depth d is taken by the
+  // path whose remaining bits are zero
+  int32_t off = 0, n = m;
+  int axis = 0, d = 0;
+  uint32_t idx = 1;
+  const uint32_t path = blockIdx.x;
+  for (int b = depth - 1; b >= 0 && n > VSM_DC_BLOCK_POINTS; b--, d++) {
+    const int32_t div = n >> 1;
+    if ((path >> b) & 1) {
+      off += div;
+      n -= div;
+      idx = 2 * idx + 1;
+    } else {
+      n = div;
+      idx = 2 * idx;
+    }
+    axis = 1 - axis;
+  }
+  if (n > VSM_DC_BLOCK_POINTS) {  // (the host chose too small a depth)
+    if (threadIdx.x == 0) *j2.error = 2;
+    return;
+  }
+  if (d < depth && (path & ((1u << (depth - d)) - 1u)) != 0) return;
+  VsmDcJob jb;
+  jb.key = j2.key;
+  jb.tri = j2.tri;
+  jb.tri_packed = nullptr;
+  jb.pt = j2.pt;
+  jb.id = j2.id;
+  dc_block_body(jb, VsmDcTask{off, n, axis, (int32_t)idx}, j2.hulls + idx);
+}
+
+// ---------------------------------------------------------------------------------------
+// Merge levels above the blocks.  mergehulls walks a seam: every step reads a few triangle records and points that
+// depend on the previous step, and in global memory each of those is an L2 round trip.  Here a workgroup takes one
+// merge node: all its threads first bring the node's points and the records the seam can touch into LDS -- the hull
+// (ghost) triangles of both halves, the triangles whose circumcircle reaches across the cut (only those can be
+// destroyed), their neighbours (read for their apex), the node's two new slots -- with a 16-bit slot -> LDS index map;
+// nodes small enough go in whole.  Then one lane zips the seam on the LDS copies (DcCachedMesh: stores also go through
+// to global memory, which therefore is always current; a record that was not foreseen is fetched on first use).
+// ---------------------------------------------------------------------------------------
+#define DC2_MERGE_THREADS 256
+#define DC2_CACHE_PTS 8192
+#define DC2_CACHE_RECS 2304
+
+struct DcCachedMesh {
+  typedef DcOTri OTri;
+  int32_t *gtri;
+  DC2_AS3 int32_t *lrec;
+  DC2_AS3 uint16_t *map;
+  DC2_AS3 const uint32_t *lpt;
+  DC2_AS3 int32_t *nrec;
+  int32_t tbase, pbase;
+  __device__ inline int slot_of(int32_t t) const {  // LDS index of record t, fetched if it is not there yet and there is room
+    const int s = t - tbase;
+    int i = map[s];
+    if (i == 0xffff) {
+      const int k = *nrec;
+      if (k >= DC2_CACHE_RECS) return -1;
+      *nrec = k + 1;
+      typedef int32_t v4i __attribute__((ext_vector_type(4)));
+      const v4i *g = (const v4i *)(gtri + (size_t)t * 8);
+      const v4i a = g[0], b = g[1];
+      DC2_AS3 v4i *d = (DC2_AS3 v4i *)(lrec + k * 8);
+      d[0] = a;
+      d[1] = b;
+      map[s] = (uint16_t)k;
+      i = k;
+    }
+    return i;
+  }
+  __device__ inline int32_t ld(int32_t t, int w) const {
+    const int i = slot_of(t);
+    return i >= 0 ? lrec[i * 8 + w] : gtri[(size_t)t * 8 + w];
+  }
+  __device__ inline void st(int32_t t, int w, int32_t v) const {
+    const int i = map[t - tbase];
+    if (i != 0xffff) lrec[i * 8 + w] = v;
+    gtri[(size_t)t * 8 + w] = v;
+  }
+  __device__ inline OTri make(int32_t &tcur) const {
+    const int32_t t = tcur++;
+    st(t, 0, -1);
+    st(t, 1, -1);
+    st(t, 2, -1);
+    st(t, 4, -1);
+    st(t, 5, -1);
+    st(t, 6, -1);
+    return OTri{t, 0};
+  }
+  __device__ inline OTri sym(OTri a) const {
+    const int32_t e = ld(a.t, a.o);
+    return OTri{e >> 2, e & 3};
+  }
+  __device__ static inline OTri lnext(OTri a) { return OTri{a.t, a.o == 2 ? 0 : a.o + 1}; }
+  __device__ static inline OTri lprev(OTri a) { return OTri{a.t, a.o == 0 ? 2 : a.o - 1}; }
+  __device__ inline int32_t org(OTri a) const { return ld(a.t, 4 + (a.o == 2 ? 0 : a.o + 1)); }
+  __device__ inline int32_t dest(OTri a) const { return ld(a.t, 4 + (a.o == 0 ? 2 : a.o - 1)); }
+  __device__ inline int32_t apex(OTri a) const { return ld(a.t, 4 + a.o); }
+  __device__ inline void set_org(OTri a, int32_t v) const { st(a.t, 4 + (a.o == 2 ? 0 : a.o + 1), v); }
+  __device__ inline void set_dest(OTri a, int32_t v) const { st(a.t, 4 + (a.o == 0 ? 2 : a.o - 1), v); }
+  __device__ inline void set_apex(OTri a, int32_t v) const { st(a.t, 4 + a.o, v); }
+  __device__ inline void bond(OTri a, OTri b) const {
+    st(a.t, a.o, b.t * 4 + b.o);
+    st(b.t, b.o, a.t * 4 + a.o);
+  }
+  __device__ inline uint32_t point(int32_t p) const { return lpt[p - pbase]; }
+  __device__ inline int32_t px(int32_t p) const { return (int32_t)(point(p) & 0xffffu); }
+  __device__ inline int32_t py(int32_t p) const { return (int32_t)(point(p) >> 16); }
+  __device__ inline int32_t ccw(int32_t a, int32_t b, int32_t c) const {
+    const uint32_t pa = point(a), pb = point(b), pc = point(c);
+    const int32_t cx = (int32_t)(pc & 0xffffu), cy = (int32_t)(pc >> 16);
+    return ((int32_t)(pa & 0xffffu) - cx) * ((int32_t)(pb >> 16) - cy) - ((int32_t)(pa >> 16) - cy) * ((int32_t)(pb & 0xffffu) - cx);
+  }
+  __device__ inline int64_t incircle(int32_t a, int32_t b, int32_t c, int32_t d) const {
+    const uint32_t pa = point(a), pb = point(b), pc = point(c), pd = point(d);
+    const int32_t dx = (int32_t)(pd & 0xffffu), dy = (int32_t)(pd >> 16);
+    const int32_t adx = (int32_t)(pa & 0xffffu) - dx, ady = (int32_t)(pa >> 16) - dy;
+    const int32_t bdx = (int32_t)(pb & 0xffffu) - dx, bdy = (int32_t)(pb >> 16) - dy;
+    const int32_t cdx = (int32_t)(pc & 0xffffu) - dx, cdy = (int32_t)(pc >> 16) - dy;
+    return (int64_t)(adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (int64_t)(bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) +
+           (int64_t)(cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
+  }
+};
+
+__global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job *__restrict__ jobs, int level) {
+  __shared__ uint32_t s_pt[DC2_CACHE_PTS];
+  __shared__ uint16_t s_map[2 * DC2_CACHE_PTS];
+  __shared__ int32_t s_rec[DC2_CACHE_RECS * 8];
+  __shared__ uint32_t s_claim[2 * DC2_CACHE_PTS / 32];
+  __shared__ int32_t s_n, s_cl, s_cr;
+  const VsmDc2Job jb = jobs[blockIdx.y];
+  const int32_t m = jb.mn[0];
+  if (m < 2) return;
+  int32_t off, n;
+  int axis;
+  if (!dc2_walk(m, level, blockIdx.x, off, n, axis) || n <= VSM_DC_BLOCK_POINTS) return;  // no such node / it is a block
+  const uint32_t idx = (1u << level) | blockIdx.x;
+  const int t = threadIdx.x;
+  const int32_t div = n >> 1;
+  const VsmDcHull l = jb.hulls[2 * idx], r = jb.hulls[2 * idx + 1];
+  DcOTri fl{l.fl_t, l.fl_o}, il{l.fr_t, l.fr_o}, ir{r.fl_t, r.fl_o}, fr{r.fr_t, r.fr_o};
+  int32_t tcur = 2 * (off + div) - 2;
+  if (n > DC2_CACHE_PTS) {  // too large for the cache: the plain mesh in global memory
+    if (t == 0) {
+      const DcMesh mesh{jb.tri, jb.pt, jb.id, jb.key};
+      mesh.merge_hulls(fl, il, ir, fr, axis, tcur);
+      jb.hulls[idx] = VsmDcHull{fl.t, fl.o, fr.t, fr.o};
+    }
+    return;
+  }
+  const int32_t tbase = 2 * off, nslots = 2 * n;
+  const int4 *grec = (const int4 *)(jb.tri + (size_t)tbase * 8);
+  if (t == 0) {
+    s_n = 0;
+    s_cl = -1;
+    s_cr = 1 << 30;
+  }
+  for (int i = t; i < n; i += DC2_MERGE_THREADS) s_pt[i] = jb.pt[off + i];
+  for (int i = t; i < nslots; i += DC2_MERGE_THREADS) s_map[i] = 0xffff;
+  for (int i = t; i < (nslots + 31) / 32; i += DC2_MERGE_THREADS) s_claim[i] = 0;
+  __syncthreads();
+  const bool whole = nslots <= DC2_CACHE_RECS;
+  if (whole) {
+    for (int i = t; i < nslots * 2; i += DC2_MERGE_THREADS) ((int4 *)s_rec)[i] = grec[i];
+    for (int i = t; i < nslots; i += DC2_MERGE_THREADS) s_map[i] = (uint16_t)i;
+    if (t == 0) s_n = nslots;
+  } else {
+    // extent of the two halves along the cut axis: largest coordinate on the left, smallest on the right
+    {
+      int32_t cl = -1, cr = 1 << 30;
+      for (int i = t; i < n; i += DC2_MERGE_THREADS) {
+        const uint32_t p = s_pt[i];
+        const int32_t c = axis == 0 ? (int32_t)(p & 0xffffu) : (int32_t)(p >> 16);
+        if (i < div)
+          cl = max(cl, c);
+        else
+          cr = min(cr, c);
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        cl = max(cl, __shfl_xor(cl, o, 64));
+        cr = min(cr, __shfl_xor(cr, o, 64));
+      }
+      if ((t & 63) == 0) {
+        atomicMax(&s_cl, cl);
+        atomicMin(&s_cr, cr);
+      }
+    }
+    __syncthreads();
+    const float fcl = (float)s_cl, fcr = (float)s_cr;
+    auto insert = [&](int s) {  // record of local slot s into the cache (the caller has claimed it)
+      const int k = atomicAdd(&s_n, 1);
+      if (k < DC2_CACHE_RECS) {
+        ((int4 *)s_rec)[2 * k] = grec[2 * s];
+        ((int4 *)s_rec)[2 * k + 1] = grec[2 * s + 1];
+        s_map[s] = (uint16_t)k;
+      }
+    };
+    auto claim = [&](int s) -> bool { return ((atomicOr(&s_claim[s >> 5], 1u << (s & 31)) >> (s & 31)) & 1u) == 0; };
+    for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
+      const int4 v = grec[2 * s + 1];
+      bool hot = false;
+      if (s == 2 * div - 2 || s == 2 * div - 1) {
+        hot = true;  // the node's own two slots
+      } else if ((v.x & v.y & v.z) < 0) {
+        hot = false;  // unused slot
+      } else if ((v.x | v.y | v.z) < 0) {
+        hot = true;  // hull triangle
+      } else {
+        const uint32_t pa = s_pt[v.x - off], pb = s_pt[v.y - off], pc = s_pt[v.z - off];
+        const float ax = (float)(pa & 0xffffu), ay = (float)(pa >> 16);
+        const float bx = (float)(pb & 0xffffu) - ax, by = (float)(pb >> 16) - ay;
+        const float cx = (float)(pc & 0xffffu) - ax, cy = (float)(pc >> 16) - ay;
+        const float d = 2.f * (bx * cy - by * cx);
+        const float b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+        const float ux = (cy * b2 - by * c2) / d, uy = (bx * c2 - cx * b2) / d;  // circumcentre relative to a
+        const float rad = sqrtf(ux * ux + uy * uy) + 1.5f;
+        const float cc = axis == 0 ? ax + ux : ay + uy;
+        hot = s < 2 * div ? (cc + rad >= fcr) : (cc - rad <= fcl);
+        hot = hot || !(d == d) || d == 0.f;
+      }
+      if (hot && claim(s)) insert(s);
+    }
+    __syncthreads();
+    const int nhot = min(s_n, DC2_CACHE_RECS);
+    __syncthreads();
+    for (int k = t; k < nhot; k += DC2_MERGE_THREADS)  // their neighbours are read too (for the apex across an edge)
+      for (int o = 0; o < 3; o++) {
+        const int32_t e = s_rec[k * 8 + o];
+        if (e < 0) continue;
+        const int s2 = (e >> 2) - tbase;
+        if (s2 >= 0 && s2 < nslots && claim(s2)) insert(s2);
+      }
+  }
+  __syncthreads();
+  if (t == 0) {
+    if (s_n > DC2_CACHE_RECS) s_n = DC2_CACHE_RECS;
+    const DcCachedMesh mesh{jb.tri, (DC2_AS3 int32_t *)s_rec, (DC2_AS3 uint16_t *)s_map, (DC2_AS3 const uint32_t *)s_pt,
+                            (DC2_AS3 int32_t *)&s_n, tbase, off};
+    dc_merge_hulls(mesh, fl, il, ir, fr, axis, tcur);
+    jb.hulls[idx] = VsmDcHull{fl.t, fl.o, fr.t, fr.o};
+  }
+}
+
+// Triangle's vertex sort for the jobs of a chunk on the device (one wave each): the verdicts go to
+// tie_out + job * out_stride; lists the wave cannot take get -1 there
+__global__ void __launch_bounds__(64) k_dc2_ties(const VsmDc2Job *__restrict__ jobs, int32_t *__restrict__ tie_out, int out_stride) {
+  const VsmDc2Job jb = jobs[blockIdx.x];
+  int32_t *out = tie_out + (size_t)blockIdx.x * out_stride;
+  const int n = *jb.count;
+  if (n <= 3 || n > jb.cap) {
+    if (threadIdx.x == 0) out[0] = n <= 3 ? 0 : -1;
+    return;
+  }
+  tie_sort(TieFromKeys{jb.keys_in}, n, out);
+}
+
+// which match stands for a pixel that several share: remap[index carried] = index Triangle's sort puts first
+__global__ void __launch_bounds__(64) k_dc2_apply_ties(const VsmDc2Job *__restrict__ jobs) {
+  const VsmDc2Job jb = jobs[blockIdx.x];
+  const int32_t c = jb.tie_out[0];
+  if (c < 0) {
+    if (threadIdx.x == 0 && jb.mn[0] >= 2) *jb.error = 3;
+    return;
+  }
+  for (int k = threadIdx.x; k < c; k += 64) {
+    const int32_t rep = jb.tie_out[1 + 2 * k], first = jb.tie_out[2 + 2 * k];
+    if (rep >= 0 && rep < jb.cap) jb.remap[rep] = first;
+  }
+}
+
+// per match what the support test compares (vsm_host_outliers_begin): flow u, flow v, disparity
+__global__ void __launch_bounds__(256) k_dc2_flows(const VsmDc2Job *__restrict__ jobs, int method) {
+  const VsmDc2Job jb = jobs[blockIdx.y];
+  const int n = jb.mn[1];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || jb.mn[0] < 2) return;
+  const vsm_p_match a = jb.list[i];
+  float *fu = (float *)jb.kd_scratch, *fv = fu + jb.kd_stride, *dp = fv + jb.kd_stride;
+  fu[i] = a.u1c - a.u1p;
+  fv[i] = a.v1c - a.v1p;
+  dp[i] = method == 1 ? a.u1c - a.u2c : a.u1p - a.u2p;
+}
+
+__global__ void __launch_bounds__(256) k_dc2_support(const VsmDc2Job *__restrict__ jobs, int method, float ftol, float dtol) {
+  const VsmDc2Job jb = jobs[blockIdx.y];
+  const int32_t m = jb.mn[0];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < 2 || t >= 2 * m) return;
+  const int4 v = *(const int4 *)(jb.tri + (size_t)t * 8 + 4);
+  if ((v.x | v.y | v.z) < 0) return;
+  const int32_t q[3] = {jb.remap[jb.id[v.y]], jb.remap[jb.id[v.z]], jb.remap[jb.id[v.x]]};
+  const float *fua = (const float *)jb.kd_scratch, *fva = fua + jb.kd_stride, *dpa = fva + jb.kd_stride;
+  float fu[3], fv[3], dp[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    fu[k] = fua[q[k]];
+    fv[k] = fva[q[k]];
+    dp[k] = dpa[q[k]];
+  }
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    const int a = e == 2 ? 0 : e, b = e == 0 ? 1 : 2;  // (0,1) (1,2) (0,2)
+    const bool flow_ok = fabsf(fu[a] - fu[b]) + fabsf(fv[a] - fv[b]) < ftol;
+    const bool disp_ok = fabsf(dp[a] - dp[b]) < dtol;
+    const bool ok = method == 0 ? flow_ok : (method == 1 ? disp_ok : (disp_ok && flow_ok));
+    if (ok) {
+      atomicAdd(&jb.support[q[a]], 1);
+      atomicAdd(&jb.support[q[b]], 1);
+    }
+  }
+}
+
+// survivors (support >= 4, viso/matcher.cpp:1369-1371; lists of up to three matches unchanged, :1210) in list order
+__device__ inline bool dc2_keep(const VsmDc2Job &jb, int32_t n, int32_t i) { return n <= 3 || jb.support[i] >= 4; }
+
+__global__ void __launch_bounds__(KD_THREADS) k_dc2_compact(const VsmDc2Job *__restrict__ jobs) {
+  __shared__ uint32_t tot[KD_THREADS / 64 + 1];
+  __shared__ int32_t s_total;
+  const VsmDc2Job jb = jobs[blockIdx.x];
+  const int t = threadIdx.x;
+  const int32_t n = jb.mn[1];
+  const int32_t per = (n + KD_THREADS - 1) / KD_THREADS;
+  const int32_t i0 = min(n, t * per), i1 = min(n, i0 + per);
+  uint32_t cnt = 0;
+  for (int32_t i = i0; i < i1; i++) cnt += dc2_keep(jb, n, i) ? 1u : 0u;
+  uint32_t pos = kd_block_scan(cnt, tot);
+  for (int32_t i = i0; i < i1; i++) jb.remap[i] = dc2_keep(jb, n, i) ? (int32_t)pos++ : -1;  // (the tie patches have been used)
+  if (t == KD_THREADS - 1) s_total = (int32_t)pos;
+  __syncthreads();
+  if (t == 0) {
+    *jb.out_count = s_total;
+    if (jb.h_out_count) *jb.h_out_count = s_total;
+  }
+  if (!jb.out) return;
+  const uint4 *src = (const uint4 *)jb.list;
+  uint4 *dst = (uint4 *)jb.out;
+  for (int32_t p = t; p < 3 * n; p += KD_THREADS) {
+    const int32_t e = p / 3, d = jb.remap[e];
+    if (d >= 0) dst[3 * d + (p - 3 * e)] = src[p];
+  }
+}
+
+// M4 computePriorStatistics (viso/matcher.cpp:734-868; host form: vsm_host_prior_statistics) over the survivors of
+// the pass-1 list: per 3x3-dilated bin the min / max of the per-stage deltas, widened to at least 20 pixels.  All
+// operands are integer-valued floats (pass-1 matches are unrefined), so the minima and maxima are kept as integers
+// (LDS atomics) and the few float operations give the host's values exactly.  Output in the device layout of the
+// match kernels: per bin {u_min, u_max, v_min, v_max} of stage 0, then stage 1, ...
+#define DC2_PRIOR_MAX_BINS 1024
+__global__ void __launch_bounds__(256) k_dc2_prior(const VsmDc2Job *__restrict__ jobs, int method, int binsize, int radius, int w, int h,
+                                                   int ub, int vb) {
+  __shared__ int32_t s_lo[DC2_PRIOR_MAX_BINS * 8], s_hi[DC2_PRIOR_MAX_BINS * 8];
+  const VsmDc2Job jb = jobs[blockIdx.x];
+  const int nb = ub * vb, ns = method == 2 ? 4 : 2;
+  const int t = threadIdx.x;
+  const int32_t n = jb.mn[1];
+  for (int i = t; i < nb * 8; i += 256) {
+    s_lo[i] = 1000000;
+    s_hi[i] = -1000000;
+  }
+  __syncthreads();
+  const float bs = (float)binsize;
+  for (int32_t i = t; i < n; i += 256) {
+    if (!dc2_keep(jb, n, i)) continue;
+    const vsm_p_match it = jb.list[i];
+    int32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float ur = it.u1c, vr = it.v1c;
+    if (method == 0) {
+      d[0] = (int32_t)(it.u1p - it.u1c);
+      d[1] = (int32_t)(it.v1p - it.v1c);
+      d[2] = (int32_t)(it.u1c - it.u1p);
+      d[3] = (int32_t)(it.v1c - it.v1p);
+    } else if (method == 1) {
+      d[0] = (int32_t)(it.u2c - it.u1c);
+      d[2] = (int32_t)(it.u1c - it.u2c);
+    } else {
+      d[0] = (int32_t)(it.u2p - it.u1p);
+      d[2] = (int32_t)(it.u2c - it.u2p);
+      d[3] = (int32_t)(it.v2c - it.v2p);
+      d[4] = (int32_t)(it.u1c - it.u2c);
+      d[6] = (int32_t)(it.u1p - it.u1c);
+      d[7] = (int32_t)(it.v1p - it.v1c);
+      ur = it.u1p;
+      vr = it.v1p;
+    }
+    const int ubin = (int)floorf(ur / bs), vbin = (int)floorf(vr / bs);
+    const int u0 = min(max(ubin - 1, 0), ub - 1), u1 = min(max(ubin + 1, 0), ub - 1);
+    const int v0 = min(max(vbin - 1, 0), vb - 1), v1 = min(max(vbin + 1, 0), vb - 1);
+    for (int v = v0; v <= v1; v++)
+      for (int u = u0; u <= u1; u++) {
+        const int b = v * ub + u;
+        for (int k = 0; k < 2 * ns; k++) {
+          atomicMin(&s_lo[b * 8 + k], d[k]);
+          atomicMax(&s_hi[b * 8 + k], d[k]);
+        }
+      }
+  }
+  __syncthreads();
+  for (int b = t; b < nb; b += 256) {
+    const bool any = s_lo[b * 8] != 1000000;
+    float *r = jb.ranges + (size_t)b * 16;
+    for (int i = 0; i < 4; i++) {
+      float l[2] = {0.f, 0.f}, hh[2] = {0.f, 0.f};
+      if (i < ns)
+        for (int k = 0; k < 2; k++) {
+          l[k] = any ? (float)s_lo[b * 8 + 2 * i + k] : (float)(-radius);
+          hh[k] = any ? (float)s_hi[b * 8 + 2 * i + k] : (float)(+radius);
+          const float delta = hh[k] - l[k];
+          if (delta < 20) {  // widen to at least 20 px (:845-854)
+            const float g = ceilf((20 - delta) / 2);
+            l[k] -= g;
+            hh[k] += g;
+          }
+        }
+      *(float4 *)(r + 4 * i) = make_float4(l[0], hh[0], l[1], hh[1]);
+    }
+  }
+}
+
+void vsm_dc2_launch_keys(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(k_dc2_keys, dim3((std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs);
+}
+void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(k_dc2_prepare, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs);
+}
+void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(k_dc2_block, dim3(1 << depth, njobs), dim3(64), 0, s, d_jobs, depth);
+}
+void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth) {
+  if (njobs <= 0) return;
+  for (int level = depth - 1; level >= 0; level--)
+    hipLaunchKernelGGL(k_dc2_merge, dim3(1 << level, njobs), dim3(DC2_MERGE_THREADS), 0, s, d_jobs, level);
+}
+void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(k_dc2_ties, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride);
+}
+void vsm_dc2_launch_support(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol, float disp_tol) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(k_dc2_apply_ties, dim3(njobs), dim3(64), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_dc2_flows, dim3((std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method);
+  hipLaunchKernelGGL(k_dc2_support, dim3((2 * std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method, flow_tol, disp_tol);
+}
+void vsm_dc2_launch_compact(hipStream_t s, const VsmDc2Job *d_jobs, int njobs) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(k_dc2_compact, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs);
+}
+void vsm_dc2_launch_prior(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int method, int binsize, int radius, int w, int h, int ub,
+                          int vb) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(k_dc2_prior, dim3(njobs), dim3(256), 0, s, d_jobs, method, binsize, radius, w, h, ub, vb);
 }

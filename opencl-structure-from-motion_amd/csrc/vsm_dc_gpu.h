@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "visomatch.h"
+
 struct VsmDcTask {  // == ExactDelaunay::Task
   int32_t off, n, axis, node;
 };
@@ -68,3 +70,53 @@ void vsm_dc_launch_ties_of_keys(hipStream_t s, int npairs, const uint64_t *keys,
 #define VSM_DC_TIE_OUT_INTS 512
 // one thread per merge node of level `level`; max_nodes >= every job's node count on that level
 void vsm_dc_launch_merge_level(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int level, int max_nodes);
+
+// ---------------------------------------------------------------------------------------
+// GPU-resident form of removeOutliers (viso/matcher.cpp:1207-1377) for the look-ahead path: the match list never
+// leaves the device between the matching pass and the survivors.  One job per frame pair and pass; every kernel
+// derives what it needs (list length, distinct points, divide-and-conquer tree) from device memory, so a whole
+// chunk's chain is enqueued without a host round trip.  What may still run on the host is Triangle's randomised
+// vertex sort (which match stands for a shared pixel): it is strictly serial, the host gets the keys through
+// host-mapped memory and answers with (carried index, right index) patches.
+// ---------------------------------------------------------------------------------------
+#define VSM_DC2_MAX_DEPTH 9  // block sub-trees of <= VSM_DC_BLOCK_POINTS points below at most this many cut levels
+struct VsmDc2Job {
+  const vsm_p_match *list;  // the compacted match list of the pass (device) ...
+  const int32_t *count;     // ... and its length (device)
+  int32_t cap, kd_stride;   // list lengths beyond `cap` are not handled here (error flag); stride of the scratch arrays
+  uint64_t *keys_in;        // [cap] packed keys (x << 34 | y << 20 | index) in list order (k_dc2_keys)
+  uint64_t *h_keys;         // the same in host-mapped memory for the host's vertex sort, or null
+  int32_t *h_n;             // host-mapped: list length (with h_keys)
+  uint64_t *key_sorted;     // [cap] distinct keys in (x,y) order
+  uint64_t *key;            // [cap] ... in kd order
+  uint32_t *kd_scratch;     // [VSM_DC_KD_SCRATCH][kd_stride]; later: flow u, flow v, disparity per match (float)
+  uint32_t *pt;             // [cap] x | y << 16 by position
+  int32_t *id;              // [cap] by position: smallest input index at that pixel
+  int32_t *tri;             // [2 cap][8] triangle records
+  VsmDcHull *hulls;         // [2 << VSM_DC2_MAX_DEPTH] by heap index of the tree node (root = 1)
+  int32_t *mn;              // [2] distinct points m, list length n (device; written by k_dc2_prepare)
+  int32_t *support;         // [cap] support count per match
+  int32_t *remap;           // [cap] match index a position's id stands for (identity + tie patches); later: output position
+  const int32_t *tie_out;   // verdict of the vertex sort: count (-1: failed), then (carried index, right index) pairs
+  vsm_p_match *out;         // survivors (device or host-mapped memory), or null (pass 1: only the statistics follow)
+  int32_t *out_count;       // device
+  int32_t *h_out_count;     // host-mapped, or null
+  float *ranges;            // pass 1: the pair's prior boxes [ub*vb][16], device layout (k_dc2_prior)
+  int32_t *error;           // host-mapped flag word: set when a pair cannot be handled on the device
+};
+void vsm_dc2_launch_keys(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list);
+void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs);
+void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth);
+void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth);  // levels depth-1 .. 0
+void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride);
+void vsm_dc2_launch_support(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol,
+                            float disp_tol);  // tie patches, flows, votes
+void vsm_dc2_launch_compact(hipStream_t s, const VsmDc2Job *d_jobs, int njobs);
+void vsm_dc2_launch_prior(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int method, int binsize, int radius, int w, int h,
+                          int ub, int vb);
+// smallest depth at which every sub-tree of a list of at most max_points points fits a block
+static inline int vsm_dc2_depth(int max_points) {
+  int d = 0;
+  while (((long)VSM_DC_BLOCK_POINTS << d) < max_points) d++;
+  return d;
+}

@@ -16,10 +16,19 @@
 
 #define VSM_KXY(k) ((k) >> 20)  // (x, y) part of a packed key (x << 34) | (y << 20) | input index
 
+struct DcOTri {  // oriented triangle handle: slot + edge
+  int32_t t, o;
+};
+
+// mergehulls (viso/triangle.cpp:5639-5960) over any mesh view M that offers DcMesh's accessors (sym, org, dest,
+// apex, set_*, bond, make, ccw, incircle, px, py): DcMesh itself (plain arrays, host and device) and the
+// LDS-cached view of the GPU's upper merge levels (DcCachedMesh, vsm_dc.hip) share this one body.
+template <class M>
+VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft, DcOTri &innerright, DcOTri &farright,
+                                  int axis, int32_t &tcur);
+
 struct DcMesh {
-  struct OTri {
-    int32_t t, o;
-  };
+  typedef DcOTri OTri;
   // one 32-byte record per triangle: tri[t*8 + o] = neighbour handle across edge o,
   // tri[t*8 + 4 + o] = vertex o (-1 = ghost corner); pt[p] = x | y << 16 by sorted position
   int32_t *tri;
@@ -83,174 +92,181 @@ struct DcMesh {
   VSM_HD inline void recurse(int32_t off, int32_t n, int axis, OTri &farleft, OTri &farright) const;
 };
 
-VSM_HD inline void DcMesh::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis,
-                                       int32_t &tcur) const {
-  int32_t ildest = dest(innerleft), ilapex = apex(innerleft);
-  int32_t irorg = org(innerright), irapex = apex(innerright);
+template <class M>
+VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft, DcOTri &innerright, DcOTri &farright,
+                                  int axis, int32_t &tcur) {
+  typedef DcOTri OTri;
+  int32_t ildest = m.dest(innerleft), ilapex = m.apex(innerleft);
+  int32_t irorg = m.org(innerright), irapex = m.apex(innerright);
   if (axis == 1) {  // horizontal cut: handles move to the bottom-/top-most hull vertices (:5666)
-    int32_t flpt = org(farleft), flapex = apex(farleft);
-    int32_t frpt = dest(farright);
-    while (py(flapex) < py(flpt)) {
-      farleft = sym(lnext(farleft));
+    int32_t flpt = m.org(farleft), flapex = m.apex(farleft);
+    int32_t frpt = m.dest(farright);
+    while (m.py(flapex) < m.py(flpt)) {
+      farleft = m.sym(M::lnext(farleft));
       flpt = flapex;
-      flapex = apex(farleft);
+      flapex = m.apex(farleft);
     }
-    OTri chk = sym(innerleft);
-    int32_t cv = apex(chk);
-    while (py(cv) > py(ildest)) {
-      innerleft = lnext(chk);
+    OTri chk = m.sym(innerleft);
+    int32_t cv = m.apex(chk);
+    while (m.py(cv) > m.py(ildest)) {
+      innerleft = M::lnext(chk);
       ilapex = ildest;
       ildest = cv;
-      chk = sym(innerleft);
-      cv = apex(chk);
+      chk = m.sym(innerleft);
+      cv = m.apex(chk);
     }
-    while (py(irapex) < py(irorg)) {
-      innerright = sym(lnext(innerright));
+    while (m.py(irapex) < m.py(irorg)) {
+      innerright = m.sym(M::lnext(innerright));
       irorg = irapex;
-      irapex = apex(innerright);
+      irapex = m.apex(innerright);
     }
-    chk = sym(farright);
-    cv = apex(chk);
-    while (py(cv) > py(frpt)) {
-      farright = lnext(chk);
+    chk = m.sym(farright);
+    cv = m.apex(chk);
+    while (m.py(cv) > m.py(frpt)) {
+      farright = M::lnext(chk);
       frpt = cv;
-      chk = sym(farright);
-      cv = apex(chk);
+      chk = m.sym(farright);
+      cv = m.apex(chk);
     }
   }
   bool changed;
   do {  // lower common tangent (:5704)
     changed = false;
-    if (ccw(ildest, ilapex, irorg) > 0) {
-      innerleft = sym(lprev(innerleft));
+    if (m.ccw(ildest, ilapex, irorg) > 0) {
+      innerleft = m.sym(M::lprev(innerleft));
       ildest = ilapex;
-      ilapex = apex(innerleft);
+      ilapex = m.apex(innerleft);
       changed = true;
     }
-    if (ccw(irapex, irorg, ildest) > 0) {
-      innerright = sym(lnext(innerright));
+    if (m.ccw(irapex, irorg, ildest) > 0) {
+      innerright = m.sym(M::lnext(innerright));
       irorg = irapex;
-      irapex = apex(innerright);
+      irapex = m.apex(innerright);
       changed = true;
     }
   } while (changed);
-  OTri leftcand = sym(innerleft), rightcand = sym(innerright);
-  OTri base = make(tcur);
-  bond(base, innerleft);
-  base = lnext(base);
-  bond(base, innerright);
-  base = lnext(base);
-  set_org(base, irorg);
-  set_dest(base, ildest);
-  if (ildest == org(farleft)) farleft = lnext(base);
-  if (irorg == dest(farright)) farright = lprev(base);
+  OTri leftcand = m.sym(innerleft), rightcand = m.sym(innerright);
+  OTri base = m.make(tcur);
+  m.bond(base, innerleft);
+  base = M::lnext(base);
+  m.bond(base, innerright);
+  base = M::lnext(base);
+  m.set_org(base, irorg);
+  m.set_dest(base, ildest);
+  if (ildest == m.org(farleft)) farleft = M::lnext(base);
+  if (irorg == m.dest(farright)) farright = M::lprev(base);
   int32_t ll = ildest, lr = irorg;
-  int32_t ul = apex(leftcand), ur = apex(rightcand);
+  int32_t ul = m.apex(leftcand), ur = m.apex(rightcand);
   for (;;) {
-    const bool lfin = ccw(ul, ll, lr) <= 0, rfin = ccw(ur, ll, lr) <= 0;
+    const bool lfin = m.ccw(ul, ll, lr) <= 0, rfin = m.ccw(ur, ll, lr) <= 0;
     if (lfin && rfin) {  // close the seam with the top bounding triangle (:5771)
-      OTri top = make(tcur);
-      set_org(top, ll);
-      set_dest(top, lr);
-      bond(top, base);
-      top = lnext(top);
-      bond(top, rightcand);
-      top = lnext(top);
-      bond(top, leftcand);
+      OTri top = m.make(tcur);
+      m.set_org(top, ll);
+      m.set_dest(top, lr);
+      m.bond(top, base);
+      top = M::lnext(top);
+      m.bond(top, rightcand);
+      top = M::lnext(top);
+      m.bond(top, leftcand);
       if (axis == 1) {  // handles back to the left-/right-most vertices
-        int32_t flpt = org(farleft), frpt = dest(farright), frapex = apex(farright);
-        OTri chk = sym(farleft);
-        int32_t cv = apex(chk);
-        while (px(cv) < px(flpt)) {
-          farleft = lprev(chk);
+        int32_t flpt = m.org(farleft), frpt = m.dest(farright), frapex = m.apex(farright);
+        OTri chk = m.sym(farleft);
+        int32_t cv = m.apex(chk);
+        while (m.px(cv) < m.px(flpt)) {
+          farleft = M::lprev(chk);
           flpt = cv;
-          chk = sym(farleft);
-          cv = apex(chk);
+          chk = m.sym(farleft);
+          cv = m.apex(chk);
         }
-        while (px(frapex) > px(frpt)) {
-          farright = sym(lprev(farright));
+        while (m.px(frapex) > m.px(frpt)) {
+          farright = m.sym(M::lprev(farright));
           frpt = frapex;
-          frapex = apex(farright);
+          frapex = m.apex(farright);
         }
       }
       return;
     }
     if (!lfin) {  // dissolve non-Delaunay edges on the left (:5814)
-      OTri ne = sym(lprev(leftcand));
-      int32_t na = apex(ne);
+      OTri ne = m.sym(M::lprev(leftcand));
+      int32_t na = m.apex(ne);
       if (na >= 0) {
-        bool bad = incircle(ll, lr, ul, na) > 0;
+        bool bad = m.incircle(ll, lr, ul, na) > 0;
         while (bad) {
-          ne = lnext(ne);
-          OTri topc = sym(ne);
-          ne = lnext(ne);
-          OTri sidec = sym(ne);
-          bond(ne, topc);
-          bond(leftcand, sidec);
-          leftcand = lnext(leftcand);
-          OTri outerc = sym(leftcand);
-          ne = lprev(ne);
-          bond(ne, outerc);
-          set_org(leftcand, ll);
-          set_dest(leftcand, -1);
-          set_apex(leftcand, na);
-          set_org(ne, -1);
-          set_dest(ne, ul);
-          set_apex(ne, na);
+          ne = M::lnext(ne);
+          OTri topc = m.sym(ne);
+          ne = M::lnext(ne);
+          OTri sidec = m.sym(ne);
+          m.bond(ne, topc);
+          m.bond(leftcand, sidec);
+          leftcand = M::lnext(leftcand);
+          OTri outerc = m.sym(leftcand);
+          ne = M::lprev(ne);
+          m.bond(ne, outerc);
+          m.set_org(leftcand, ll);
+          m.set_dest(leftcand, -1);
+          m.set_apex(leftcand, na);
+          m.set_org(ne, -1);
+          m.set_dest(ne, ul);
+          m.set_apex(ne, na);
           ul = na;
           ne = sidec;
-          na = apex(ne);
-          bad = na >= 0 && incircle(ll, lr, ul, na) > 0;
+          na = m.apex(ne);
+          bad = na >= 0 && m.incircle(ll, lr, ul, na) > 0;
         }
       }
     }
     if (!rfin) {  // ... and on the right (:5862)
-      OTri ne = sym(lnext(rightcand));
-      int32_t na = apex(ne);
+      OTri ne = m.sym(M::lnext(rightcand));
+      int32_t na = m.apex(ne);
       if (na >= 0) {
-        bool bad = incircle(ll, lr, ur, na) > 0;
+        bool bad = m.incircle(ll, lr, ur, na) > 0;
         while (bad) {
-          ne = lprev(ne);
-          OTri topc = sym(ne);
-          ne = lprev(ne);
-          OTri sidec = sym(ne);
-          bond(ne, topc);
-          bond(rightcand, sidec);
-          rightcand = lprev(rightcand);
-          OTri outerc = sym(rightcand);
-          ne = lnext(ne);
-          bond(ne, outerc);
-          set_org(rightcand, -1);
-          set_dest(rightcand, lr);
-          set_apex(rightcand, na);
-          set_org(ne, ur);
-          set_dest(ne, -1);
-          set_apex(ne, na);
+          ne = M::lprev(ne);
+          OTri topc = m.sym(ne);
+          ne = M::lprev(ne);
+          OTri sidec = m.sym(ne);
+          m.bond(ne, topc);
+          m.bond(rightcand, sidec);
+          rightcand = M::lprev(rightcand);
+          OTri outerc = m.sym(rightcand);
+          ne = M::lnext(ne);
+          m.bond(ne, outerc);
+          m.set_org(rightcand, -1);
+          m.set_dest(rightcand, lr);
+          m.set_apex(rightcand, na);
+          m.set_org(ne, ur);
+          m.set_dest(ne, -1);
+          m.set_apex(ne, na);
           ur = na;
           ne = sidec;
-          na = apex(ne);
-          bad = na >= 0 && incircle(ll, lr, ur, na) > 0;
+          na = m.apex(ne);
+          bad = na >= 0 && m.incircle(ll, lr, ur, na) > 0;
         }
       }
     }
-    if (lfin || (!rfin && incircle(ul, ll, lr, ur) > 0)) {  // new cross edge ll--ur (:5911)
-      bond(base, rightcand);
-      base = lprev(rightcand);
-      set_dest(base, ll);
+    if (lfin || (!rfin && m.incircle(ul, ll, lr, ur) > 0)) {  // new cross edge ll--ur (:5911)
+      m.bond(base, rightcand);
+      base = M::lprev(rightcand);
+      m.set_dest(base, ll);
       lr = ur;
-      rightcand = sym(base);
-      ur = apex(rightcand);
+      rightcand = m.sym(base);
+      ur = m.apex(rightcand);
     } else {  // new cross edge ul--lr (:5920)
-      bond(base, leftcand);
-      base = lnext(leftcand);
-      set_org(base, lr);
+      m.bond(base, leftcand);
+      base = M::lnext(leftcand);
+      m.set_org(base, lr);
       ll = ul;
-      leftcand = sym(base);
-      ul = apex(leftcand);
+      leftcand = m.sym(base);
+      ul = m.apex(leftcand);
     }
   }
 }
 
+
+VSM_HD inline void DcMesh::merge_hulls(OTri &farleft, OTri &innerleft, OTri &innerright, OTri &farright, int axis,
+                                       int32_t &tcur) const {
+  dc_merge_hulls(*this, farleft, innerleft, innerright, farright, axis, tcur);
+}
 
 // one sub-problem: positions [off, off+n).  Selection (alternateaxes) and triangulation
 // (divconqrecurse) share one recursion; the caller has already brought the right keys into

@@ -705,6 +705,33 @@ void ExactDelaunay::resolve_ties() {
   ties_resolved_ = true;
 }
 
+int32_t ExactDelaunay::sort_ties(const uint64_t *keys, int32_t n, int32_t *pairs, int32_t cap) {
+  if (n < 2) return 0;
+  emu_.assign(keys, keys + n);
+  stop_.resize(2 * ((size_t)n / 64 + 2));
+  seed_ = 1;  // triangleinit(), :4031
+  uint64_t *e = emu_.data();
+  vertex_sort(e, n);
+  int32_t np = 0;
+  for (int32_t i = 0; i < n;) {  // of equal points the first one in this order is the vertex (:6183)
+    int32_t j = i + 1;
+    while (j < n && KXY(e[j]) == KXY(e[i])) j++;
+    if (j - i > 1) {
+      int32_t rep = (int32_t)(e[i] & 0xfffffu);
+      for (int32_t k = i + 1; k < j; k++) rep = std::min(rep, (int32_t)(e[k] & 0xfffffu));
+      const int32_t first = (int32_t)(e[i] & 0xfffffu);
+      if (rep != first) {
+        if (np >= cap) return -1;
+        pairs[2 * np] = rep;
+        pairs[2 * np + 1] = first;
+        np++;
+      }
+    }
+    i = j;
+  }
+  return np;
+}
+
 void ExactDelaunay::apply_ties() {
   if (!ties_resolved_) resolve_ties();
   if (patches_.empty()) return;

@@ -149,6 +149,10 @@ class ExactDelaunay {
     ties_resolved_ = true;
   }
   const std::vector<std::pair<int32_t, int32_t>> &ties() const { return patches_; }
+  // The vertex sort alone, for a solver that keeps the triangulation elsewhere (the GPU-resident look-ahead path):
+  // keys = (x << 34) | (y << 20) | index in list order; writes (smallest index at a shared pixel, index the sort
+  // puts first) for every shared pixel where the two differ; returns their number, or -1 if there are more than cap.
+  int32_t sort_ties(const uint64_t *keys, int32_t n, int32_t *pairs, int32_t cap);
   void order_keys(VsmForkJoin *pool = nullptr) {
     if (!ordered_) kd_order(m_, pool);
     ordered_ = true;

@@ -28,8 +28,8 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_num_features", "vsm_get_features", "vsm_set_stage_capture", "vsm_stage_size", "vsm_stage_get",
            "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
            "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
-           "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
-           "vsm_sequence_get_timings", "vsm_version",
+           "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_host_outliers_and_prior", "vsm_debug_dc2", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
+           "vsm_sequence_get_timings", "vsm_sequence_path", "vsm_version",
            "vsm_vo_stereo_default_params", "vsm_vo_stereo_create", "vsm_vo_stereo_destroy", "vsm_vo_stereo_process",
            "vsm_vo_stereo_process_device", "vsm_vo_stereo_process_matches", "vsm_vo_stereo_get_motion",
            "vsm_vo_stereo_motion_valid", "vsm_vo_stereo_num_matches", "vsm_vo_stereo_get_matches",
@@ -120,10 +120,13 @@ def lib():
         L.vsm_debug_dc_bench.restype = C.c_double
         L.vsm_host_ties.argtypes = [vp, vp, i32, vp, i32]
         L.vsm_debug_ties_gpu.argtypes = [vp, vp, i32, vp, i32, vp]
+        L.vsm_host_outliers_and_prior.argtypes = [C.POINTER(VsmParams), vp, i32, i32, vp, i32, vp, i32, i32]
+        L.vsm_debug_dc2.argtypes = [C.POINTER(VsmParams), vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, vp]
         L.vsm_sequence_run.argtypes = [vp, vp, vp, C.c_int64, C.c_int, i32, i32, i32, i32, i32, vp, vp]
         L.vsm_sequence_num_matches.argtypes = [vp, i32]
         L.vsm_sequence_get_matches.argtypes = [vp, i32, vp, i32]
         L.vsm_sequence_get_timings.argtypes = [vp, vp]
+        L.vsm_sequence_path.argtypes = [vp]
         vop = C.POINTER(VsmVoStereoParams)
         L.vsm_vo_stereo_default_params.argtypes = [vop]
         L.vsm_vo_stereo_create.restype = vp
@@ -296,6 +299,29 @@ def ties(pts, gpu=False):
         return None, us.value
     o = out[:k]
     return o[np.lexsort(o.T[::-1])], us.value
+
+
+def remove_outliers(matches, method, w, h, gpu=False, gpu_ties=False, copies=1, **params):
+    """Matcher::removeOutliers + computePriorStatistics on a match list: host code of the per-frame path (gpu=False) or
+    the GPU-resident chain of the look-ahead path; returns (survivors, ranges in device layout, kernel microseconds)"""
+    p = default_params()
+    for k, v in params.items():
+        setattr(p, k, v)
+    m = np.ascontiguousarray(matches, dtype=P_MATCH)
+    n = len(m)
+    out = np.zeros(max(n, 1), dtype=P_MATCH)
+    ub, vb = -(-w // p.match_binsize), -(-h // p.match_binsize)
+    rg = np.zeros((ub * vb, 16), dtype=np.float32)
+    us = C.c_double(0)
+    if gpu:
+        k = lib().vsm_debug_dc2(C.byref(p), m.ctypes.data_as(C.c_void_p), n, method, int(gpu_ties), copies, out.ctypes.data_as(C.c_void_p),
+                                len(out), rg.ctypes.data_as(C.c_void_p), w, h, C.cast(C.byref(us), C.c_void_p))
+    else:
+        k = lib().vsm_host_outliers_and_prior(C.byref(p), m.ctypes.data_as(C.c_void_p), n, method, out.ctypes.data_as(C.c_void_p), len(out),
+                                              rg.ctypes.data_as(C.c_void_p), w, h)
+    if k < 0:
+        raise VisoMatchError(f"remove_outliers: code {k}")
+    return out[:k].copy(), rg, us.value
 
 
 def default_params():
@@ -483,6 +509,10 @@ class Matcher:
         if n:
             L.vsm_sequence_get_matches(self.h, f, a.ctypes.data_as(C.c_void_p), n)
         return a
+
+    def sequence_path(self):
+        """2: the last run_sequence went through the GPU-resident form, 1: through the host-shared form"""
+        return lib().vsm_sequence_path(self.h)
 
     def sequence_timings(self):
         t = np.zeros(4, dtype=np.float64)
