@@ -30,6 +30,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before anything initialises HIP: see visomatch.py
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "opencl-structure-from-motion_amd"

@@ -2010,6 +2010,23 @@ int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, i
     if (kernel_us) *kernel_us = ms * 1e3;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (const char *dump = getenv("VSM_DC2_DUMP")) {  // debugging aid: the first job's triangulation as the device left it
+      int32_t mn[2] = {0, 0};
+      (void)hipMemcpy(mn, B.pp[0].mn, 8, hipMemcpyDeviceToHost);
+      const int32_t mm = std::max(mn[0], 0);
+      std::vector<int32_t> tri((size_t)mm * 16), idv(mm);
+      std::vector<uint32_t> ptv(mm);
+      (void)hipMemcpy(tri.data(), B.pp[0].tri, tri.size() * 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(ptv.data(), B.pp[0].pt, ptv.size() * 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(idv.data(), B.pp[0].id, idv.size() * 4, hipMemcpyDeviceToHost);
+      if (FILE *f = fopen(dump, "wb")) {
+        fwrite(mn, 4, 2, f);
+        fwrite(tri.data(), 4, tri.size(), f);
+        fwrite(ptv.data(), 4, ptv.size(), f);
+        fwrite(idv.data(), 4, idv.size(), f);
+        fclose(f);
+      }
+    }
     if (ok && *B.h_error) {
       result = -2;
     } else if (ok) {

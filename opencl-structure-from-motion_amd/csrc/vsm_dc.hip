@@ -16,6 +16,7 @@
 
 #include "vsm_dc_gpu.h"
 #include "vsm_dc_mesh.h"
+#include "vsm_dc_lds.h"
 #include "vsm_internal.h"
 
 // ---------------------------------------------------------------------------------------
@@ -777,7 +778,6 @@ void vsm_dc_launch_ties_of_keys(hipStream_t s, int npairs, const uint64_t *keys,
 // block sub-trees -> merge levels through an LDS record cache -> tie patches, support votes -> survivors
 // (-> prior statistics for pass 1).  Every kernel finds its work from the list length / point count in device memory.
 // =======================================================================================
-#define DC2_AS3 __attribute__((address_space(3)))
 
 __global__ void __launch_bounds__(256) k_dc2_keys(const VsmDc2Job *__restrict__ jobs) {
   const VsmDc2Job jb = jobs[blockIdx.y];
@@ -887,40 +887,70 @@ __device__ inline bool dc2_walk(int32_t m, int depth, uint32_t path, int32_t &of
   return true;
 }
 
+// One wave per block sub-tree (<= VSM_DC_BLOCK_POINTS points) as k_dc_block, on the 16-bit local mesh: 22 KB of LDS per
+// wave instead of 40, so seven waves share a CU.
 __global__ void __launch_bounds__(64) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
+  __shared__ __attribute__((aligned(16))) dc2_word s_rec[2 * VSM_DC_BLOCK_POINTS * 8];
+  __shared__ uint64_t s_key[VSM_DC_BLOCK_POINTS];
+  __shared__ uint32_t s_pt[VSM_DC_BLOCK_POINTS];
+  __shared__ Dc2Hull16 s_hull[2 << DCB_DEPTH];
   const VsmDc2Job j2 = jobs[blockIdx.y];
   const int32_t m = j2.mn[0];
   if (m < 2) return;
   // the block at the end of path p (depth bits); a sub-tree that fits a block at a smaller depth d is taken by the
   // path whose remaining bits are zero
-  int32_t off = 0, n = m;
-  int axis = 0, d = 0;
-  uint32_t idx = 1;
+  int32_t boff = 0, bn = m;
+  int baxis = 0, d = 0;
+  uint32_t bidx = 1;
   const uint32_t path = blockIdx.x;
-  for (int b = depth - 1; b >= 0 && n > VSM_DC_BLOCK_POINTS; b--, d++) {
-    const int32_t div = n >> 1;
+  for (int b = depth - 1; b >= 0 && bn > VSM_DC_BLOCK_POINTS; b--, d++) {
+    const int32_t div = bn >> 1;
     if ((path >> b) & 1) {
-      off += div;
-      n -= div;
-      idx = 2 * idx + 1;
+      boff += div;
+      bn -= div;
+      bidx = 2 * bidx + 1;
     } else {
-      n = div;
-      idx = 2 * idx;
+      bn = div;
+      bidx = 2 * bidx;
     }
-    axis = 1 - axis;
+    baxis = 1 - baxis;
   }
-  if (n > VSM_DC_BLOCK_POINTS) {  // (the host chose too small a depth)
+  if (bn > VSM_DC_BLOCK_POINTS) {  // (the host chose too small a depth)
     if (threadIdx.x == 0) *j2.error = 2;
     return;
   }
   if (d < depth && (path & ((1u << (depth - d)) - 1u)) != 0) return;
-  VsmDcJob jb;
-  jb.key = j2.key;
-  jb.tri = j2.tri;
-  jb.tri_packed = nullptr;
-  jb.pt = j2.pt;
-  jb.id = j2.id;
-  dc_block_body(jb, VsmDcTask{off, n, axis, (int32_t)idx}, j2.hulls + idx);
+  const int lane = threadIdx.x;
+  for (int i = lane; i < bn; i += 64) s_key[i] = j2.key[boff + i];
+  {
+    dc2_v4u ones;
+    ones.x = ones.y = ones.z = ones.w = 0xffffffffu;
+    for (int i = lane; i < 2 * bn * (int)sizeof(dc2_word) / 2; i += 64) ((dc2_v4u *)s_rec)[i] = ones;
+  }
+  __syncthreads();
+  DcBlockMesh mesh;
+  mesh.rec = (DC2_AS3 dc2_word *)s_rec;
+  mesh.pt = (DC2_AS3 const uint32_t *)s_pt;
+  mesh.key = (DC2_AS3 uint64_t *)s_key;
+  mesh.ptw = (DC2_AS3 uint32_t *)s_pt;
+  mesh.gid = j2.id + boff;
+  dc2_block_leaf_run(mesh, lane, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+  __syncthreads();
+  for (int L = DC2_BLOCK_DEPTH - 1; L >= 0; L--) {
+    dc2_block_merge_run(mesh, lane, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+    __syncthreads();
+  }
+  // records out under global numbering
+  int32_t *gt = j2.tri + (size_t)2 * boff * 8;
+  for (int i = lane; i < 2 * bn * 8; i += 64) {
+    const uint32_t v = s_rec[i];
+    gt[i] = v == DC2_NONE ? -1 : (int32_t)v + ((i & 4) ? boff : 8 * boff);
+  }
+  for (int i = lane; i < bn; i += 64) j2.pt[boff + i] = s_pt[i];
+  if (lane == 0) {
+    const Dc2Hull16 hl = s_hull[1];
+    j2.hulls[bidx] = VsmDcHull{hl.fl_t + 2 * boff, hl.fl_o, hl.fr_t + 2 * boff, hl.fr_o};
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -933,94 +963,19 @@ __global__ void __launch_bounds__(64) k_dc2_block(const VsmDc2Job *__restrict__ 
 // to global memory, which therefore is always current; a record that was not foreseen is fetched on first use).
 // ---------------------------------------------------------------------------------------
 #define DC2_MERGE_THREADS 256
-#define DC2_CACHE_PTS 8192
-#define DC2_CACHE_RECS 2304
+#define DC2_CACHE_PTS 8192   // mapped form: points + 16-bit map in LDS
+#define DC2_CACHE_RECS 4608  // ... and this many 16-byte record lines
+#define DC2_WHOLE_PTS 4416   // nodes up to this many points sit in LDS whole (36 bytes per point)
 
-struct DcCachedMesh {
-  typedef DcOTri OTri;
-  int32_t *gtri;
-  DC2_AS3 int32_t *lrec;
-  DC2_AS3 uint16_t *map;
-  DC2_AS3 const uint32_t *lpt;
-  DC2_AS3 int32_t *nrec;
-  int32_t tbase, pbase;
-  __device__ inline int slot_of(int32_t t) const {  // LDS index of record t, fetched if it is not there yet and there is room
-    const int s = t - tbase;
-    int i = map[s];
-    if (i == 0xffff) {
-      const int k = *nrec;
-      if (k >= DC2_CACHE_RECS) return -1;
-      *nrec = k + 1;
-      typedef int32_t v4i __attribute__((ext_vector_type(4)));
-      const v4i *g = (const v4i *)(gtri + (size_t)t * 8);
-      const v4i a = g[0], b = g[1];
-      DC2_AS3 v4i *d = (DC2_AS3 v4i *)(lrec + k * 8);
-      d[0] = a;
-      d[1] = b;
-      map[s] = (uint16_t)k;
-      i = k;
-    }
-    return i;
-  }
-  __device__ inline int32_t ld(int32_t t, int w) const {
-    const int i = slot_of(t);
-    return i >= 0 ? lrec[i * 8 + w] : gtri[(size_t)t * 8 + w];
-  }
-  __device__ inline void st(int32_t t, int w, int32_t v) const {
-    const int i = map[t - tbase];
-    if (i != 0xffff) lrec[i * 8 + w] = v;
-    gtri[(size_t)t * 8 + w] = v;
-  }
-  __device__ inline OTri make(int32_t &tcur) const {
-    const int32_t t = tcur++;
-    st(t, 0, -1);
-    st(t, 1, -1);
-    st(t, 2, -1);
-    st(t, 4, -1);
-    st(t, 5, -1);
-    st(t, 6, -1);
-    return OTri{t, 0};
-  }
-  __device__ inline OTri sym(OTri a) const {
-    const int32_t e = ld(a.t, a.o);
-    return OTri{e >> 2, e & 3};
-  }
-  __device__ static inline OTri lnext(OTri a) { return OTri{a.t, a.o == 2 ? 0 : a.o + 1}; }
-  __device__ static inline OTri lprev(OTri a) { return OTri{a.t, a.o == 0 ? 2 : a.o - 1}; }
-  __device__ inline int32_t org(OTri a) const { return ld(a.t, 4 + (a.o == 2 ? 0 : a.o + 1)); }
-  __device__ inline int32_t dest(OTri a) const { return ld(a.t, 4 + (a.o == 0 ? 2 : a.o - 1)); }
-  __device__ inline int32_t apex(OTri a) const { return ld(a.t, 4 + a.o); }
-  __device__ inline void set_org(OTri a, int32_t v) const { st(a.t, 4 + (a.o == 2 ? 0 : a.o + 1), v); }
-  __device__ inline void set_dest(OTri a, int32_t v) const { st(a.t, 4 + (a.o == 0 ? 2 : a.o - 1), v); }
-  __device__ inline void set_apex(OTri a, int32_t v) const { st(a.t, 4 + a.o, v); }
-  __device__ inline void bond(OTri a, OTri b) const {
-    st(a.t, a.o, b.t * 4 + b.o);
-    st(b.t, b.o, a.t * 4 + a.o);
-  }
-  __device__ inline uint32_t point(int32_t p) const { return lpt[p - pbase]; }
-  __device__ inline int32_t px(int32_t p) const { return (int32_t)(point(p) & 0xffffu); }
-  __device__ inline int32_t py(int32_t p) const { return (int32_t)(point(p) >> 16); }
-  __device__ inline int32_t ccw(int32_t a, int32_t b, int32_t c) const {
-    const uint32_t pa = point(a), pb = point(b), pc = point(c);
-    const int32_t cx = (int32_t)(pc & 0xffffu), cy = (int32_t)(pc >> 16);
-    return ((int32_t)(pa & 0xffffu) - cx) * ((int32_t)(pb >> 16) - cy) - ((int32_t)(pa >> 16) - cy) * ((int32_t)(pb & 0xffffu) - cx);
-  }
-  __device__ inline int64_t incircle(int32_t a, int32_t b, int32_t c, int32_t d) const {
-    const uint32_t pa = point(a), pb = point(b), pc = point(c), pd = point(d);
-    const int32_t dx = (int32_t)(pd & 0xffffu), dy = (int32_t)(pd >> 16);
-    const int32_t adx = (int32_t)(pa & 0xffffu) - dx, ady = (int32_t)(pa >> 16) - dy;
-    const int32_t bdx = (int32_t)(pb & 0xffffu) - dx, bdy = (int32_t)(pb >> 16) - dy;
-    const int32_t cdx = (int32_t)(pc & 0xffffu) - dx, cdy = (int32_t)(pc >> 16) - dy;
-    return (int64_t)(adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (int64_t)(bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) +
-           (int64_t)(cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
-  }
-};
-
-__global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job *__restrict__ jobs, int level) {
-  __shared__ uint32_t s_pt[DC2_CACHE_PTS];
-  __shared__ uint16_t s_map[2 * DC2_CACHE_PTS];
-  __shared__ int32_t s_rec[DC2_CACHE_RECS * 8];
-  __shared__ uint32_t s_claim[2 * DC2_CACHE_PTS / 32];
+// dynamic LDS: [rec_cap][8] 16-bit records, [pts_cap] points, then for the mapped form [2 pts_cap / 32] claim bits and
+// [2 pts_cap] map entries - sized by the host for the largest node of the level, so the small nodes of the lower levels
+// leave room for several workgroups per CU
+__global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job *__restrict__ jobs, int level, int pts_cap, int rec_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dc2_lds[];
+  uint16_t *s_rec = (uint16_t *)dc2_lds;
+  uint32_t *s_pt = (uint32_t *)(s_rec + (size_t)rec_cap * 8);
+  uint32_t *s_claim = s_pt + pts_cap;
+  uint16_t *s_map = (uint16_t *)(s_claim + (2 * pts_cap + 31) / 32);
   __shared__ int32_t s_n, s_cl, s_cr;
   const VsmDc2Job jb = jobs[blockIdx.y];
   const int32_t m = jb.mn[0];
@@ -1032,33 +987,72 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
   const int t = threadIdx.x;
   const int32_t div = n >> 1;
   const VsmDcHull l = jb.hulls[2 * idx], r = jb.hulls[2 * idx + 1];
-  DcOTri fl{l.fl_t, l.fl_o}, il{l.fr_t, l.fr_o}, ir{r.fl_t, r.fl_o}, fr{r.fr_t, r.fr_o};
-  int32_t tcur = 2 * (off + div) - 2;
-  if (n > DC2_CACHE_PTS) {  // too large for the cache: the plain mesh in global memory
+  const int32_t tbase = 2 * off, nslots = 2 * n;
+  int32_t tcur = 2 * div - 2;  // local: the node's own two slots
+  const bool whole = nslots <= rec_cap && n <= pts_cap;
+  if (sizeof(dc2_word) != 2 || (!whole && (n > pts_cap || n > DC2_CACHE_PTS))) {  // too large for either form: the plain mesh in global memory
     if (t == 0) {
+      DcOTri fl{l.fl_t, l.fl_o}, il{l.fr_t, l.fr_o}, ir{r.fl_t, r.fl_o}, fr{r.fr_t, r.fr_o};
+      int32_t tg = 2 * (off + div) - 2;
       const DcMesh mesh{jb.tri, jb.pt, jb.id, jb.key};
-      mesh.merge_hulls(fl, il, ir, fr, axis, tcur);
+      mesh.merge_hulls(fl, il, ir, fr, axis, tg);
       jb.hulls[idx] = VsmDcHull{fl.t, fl.o, fr.t, fr.o};
     }
     return;
   }
-  const int32_t tbase = 2 * off, nslots = 2 * n;
-  const int4 *grec = (const int4 *)(jb.tri + (size_t)tbase * 8);
+  DcOTri fl{l.fl_t - tbase, l.fl_o}, il{l.fr_t - tbase, l.fr_o}, ir{r.fl_t - tbase, r.fl_o}, fr{r.fr_t - tbase, r.fr_o};
+  int32_t *gnode = jb.tri + (size_t)tbase * 8;
+  const dc2_v4i *grec = (const dc2_v4i *)gnode;
+  const int32_t tbase4 = 4 * tbase;
+  auto pack = [&](const dc2_v4i a, const dc2_v4i b) -> dc2_v4u {  // a global record as a local 16-bit one
+    dc2_v4u o;
+    o.x = (uint32_t)((a.x < 0 ? -1 : a.x - tbase4) & 0xffff) | ((uint32_t)(a.y < 0 ? -1 : a.y - tbase4) << 16);
+    o.y = (uint32_t)((a.z < 0 ? -1 : a.z - tbase4) & 0xffff) | 0xffff0000u;
+    o.z = (uint32_t)((b.x < 0 ? -1 : b.x - off) & 0xffff) | ((uint32_t)(b.y < 0 ? -1 : b.y - off) << 16);
+    o.w = (uint32_t)((b.z < 0 ? -1 : b.z - off) & 0xffff) | 0xffff0000u;
+    return o;
+  };
   if (t == 0) {
     s_n = 0;
     s_cl = -1;
     s_cr = 1 << 30;
   }
   for (int i = t; i < n; i += DC2_MERGE_THREADS) s_pt[i] = jb.pt[off + i];
+  if (whole) {
+    for (int s = t; s < nslots; s += DC2_MERGE_THREADS) ((dc2_v4u *)s_rec)[s] = pack(grec[2 * s], grec[2 * s + 1]);
+    __syncthreads();
+    if (t == 0) {
+      DcLdsMesh<false> mesh;
+      mesh.rec = (DC2_AS3 dc2_word *)s_rec;
+      mesh.pt = (DC2_AS3 const uint32_t *)s_pt;
+      dc_merge_hulls(mesh, fl, il, ir, fr, axis, tcur);
+      jb.hulls[idx] = VsmDcHull{fl.t + tbase, fl.o, fr.t + tbase, fr.o};
+    }
+    __syncthreads();
+    // everything back under global numbering (a record is two 16-byte stores)
+    for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
+      const dc2_v4u o = ((const dc2_v4u *)s_rec)[s];
+      auto nb = [&](uint32_t v) -> int32_t { return v == 0xffffu ? -1 : (int32_t)v + tbase4; };
+      auto vx = [&](uint32_t v) -> int32_t { return v == 0xffffu ? -1 : (int32_t)v + off; };
+      dc2_v4i a, b;
+      a.x = nb(o.x & 0xffffu);
+      a.y = nb(o.x >> 16);
+      a.z = nb(o.y & 0xffffu);
+      a.w = -1;
+      b.x = vx(o.z & 0xffffu);
+      b.y = vx(o.z >> 16);
+      b.z = vx(o.w & 0xffffu);
+      b.w = -1;
+      ((dc2_v4i *)gnode)[2 * s] = a;
+      ((dc2_v4i *)gnode)[2 * s + 1] = b;
+    }
+    return;
+  }
+  // ---- mapped form ----
   for (int i = t; i < nslots; i += DC2_MERGE_THREADS) s_map[i] = 0xffff;
   for (int i = t; i < (nslots + 31) / 32; i += DC2_MERGE_THREADS) s_claim[i] = 0;
   __syncthreads();
-  const bool whole = nslots <= DC2_CACHE_RECS;
-  if (whole) {
-    for (int i = t; i < nslots * 2; i += DC2_MERGE_THREADS) ((int4 *)s_rec)[i] = grec[i];
-    for (int i = t; i < nslots; i += DC2_MERGE_THREADS) s_map[i] = (uint16_t)i;
-    if (t == 0) s_n = nslots;
-  } else {
+  {
     // extent of the two halves along the cut axis: largest coordinate on the left, smallest on the right
     {
       int32_t cl = -1, cr = 1 << 30;
@@ -1084,15 +1078,14 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
     const float fcl = (float)s_cl, fcr = (float)s_cr;
     auto insert = [&](int s) {  // record of local slot s into the cache (the caller has claimed it)
       const int k = atomicAdd(&s_n, 1);
-      if (k < DC2_CACHE_RECS) {
-        ((int4 *)s_rec)[2 * k] = grec[2 * s];
-        ((int4 *)s_rec)[2 * k + 1] = grec[2 * s + 1];
+      if (k < rec_cap) {
+        ((dc2_v4u *)s_rec)[k] = pack(grec[2 * s], grec[2 * s + 1]);
         s_map[s] = (uint16_t)k;
       }
     };
     auto claim = [&](int s) -> bool { return ((atomicOr(&s_claim[s >> 5], 1u << (s & 31)) >> (s & 31)) & 1u) == 0; };
     for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
-      const int4 v = grec[2 * s + 1];
+      const dc2_v4i v = grec[2 * s + 1];
       bool hot = false;
       if (s == 2 * div - 2 || s == 2 * div - 1) {
         hot = true;  // the node's own two slots
@@ -1116,23 +1109,30 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
       if (hot && claim(s)) insert(s);
     }
     __syncthreads();
-    const int nhot = min(s_n, DC2_CACHE_RECS);
+    const int nhot = min(s_n, rec_cap);
     __syncthreads();
     for (int k = t; k < nhot; k += DC2_MERGE_THREADS)  // their neighbours are read too (for the apex across an edge)
       for (int o = 0; o < 3; o++) {
-        const int32_t e = s_rec[k * 8 + o];
-        if (e < 0) continue;
-        const int s2 = (e >> 2) - tbase;
-        if (s2 >= 0 && s2 < nslots && claim(s2)) insert(s2);
+        const uint32_t e = s_rec[k * 8 + o];
+        if (e == 0xffffu) continue;
+        const int s2 = (int)(e >> 2);
+        if (s2 < nslots && claim(s2)) insert(s2);
       }
   }
   __syncthreads();
   if (t == 0) {
-    if (s_n > DC2_CACHE_RECS) s_n = DC2_CACHE_RECS;
-    const DcCachedMesh mesh{jb.tri, (DC2_AS3 int32_t *)s_rec, (DC2_AS3 uint16_t *)s_map, (DC2_AS3 const uint32_t *)s_pt,
-                            (DC2_AS3 int32_t *)&s_n, tbase, off};
+    if (s_n > rec_cap) s_n = rec_cap;
+    DcLdsMesh<true> mesh;
+    mesh.rec = (DC2_AS3 dc2_word *)s_rec;
+    mesh.pt = (DC2_AS3 const uint32_t *)s_pt;
+    mesh.map = (DC2_AS3 uint16_t *)s_map;
+    mesh.nrec = (DC2_AS3 int32_t *)&s_n;
+    mesh.gtri = gnode;
+    mesh.rec_cap = rec_cap;
+    mesh.tbase4 = tbase4;
+    mesh.pbase = off;
     dc_merge_hulls(mesh, fl, il, ir, fr, axis, tcur);
-    jb.hulls[idx] = VsmDcHull{fl.t, fl.o, fr.t, fr.o};
+    jb.hulls[idx] = VsmDcHull{fl.t + tbase, fl.o, fr.t + tbase, fr.o};
   }
 }
 
@@ -1323,10 +1323,29 @@ void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, in
   if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_block, dim3(1 << depth, njobs), dim3(64), 0, s, d_jobs, depth);
 }
-void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth) {
+void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth, int max_list) {
   if (njobs <= 0) return;
-  for (int level = depth - 1; level >= 0; level--)
-    hipLaunchKernelGGL(k_dc2_merge, dim3(1 << level, njobs), dim3(DC2_MERGE_THREADS), 0, s, d_jobs, level);
+  static const bool big_lds = hipFuncSetAttribute((const void *)k_dc2_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
+  for (int level = depth - 1; level >= 0; level--) {
+    // the largest node of the level: ceil(max_list / 2^level) points
+    const int nmax = ((max_list + (1 << level) - 1) >> level) + 1;
+    int pts_cap = (nmax + 63) & ~63, rec_cap;
+    size_t bytes;
+    if (pts_cap <= DC2_WHOLE_PTS) {  // whole nodes: 2 records of 16 bytes + 4 bytes per point
+      rec_cap = 2 * pts_cap;
+      bytes = (size_t)rec_cap * 16 + (size_t)pts_cap * 4 + 64;
+    } else {  // mapped form (a node beyond DC2_CACHE_PTS points goes through global memory)
+      pts_cap = std::min(pts_cap, DC2_CACHE_PTS);
+      rec_cap = DC2_CACHE_RECS;
+      bytes = (size_t)rec_cap * 16 + (size_t)pts_cap * 4 + (size_t)((2 * pts_cap + 31) / 32) * 4 + (size_t)pts_cap * 4 + 64;
+    }
+    if (!big_lds && bytes > 64 * 1024) {  // (not expected) within the default limit: the nodes that do not fit go through global memory
+      pts_cap = 1536;
+      rec_cap = 2 * pts_cap;
+      bytes = (size_t)rec_cap * 16 + (size_t)pts_cap * 4 + 64;
+    }
+    hipLaunchKernelGGL(k_dc2_merge, dim3(1 << level, njobs), dim3(DC2_MERGE_THREADS), bytes, s, d_jobs, level, pts_cap, rec_cap);
+  }
 }
 void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride) {
   if (njobs <= 0) return;

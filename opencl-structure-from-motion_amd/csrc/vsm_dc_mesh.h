@@ -27,6 +27,11 @@ template <class M>
 VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft, DcOTri &innerright, DcOTri &farright,
                                   int axis, int32_t &tcur);
 
+// divconqrecurse + alternateaxes' leaf rule (viso/triangle.cpp:5963, :5596) over a mesh view M that additionally offers the
+// leaves' access to keys and points: key_at(i) (reference to the packed key at position i), put_point(i, x | y << 16, id)
+template <class M>
+VSM_HD inline void dc_recurse(const M &m, int32_t off, int32_t n, int axis, DcOTri &farleft, DcOTri &farright);
+
 struct DcMesh {
   typedef DcOTri OTri;
   // one 32-byte record per triangle: tri[t*8 + o] = neighbour handle across edge o,
@@ -63,6 +68,11 @@ struct DcMesh {
   VSM_HD inline void bond(OTri a, OTri b) const {
     tri[(size_t)a.t * 8 + a.o] = b.t * 4 + b.o;
     tri[(size_t)b.t * 8 + b.o] = a.t * 4 + a.o;
+  }
+  VSM_HD inline uint64_t &key_at(int32_t i) const { return key[i]; }
+  VSM_HD inline void put_point(int32_t i, uint32_t p, int32_t idv) const {
+    pt[i] = p;
+    id[i] = idv;
   }
   VSM_HD inline int32_t px(int32_t p) const { return (int32_t)(pt[p] & 0xffffu); }
   VSM_HD inline int32_t py(int32_t p) const { return (int32_t)(pt[p] >> 16); }
@@ -159,6 +169,7 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
   int32_t ul = m.apex(leftcand), ur = m.apex(rightcand);
   for (;;) {
     const bool lfin = m.ccw(ul, ll, lr) <= 0, rfin = m.ccw(ur, ll, lr) <= 0;
+
     if (lfin && rfin) {  // close the seam with the top bounding triangle (:5771)
       OTri top = m.make(tcur);
       m.set_org(top, ll);
@@ -271,99 +282,228 @@ VSM_HD inline void DcMesh::merge_hulls(OTri &farleft, OTri &innerleft, OTri &inn
 // one sub-problem: positions [off, off+n).  Selection (alternateaxes) and triangulation
 // (divconqrecurse) share one recursion; the caller has already brought the right keys into
 // this slice.  Triangle slots: leaves use 2*off.., the merge at boundary b uses 2b-2, 2b-1.
-VSM_HD inline void DcMesh::recurse(int32_t off, int32_t n, int axis, OTri &farleft, OTri &farright) const {
-  uint64_t *a = key + off;
-  if (n <= 3) {  // leaf: always ordered by x (then y), :5596-5600
-    if (VSM_KXY(a[0]) > VSM_KXY(a[1])) swap_keys(a[0], a[1]);
+// a leaf of two or three points: ordered by x (then y), :5596-5600, then the edge / triangle cases of divconqrecurse
+template <class M>
+VSM_HD inline void dc_leaf(const M &m, int32_t off, int32_t n, DcOTri &farleft, DcOTri &farright) {
+  typedef DcOTri OTri;
+  {
+    uint64_t k0 = m.key_at(off), k1 = m.key_at(off + 1), k2 = n == 3 ? m.key_at(off + 2) : 0;
+    if (VSM_KXY(k0) > VSM_KXY(k1)) DcMesh::swap_keys(k0, k1);
     if (n == 3) {
-      if (VSM_KXY(a[1]) > VSM_KXY(a[2])) swap_keys(a[1], a[2]);
-      if (VSM_KXY(a[0]) > VSM_KXY(a[1])) swap_keys(a[0], a[1]);
+      if (VSM_KXY(k1) > VSM_KXY(k2)) DcMesh::swap_keys(k1, k2);
+      if (VSM_KXY(k0) > VSM_KXY(k1)) DcMesh::swap_keys(k0, k1);
     }
-    for (int32_t i = 0; i < n; i++) {
-      pt[off + i] = (uint32_t)(a[i] >> 34) | ((uint32_t)((a[i] >> 20) & 0x3fff) << 16);
-      id[off + i] = (int32_t)(a[i] & 0xfffff);
-    }
+    m.key_at(off) = k0;
+    m.key_at(off + 1) = k1;
+    if (n == 3) m.key_at(off + 2) = k2;
+    const uint64_t a[3] = {k0, k1, k2};
+    for (int32_t i = 0; i < n; i++)
+      m.put_point(off + i, (uint32_t)(a[i] >> 34) | ((uint32_t)((a[i] >> 20) & 0x3fff) << 16), (int32_t)(a[i] & 0xfffff));
     int32_t tcur = 2 * off;
     const int32_t p0 = off, p1 = off + 1, p2 = off + 2;
     if (n == 2) {  // one edge = two ghost triangles (:5978)
-      farleft = make(tcur);
-      set_org(farleft, p0);
-      set_dest(farleft, p1);
-      farright = make(tcur);
-      set_org(farright, p1);
-      set_dest(farright, p0);
-      bond(farleft, farright);
-      farleft = lprev(farleft);
-      farright = lnext(farright);
-      bond(farleft, farright);
-      farleft = lprev(farleft);
-      farright = lnext(farright);
-      bond(farleft, farright);
-      farleft = lprev(farright);
+      farleft = m.make(tcur);
+      m.set_org(farleft, p0);
+      m.set_dest(farleft, p1);
+      farright = m.make(tcur);
+      m.set_org(farright, p1);
+      m.set_dest(farright, p0);
+      m.bond(farleft, farright);
+      farleft = M::lprev(farleft);
+      farright = M::lnext(farright);
+      m.bond(farleft, farright);
+      farleft = M::lprev(farleft);
+      farright = M::lnext(farright);
+      m.bond(farleft, farright);
+      farleft = M::lprev(farright);
       return;
     }
-    OTri mid = make(tcur), t1 = make(tcur), t2 = make(tcur), t3 = make(tcur);  // (:6006)
-    const int32_t area = ccw(p0, p1, p2);
+    OTri mid = m.make(tcur), t1 = m.make(tcur), t2 = m.make(tcur), t3 = m.make(tcur);  // (:6006)
+    const int32_t area = m.ccw(p0, p1, p2);
     if (area == 0) {
-      set_org(mid, p0);
-      set_dest(mid, p1);
-      set_org(t1, p1);
-      set_dest(t1, p0);
-      set_org(t2, p2);
-      set_dest(t2, p1);
-      set_org(t3, p1);
-      set_dest(t3, p2);
-      bond(mid, t1);
-      bond(t2, t3);
-      mid = lnext(mid);
-      t1 = lprev(t1);
-      t2 = lnext(t2);
-      t3 = lprev(t3);
-      bond(mid, t3);
-      bond(t1, t2);
-      mid = lnext(mid);
-      t1 = lprev(t1);
-      t2 = lnext(t2);
-      t3 = lprev(t3);
-      bond(mid, t1);
-      bond(t2, t3);
+      m.set_org(mid, p0);
+      m.set_dest(mid, p1);
+      m.set_org(t1, p1);
+      m.set_dest(t1, p0);
+      m.set_org(t2, p2);
+      m.set_dest(t2, p1);
+      m.set_org(t3, p1);
+      m.set_dest(t3, p2);
+      m.bond(mid, t1);
+      m.bond(t2, t3);
+      mid = M::lnext(mid);
+      t1 = M::lprev(t1);
+      t2 = M::lnext(t2);
+      t3 = M::lprev(t3);
+      m.bond(mid, t3);
+      m.bond(t1, t2);
+      mid = M::lnext(mid);
+      t1 = M::lprev(t1);
+      t2 = M::lnext(t2);
+      t3 = M::lprev(t3);
+      m.bond(mid, t1);
+      m.bond(t2, t3);
       farleft = t1;
       farright = t2;
     } else {
       const int32_t b = area > 0 ? p1 : p2, c = area > 0 ? p2 : p1;
-      set_org(mid, p0);
-      set_dest(t1, p0);
-      set_org(t3, p0);
-      set_dest(mid, b);
-      set_org(t1, b);
-      set_dest(t2, b);
-      set_apex(mid, c);
-      set_org(t2, c);
-      set_dest(t3, c);
-      bond(mid, t1);
-      mid = lnext(mid);
-      bond(mid, t2);
-      mid = lnext(mid);
-      bond(mid, t3);
-      t1 = lprev(t1);
-      t2 = lnext(t2);
-      bond(t1, t2);
-      t1 = lprev(t1);
-      t3 = lprev(t3);
-      bond(t1, t3);
-      t2 = lnext(t2);
-      t3 = lprev(t3);
-      bond(t2, t3);
+      m.set_org(mid, p0);
+      m.set_dest(t1, p0);
+      m.set_org(t3, p0);
+      m.set_dest(mid, b);
+      m.set_org(t1, b);
+      m.set_dest(t2, b);
+      m.set_apex(mid, c);
+      m.set_org(t2, c);
+      m.set_dest(t3, c);
+      m.bond(mid, t1);
+      mid = M::lnext(mid);
+      m.bond(mid, t2);
+      mid = M::lnext(mid);
+      m.bond(mid, t3);
+      t1 = M::lprev(t1);
+      t2 = M::lnext(t2);
+      m.bond(t1, t2);
+      t1 = M::lprev(t1);
+      t3 = M::lprev(t3);
+      m.bond(t1, t3);
+      t2 = M::lnext(t2);
+      t3 = M::lprev(t3);
+      m.bond(t2, t3);
       farleft = t1;
-      farright = area > 0 ? t2 : lnext(farleft);
+      farright = area > 0 ? t2 : M::lnext(farleft);
     }
+    return;
+  }
+}
+
+template <class M>
+VSM_HD inline void dc_recurse(const M &m, int32_t off, int32_t n, int axis, DcOTri &farleft, DcOTri &farright) {
+  typedef DcOTri OTri;
+  if (n <= 3) {
+    dc_leaf(m, off, n, farleft, farright);
     return;
   }
   const int32_t divider = n >> 1;  // kd_order() has already arranged both halves
   OTri innerleft, innerright;
-  recurse(off, divider, 1 - axis, farleft, innerleft);
-  recurse(off + divider, n - divider, 1 - axis, innerright, farright);
+  dc_recurse(m, off, divider, 1 - axis, farleft, innerleft);
+  dc_recurse(m, off + divider, n - divider, 1 - axis, innerright, farright);
   int32_t tcur = 2 * (off + divider) - 2;
-  merge_hulls(farleft, innerleft, innerright, farright, axis, tcur);
+  dc_merge_hulls(m, farleft, innerleft, innerright, farright, axis, tcur);
 }
 
+VSM_HD inline void DcMesh::recurse(int32_t off, int32_t n, int axis, OTri &farleft, OTri &farright) const {
+  dc_recurse(*this, off, n, axis, farleft, farright);
+}
+
+// The same without recursion, for GPU lanes (a recursive device function needs a dynamic stack per lane): post-order walk
+// of the halving tree with an explicit stack of at most MAXDEPTH pending nodes (n <= 3 * 2^(MAXDEPTH-1) points).
+template <int MAXDEPTH, class M>
+VSM_HD inline void dc_build_iter(const M &m, int32_t off0, int32_t n0, int axis0, DcOTri &farleft, DcOTri &farright) {
+  typedef DcOTri OTri;
+  // pending nodes: position, size, axis | phase << 8, and (once the left child is done) its two hull handles
+  int32_t s_off[MAXDEPTH], s_n[MAXDEPTH], s_ap[MAXDEPTH], s_flt[MAXDEPTH], s_flo[MAXDEPTH], s_ilt[MAXDEPTH], s_ilo[MAXDEPTH];
+  int sp = 0;
+  s_off[0] = off0;
+  s_n[0] = n0;
+  s_ap[0] = axis0;
+  OTri rl{0, 0}, rr{0, 0};  // hull handles of the node finished last
+  for (;;) {
+    const int32_t off = s_off[sp], n = s_n[sp], axis = s_ap[sp] & 0xff, phase = s_ap[sp] >> 8;
+    if (n <= 3) {
+      dc_leaf(m, off, n, rl, rr);
+    } else if (phase == 0) {
+      s_ap[sp] = axis | (1 << 8);
+      s_off[sp + 1] = off;
+      s_n[sp + 1] = n >> 1;
+      s_ap[sp + 1] = 1 - axis;
+      sp++;
+      continue;
+    } else if (phase == 1) {
+      s_flt[sp] = rl.t;
+      s_flo[sp] = rl.o;
+      s_ilt[sp] = rr.t;
+      s_ilo[sp] = rr.o;
+      s_ap[sp] = axis | (2 << 8);
+      const int32_t div = n >> 1;
+      s_off[sp + 1] = off + div;
+      s_n[sp + 1] = n - div;
+      s_ap[sp + 1] = 1 - axis;
+      sp++;
+      continue;
+    } else {
+      OTri fl{s_flt[sp], s_flo[sp]}, il{s_ilt[sp], s_ilo[sp]}, ir = rl, fr = rr;
+      int32_t tcur = 2 * (off + (n >> 1)) - 2;
+      dc_merge_hulls(m, fl, il, ir, fr, axis, tcur);
+      rl = fl;
+      rr = fr;
+    }
+    if (sp == 0) break;
+    sp--;
+  }
+  farleft = rl;
+  farright = rr;
+}
+
+// And without any indexed local storage (on the GPU a lane's indexed private array means scratch memory or indirect
+// register addressing): for sub-trees of at most 24 points, i.e. at most three cut levels above the leaves.  A pending
+// node is named by its depth and path from the root - position, size and axis are recomputed from those -, its phase
+// sits in two bits per level, and the left child's hull handles wait in one packed word per level (s0..s3).
+template <class M>
+VSM_HD inline void dc_build_small(const M &m, int32_t off0, int32_t n0, int axis0, DcOTri &farleft, DcOTri &farright) {
+  typedef DcOTri OTri;
+  int d = 0;
+  uint32_t path = 0, phase = 0;
+  uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  OTri rl{0, 0}, rr{0, 0};  // hull handles of the node finished last
+  for (;;) {
+    int32_t off = off0, n = n0, axis = axis0;
+    for (int b = d - 1; b >= 0; b--) {
+      const int32_t div = n >> 1;
+      if ((path >> b) & 1) {
+        off += div;
+        n -= div;
+      } else {
+        n = div;
+      }
+      axis = 1 - axis;
+    }
+    const uint32_t ph = (phase >> (2 * d)) & 3u;
+    if (n <= 3) {
+      dc_leaf(m, off, n, rl, rr);
+    } else if (ph == 0) {  // left child first
+      phase = (phase & ~(3u << (2 * d))) | (1u << (2 * d));
+      d++;
+      path <<= 1;
+      phase &= ~(3u << (2 * d));
+      continue;
+    } else if (ph == 1) {  // the left child is done: keep its handles, then the right child
+      const uint64_t pk = ((uint64_t)(uint32_t)rl.t << 34) | ((uint64_t)(uint32_t)rl.o << 32) | ((uint64_t)(uint32_t)rr.t << 2) | (uint32_t)rr.o;
+      if (d == 0)
+        s0 = pk;
+      else if (d == 1)
+        s1 = pk;
+      else if (d == 2)
+        s2 = pk;
+      else
+        s3 = pk;
+      phase = (phase & ~(3u << (2 * d))) | (2u << (2 * d));
+      d++;
+      path = (path << 1) | 1u;
+      phase &= ~(3u << (2 * d));
+      continue;
+    } else {
+      const uint64_t pk = d == 0 ? s0 : (d == 1 ? s1 : (d == 2 ? s2 : s3));
+      OTri fl{(int32_t)(pk >> 34), (int32_t)((pk >> 32) & 3u)}, il{(int32_t)((pk >> 2) & 0x3fffffffu), (int32_t)(pk & 3u)}, ir = rl, fr = rr;
+      int32_t tcur = 2 * (off + (n >> 1)) - 2;
+      dc_merge_hulls(m, fl, il, ir, fr, axis, tcur);
+      rl = fl;
+      rr = fr;
+    }
+    if (d == 0) break;
+    d--;
+    path >>= 1;
+  }
+  farleft = rl;
+  farright = rr;
+}

@@ -663,9 +663,14 @@ void ExactDelaunay::solve_merges() {
 
 void ExactDelaunay::solve_tasks(VsmForkJoin *pool) {
   const DcMesh mesh = this->mesh();
+  // (VSM_DC_ITER=1: the explicit-stack form the GPU lanes use, dc_build_iter - a test switch, same result)
+  static const bool iter = getenv("VSM_DC_ITER") && atoi(getenv("VSM_DC_ITER")) != 0;
   auto one = [&](int t) {
     Node &nd = nodes_[tasks_[t].node];
-    mesh.recurse(nd.off, nd.n, nd.axis, nd.fl, nd.fr);
+    if (iter)
+      dc_build_iter<40>(mesh, nd.off, nd.n, nd.axis, nd.fl, nd.fr);
+    else
+      mesh.recurse(nd.off, nd.n, nd.axis, nd.fl, nd.fr);
   };
   if (pool && pool->size() > 1 && tasks_.size() > 1) {
     pool->run((int)tasks_.size(), one);
