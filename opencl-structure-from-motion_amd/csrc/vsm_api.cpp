@@ -1173,8 +1173,12 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
 
   // The GPU-resident form (vsm_seq2.inc) takes the run unless VSM_SEQ_V2=0 asks for the host-shared form below, or
   // it declines (lists beyond what its device-side vertex sort / kd order were written for).
+  // Which one is faster depends on how many host threads this rank has: the host-shared form lives off them (200 frames
+  // 1242x375: 8.0 ms with 16 threads, 17 with 4, 24 with 2), the GPU-resident one does not care (9.5 ms with 16, 4 or 2) -
+  // its triangulation kernels are chains of single-lane seam walks, at which a CPU core is much faster than a GPU lane.
   h->seq_v2_frames = 0;
-  if (!(getenv("VSM_SEQ_V2") && atoi(getenv("VSM_SEQ_V2")) == 0)) {
+  const bool v2 = getenv("VSM_SEQ_V2") ? atoi(getenv("VSM_SEQ_V2")) != 0 : h->pool->size() <= 12;
+  if (v2) {
     const int rc = sequence_run_v2(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
     if (rc != VSM_SEQ2_DECLINED) return rc;
     h->seq_v2_frames = 0;
