@@ -79,9 +79,18 @@ void vsm_set_intrinsics(vsm_handle *h, double f, double cu, double cv, double ba
 int vsm_push_back(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int32_t width, int32_t height, int32_t bpl,
                   int replace);
 
-/* Same, for images that already live in this device's HBM (the bench's resident-input path). */
+/* Same, for images that already live in this device's HBM (the bench's resident-input path).
+ * Ordering and lifetime contract of every entry point that takes device pointers (this one, vsm_sequence_run with
+ * on_device = 1, vsm_vo_stereo_process_device, vsm_vo_mono_process_device):
+ *  - the images are READ ASYNCHRONOUSLY on the handle's own (non-blocking) stream.  Work that produces them on another
+ *    stream must have completed, or be ordered in front with vsm_wait_for_stream() right before the call;
+ *  - they must stay valid and unchanged until the handle has consumed them: until the next synchronising call on the
+ *    handle for a push (vsm_match, any getter), until the call returns for vsm_sequence_run and the VO entry points. */
 int vsm_push_back_device(vsm_handle *h, const uint8_t *dI1, const uint8_t *dI2, int32_t width, int32_t height,
                          int32_t bpl, int replace);
+/* orders everything the handle enqueues from now on behind the work `hip_stream` (a hipStream_t; NULL = the null stream)
+ * holds at this moment: an event recorded there, a wait on the handle's stream - no host synchronisation */
+int vsm_wait_for_stream(vsm_handle *h, void *hip_stream);
 
 /* Matcher::matchFeatures(method, Tr_delta), viso/matcher.cpp:183-241.  method 0 flow, 1 stereo,
  * 2 quad.  Tr_delta: NULL or 12 doubles = rows 0..2 of the 4x4 matrix, row-major

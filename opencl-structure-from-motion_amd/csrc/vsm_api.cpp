@@ -368,6 +368,7 @@ struct vsm_handle {
   vsm_params param;  // match_radius already halved for half_resolution (viso/matcher.cpp:59-60)
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t input_ev = nullptr;   // vsm_wait_for_stream(): the producer stream's marker
   hipEvent_t idle_wait = nullptr;  // blocking-sync event (pass 2 of a chunk done): the look-ahead caller sleeps on it, its CPU goes to the host pool
   hipEvent_t seq_ev[2] = {nullptr, nullptr};  // look-ahead markers: features done / pass 1 done (blocking sync too)
   static constexpr int kDcBanks = 4;  // chunks whose final stage may be in flight at once
@@ -407,6 +408,8 @@ struct vsm_handle {
   // results of the sequence API
   std::vector<std::vector<vsm_p_match>> seq_matches;
   double seq_timings[4] = {0, 0, 0, 0};
+  bool dc_gpu_broken = false;    // a Delaunay stream reported a HIP error once: the host-shared form keeps off the GPU share from then on
+  std::atomic<int> seq_hip_error{0};  // set by a chunk whose GPU share failed during the current vsm_sequence_run
   struct Seq2 *seq2 = nullptr;   // GPU-resident look-ahead path (vsm_seq2.inc): streams, slabs, result arena
   int32_t seq_v2_frames = 0;     // > 0: the last sequence's results are in seq2's arena, not in seq_matches
 
@@ -501,6 +504,10 @@ static void reset_ring_state(vsm_handle *h) {
 void vsm_destroy(vsm_handle *h) {
   if (!h) return;
   (void)hipStreamSynchronize(h->stream);
+  for (hipStream_t st : h->dc_stream)
+    if (st) (void)hipStreamSynchronize(st);
+  for (hipStream_t st : h->tie_stream)
+    if (st) (void)hipStreamSynchronize(st);
   seq2_destroy(h);
   ctx_destroy(h->ring);
   ctx_destroy(h->seq);
@@ -519,6 +526,7 @@ void vsm_destroy(vsm_handle *h) {
     if (e) (void)hipEventDestroy(e);
   if (h->hm_ties) (void)hipHostFree(h->hm_ties);
   if (h->idle_wait) (void)hipEventDestroy(h->idle_wait);
+  if (h->input_ev) (void)hipEventDestroy(h->input_ev);
   for (hipEvent_t e : h->seq_ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -612,6 +620,14 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
   // Host images were copied into the staging buffer, so the caller may free or overwrite them as
   // soon as we return (matcherMex does).  Device-resident images: the source must stay valid until
   // the next call that needs the push's results settles it.  Either way the push is asynchronous.
+  return VSM_OK;
+}
+
+int vsm_wait_for_stream(vsm_handle *h, void *hip_stream) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->input_ev) HIPCHK(hipEventCreateWithFlags(&h->input_ev, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(h->input_ev, (hipStream_t)hip_stream));
+  HIPCHK(hipStreamWaitEvent(h->stream, h->input_ev, 0));
   return VSM_OK;
 }
 
@@ -1017,6 +1033,9 @@ static void dc_enqueue_gpu(DcChunk *ch, bool wait_here = false) {
     }
     return;
   }
+  // (VSM_DC_FAULT_INJECT=1, tests only: the completion callback is "lost" - dc_wait()'s watchdog has to notice)
+  const bool lose_callback = getenv("VSM_DC_FAULT_INJECT") && atoi(getenv("VSM_DC_FAULT_INJECT")) == 1;
+  if (ok && maxt > 0 && lose_callback) return;
   if (ok && maxt > 0 && hipLaunchHostFunc(s2, dc_after_gpu, ch) == hipSuccess) return;
   // nothing for the GPU, or it could not be used: the host solves the sub-trees too
   if (maxt > 0) {
@@ -1099,30 +1118,60 @@ static void dc_submit_a(DcChunk *ch) {
   });
 }
 
-static void dc_wait(DcChunk *ch) {  // until the chunk's final lists are in seq_matches
+// Until the chunk's final lists are in seq_matches.  The GPU's part normally takes a millisecond or two and reports back
+// through a host function on its stream.  If nothing has been heard after the watchdog time (VSM_DC_WATCHDOG_MS, default
+// 20 s) the stream itself is asked: hipStreamSynchronize() either returns an error - the device faulted; that is logged
+// with HIP's own message, remembered in the handle (no GPU share from then on) and reported by vsm_sequence_run as
+// VSM_EHIP - or it returns success, in which case the device's results are complete and only the callback went missing.
+// Either way nothing on the device can touch the chunk's slabs any more when the host takes over, and the chunk and
+// its bank stay alive until then (they are owned by vsm_sequence_run, which calls this for every chunk before it returns).
+static void dc_wait(DcChunk *ch) {
+  const double watchdog_us = (getenv("VSM_DC_WATCHDOG_MS") ? atof(getenv("VSM_DC_WATCHDOG_MS")) : 20000.0) * 1e3;
+  vsm_handle *h = ch->h;
   if (!ch->submitted) {  // (left early, between setting it up and submitting it: only its vertex sorts may be in flight)
-    while (!ch->ties_done.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    const double t0 = vsm_now_us();
+    while (!ch->ties_done.load(std::memory_order_acquire)) {
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+      if (vsm_now_us() - t0 > watchdog_us) {
+        const hipError_t e = hipStreamSynchronize(h->tie_stream[ch->bank & 1]);
+        if (e != hipSuccess) {
+          fprintf(stderr, "visomatch: the vertex-sort stream of the Delaunay stage failed: %s\n", hipGetErrorString(e));
+          h->dc_gpu_broken = true;
+          h->seq_hip_error.store(1);
+        }
+        ch->ties_done.store(1, std::memory_order_release);
+      }
+    }
     return;
   }
   const double t0 = vsm_now_us();
   while (ch->stage.load(std::memory_order_acquire) < 2) {
     std::this_thread::sleep_for(std::chrono::microseconds(50));
-    // The GPU's part normally takes a millisecond or two.  If its end has not been reported after 20 s (a stream in an
-    // error state never runs its host function), the host does the pairs itself rather than wait forever.
-    if (ch->stage.load(std::memory_order_acquire) == 1 && vsm_now_us() - t0 > 20e6 && !ch->b_once.exchange(true)) {
-      fprintf(stderr, "visomatch: the GPU share of the Delaunay stage did not report back, finishing the chunk on the host\n");
-      DcBank &B = *ch->B;
-      for (int i = 0; i < ch->n; i++)
-        if (B.nt[i] > 0) B.nt[i] = -1;
-      ch->full = false;
-      if (ch->ties_gpu) {  // (its vertex sorts will not report either: the host's verdicts)
-        for (int i = 0; i < ch->n; i++) const_cast<int32_t *>(ch->ties)[(size_t)i * VSM_DC_TIE_OUT_INTS] = -1;
-        ch->ties_done.store(1, std::memory_order_release);
+    if (ch->stage.load(std::memory_order_acquire) == 1 && vsm_now_us() - t0 > watchdog_us && !ch->b_once.exchange(true)) {
+      const hipError_t e = hipStreamSynchronize(ch->stream);  // (blocks until the stream has drained or failed)
+      hipError_t et = hipSuccess;
+      if (ch->ties_gpu) et = hipStreamSynchronize(h->tie_stream[ch->bank & 1]);
+      if (e != hipSuccess || et != hipSuccess) {
+        fprintf(stderr, "visomatch: the GPU share of the Delaunay stage failed (%s); finishing the chunk on the host, no GPU share from now on\n",
+                hipGetErrorString(e != hipSuccess ? e : et));
+        h->dc_gpu_broken = true;
+        h->seq_hip_error.store(1);
+        DcBank &B = *ch->B;
+        for (int i = 0; i < ch->n; i++)
+          if (B.nt[i] > 0) B.nt[i] = -1;
+        ch->full = false;
+        if (ch->ties_gpu) {  // (its vertex sorts will not report either: the host's verdicts)
+          for (int i = 0; i < ch->n; i++) const_cast<int32_t *>(ch->ties)[(size_t)i * VSM_DC_TIE_OUT_INTS] = -1;
+          ch->ties_done.store(1, std::memory_order_release);
+        }
+      } else {
+        fprintf(stderr, "visomatch: the GPU share of the Delaunay stage finished without reporting back; continuing with its results\n");
+        if (ch->ties_gpu) ch->ties_done.store(1, std::memory_order_release);
       }
       dc_submit_b(ch);
     }
   }
-  ch->h->pool->wait(ch->b);
+  h->pool->wait(ch->b);
 }
 
 }  // extern "C"
@@ -1140,6 +1189,10 @@ static int sequence_fallback(vsm_handle *h, const uint8_t *left, const uint8_t *
                              const uint8_t *Tr_valid) {
   // rarely used configurations (mono input, refinement==2) go frame by frame on a fresh ring
   (void)hipStreamSynchronize(h->stream);
+  for (hipStream_t st : h->dc_stream)
+    if (st) (void)hipStreamSynchronize(st);
+  for (hipStream_t st : h->tie_stream)
+    if (st) (void)hipStreamSynchronize(st);
   seq2_destroy(h);
   ctx_destroy(h->ring);
   reset_ring_state(h);
@@ -1214,7 +1267,8 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   // 2: 33.1 / 25.8; host only: 14.0, 25.3, 43.4, 70.8); VSM_DC_FULL=0/1 decides otherwise
   const bool dc_full = getenv("VSM_DC_FULL") ? atoi(getenv("VSM_DC_FULL")) != 0 : h->pool->size() <= 6;
   const int dc_top = getenv("VSM_DC_TOP") ? atoi(getenv("VSM_DC_TOP")) : 240;  // merge nodes up to this size follow on the GPU
-  bool dc_gpu = dc_env;
+  bool dc_gpu = dc_env && !h->dc_gpu_broken;
+  h->seq_hip_error.store(0);
   for (hipStream_t &st : h->dc_stream)
     if (dc_gpu && !st) dc_gpu = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;  // (stream priorities make no measurable difference)
   // VSM_DC_TIES=1: Triangle's randomised vertex sort on the GPU too (k_dc_ties_of_keys, one wave per pair, started right
@@ -1606,7 +1660,8 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   if (vsm_debug_timing())
     fprintf(stderr, "seq: entry->start %.0f us, gpu %.0f, host %.0f, total %.0f\n", tstart - t_entry, tg, thost,
             h->seq_timings[2]);
-  return VSM_OK;
+  // (a Delaunay stream that failed: the lists are complete - the host finished those chunks - but the caller must know)
+  return h->seq_hip_error.load() ? VSM_EHIP : VSM_OK;
 }
 
 int32_t vsm_sequence_num_matches(vsm_handle *h, int32_t frame) {

@@ -28,7 +28,7 @@ FEATURE_SETS = {"1p1": 0, "2p1": 1, "1c1": 2, "2c1": 3, "1p2": 4, "2p2": 5, "1c2
 
 # every symbol include/visomatch.h declares
 EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsics", "vsm_push_back",
-           "vsm_push_back_device", "vsm_match", "vsm_num_matches", "vsm_get_matches", "vsm_bucket", "vsm_gain",
+           "vsm_push_back_device", "vsm_wait_for_stream", "vsm_match", "vsm_num_matches", "vsm_get_matches", "vsm_bucket", "vsm_gain",
            "vsm_num_features", "vsm_get_features", "vsm_set_stage_capture", "vsm_stage_size", "vsm_stage_get",
            "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
            "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
@@ -96,6 +96,7 @@ def lib():
         L.vsm_set_intrinsics.argtypes = [vp] + [C.c_double] * 4
         L.vsm_push_back.argtypes = [vp, vp, vp, i32, i32, i32, C.c_int]
         L.vsm_push_back_device.argtypes = [vp, vp, vp, i32, i32, i32, C.c_int]
+        L.vsm_wait_for_stream.argtypes = [vp, vp]
         L.vsm_match.argtypes = [vp, i32, vp]
         L.vsm_num_matches.argtypes = [vp]
         L.vsm_get_matches.argtypes = [vp, vp, i32]
@@ -334,6 +335,16 @@ def default_params():
     return p
 
 
+def _order_behind_torch(handle, *tensors):
+    """device-resident inputs: the library reads them asynchronously on its own stream, so its stream is made to wait for
+    whatever torch's current stream holds (the kernels or copies that produce the tensors) - vsm_wait_for_stream"""
+    import torch
+    dev = tensors[0].device
+    rc = lib().vsm_wait_for_stream(handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise VisoMatchError(f"vsm_wait_for_stream failed with {rc}")
+
+
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
@@ -343,6 +354,8 @@ class Matcher:
     vsm_push_back) or CUDA/HIP torch tensors (device-resident path, vsm_push_back_device)."""
 
     OK, EDIMS, ENOTREADY, EHIP, EARG = 0, -1, -2, -3, -4
+
+    _inputs = None
 
     def __init__(self, stage_capture=False, **params):
         L = lib()
@@ -374,6 +387,8 @@ class Matcher:
             if I2 is not None:
                 assert I2.is_cuda and I2.shape == I1.shape and I2.stride() == I1.stride()
                 p2 = C.c_void_p(I2.data_ptr())
+            _order_behind_torch(self.h, I1)
+            self._inputs = (I1, I2)      # the push reads them asynchronously: kept alive until the next push
             return L.vsm_push_back_device(self.h, C.c_void_p(I1.data_ptr()), p2, w, h, bpl, int(replace))
         I1 = np.ascontiguousarray(I1, dtype=np.uint8)
         h, w = I1.shape
@@ -477,6 +492,7 @@ class Matcher:
             assert left.is_cuda and left.dim() == 3 and left.stride(2) == 1
             F, h, w = left.shape
             bpl, fs = left.stride(1), left.stride(0)
+            _order_behind_torch(self.h, left)
             pl = C.c_void_p(left.data_ptr())
             pr = None
             if right is not None:
@@ -579,6 +595,7 @@ class VisualOdometryStereo:
         if _is_torch(I1):
             assert I1.is_cuda and I2.is_cuda and I1.shape == I2.shape and I1.stride() == I2.stride()
             h, w = I1.shape
+            _order_behind_torch(L.vsm_vo_stereo_matcher(self.h), I1)
             ok = L.vsm_vo_stereo_process_device(self.h, C.c_void_p(I1.data_ptr()), C.c_void_p(I2.data_ptr()), w, h,
                                                 I1.stride(0), int(replace))
         else:
@@ -657,6 +674,7 @@ class VisualOdometryMono:
         if _is_torch(I):
             assert I.is_cuda and I.dim() == 2 and I.stride(1) == 1
             h, w = I.shape
+            _order_behind_torch(L.vsm_vo_mono_matcher(self.h), I)
             ok = L.vsm_vo_mono_process_device(self.h, C.c_void_p(I.data_ptr()), w, h, I.stride(0), int(replace))
         else:
             I = np.ascontiguousarray(I, dtype=np.uint8)

@@ -206,13 +206,15 @@ def test_reference_vo_runs_on_dropin_matcher(synth, tmp_path, binary):
 
 @pytest.mark.parametrize("chunk", ["1", "3", "50"])
 @pytest.mark.parametrize("method", [2, 0, 1])
-@pytest.mark.parametrize("final_stage", ["as it comes", "shared with the GPU", "all on the GPU"])
+@pytest.mark.parametrize("final_stage", ["as it comes", "shared with the GPU", "all on the GPU", "GPU-resident form"])
 def test_sequence_api_equals_frame_by_frame(vm, B, synth, monkeypatch, method, chunk, final_stage):
     """look-ahead API == pushBack+matchFeatures per frame (oracle), across chunk boundaries; with the final stage
     (exact Delaunay support test) where the chunk size puts it - the host for these short chunks - and forced
-    through both forms of the GPU share, for flow, stereo and quad matching"""
+    through both forms of the GPU share, for flow, stereo and quad matching; and through the GPU-resident form of the
+    whole path (lists stay in HBM, removeOutliers + prior statistics as device kernels)"""
     monkeypatch.setenv("VSM_SEQ_CHUNK", chunk)
-    if final_stage != "as it comes":
+    monkeypatch.setenv("VSM_SEQ_V2", "1" if final_stage == "GPU-resident form" else "0")
+    if final_stage not in ("as it comes", "GPU-resident form"):
         monkeypatch.setenv("VSM_DC_GPU", "1")
         monkeypatch.setenv("VSM_DC_FULL", "1" if final_stage == "all on the GPU" else "0")
     seq = synth.stereo_sequence(31, 417, 163, 7, disparity=10, ramp=(1, 12))
@@ -220,6 +222,7 @@ def test_sequence_api_equals_frame_by_frame(vm, B, synth, monkeypatch, method, c
     right = np.stack([r for _, r in seq])
     g = vm.Matcher()
     got = g.run_sequence(left, right, method)
+    assert g.sequence_path() == (2 if final_stage == "GPU-resident form" else 1)
     c = B.CpuMatcher("oracle")
     for f, (l, r) in enumerate(seq):
         c.push_back(l, r)
@@ -229,12 +232,14 @@ def test_sequence_api_equals_frame_by_frame(vm, B, synth, monkeypatch, method, c
     g.close()
 
 
-@pytest.mark.parametrize("chunk", ["50", "16", "17"])
-def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, chunk):
+@pytest.mark.parametrize("form", ["host-shared", "GPU-resident"])
+@pytest.mark.parametrize("chunk", ["50", "16", "17", "7"])
+def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, chunk, form):
     """config 2 through the look-ahead API: 60 frames resident in HBM, replayed Tr_delta; chunk 16 / 17 make
-    it a sequence of four chunks (three frame banks, two pair banks and the slab banks all come round)"""
+    it a sequence of four chunks (three frame banks, the pair banks and the slab banks all come round), chunk 7 one of nine"""
     import torch
     monkeypatch.setenv("VSM_SEQ_CHUNK", chunk)
+    monkeypatch.setenv("VSM_SEQ_V2", "1" if form == "GPU-resident" else "0")
     monkeypatch.setenv("VSM_DC_GPU", "1")   # (chunks with fewer pairs than host threads would stay on the host)
     g = G.load("cfg2_seq200_tr")
     w, h, nf = int(g["w"]), int(g["h"]), 60
@@ -260,6 +265,7 @@ def test_sequence_api_final_stage_variants(vm, synth, monkeypatch, env):
     one overflows the level table and falls back to the host pair by pair) all give the reference's lists"""
     import torch
     monkeypatch.setenv("VSM_DC_GPU", "1")   # (chunks with fewer pairs than host threads would stay on the host)
+    monkeypatch.setenv("VSM_SEQ_V2", "0")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     g = G.load("cfg2_seq200_tr")
@@ -616,3 +622,120 @@ def test_delaunay_subtrees_on_gpu(vm):
                           (480, -1), (100, -1), (14, -1), (5000, -1)):
             for kd in (False, True):
                 assert np.array_equal(whole, canon(vm.delaunay_gpu_split(p, leaf, top, kd))), (len(p), leaf, top, kd)
+
+
+def test_gpu_resident_remove_outliers_chain(vm):
+    """the device chain of the GPU-resident look-ahead form (keys, (x,y) sort + duplicates + kd order, block sub-trees on the
+    16-bit LDS mesh, merge levels whole in LDS / through the mapped cache, tie patches from the device's or the host's
+    vertex sort, support votes, survivors, prior statistics) against the host code of the per-frame path: survivors and
+    prior boxes byte for byte, list lengths around every structural boundary (3 | 4, one block | two, whole | mapped merge)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("dc2_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dc2_check.py"))
+    dc2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dc2)
+    for n in (0, 3, 4, 5, 17, 100, 480, 481, 961, 2000, 4500, 7400, 9000):
+        for method in (0, 1, 2):
+            for grid in (False, True):
+                lst = dc2.make_list(n, grid=grid)
+                hs, hr, _ = vm.remove_outliers(lst, method, 1242, 375)
+                for gt in (False, True):
+                    if gt and n > 8192:
+                        continue
+                    gs, gr, _ = vm.remove_outliers(lst, method, 1242, 375, gpu=True, gpu_ties=gt, copies=2)
+                    assert _same(hs, gs) and np.array_equal(hr, gr), (n, method, grid, gt, len(hs), len(gs))
+    lst = dc2.make_list(60, dup=0)
+    lst["u1c"], lst["v1c"] = 100, 50                       # every match at one pixel: no triangulation, nothing survives
+    assert len(vm.remove_outliers(lst, 2, 1242, 375, gpu=True)[0]) == len(vm.remove_outliers(lst, 2, 1242, 375)[0]) == 0
+    lst = dc2.make_list(300, dup=0)
+    lst["v1c"] = 40                                          # collinear
+    assert _same(vm.remove_outliers(lst, 2, 1242, 375, gpu=True)[0], vm.remove_outliers(lst, 2, 1242, 375)[0])
+
+
+@pytest.mark.parametrize("form", ["host-shared", "GPU-resident"])
+def test_all_eight_sequences_of_config_4_on_one_gpu(vm, synth, monkeypatch, form):
+    """config 4 = eight independent sequences, one per GPU.  Without the 8-GPU node every rank's sequence still has to go
+    through the HIP path somewhere: seeds 1234..1241, 40 frames each, look-ahead API, final lists against the
+    reference's hashes (tests/golden/cfg4_seq200_tr_8seeds.npz)"""
+    import torch
+    monkeypatch.setenv("VSM_SEQ_V2", "1" if form == "GPU-resident" else "0")
+    monkeypatch.setenv("VSM_DC_GPU", "1")
+    monkeypatch.setenv("VSM_SEQ_CHUNK", "20")
+    g = G.load("cfg4_seq200_tr_8seeds")
+    w, h, nf = 1242, 375, 40
+    m = vm.Matcher()
+    m.set_intrinsics(*[float(x) for x in g["intr"]])
+    for seed in range(1234, 1242):
+        key = f"s{seed}"
+        cv = synth.canvas(seed, w, h)
+        fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
+        left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
+        right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
+        tr = np.ascontiguousarray(g[key + "_tr_in"][:nf].reshape(nf, 16)[:, :12])
+        got = m.run_sequence(left, right, 2, tr, g[key + "_tr_valid"][:nf])
+        for f in range(nf):
+            assert len(got[f]) == int(g[key + "_counts"][f]) and G.sha(got[f]) == str(g[key + "_hashes"][f]), (seed, f)
+    m.close()
+
+
+def test_inputs_produced_asynchronously_on_another_stream(vm, B, synth):
+    """device-resident inputs are read on the handle's own stream: the wrapper orders that stream behind torch's current
+    one (vsm_wait_for_stream), so images that a side stream is still writing when push_back / run_sequence are called -
+    behind a long-running kernel - arrive complete"""
+    import torch
+    seq = synth.stereo_sequence(5, 500, 200, 4)
+    left = np.stack([l for l, _ in seq])
+    right = np.stack([r for _, r in seq])
+    c = B.CpuMatcher("oracle")
+    want = []
+    for l, r in seq:
+        c.push_back(l, r)
+        c.match(2)
+        want.append(c.matches())
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device="cuda")
+    hl, hr = torch.from_numpy(left).pin_memory(), torch.from_numpy(right).pin_memory()
+    g = vm.Matcher()
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            big = big @ big * 1e-4                       # tens of milliseconds of work in front of the copies
+        dl, dr = hl.to("cuda", non_blocking=True), hr.to("cuda", non_blocking=True)
+        got = g.run_sequence(dl, dr, 2)                  # called while the copies are still queued
+    for f in range(len(seq)):
+        assert _same(got[f], want[f]), f
+    g2 = vm.Matcher()
+    with torch.cuda.stream(side):
+        for f in range(len(seq)):
+            for _ in range(5):
+                big = big @ big * 1e-4
+            a, b = hl[f].to("cuda", non_blocking=True), hr[f].to("cuda", non_blocking=True)
+            assert g2.push_back(a, b) == 0
+            g2.match(2)
+            assert _same(g2.matches(), want[f]), f
+    torch.cuda.synchronize()
+    g.close()
+    g2.close()
+
+
+def test_lost_completion_callback_of_the_delaunay_share(vm, synth, monkeypatch):
+    """host-shared look-ahead form, fault injection: the host function that reports the end of the GPU's share of a
+    chunk's Delaunay stage never runs (VSM_DC_FAULT_INJECT=1).  dc_wait()'s watchdog (shortened to 0.3 s) synchronises the
+    stream, finds it healthy and carries on with the device's results: same lists, no error"""
+    import torch
+    monkeypatch.setenv("VSM_SEQ_V2", "0")
+    monkeypatch.setenv("VSM_DC_GPU", "1")
+    monkeypatch.setenv("VSM_DC_FAULT_INJECT", "1")
+    monkeypatch.setenv("VSM_DC_WATCHDOG_MS", "300")
+    monkeypatch.setenv("VSM_SEQ_CHUNK", "10")
+    g = G.load("cfg2_seq200_tr")
+    w, h, nf = int(g["w"]), int(g["h"]), 20
+    cv = synth.canvas(int(g["seed"]), w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
+    left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
+    right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
+    m = vm.Matcher()
+    m.set_intrinsics(*[float(x) for x in g["intr"]])
+    got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
+    for f in range(nf):
+        assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), f
+    m.close()

@@ -38,8 +38,10 @@ def _worker(rank, world, port, out):
     n = len(m.matches())
     shard.barrier(dist)
     units, seconds = 10.0 * (rank + 1), 2.0 + rank      # rank0: 10 units in 2 s, rank1: 20 units in 3 s
-    tot, tmax, ok = shard.aggregate(dist, torch, units, seconds, all_ok=(rank == 0 or True))
-    out.put((rank, seed, n, tot, tmax, ok))
+    tot, tmax, ok = shard.aggregate(dist, torch, units, seconds, all_ok=True)
+    # one rank reports a failed verification: every rank must see it (MIN reduction), sums and maxima unchanged
+    tot2, tmax2, ok2 = shard.aggregate(dist, torch, units, seconds, all_ok=(rank == 0))
+    out.put((rank, seed, n, tot, tmax, ok, tot2, tmax2, ok2))
     dist.destroy_process_group()
 
 
@@ -54,9 +56,11 @@ def test_two_rank_aggregation():
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
-    (r0, s0, n0, tot0, t0, ok0), (r1, s1, n1, tot1, t1, ok1) = res
+    (r0, s0, n0, tot0, t0, ok0, tb0, tmb0, okb0), (r1, s1, n1, tot1, t1, ok1, tb1, tmb1, okb1) = res
     assert (s0, s1) == (1234, 1235)
     assert n0 > 50 and n1 > 50 and n0 != n1          # independent sequences, independent results
     assert tot0 == tot1 == 30.0 and t0 == t1 == 3.0   # sum of units / max of seconds on every rank
     assert ok0 and ok1
+    assert not okb0 and not okb1                      # rank 1 said "not verified": both ranks know
+    assert tb0 == tb1 == 30.0 and tmb0 == tmb1 == 3.0
     assert abs(tot0 / t0 - 10.0) < 1e-12
