@@ -1227,10 +1227,11 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   // The GPU-resident form (vsm_seq2.inc) takes the run unless VSM_SEQ_V2=0 asks for the host-shared form below, or
   // it declines (lists beyond what its device-side vertex sort / kd order were written for).
   // Which one is faster depends on how many host threads this rank has: the host-shared form lives off them (200 frames
-  // 1242x375: 8.0 ms with 16 threads, 17 with 4, 24 with 2), the GPU-resident one does not care (9.5 ms with 16, 4 or 2) -
-  // its triangulation kernels are chains of single-lane seam walks, at which a CPU core is much faster than a GPU lane.
+  // 1242x375: 8.0 ms with 16 threads, 11.6 with 8, 17 with 4, 24 with 2), the GPU-resident one does not care (9.4 ms with 16,
+  // 8, 4 or 2) - its triangulation kernels are chains of single-lane seam walks, at which a CPU core is much faster than a
+  // GPU lane.  VSM_SEQ_V2=0 / 1 decides otherwise.
   h->seq_v2_frames = 0;
-  const bool v2 = getenv("VSM_SEQ_V2") ? atoi(getenv("VSM_SEQ_V2")) != 0 : h->pool->size() <= 12;
+  const bool v2 = getenv("VSM_SEQ_V2") ? atoi(getenv("VSM_SEQ_V2")) != 0 : h->pool->size() <= 11;
   if (v2) {
     const int rc = sequence_run_v2(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
     if (rc != VSM_SEQ2_DECLINED) return rc;
@@ -1665,12 +1666,13 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
 }
 
 int32_t vsm_sequence_num_matches(vsm_handle *h, int32_t frame) {
+  if (h->seq_v2_frames > 0 && frame >= 0 && frame < h->seq_v2_frames && h->seq2->frame_on_host[frame]) return (int32_t)h->seq_matches[frame].size();
   if (h->seq_v2_frames > 0) return (frame >= 0 && frame < h->seq_v2_frames) ? h->seq2->res_cnt[frame] : 0;
   return (frame >= 0 && frame < (int32_t)h->seq_matches.size()) ? (int32_t)h->seq_matches[frame].size() : 0;
 }
 
 int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out, int32_t cap) {
-  if (h->seq_v2_frames > 0) {
+  if (h->seq_v2_frames > 0 && !(frame >= 0 && frame < h->seq_v2_frames && h->seq2->frame_on_host[frame])) {
     if (frame < 0 || frame >= h->seq_v2_frames) return 0;
     int32_t n = h->seq2->res_cnt[frame];
     if (n > cap) n = cap;
