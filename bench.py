@@ -58,6 +58,12 @@ def algorithmic_bytes(kernel, counts):
         return counts["imgs"] * (4 * Ph * Hh)
     if kernel == "k_emit":               # 32 B descriptor gather + 48 B record per feature
         return counts["imgs"] * 80 * counts.get("N", 0)
+    if kernel == "k_dc_block" and "M" in counts:            # keys in, 32-byte triangle records + points + ids out
+        return 80 * counts["M"]
+    if kernel == "k_dc_merge" and "M" in counts:            # every level re-reads and re-writes the records near its seams: <= one pass
+        return 2 * 64 * counts["M"]
+    if kernel == "k_dc_prepare_kd_order" and "M" in counts: # keys in and out, 28 bytes of list scratch per point
+        return 44 * counts["M"]
     return None
 
 
@@ -203,25 +209,53 @@ def main():
             mono = {"error": repr(e)}
 
     # ---- verification (outside the timed region): final lists vs the reference's hashes -----
-    verified = None
-    if not args.no_verify and key == f"s{seed}":
-        lists, lists_pf = [], []
-        run_sequence(lists)
-        m.close()
-        m = vm.Matcher()           # fresh ring buffer: frame 0 has no predecessor, like the fixture
-        m.set_intrinsics(*intr)
-        if not args.no_per_frame:
-            run_frames(lists_pf)
-        else:
-            lists_pf = lists
-        ok = all(len(l[f]) == int(g[key + "_counts"][f]) and sha(l[f]) == str(g[key + "_hashes"][f])
-                 for f in range(nf) for l in (lists, lists_pf))
-        _, _, verified = shard.aggregate(dmod, torch, 0, 0, comm_dev, all_ok=bool(ok))
+    # (every rank takes part in the reduction, whether it has a golden trail for its seed or not)
+    verified, n_verified = None, 0
+    if not args.no_verify:
+        ok, have = True, key == f"s{seed}"
+        if have:
+            lists, lists_pf = [], []
+            run_sequence(lists)
+            m.close()
+            m = vm.Matcher()           # fresh ring buffer: frame 0 has no predecessor, like the fixture
+            m.set_intrinsics(*intr)
+            if not args.no_per_frame:
+                run_frames(lists_pf)
+            else:
+                lists_pf = lists
+            ok = all(len(l[f]) == int(g[key + "_counts"][f]) and sha(l[f]) == str(g[key + "_hashes"][f])
+                     for f in range(nf) for l in (lists, lists_pf))
+        n_verified, _, verified = shard.aggregate(dmod, torch, 1 if have else 0, 0, comm_dev, all_ok=bool(ok))
+        n_verified = int(n_verified)
+        if n_verified == 0:
+            verified = None
+
+    lookahead_form = m.sequence_path()
+    # ---- the same look-ahead call fed from host memory (PCIe inclusive: the reference's pushBack takes host images) ----
+    host_in_value = None
+    if not args.no_per_frame:
+        hl, hr = np.ascontiguousarray(host[:, 0]), np.ascontiguousarray(host[:, 1])
+        m.run_sequence(hl, hr, 2, tr12, trv, fetch=False)
+        shard.barrier(dmod, comm_dev)
+        th = time.perf_counter()
+        for _ in range(3):
+            m.run_sequence(hl, hr, 2, tr12, trv, fetch=False)
+        hdt = time.perf_counter() - th
+        hp, hdt, _ = shard.aggregate(dmod, torch, 3 * nf, hdt, comm_dev)
+        host_in_value = hp / hdt
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
+
+    # ---- secondary configurations (BASELINE.json configs[2] and [4]): rank 0, N = 1 only, parity flag included ----
+    secondary = None
+    if world == 1 and not args.no_per_frame:
+        try:
+            secondary = secondary_configs(vm, synth, torch, dev)
+        except Exception as e:  # informational legs never take the headline down with them
+            secondary = {"error": repr(e)}
 
     # ---- roofline leg: per-kernel HIP-event durations over one more sequence --------------
     m.set_profiling(True)
@@ -229,8 +263,12 @@ def main():
     torch.cuda.synchronize()
     stats = m.kernel_stats()
     m.set_profiling(False)
-    # dominant kernel on the HBM side (k_export_list is a PCIe copy into pinned host memory)
-    dom = max((k for k in stats if k != "k_export_list"), key=lambda k: stats[k][0])
+    # The hot path proper (filter + match + refinement kernels on the main stream) and, announced beside it, whatever leads
+    # over ALL streams - the exact Delaunay kernels run on streams of their own (k_export_list is a PCIe copy, not HBM)
+    hot = [k for k in stats if stats[k][1] and not k.startswith("k_dc_") and k != "k_export_list"]
+    dom = max(hot, key=lambda k: stats[k][0])
+    dom_all = max((k for k in stats if stats[k][1] and k != "k_export_list"), key=lambda k: stats[k][0])
+    gpu_total_ms = sum(v[0] for k, v in stats.items() if k != "k_export_list")
     dom_ms, dom_n = stats[dom]
     # per-launch work counters of the dominant kernel from one representative frame pair
     # (features/candidates are stationary over this sequence)
@@ -244,15 +282,28 @@ def main():
     work = None
     if not args.no_cpu_baseline:
         cpu, work = cpu_baseline(host, tr_in, tr_valid, intr)
-    # HBM traffic per launch from the committed rocprofv3 PMC summary of this same command
-    # (tools/pmc_summary.py; PMC passes cannot run inside the timed process)
-    pmc = {}
+    # HBM traffic per launch: rocprofv3 PMC passes cannot run inside the timed process, so this figure comes from the
+    # committed summary of the same command (tools/profile_all.sh -> tools/pmc_summary.py) and is labelled as such, with
+    # the commit the summary was taken at; it is dropped if the library has been rebuilt since
+    pmc, pmc_src = {}, None
     try:
         import csv
-        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_lookahead_pmc_hbm.csv"))):
+        pmc_path = os.path.join(ROOT, "profiles", "r02_lookahead_pmc_hbm.csv")
+        lib_path = os.path.join(ROOT, PKG, "libvisomatch.so")
+        meta = {}
+        for line in open(pmc_path):
+            if line.startswith("#") and ":" in line:
+                a, b = line[1:].split(":", 1)
+                meta[a.strip()] = b.strip()
+        rows = csv.DictReader(l for l in open(pmc_path) if not l.startswith("#"))
+        for r in rows:
             pmc[r["bench_name"]] = int(float(r["traffic_bytes_per_launch"]))
-    except Exception:
-        pass
+        pmc_src = {"file": "profiles/r02_lookahead_pmc_hbm.csv", "commit": meta.get("commit"), "taken": meta.get("taken"),
+                   "older_than_library": bool(os.path.getmtime(pmc_path) + 1 < os.path.getmtime(lib_path))}
+    except FileNotFoundError:
+        pmc_src = {"file": None, "note": "no committed PMC summary"}
+    except Exception as e:
+        pmc_src = {"file": None, "note": repr(e)}
 
     def roofline_of(kname):
         ms, nl = stats[kname]
@@ -277,6 +328,22 @@ def main():
 
     roof = roofline_of(dom)
     roof_all = {k: r for k in stats if stats[k][1] for r in [roofline_of(k)] if r}
+    if roof is not None:
+        roof["traffic_source"] = pmc_src
+        da = roof_all.get(dom_all)
+        roof["dominant_all_streams"] = {"kernel": dom_all, "share_of_gpu_kernel_time": round(stats[dom_all][0] / max(gpu_total_ms, 1e-9), 3),
+                                        "avg_launch_us": round(stats[dom_all][0] / stats[dom_all][1] * 1e3, 2),
+                                        "frac": da["frac"] if da else None,
+                                        "what": "kernel with the largest summed duration over all streams of the profiled pass"}
+        # B * fps / peak with B = the algorithmic bytes of one frame pair (oracle's work counters)
+        if work is not None:
+            Bp = 2 * (W * H + 2 * P * H + 10 * Ph * Hh + 80 * work["N"]) + 48 * (work["Q1"] + work["Q2"]) + \
+                8 * (work["C1"] + work["C2"]) + 32 * (work["S1"] + work["S2"]) + 1248 * work["M"] + 48 * work["M"]
+            gpu_only_fps = nf / (gpu_total_ms * 1e-3)
+            roof["whole_path"] = {"bytes_per_frame_pair": int(Bp), "frac": round(Bp * value / world / (HBM_PEAK_GBS * 1e9), 6),
+                                  "frac_gpu_kernels_only": round(Bp * gpu_only_fps / (HBM_PEAK_GBS * 1e9), 6),
+                                  "what": "B * frame-pairs/s / 8 TB/s per GPU; gpu_kernels_only = with the summed kernel durations of all "
+                                          "streams (PCIe export excluded) instead of the wall clock"}
     out = {
         "metric": "stereo frame-pairs/sec (1242x375) through pushBack+matchFeatures(2), p_matched bit-exact",
         "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -305,12 +372,96 @@ def main():
         # what the main stream's kernels alone would sustain: frames / their summed HIP-event durations in the profiled pass
         "gpu_phases_only_frame_pairs_per_s": round(nf / (sum(v[0] for v in stats.values()) * 1e-3), 1),
         "host_threads": int(os.environ["VSM_HOST_THREADS"]),
+        "host_cpus": {"os_cpu_count": os.cpu_count(), "cgroup_quota": ncpu, "model": cpu_model()},
+        "lookahead_form": {2: "GPU-resident (lists stay in HBM; host only runs Triangle's vertex sort)",
+                           1: "host-shared (prior statistics and the top of the exact Delaunay on the host pool)"}.get(lookahead_form),
+        "lookahead_host_inputs": {"value": round(host_in_value, 3) if host_in_value else None, "unit": "frame-pairs/s",
+                                  "what": "the same look-ahead call fed from pageable host memory (on_device = 0): PCIe inclusive"},
+        "secondary_configs": secondary,
+        "verified_ranks": n_verified,
         "step_ms_rank0": step_ms,
         "match_timings_us_last_frame": m.timings(),
     }
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
+def secondary_configs(vm, synth, torch, dev):
+    """BASELINE.json configs[2] (640x480 mono, flow matching) and configs[4] (2048x1024 stereo at ~20 k dense features per
+    image, and the denser 40 k variant) on this GPU: throughput plus parity against the reference's committed hashes."""
+    import hashlib
+    out = {}
+    gdir = os.path.join(ROOT, "tests", "golden")
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+    # configs[2]: per-frame API, flow matching (the look-ahead entry point takes stereo input)
+    g = np.load(os.path.join(gdir, "cfg3_640x480_mono.npz"))
+    w, h, nfx = int(g["w"]), int(g["h"]), 60
+    seq = synth.mono_sequence(int(g["seed"]), w, h, nfx, blur=int(g["blur"]))
+    fr = torch.from_numpy(np.stack(seq)).to(dev)
+    m = vm.Matcher()
+    ok = True
+    for f in range(int(g["n_frames"])):
+        m.push_back(fr[f])
+        m.match_features(0)
+        fin = m.get_matches()
+        ok = ok and len(fin) == int(g["counts"][f][-1]) and sha(fin) == str(g["hashes"][f][-1])
+    m.close()
+    m = vm.Matcher()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for f in range(nfx):
+        m.push_back(fr[f])
+        m.match_features(0)
+    dt = time.perf_counter() - t
+    m.close()
+    out["cfg3_640x480_mono_flow"] = {"value": round(nfx / dt, 1), "unit": "frames/s", "api": "per frame (vsm_push_back_device + vsm_match(0))",
+                                     "bit_exact_vs_reference_hashes": bool(ok)}
+    # configs[4]
+    for name, label in (("cfg5_2048x1024_quad_20k", "cfg5_2048x1024_20k_dense"), ("cfg5_2048x1024_quad", "cfg5_2048x1024_40k_dense")):
+        g = np.load(os.path.join(gdir, name + ".npz"))
+        w, h, gn = int(g["w"]), int(g["h"]), int(g["n_frames"])
+        nfx = 24
+        seq = synth.stereo_sequence(int(g["seed"]), w, h, nfx, blur=int(g["blur"]))
+        L = torch.from_numpy(np.stack([l for l, _ in seq])).to(dev)
+        R = torch.from_numpy(np.stack([r for _, r in seq])).to(dev)
+        m = vm.Matcher()
+        got = m.run_sequence(L[:gn], R[:gn], 2)
+        ok = all(len(got[f]) == int(g["counts"][f][-1]) and sha(got[f]) == str(g["hashes"][f][-1]) for f in range(gn))
+        os.environ["VSM_SEQ_CHUNK"] = "12"
+        try:
+            m.run_sequence(L, R, 2, fetch=False)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            m.run_sequence(L, R, 2, fetch=False)
+            dt = time.perf_counter() - t
+        finally:
+            del os.environ["VSM_SEQ_CHUNK"]
+        form = m.sequence_path()
+        t2 = time.perf_counter()
+        for f in range(8):
+            m.push_back(L[f], R[f])
+            m.match_features(2)
+        dt2 = time.perf_counter() - t2
+        m.close()
+        out[label] = {"lookahead": {"value": round(nfx / dt, 1), "unit": "frame-pairs/s", "form": form, "frames": nfx, "chunk": 12},
+                      "per_frame_api": {"value": round(8 / dt2, 1), "unit": "frame-pairs/s"},
+                      "dense_features_per_image": int(g["counts"][0][1]), "matches_per_pair": int(g["counts"][1][-1]),
+                      "blur": int(g["blur"]), "bit_exact_vs_reference_hashes": bool(ok)}
+    return out
 
 
 def mono_leg(vm, with_cpu):
@@ -406,9 +557,59 @@ def cpu_baseline(host, tr_in, tr_valid, intr, budget_s=20.0):
                 break
         vo_fps = round(k / (time.perf_counter() - t1), 3)
         rv.close()
+    allc = None
+    try:
+        allc = cpu_all_cores(kind, host.shape[2], host.shape[3], intr)
+    except Exception as e:  # (a box that cannot spawn that many processes still reports the single-core leg)
+        allc = {"error": repr(e)}
     return (dict(value=round(n / dt, 3), unit="frame-pairs/s", cores=1, kind=kind,
                  sample=f"first {n} frames of the same sequence, pushBack+matchFeatures(2), 1 thread",
-                 vo_process_frames_per_s=vo_fps), work)
+                 vo_process_frames_per_s=vo_fps, all_cores=allc), work)
+
+
+def _cpu_worker(args):
+    """one process = one independent sequence through the CPU matcher (spawned by cpu_all_cores)"""
+    kind, seed, w, h, frames, intr, t_go = args
+    sys.path.insert(0, ROOT)
+    from oracle import bindings as B
+    synth = importlib.import_module(PKG + ".synth")
+    cv = synth.canvas(seed, w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(frames)]
+    cm = B.CpuMatcher("ref" if kind == "reference" else "oracle")
+    cm.set_intrinsics(*intr)
+    while time.time() < t_go:      # common start
+        time.sleep(0.001)
+    t0 = time.time()
+    for l, r in fr:
+        cm.push_back(l, r)
+        cm.match(2)
+    t1 = time.time()
+    cm.close()
+    return t0, t1, frames
+
+
+def cpu_all_cores(kind, w, h, intr, frames=24):
+    """the CPU matcher as one process per core, up to every core this job may use (cgroup
+    quota), each on its own sequence; aggregate frame-pairs/s over the common window"""
+    import multiprocessing as mp
+    quota = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = min(quota, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    procs = max(1, min(quota, 64))
+    ctx = mp.get_context("spawn")
+    t_go = time.time() + 6.0 + 0.05 * procs     # (imports and frame synthesis happen before the common start)
+    with ctx.Pool(procs) as pool:
+        res = pool.map(_cpu_worker, [(kind, 1234 + i, w, h, frames, intr, t_go) for i in range(procs)])
+    t0 = min(r[0] for r in res)
+    t1 = max(r[1] for r in res)
+    total = sum(r[2] for r in res)
+    return dict(value=round(total / (t1 - t0), 3), unit="frame-pairs/s", processes=procs, nproc=os.cpu_count(), cpu_quota=quota,
+                cpu_model=cpu_model(), kind=kind,
+                sample=f"{procs} processes x {frames} frames 1242x375 (one sequence each, seeds 1234..), pushBack+matchFeatures(2)")
 
 
 if __name__ == "__main__":

@@ -415,6 +415,12 @@ struct vsm_handle {
 
   uint8_t *stage_host = nullptr;  // pinned staging for host images
   size_t stage_bytes = 0;
+  // look-ahead calls fed from host memory: two pinned slots a chunk's images are gathered into (by the pool, in parallel)
+  // and their device twins; an event per slot says when its upload has been consumed
+  uint8_t *seq_stage_h[2] = {nullptr, nullptr}, *seq_stage_d[2] = {nullptr, nullptr};
+  size_t seq_stage_bytes = 0;
+  hipEvent_t seq_stage_ev[2] = {nullptr, nullptr};
+  int seq_stage_next = 0;
   VsmProf prof;
   VsmPool *pool = nullptr;
   VsmForkJoin *fj = nullptr;
@@ -512,6 +518,11 @@ void vsm_destroy(vsm_handle *h) {
   ctx_destroy(h->ring);
   ctx_destroy(h->seq);
   if (h->stage_host) (void)hipHostFree(h->stage_host);
+  for (int k = 0; k < 2; k++) {
+    if (h->seq_stage_h[k]) (void)hipHostFree(h->seq_stage_h[k]);
+    if (h->seq_stage_d[k]) (void)hipFree(h->seq_stage_d[k]);
+    if (h->seq_stage_ev[k]) (void)hipEventDestroy(h->seq_stage_ev[k]);
+  }
   for (int b = 0; b < vsm_handle::kDcBanks; b++)
     if (h->dc_bank[b]) {
       h->dc_bank[b]->release();
@@ -999,19 +1010,32 @@ static void dc_enqueue_gpu(DcChunk *ch, bool wait_here = false) {
          // (k_dc_block writes every slot of every sub-tree; the per-lane kernels rely on empty slots reading -1)
          (ch->block || hipMemset2DAsync(B.d_tri, sp * 64, 0xff, (size_t)maxm * 64, rows, s2) == hipSuccess);
     if (ok) {
-      if (ch->device_kd) vsm_dc_launch_kd_order(s2, B.d_jobs, ch->n);
+      VsmProf &pf = h->prof;
+      if (ch->device_kd) {
+        pf.begin(VSM_K_DC_KD, s2);
+        vsm_dc_launch_kd_order(s2, B.d_jobs, ch->n);
+        pf.end(s2);
+      }
+      pf.begin(VSM_K_DC_BLOCK, s2);
       if (ch->block) {
         vsm_dc_launch_blocks(s2, B.d_jobs, ch->n, maxt);
       } else {
         vsm_dc_launch_subtrees(s2, B.d_jobs, ch->n, maxt);
       }
-      for (int l = 0; l < maxlev; l++) vsm_dc_launch_merge_level(s2, B.d_jobs, ch->n, l, lev_nodes[l]);
+      pf.end(s2);
+      if (maxlev > 0) {
+        pf.begin(VSM_K_DC_MERGE, s2);
+        for (int l = 0; l < maxlev; l++) vsm_dc_launch_merge_level(s2, B.d_jobs, ch->n, l, lev_nodes[l]);
+        pf.end(s2);
+      }
       if (ch->block && ch->full) {
         // the triangulations are complete on the device: count the support there, only the counts travel
         ok = hipMemcpy2DAsync(B.d_flow, sp * 12, B.h_flow, sp * 12, sp * 12, rows, hipMemcpyHostToDevice, s2) == hipSuccess &&
              hipMemset2DAsync(B.d_support, sp * 4, 0, (size_t)maxin * 4, rows, s2) == hipSuccess;
         if (ok) {
+          pf.begin(VSM_K_DC_SUPPORT, s2);
           vsm_dc_launch_support(s2, B.d_jobs, ch->n, maxm, ch->method, (float)ch->p.outlier_flow_tolerance, (float)ch->p.outlier_disp_tolerance);
+          pf.end(s2);
           ok = hipMemcpy2DAsync(B.h_support, sp * 4, B.d_support, sp * 4, (size_t)maxin * 4, rows, hipMemcpyDeviceToHost, s2) == hipSuccess;
         }
       } else {
@@ -1172,6 +1196,45 @@ static void dc_wait(DcChunk *ch) {
     }
   }
   h->pool->wait(ch->b);
+}
+
+// Host images of a look-ahead chunk: a pageable 2-D copy is staged row by row by the runtime (milliseconds per image), so
+// the pool gathers the chunk's 2 n images into a pinned slot (w bytes per row), one upload follows, and k_ingest reads the
+// device twin like any device-resident input.  Two slots alternate; a slot is reused once its ingest has run.
+static int seq_ingest_host_frames(vsm_handle *h, VsmCtx &c, int first_img, const uint8_t *left, const uint8_t *right, int64_t frame_stride,
+                                  int32_t bpl, int32_t w, int32_t hh, int32_t f0, int n) {
+  const size_t img = (size_t)w * hh, need = 2 * img * (size_t)h->seq_chunk;
+  if (h->seq_stage_bytes < need) {
+    (void)hipStreamSynchronize(h->stream);
+    for (int k = 0; k < 2; k++) {
+      if (h->seq_stage_h[k]) (void)hipHostFree(h->seq_stage_h[k]);
+      if (h->seq_stage_d[k]) (void)hipFree(h->seq_stage_d[k]);
+      h->seq_stage_h[k] = h->seq_stage_d[k] = nullptr;
+      HIPCHK(hipHostMalloc((void **)&h->seq_stage_h[k], need, hipHostMallocDefault));
+      HIPCHK(hipMalloc((void **)&h->seq_stage_d[k], need));
+      if (!h->seq_stage_ev[k]) HIPCHK(hipEventCreateWithFlags(&h->seq_stage_ev[k], hipEventDisableTiming));
+      HIPCHK(hipEventRecord(h->seq_stage_ev[k], h->stream));
+    }
+    h->seq_stage_bytes = need;
+  }
+  const int slot = h->seq_stage_next;
+  h->seq_stage_next ^= 1;
+  HIPCHK(hipEventSynchronize(h->seq_stage_ev[slot]));  // its previous content has been ingested
+  uint8_t *dst = h->seq_stage_h[slot];
+  h->pool->run(2 * n, [&](int t) {
+    const int i = t >> 1, side = t & 1;
+    const uint8_t *src = (side ? right : left) + (size_t)(f0 + i) * frame_stride;
+    uint8_t *d = dst + ((size_t)side * n + i) * img;
+    if (bpl == w) {
+      memcpy(d, src, img);
+    } else {
+      for (int32_t v = 0; v < hh; v++) memcpy(d + (size_t)v * w, src + (size_t)v * bpl, w);
+    }
+  });
+  HIPCHK(hipMemcpyAsync(h->seq_stage_d[slot], dst, 2 * img * n, hipMemcpyHostToDevice, h->stream));
+  vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first_img, h->seq_stage_d[slot], h->seq_stage_d[slot] + img * n, img, w, n, c.dims);
+  HIPCHK(hipEventRecord(h->seq_stage_ev[slot], h->stream));
+  return VSM_OK;
 }
 
 }  // extern "C"
@@ -1347,14 +1410,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first_img, left + (size_t)f0 * frame_stride,
                         right + (size_t)f0 * frame_stride, (size_t)frame_stride, bpl, n, c.dims);
     } else {
-      for (int i = 0; i < n; i++) {
-        hipError_t e = hipMemcpy2DAsync(c.h_imgs[first_img + 2 * i].img, c.dims.bpl, left + (size_t)(f0 + i) * frame_stride, bpl, w, hh,
-                                        hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess)
-          e = hipMemcpy2DAsync(c.h_imgs[first_img + 2 * i + 1].img, c.dims.bpl, right + (size_t)(f0 + i) * frame_stride, bpl, w, hh,
-                               hipMemcpyHostToDevice, h->stream);
-        if (e != hipSuccess) return e;
-      }
+      if (seq_ingest_host_frames(h, c, first_img, left, right, frame_stride, bpl, w, hh, f0, n) != VSM_OK) return hipErrorUnknown;
     }
     vsm_launch_features(h->stream, h->prof, c.d_imgs, first_img, 2 * n, c.dims, c.f1, c.f2, c.f_stride, p.nms_tau,
                         p.multi_stage, p.half_resolution, p.match_binsize, c.h_imgs.data());
@@ -1463,10 +1519,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     HIPCHK(hipGetLastError());
     // (kernel timing: the spans are read once, after the last chunk - the event pool grows over the sequence instead of
     // the pipeline being drained per chunk, so the profiled pass overlaps its kernels like any other)
-    if (h->prof.on && j + 1 == nchunks) {
-      HIPCHK(hipStreamSynchronize(h->stream));
-      h->prof.resolve();
-    }
+    // (kernel timing is resolved at the end of the run, when the Delaunay streams have drained too)
     if (vsm_debug_timing()) fprintf(stderr, "  chunk %d: pass2 launched %.0f us ago, waited %.0f us for it\n", j, t0 - q.t_pass2, now_us() - t0);
     tg += now_us() - t0;
     if (q.dc) {
@@ -1653,6 +1706,12 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     for (auto &t : tickets)
       if (t) h->pool->wait(t);
     thost += now_us() - tb;
+    if (h->prof.on) {
+      HIPCHK(hipStreamSynchronize(h->stream));
+      for (hipStream_t st : h->dc_stream)
+        if (st) HIPCHK(hipStreamSynchronize(st));
+      h->prof.resolve();
+    }
   }
   h->seq_timings[0] = tg;
   h->seq_timings[1] = thost;
@@ -1762,7 +1821,8 @@ int32_t vsm_get_filter_responses(vsm_handle *h, int16_t *f1, int16_t *f2) {
 static const char *kKernelNames[VSM_K_COUNT] = {
     "k_ingest", "k_halve", "k_filters<true>", "k_filters<false>", "k_nms:dense", "k_nms:sparse", "k_scan_cells", "k_emit", "k_bin_scan",
     "k_bin_scatter", "k_bin_rank", "k_match<16>:pass1", "k_compact_matches:pass1", "k_match<16>:pass2",
-    "k_compact_matches:pass2", "k_refine", "k_export_list"};
+    "k_compact_matches:pass2", "k_refine", "k_export_list",
+    "k_dc_keys", "k_dc_vertex_sort", "k_dc_prepare_kd_order", "k_dc_block", "k_dc_merge", "k_dc_support", "k_dc_compact", "k_dc_prior"};
 
 void vsm_set_profiling(vsm_handle *h, int on) {
   h->prof.on = on != 0;
@@ -2061,8 +2121,7 @@ int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, i
       }
     }
     dc2_enqueue_mesh(nullptr, B, copies, n);
-    vsm_dc2_launch_support(nullptr, B.d_jobs, copies, n, method, (float)p->outlier_flow_tolerance, (float)p->outlier_disp_tolerance);
-    vsm_dc2_launch_compact(nullptr, B.d_jobs, copies);
+    dc2_enqueue_votes(nullptr, B, copies, n, method, (float)p->outlier_flow_tolerance, (float)p->outlier_disp_tolerance);
     if (ranges) vsm_dc2_launch_prior(nullptr, B.d_jobs, copies, method, p->match_binsize, p->match_radius, w, hh, ub, vb);
     (void)hipEventRecord(e1, nullptr);
     ok = ok && hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <vector>
 
 #include "visomatch.h"
@@ -88,10 +89,14 @@ struct VsmPair {
 // roofline leg).  Off by default: events cost a few microseconds per launch.
 enum VsmKernelId {
   VSM_K_INGEST = 0, VSM_K_HALVE, VSM_K_SOBEL_FULL, VSM_K_FILTERS, VSM_K_NMS, VSM_K_NMS_SPARSE, VSM_K_SCAN, VSM_K_EMIT, VSM_K_BINSCAN, VSM_K_BINSCATTER, VSM_K_BINRANK,
-  VSM_K_MATCH1, VSM_K_COMPACT1, VSM_K_MATCH2, VSM_K_COMPACT2, VSM_K_REFINE, VSM_K_EXPORT, VSM_K_COUNT
+  VSM_K_MATCH1, VSM_K_COMPACT1, VSM_K_MATCH2, VSM_K_COMPACT2, VSM_K_REFINE, VSM_K_EXPORT,
+  // the exact Delaunay stage of the look-ahead forms (their own streams; launched from the caller's and from pool threads)
+  VSM_K_DC_KEYS, VSM_K_DC_TIES, VSM_K_DC_KD, VSM_K_DC_BLOCK, VSM_K_DC_MERGE, VSM_K_DC_SUPPORT, VSM_K_DC_COMPACT, VSM_K_DC_PRIOR,
+  VSM_K_COUNT
 };
 struct VsmProf {
   bool on = false;
+  std::mutex mu;  // begin() .. end() of one launch hold it: spans come from several threads
   std::vector<hipEvent_t> pool;
   size_t used = 0;
   struct Span { int id; hipEvent_t a, b; };
@@ -108,6 +113,7 @@ struct VsmProf {
   }
   void begin(int id, hipStream_t s) {
     if (!on) return;
+    mu.lock();
     Span sp{id, get(), get()};
     (void)hipEventRecord(sp.a, s);
     open.push_back(sp);
@@ -115,8 +121,10 @@ struct VsmProf {
   void end(hipStream_t s) {
     if (!on) return;
     (void)hipEventRecord(open.back().b, s);
+    mu.unlock();
   }
-  void resolve() {  // call after the stream has been synchronised
+  void resolve() {  // call after every stream that carries spans has been synchronised
+    std::lock_guard<std::mutex> lk(mu);
     for (const Span &sp : open) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {

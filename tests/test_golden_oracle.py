@@ -34,5 +34,12 @@ def test_cfg5_highres_hashes(B, synth):
     G.replay_hashed(G.load("cfg5_2048x1024_quad"), synth, _oracle(B))
 
 
+def test_cfg5_as_specified_20k_dense_features_hashes(B, synth):
+    """config 5 with the blur radius (29) at which a 2048x1024 image has ~20 k dense features, as BASELINE.json words it"""
+    g = G.load("cfg5_2048x1024_quad_20k")
+    assert 19000 < int(g["counts"][0][1]) < 21500
+    G.replay_hashed(g, synth, _oracle(B), frames=3)
+
+
 def test_cfg2_sequence_with_feedback(B, synth):
     G.replay_vo_sequence(G.load("cfg2_seq200_tr"), synth, _oracle(B), n_frames=6)

@@ -89,6 +89,34 @@ def test_golden_cfg5_highres_lookahead_gpu_final_stage(vm, synth, monkeypatch, f
     m.close()
 
 
+def test_golden_cfg5_as_specified_20k(vm, synth):
+    """config 5 as BASELINE.json words it (~20 k dense features per 2048x1024 image; blur radius 29, see make_golden.py):
+    six frames through the per-frame API, features and every match stage against the reference's hashes"""
+    G.replay_hashed(G.load("cfg5_2048x1024_quad_20k"), synth, _gpu(vm))
+
+
+@pytest.mark.parametrize("form", ["host-shared, final stage all on the GPU", "host-shared, final stage shared", "GPU-resident"])
+def test_golden_cfg5_as_specified_20k_lookahead(vm, synth, monkeypatch, form):
+    """... and through the look-ahead API (chunks of 3 frames) with the exact Delaunay stage on the GPU in every form:
+    16.6 k matches per pair = more points than the LDS-whole merge levels and the 16-bit kd lists take"""
+    import torch
+    g = G.load("cfg5_2048x1024_quad_20k")
+    w, h, nf, method = int(g["w"]), int(g["h"]), int(g["n_frames"]), int(g["method"])
+    seq = synth.stereo_sequence(int(g["seed"]), w, h, nf, blur=int(g["blur"]))
+    monkeypatch.setenv("VSM_SEQ_CHUNK", "3")
+    monkeypatch.setenv("VSM_SEQ_V2", "1" if form == "GPU-resident" else "0")
+    monkeypatch.setenv("VSM_DC_GPU", "1")
+    monkeypatch.setenv("VSM_DC_FULL", "1" if "all on the GPU" in form else "0")
+    m = vm.Matcher()
+    left = torch.from_numpy(np.stack([l for l, _ in seq])).cuda()
+    right = torch.from_numpy(np.stack([r for _, r in seq])).cuda()
+    got = m.run_sequence(left, right, method)
+    assert m.sequence_path() == (2 if form == "GPU-resident" else 1)
+    for f in range(nf):
+        assert len(got[f]) == int(g["counts"][f][-1]) and G.sha(got[f]) == str(g["hashes"][f][-1]), f
+    m.close()
+
+
 def test_golden_cfg2_sequence_feedback(vm, synth):
     G.replay_vo_sequence(G.load("cfg2_seq200_tr"), synth, _gpu(vm), n_frames=40)
 
