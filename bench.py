@@ -30,7 +30,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before anything initialises HIP: see visomatch.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")   # before anything initialises HIP: see visomatch.py
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -165,6 +165,7 @@ def main():
     total_pairs, elapsed, _ = shard.aggregate(dmod, torch, nf * args.steps, elapsed, comm_dev)
     value = total_pairs / elapsed
     seq_t = m.sequence_timings()          # phase split of the last timed step (rank-local)
+    lookahead_form = m.sequence_path()
 
     # ---- the same sequence through the per-frame (drop-in) entry points ---------------------
     per_frame_value = None
@@ -230,7 +231,6 @@ def main():
         if n_verified == 0:
             verified = None
 
-    lookahead_form = m.sequence_path()
     # ---- the same look-ahead call fed from host memory (PCIe inclusive: the reference's pushBack takes host images) ----
     host_in_value = None
     if not args.no_per_frame:

@@ -596,8 +596,13 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
   h->dims_c[1] = hh;
   h->dims_c[2] = c.dims.bpl;
   const int n_img = I2 ? 2 : 1;
+  // (VSM_FRONT=0: the three separate passes - ingest, halving, full-resolution Sobel - instead of the fused front end)
+  const bool fused_front = h->param.half_resolution && !(getenv("VSM_FRONT") && atoi(getenv("VSM_FRONT")) == 0);
   if (on_device) {
-    vsm_launch_ingest(h->stream, h->prof, c.d_imgs, slot * 2, I1, I2, 0, bpl, 1, c.dims);
+    if (fused_front)
+      vsm_launch_front(h->stream, h->prof, c.d_imgs, slot * 2, I1, I2, 0, bpl, 1, c.dims, 1);
+    else
+      vsm_launch_ingest(h->stream, h->prof, c.d_imgs, slot * 2, I1, I2, 0, bpl, 1, c.dims);
   } else {
     // Host images: rows go through our own pinned, pre-padded staging buffer (a pageable 2-D copy
     // is staged row by row by the runtime and costs milliseconds).  The caller's buffer is free as
@@ -616,9 +621,13 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
       for (int32_t v = 0; v < hh; v++) memcpy(st + (size_t)v * c.dims.bpl, srcs[k] + (size_t)v * bpl, w);
       HIPCHK(hipMemcpyAsync(c.h_imgs[slot * 2 + k].img, st, plane, hipMemcpyHostToDevice, h->stream));
     }
+    // (the padded copies are in place: they are the fused front end's source)
+    if (fused_front)
+      vsm_launch_front(h->stream, h->prof, c.d_imgs, slot * 2, c.h_imgs[slot * 2].img, I2 ? c.h_imgs[slot * 2 + 1].img : nullptr, 0,
+                       c.dims.bpl, 1, c.dims, 0);
   }
   vsm_launch_features(h->stream, h->prof, c.d_imgs, slot * 2, n_img, c.dims, c.f1, c.f2, c.f_stride, h->param.nms_tau,
-                      h->param.multi_stage, h->param.half_resolution, h->param.match_binsize, c.h_imgs.data());
+                      h->param.multi_stage, h->param.half_resolution, h->param.match_binsize, c.h_imgs.data(), fused_front ? 1 : 0);
   HIPCHK(hipGetLastError());
   h->have[slot] = true;
   h->right[slot] = (I2 != nullptr);
@@ -1232,7 +1241,10 @@ static int seq_ingest_host_frames(vsm_handle *h, VsmCtx &c, int first_img, const
     }
   });
   HIPCHK(hipMemcpyAsync(h->seq_stage_d[slot], dst, 2 * img * n, hipMemcpyHostToDevice, h->stream));
-  vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first_img, h->seq_stage_d[slot], h->seq_stage_d[slot] + img * n, img, w, n, c.dims);
+  if (h->param.half_resolution && !(getenv("VSM_FRONT") && atoi(getenv("VSM_FRONT")) == 0))
+    vsm_launch_front(h->stream, h->prof, c.d_imgs, first_img, h->seq_stage_d[slot], h->seq_stage_d[slot] + img * n, img, w, n, c.dims, 0);
+  else
+    vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first_img, h->seq_stage_d[slot], h->seq_stage_d[slot] + img * n, img, w, n, c.dims);
   HIPCHK(hipEventRecord(h->seq_stage_ev[slot], h->stream));
   return VSM_OK;
 }
@@ -1406,14 +1418,19 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     const int32_t f0 = chunk_start[k];
     const int n = chunk_start[k + 1] - f0;
     const int first_img = 2 * (k % 3) * C;
+    const bool fused_front = p.half_resolution && !(getenv("VSM_FRONT") && atoi(getenv("VSM_FRONT")) == 0);
     if (on_device) {
-      vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first_img, left + (size_t)f0 * frame_stride,
-                        right + (size_t)f0 * frame_stride, (size_t)frame_stride, bpl, n, c.dims);
+      if (fused_front)
+        vsm_launch_front(h->stream, h->prof, c.d_imgs, first_img, left + (size_t)f0 * frame_stride, right + (size_t)f0 * frame_stride,
+                         (size_t)frame_stride, bpl, n, c.dims, 0);
+      else
+        vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first_img, left + (size_t)f0 * frame_stride,
+                          right + (size_t)f0 * frame_stride, (size_t)frame_stride, bpl, n, c.dims);
     } else {
       if (seq_ingest_host_frames(h, c, first_img, left, right, frame_stride, bpl, w, hh, f0, n) != VSM_OK) return hipErrorUnknown;
     }
     vsm_launch_features(h->stream, h->prof, c.d_imgs, first_img, 2 * n, c.dims, c.f1, c.f2, c.f_stride, p.nms_tau,
-                        p.multi_stage, p.half_resolution, p.match_binsize, c.h_imgs.data());
+                        p.multi_stage, p.half_resolution, p.match_binsize, c.h_imgs.data(), fused_front ? 1 : 0);
     return hipEventRecord(h->seq_ev[0], h->stream);
   };
   // what a chunk needs from one step to the next
@@ -1821,7 +1838,7 @@ int32_t vsm_get_filter_responses(vsm_handle *h, int16_t *f1, int16_t *f2) {
 static const char *kKernelNames[VSM_K_COUNT] = {
     "k_ingest", "k_halve", "k_filters<true>", "k_filters<false>", "k_nms:dense", "k_nms:sparse", "k_scan_cells", "k_emit", "k_bin_scan",
     "k_bin_scatter", "k_bin_rank", "k_match<16>:pass1", "k_compact_matches:pass1", "k_match<16>:pass2",
-    "k_compact_matches:pass2", "k_refine", "k_export_list",
+    "k_compact_matches:pass2", "k_refine", "k_export_list", "k_front",
     "k_dc_keys", "k_dc_vertex_sort", "k_dc_prepare_kd_order", "k_dc_block", "k_dc_merge", "k_dc_support", "k_dc_compact", "k_dc_prior"};
 
 void vsm_set_profiling(vsm_handle *h, int on) {

@@ -44,7 +44,7 @@ struct VsmDcJob {  // one triangulation; all pointers are device pointers
   const uint64_t *tie_keys;  // [n_in] packed keys in input order, or null
   int32_t *tie_out;          // [1 + 2 * VSM_DC_TIE_PATCHES]: count (-1: not done here), then (index carried, index it should be)
 };
-#define VSM_DC_TIE_POINTS 8192   // lists up to this length are sorted inside LDS
+#define VSM_DC_TIE_POINTS 10240  // lists up to this length are sorted inside LDS (12 bytes per point + masks + stack: 141 KB)
 #define VSM_DC_TIE_PATCHES 255
 
 // kd order of the jobs that bring key_sorted: one workgroup per job (ExactDelaunay::kd_order on the device)

@@ -90,6 +90,7 @@ struct VsmPair {
 enum VsmKernelId {
   VSM_K_INGEST = 0, VSM_K_HALVE, VSM_K_SOBEL_FULL, VSM_K_FILTERS, VSM_K_NMS, VSM_K_NMS_SPARSE, VSM_K_SCAN, VSM_K_EMIT, VSM_K_BINSCAN, VSM_K_BINSCATTER, VSM_K_BINRANK,
   VSM_K_MATCH1, VSM_K_COMPACT1, VSM_K_MATCH2, VSM_K_COMPACT2, VSM_K_REFINE, VSM_K_EXPORT,
+  VSM_K_FRONT,  // fused ingest + half-resolution image + full-resolution Sobel (half_resolution = 1)
   // the exact Delaunay stage of the look-ahead forms (their own streams; launched from the caller's and from pool threads)
   VSM_K_DC_KEYS, VSM_K_DC_TIES, VSM_K_DC_KD, VSM_K_DC_BLOCK, VSM_K_DC_MERGE, VSM_K_DC_SUPPORT, VSM_K_DC_COMPACT, VSM_K_DC_PRIOR,
   VSM_K_COUNT
@@ -140,9 +141,13 @@ struct VsmProf {
 // ---- launchers (vsm_kernels.hip) ----
 void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0,
                        const uint8_t *src1, size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d);
+// half_resolution = 1 only: caller image(s) -> [padded copy if write_img], half-resolution image, full-resolution Sobel planes
+// in one pass; vsm_launch_features(front_done = 1) then skips its own halving and full-resolution Sobel
+void vsm_launch_front(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0, const uint8_t *src1,
+                      size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d, int write_img);
 void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d,
                          int16_t *f1, int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res,
-                         int binsize, const VsmImage *h_imgs);
+                         int binsize, const VsmImage *h_imgs, int front_done = 0);
 void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
                       const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq);
 void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair *d_pairs, int npairs, int pass, int n_upper);

@@ -194,6 +194,122 @@ __global__ void __launch_bounds__(256)
 #undef FPB
 
 // ---------------------------------------------------------------------------------------
+// Fused front end for half_resolution = 1: ONE pass over the caller's image produces what k_ingest + k_halve +
+// k_filters<true> produced in three (each streaming the full image): the padded copy (only where something reads it
+// later - the per-frame path's getGain), the half-resolution image (F0, viso/matcher.cpp:636-647) and the full-resolution
+// Sobel planes (F1, viso/filter.cpp:316-324), which only the refinement reads.
+// A block owns a tile of 128 x 32 pixels.  Its 36 x 136 bytes of input (2 rows / 4 bytes of halo) go to LDS as coalesced
+// dword loads in the layout of the PADDED byte stream (row stride bpl, pad bytes 0, positions outside the image 0 - the
+// reference's filters run over that stream and wrap at row ends): caller rows need no alignment (two aligned dwords and a
+// byte funnel shift per LDS dword, as in k_ingest).  Then every thread takes a 4 x 4 patch from an 8 x 12-byte LDS window
+// with exactly k_filters' arithmetic, and 4 half-resolution pixels.
+// ---------------------------------------------------------------------------------------
+#define FRONT_TW 128
+#define FRONT_TH 32
+#define FRONT_LW (FRONT_TW + 8)  // bytes per LDS row
+#define FRONT_LH (FRONT_TH + 4)
+__global__ void __launch_bounds__(256)
+    k_front(const VsmImage *__restrict__ imgs, int first, const uint8_t *__restrict__ src0, const uint8_t *__restrict__ src1,
+            size_t frame_stride, int src_bpl, int sides, VsmDims d, int write_img) {
+  __shared__ uint32_t s_in[FRONT_LH][FRONT_LW / 4];
+  const int fr = blockIdx.z / sides, side = blockIdx.z - fr * sides;
+  const uint8_t *__restrict__ src = (side ? src1 : src0) + (size_t)fr * frame_stride;
+  const VsmImage &im = imgs[first + 2 * fr + side];
+  const int bpl = d.bpl, h = d.h, w = d.w;
+  const int x0 = blockIdx.x * FRONT_TW, y0 = blockIdx.y * FRONT_TH;
+  const int t = threadIdx.x;
+  // ---- tile of the padded stream into LDS ----
+  for (int e = t; e < FRONT_LH * (FRONT_LW / 4); e += 256) {
+    const int r = e / (FRONT_LW / 4), c = e - r * (FRONT_LW / 4);
+    int y = y0 - 2 + r, x = x0 - 4 + 4 * c;  // stream position y * bpl + x; x may run into the neighbouring stream rows
+    if (x < 0) {
+      x += bpl;
+      y -= 1;
+    } else if (x >= bpl) {
+      x -= bpl;
+      y += 1;
+    }
+    uint32_t v = 0;
+    if (y >= 0 && y < h && x < w) {
+      const uintptr_t a = (uintptr_t)(src + (size_t)y * src_bpl + x);
+      const uint32_t sh = (uint32_t)(a & 3);
+      const int nvalid = min(4, w - x);  // bytes of this dword that belong to the row
+      const uint32_t lo = ldg_u32((const void *)(a - sh));
+      const uint32_t hi = ((int)(4 - sh) < nvalid) ? ldg_u32((const void *)(a - sh + 4)) : 0u;
+      v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+      if (nvalid < 4) v &= (1u << (8 * nvalid)) - 1u;
+    }
+    s_in[r][c] = v;
+  }
+  __syncthreads();
+  // ---- padded copy (pad bytes 0), where asked for ----
+  if (write_img) {
+    for (int e = t; e < FRONT_TH * (FRONT_TW / 4); e += 256) {
+      const int r = e / (FRONT_TW / 4), c = e - r * (FRONT_TW / 4);
+      const int y = y0 + r, x4 = x0 + 4 * c;
+      if (y < h && x4 < bpl) *(VSM_AS1 uint32_t *)(im.img + (size_t)y * bpl + x4) = s_in[r + 2][c + 1];
+    }
+  }
+  // ---- half-resolution image: 64 x 16 pixels of this tile, 4 per thread ----
+  {
+    const int hy = t >> 4, hx4 = (t & 15) * 4;
+    const int my = (y0 >> 1) + hy, mx4 = (x0 >> 1) + hx4;
+    if (my < d.mh && mx4 < d.mbpl) {
+      const uint32_t a0 = s_in[2 + 2 * hy][1 + (hx4 >> 1)], a1 = s_in[2 + 2 * hy][2 + (hx4 >> 1)];
+      const uint32_t b0 = s_in[3 + 2 * hy][1 + (hx4 >> 1)], b1 = s_in[3 + 2 * hy][2 + (hx4 >> 1)];
+      uint32_t out = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t ta = k < 2 ? a0 : a1, tb = k < 2 ? b0 : b1;
+        const int sh = (k & 1) * 16;
+        const uint32_t sum = ((ta >> sh) & 0xff) + ((ta >> (sh + 8)) & 0xff) + ((tb >> sh) & 0xff) + ((tb >> (sh + 8)) & 0xff);
+        if (mx4 + k < d.mw) out |= (sum >> 2) << (8 * k);
+      }
+      *(VSM_AS1 uint32_t *)(im.imgm + (size_t)my * d.mbpl + mx4) = out;
+    }
+  }
+  // ---- full-resolution Sobel: 4 x 4 patch per thread ----
+  const int tx = t & 31, ty = t >> 5;
+  const int x4 = x0 + 4 * tx, yb = y0 + 4 * ty;
+  if (x4 >= bpl || yb >= h) return;
+  uint32_t Wn[8][3];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) Wn[r][q] = s_in[4 * ty + r][tx + q];
+  }
+#define FPB(r, i) ((int)((Wn[(r)][(i) >> 2] >> (8 * ((i)&3))) & 0xffu))
+  const int lo = 2 * bpl, hi = (h - 2) * bpl;
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) {
+    const int y = yb + rr;
+    if (y >= h) break;
+    const int f0 = y * bpl + x4;
+    // column pass at stream positions f0-2 .. f0+5 (window index 2..9); zero outside rows [2,h-3]
+    int S[8], D[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int g = f0 + i - 2;
+      const bool ok = g >= lo && g < hi;
+      const int a = FPB(rr, i + 2), b = FPB(rr + 1, i + 2), c = FPB(rr + 2, i + 2), dd = FPB(rr + 3, i + 2), e = FPB(rr + 4, i + 2);
+      S[i] = ok ? a + 4 * b + 6 * c + 4 * dd + e : 0;
+      D[i] = ok ? a + 2 * b - 2 * dd - e : 0;
+    }
+    uint32_t du = 0, dv = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int hu = S[k] + 2 * S[k + 1] - 2 * S[k + 3] - S[k + 4];
+      const int hv = D[k] + 4 * D[k + 1] + 6 * D[k + 2] + 4 * D[k + 3] + D[k + 4];
+      du |= (uint32_t)min(max((hu >> 7) + 128, 0), 255) << (8 * k);
+      dv |= (uint32_t)min(max((hv >> 7) + 128, 0), 255) << (8 * k);
+    }
+    *(VSM_AS1 uint32_t *)(im.du_full + f0) = du;
+    *(VSM_AS1 uint32_t *)(im.dv_full + f0) = dv;
+  }
+#undef FPB
+}
+
+// ---------------------------------------------------------------------------------------
 // N1 nonMaximumSuppression, viso/matcher.cpp:330-431 (Neubeck & Van Gool alg. 4).
 // One wavefront per (cell, filter).  Lanes load the (n+1)^2 cell pixels (u fastest: contiguous
 // int16 rows) and a 64-lane min-reduction over the key (value, scan position) yields the
@@ -1391,10 +1507,19 @@ void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int f
   pf.end(s);
 }
 
+void vsm_launch_front(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0, const uint8_t *src1,
+                      size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d, int write_img) {
+  const int sides = src1 ? 2 : 1;
+  dim3 grid(cdiv(d.bpl, FRONT_TW), cdiv(d.h, FRONT_TH), n_frames * sides);
+  pf.begin(VSM_K_FRONT, s);
+  hipLaunchKernelGGL(k_front, grid, dim3(256), 0, s, d_imgs, first, src0, src1, frame_stride, src_bpl, sides, d, write_img);
+  pf.end(s);
+}
+
 void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d,
                          int16_t *f1, int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res,
-                         int binsize, const VsmImage *h_imgs) {
-  if (half_res) {
+                         int binsize, const VsmImage *h_imgs, int front_done) {
+  if (half_res && !front_done) {
     pf.begin(VSM_K_HALVE, s);
     hipLaunchKernelGGL(k_halve, dim3(cdiv(d.mbpl / 4, 256), d.mh, n_img), dim3(256), 0, s, d_imgs, first, d);
     pf.end(s);

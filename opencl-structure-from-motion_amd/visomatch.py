@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # The look-ahead path keeps four streams busy at once (main, pass-1 chain, two final-stage chains); the HIP runtime maps
 # streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the null stream's) and streams that share a queue
 # serialise.  Read when the runtime initialises, so it only helps if nothing in this process has touched the GPU yet.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 LIB_PATH = os.environ.get("VSM_LIB_PATH") or os.path.join(HERE, "libvisomatch.so")  # override: kernel experiments
 
 P_MATCH = np.dtype(
