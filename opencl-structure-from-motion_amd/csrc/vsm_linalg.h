@@ -5,6 +5,12 @@
 // The mono egomotion (viso/viso_mono.cpp) is a chain of these; its results feed the caller's pose,
 // so every operation here keeps the reference's order of floating-point operations -- build with
 // -ffp-contract=off.  Header-only, no allocation, usable from host and device code alike.
+//
+// Provenance: `svd` below follows viso/matrix.cpp:586-850 step for step, which itself is the `svdcmp` routine of
+// Numerical Recipes in C (Householder bidiagonalisation + implicit-shift QR, same variable roles: anorm, rv1, flag,
+// nm, its) plus the reference's descending sort and sign convention.  The closeness is deliberate and unavoidable:
+// the results must be bit-identical in double precision, which pins the order of every operation of a published
+// algorithm; only the loop interchange for n <= 16 and the device form (vsm_svd_coop.h) are this repository's own.
 #pragma once
 
 #include <math.h>

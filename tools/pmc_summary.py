@@ -14,7 +14,7 @@ import collections
 import csv
 import sys
 
-NAMES = {"k_match<2>": "k_match<16>:pass2", "k_match<4>": "k_match<16>:pass1", "k_nms_tile": "k_nms:dense",
+NAMES = {"k_match<2>": "k_match<16>:pass2", "k_match<4>": "k_match<16>:pass1", "k_match<8>": "k_match<16>:pass1", "k_nms_tile": "k_nms:dense",
          "k_nms_tile8": "k_nms:sparse", "k_nms_fixed<3, 16, 8, 1>": "k_nms:dense", "k_nms_fixed<9, 4, 4, 8>": "k_nms:sparse",
          "k_compact_write": "k_compact_matches"}
 
