@@ -154,7 +154,7 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
     size_t feat, count, cand, cell_off, bin_start, bin_cnt, binid, s_idx, s_uv, s_desc, s_rank, tmp;
   };
   struct ImgOff {
-    size_t img, imgm, du, dv, duf, dvf;
+    size_t img, imgm, du, dv, duvt;
     SetOff set[2];
   };
   std::vector<ImgOff> io(nimg);
@@ -163,8 +163,7 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
     io[i].imgm = p.half_resolution ? take(mres) : io[i].img;
     io[i].du = take(mres);
     io[i].dv = take(mres);
-    io[i].duf = p.half_resolution ? take(full) : io[i].du;
-    io[i].dvf = p.half_resolution ? take(full) : io[i].dv;
+    io[i].duvt = p.half_resolution ? take((size_t)d.bpl * ((d.h + 7) & ~7) * 2 + 256) : 0;  // (+ one tile row of slack: windows load the tile to their right)
     for (int k = 0; k < 2; k++) {
       const size_t cap = c.cap_set[k];
       io[i].set[k].feat = take(cap * 48);
@@ -225,8 +224,9 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
     im.imgm = b + io[i].imgm;
     im.du = b + io[i].du;
     im.dv = b + io[i].dv;
-    im.du_full = b + io[i].duf;
-    im.dv_full = b + io[i].dvf;
+    im.du_full = p.half_resolution ? nullptr : im.du;
+    im.dv_full = p.half_resolution ? nullptr : im.dv;
+    im.duv_tiled = p.half_resolution ? b + io[i].duvt : nullptr;
     for (int k = 0; k < 2; k++) {
       VsmSet &s = im.set[k];
       s.feat = (int32_t *)(b + io[i].set[k].feat);
@@ -1821,8 +1821,20 @@ int32_t vsm_get_gradients(vsm_handle *h, int32_t which, int32_t full, uint8_t *d
   if (full && !h->param.half_resolution) return 0;
   const VsmImage &im = c.h_imgs[slot * 2 + side];
   const int32_t bytes = full ? c.dims.bpl * c.dims.h : c.dims.mbpl * c.dims.mh;
-  if (du && hipMemcpy(du, full ? im.du_full : im.du, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-  if (dv && hipMemcpy(dv, full ? im.dv_full : im.dv, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (full) {  // the tiled plane (8 x 8 tiles: 8 du bytes, 8 dv bytes per tile row), un-tiled here
+    const int bpl = c.dims.bpl, hh = c.dims.h;
+    std::vector<uint8_t> t((size_t)bpl * ((hh + 7) & ~7) * 2);
+    if (hipMemcpy(t.data(), im.duv_tiled, t.size(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    for (int y = 0; y < hh; y++)
+      for (int x = 0; x < bpl; x++) {
+        const size_t a = ((size_t)(y >> 3) * (size_t)(bpl >> 3) + (size_t)(x >> 3)) * 128 + (size_t)((y & 7) * 16 + (x & 7));
+        if (du) du[(size_t)y * bpl + x] = t[a];
+        if (dv) dv[(size_t)y * bpl + x] = t[a + 8];
+      }
+    return bytes;
+  }
+  if (du && hipMemcpy(du, im.du, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (dv && hipMemcpy(dv, im.dv, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return bytes;
 }
 

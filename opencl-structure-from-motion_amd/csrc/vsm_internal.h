@@ -40,7 +40,8 @@ struct VsmImage {
   uint8_t *img;      // [h][bpl]  padded copy of the input (pad = 0)
   uint8_t *imgm;     // matching-resolution image: half image, or == img
   uint8_t *du, *dv;  // matching-resolution Sobel responses
-  uint8_t *du_full, *dv_full;  // full-resolution Sobel responses (half_resolution only; else == du,dv)
+  uint8_t *du_full, *dv_full;  // full-resolution Sobel responses when the matching resolution IS the full one (== du, dv); else null
+  uint8_t *duv_tiled;          // half_resolution: both full-resolution responses in 8 x 8 tiles (vsm_tiled_at in vsm_kernels.hip); else null
   VsmSet set[2];     // 0 sparse, 1 dense
 };
 

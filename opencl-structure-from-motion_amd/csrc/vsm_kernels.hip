@@ -111,6 +111,16 @@ __global__ void __launch_bounds__(256) k_halve(const VsmImage *__restrict__ imgs
 // row it stores one dword of du, one of dv and, for the matching-resolution image, 8 bytes each
 // of f1 and f2.  FULL = true: full-resolution image -> du_full,dv_full only.
 // ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------
+// Full-resolution Sobel planes of half_resolution = 1 (read by the refinement only, as scattered 9 x 9 neighbourhoods):
+// ONE plane of 8 x 8-pixel tiles, 128 bytes each = one cache line: tile row = 8 du bytes then 8 dv bytes.  A refinement
+// window (9 rows x 9 columns of both responses) lies in exactly 4 lines instead of 16, its row in two 16-byte loads.
+// du of pixel (x, y) at vsm_tiled_at(bpl, x, y), dv 8 bytes further.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ size_t vsm_tiled_at(int bpl, int x, int y) {
+  return ((size_t)(y >> 3) * (size_t)(bpl >> 3) + (size_t)(x >> 3)) * 128 + (size_t)((y & 7) * 16 + (x & 7));
+}
+
 #define FPB(r, i) ((int)((Wn[(r)][(i) >> 2] >> (8 * ((i)&3))) & 0xffu))
 template <bool FULL>
 __global__ void __launch_bounds__(256)
@@ -134,8 +144,8 @@ __global__ void __launch_bounds__(256)
     }
   }
   const int lo = 2 * bpl, hi = (h - 2) * bpl;
-  uint8_t *__restrict__ odu = FULL ? im.du_full : im.du;
-  uint8_t *__restrict__ odv = FULL ? im.dv_full : im.dv;
+  uint8_t *__restrict__ odu = FULL ? im.duv_tiled : im.du;
+  uint8_t *__restrict__ odv = FULL ? im.duv_tiled + 8 : im.dv;
   int16_t *f1 = FULL ? nullptr : f1base + (size_t)blockIdx.z * f_stride;
   int16_t *f2 = FULL ? nullptr : f2base + (size_t)blockIdx.z * f_stride;
 #pragma unroll
@@ -162,8 +172,9 @@ __global__ void __launch_bounds__(256)
       du |= (uint32_t)min(max((hu >> 7) + 128, 0), 255) << (8 * k);
       dv |= (uint32_t)min(max((hv >> 7) + 128, 0), 255) << (8 * k);
     }
-    *(uint32_t *)(odu + f0) = du;
-    *(uint32_t *)(odv + f0) = dv;
+    const size_t o0 = FULL ? vsm_tiled_at(bpl, x4, y) : (size_t)f0;
+    *(uint32_t *)(odu + o0) = du;
+    *(uint32_t *)(odv + o0) = dv;
     if (!FULL) {
       int16_t o1[4], o2[4];
 #pragma unroll
@@ -303,8 +314,9 @@ __global__ void __launch_bounds__(256)
       du |= (uint32_t)min(max((hu >> 7) + 128, 0), 255) << (8 * k);
       dv |= (uint32_t)min(max((hv >> 7) + 128, 0), 255) << (8 * k);
     }
-    *(VSM_AS1 uint32_t *)(im.du_full + f0) = du;
-    *(VSM_AS1 uint32_t *)(im.dv_full + f0) = dv;
+    const size_t o0 = vsm_tiled_at(bpl, x4, y);
+    *(VSM_AS1 uint32_t *)(im.duv_tiled + o0) = du;
+    *(VSM_AS1 uint32_t *)(im.duv_tiled + o0 + 8) = dv;
   }
 #undef FPB
 }
@@ -957,12 +969,18 @@ __device__ __forceinline__ VsmQuery load_query(const VsmSet &A, int i) {
 #ifndef VSM_UVL
 #define VSM_UVL 2  // 16-byte coordinate loads in flight per lane
 #endif
+#ifndef VSM_JUDGE2
+#define VSM_JUDGE2 0
+#endif
+#ifndef VSM_MATCH_BLOCK
+#define VSM_MATCH_BLOCK 256  // threads per block of k_match
+#endif
 #ifndef VSM_RELOAD_WINNER
 #define VSM_RELOAD_WINNER 1  // 1: keep only the winner's position while scanning, fetch its record afterwards
 #endif
 typedef unsigned short vsm_us2 __attribute__((ext_vector_type(2)));
 
-template <int G>
+template <int G, bool RELOAD = true>
 __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, const VsmDims &d, const VsmMatchCfg &cfg,
                                                bool prior, float r_umin, float r_umax, float r_vmin, float r_vmax,
                                                bool flow, double u_, double v_, int lane) {
@@ -1041,6 +1059,48 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
       }
     }
   };
+#if VSM_JUDGE2
+  // two parked candidates per round trip: both records are requested before either is looked at
+  auto eval = [&](int p, const uint4 &a, const uint4 &b, uint32_t rk, uint32_t w) {
+    double cost = (double)sad32(q.da, q.db, a, b);
+    if (cost <= best) {
+      if (pred) {
+        double du = (double)(int)(w & 0xffffu) - u_;
+        double dv = (double)(int)(w >> 16) - v_;
+        double dist = sqrt(du * du + dv * dv);
+        cost += 4 * dist;
+      }
+      if (cost < best || (cost == best && rk < brank)) {
+        best = cost;
+        brank = rk;
+        bestq = (uint32_t)p;
+      }
+    }
+  };
+  auto pop_and_judge = [&]() {
+    if (nq > 0) {
+      const bool two = nq > 1;
+      const int pa = q0p, pb = two ? q1p : q0p;
+      const uint4 a0 = ldg_u4(B.s_desc + 2 * pa), a1 = ldg_u4(B.s_desc + 2 * pa + 1);
+      const uint4 b0 = ldg_u4(B.s_desc + 2 * pb), b1 = ldg_u4(B.s_desc + 2 * pb + 1);
+      const uint32_t rka = (uint32_t)ldg_i32(B.s_rank + pa), rkb = (uint32_t)ldg_i32(B.s_rank + pb);
+      uint32_t wa = 0, wb = 0;
+      if (pred) {
+        wa = ldg_u32(B.s_uv + pa);
+        wb = ldg_u32(B.s_uv + pb);
+      }
+      if (two) {
+        q0p = q2p;
+        q1p = q3p;
+        nq -= 2;
+      } else {
+        nq = 0;
+      }
+      eval(pa, a0, a1, rka, wa);
+      if (two) eval(pb, b0, b1, rkb, wb);
+    }
+  };
+#else
   auto pop_and_judge = [&]() {  // lanes with a parked candidate take their newest one
     if (nq > 0) {
       const int p = q0p;
@@ -1051,6 +1111,7 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
       judge(p);
     }
   };
+#endif
   for (int ubin = ubmin; ubin <= ubmax && !empty; ubin++) {
     const int b0 = (q.c * d.ub + ubin) * vrows;
     const int q0 = ldg_i32(B.bin_start + b0 + vfmin), q1 = ldg_i32(B.bin_start + b0 + vfmax + 1);
@@ -1100,6 +1161,7 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
       brank = ork;
     }
   }
+  if (!RELOAD) return bestq;  // (the staged form: the next stage's kernel fetches the winner)
   if (bestq == VSM_NONE) {  // group-uniform
     q = load_query(B, 0);
     return VSM_NONE;
@@ -1140,7 +1202,7 @@ __device__ __forceinline__ int index_of(const VsmSet &B, uint32_t pos) { return 
 #define VSM_MATCH_WAVES 4  // waves per SIMD the register allocator must leave room for
 #endif
 template <int G>
-__global__ void __launch_bounds__(256, VSM_MATCH_WAVES)
+__global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
     k_match(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
             VsmJob job0, VsmDims d, VsmMatchCfg cfg, int nbx, int npairs) {
   // flattened grid: logical block -> (frame pair, block within pair), XCD-contiguous
@@ -1228,6 +1290,137 @@ __global__ void __launch_bounds__(256, VSM_MATCH_WAVES)
     pair.flag[qi] = ok ? 1 : 0;
     if (ok) pair.raw[qi] = m;
   }
+}
+
+// The same chains, one kernel per stage (VSM_MATCH_STAGED=1, an experiment): a stage keeps only its own query in registers
+// (68-84 VGPRs, 5-7 waves per SIMD instead of 106 / 4) and the double-precision distance term is compiled only into the
+// stages that can have a prediction.  Measured on MI355X, 50 pairs per launch: 155 us for the four stage kernels against
+// 122 us for the single launch - occupancy is not what bounds the chain (texture addresser 33 % busy, VALU 39 %); the
+// extra state round trip per stage and four ramp-ups / tails cost more than the resident waves win.  State between stages: one word per query and stage in the query's own result
+// slot pair.raw[qi] (nobody else reads it before the last stage writes the record): winner position | class << 30, position
+// VSM_CHAIN_NONE = empty window, i.e. feature 0 of the searched set (viso/matcher.cpp:898), whose class the word carries.
+// KIND: 0..3 = the four stages of a quad chain (:1088-1153), 4,5 = flow (:1006-1041), 6,7 = stereo (:1045-1084).
+#define VSM_CHAIN_NONE 0x3fffffffu
+__device__ __forceinline__ uint32_t chain_uv(const VsmSet &B, uint32_t st) {  // packed coordinates of a stage's winner
+  const uint32_t pos = st & VSM_CHAIN_NONE;
+  if (pos == VSM_CHAIN_NONE) {
+    const int4 hd = ldg_i4(B.feat);
+    return (uint32_t)hd.x | ((uint32_t)hd.y << 16);
+  }
+  return ldg_u32(B.s_uv + pos);
+}
+__device__ __forceinline__ int chain_index(const VsmSet &B, uint32_t st) {
+  const uint32_t pos = st & VSM_CHAIN_NONE;
+  return pos == VSM_CHAIN_NONE ? 0 : ldg_i32(B.s_idx + pos);
+}
+
+template <int G, int KIND>
+__global__ void __launch_bounds__(VSM_MATCH_BLOCK)
+    k_chain(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs, VsmJob job0,
+            VsmDims d, VsmMatchCfg cfg, int nbx, int npairs) {
+  constexpr bool QUAD = KIND < 4, FLOWM = KIND == 4 || KIND == 5;
+  constexpr int STAGE = QUAD ? KIND : (KIND & 1);  // 0-based stage within the chain
+  constexpr bool FIRST = STAGE == 0, LAST = QUAD ? STAGE == 3 : STAGE == 1;
+  constexpr bool FLOW = QUAD ? (STAGE == 1 || STAGE == 3) : FLOWM;  // window in both axes (else +-disp_tol rows)
+  constexpr bool MAYPRED = QUAD && FLOW;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int pj = lb / nbx, bx = lb - pj * nbx;
+  if (pj >= npairs) return;
+  const VsmJob &jb = jobs ? jobs[pj] : job0;
+  const VsmPair &pair = pairs[pj];
+  const int lane = threadIdx.x & (G - 1);
+  const int qi = (bx * blockDim.x + threadIdx.x) / G;
+  const int si = cfg.sparse ? 0 : 1;
+  if (qi >= jb.nq[si]) return;
+  const VsmSet &s1p = imgs[jb.img_prev].set[si], &s2p = imgs[jb.img_prev + 1].set[si];
+  const VsmSet &s1c = imgs[jb.img_curr].set[si], &s2c = imgs[jb.img_curr + 1].set[si];
+  // A: the set the chain starts in; P: the set the previous stage searched; B: the set this stage searches
+  const VsmSet &A = QUAD ? s1p : s1c;
+  const VsmSet &P = QUAD ? (STAGE == 1 ? s2p : (STAGE == 2 ? s2c : s1c)) : (FLOWM ? s1p : s2c);
+  const VsmSet &B = QUAD ? (STAGE == 0 ? s2p : (STAGE == 1 ? s2c : (STAGE == 2 ? s1c : s1p))) : (STAGE == 1 ? s1c : (FLOWM ? s1p : s2c));
+  uint32_t *st = (uint32_t *)(pair.raw + qi);
+  const bool prior = cfg.use_prior != 0;
+  VsmQuery q;
+  int u0, v0;
+  if (FIRST) {
+    q = load_query(A, qi);
+    u0 = q.u();
+    v0 = q.v();
+  } else {
+    const uint32_t prev = ldg_u32(st + STAGE - 1);
+    const int4 hd = ldg_i4(A.feat + (size_t)qi * 12);
+    u0 = hd.x;
+    v0 = hd.y;
+    const uint32_t pos = prev & VSM_CHAIN_NONE;
+    if (pos == VSM_CHAIN_NONE) {
+      q = load_query(P, 0);
+    } else {
+      q.uv = ldg_u32(P.s_uv + pos);
+      q.da = ldg_u4(P.s_desc + 2 * pos);
+      q.db = ldg_u4(P.s_desc + 2 * pos + 1);
+    }
+    q.c = (int)(prev >> 30);
+  }
+  float4 r = make_float4(0, 0, 0, 0);
+  if (prior) {
+    const uint4 rr = ldg_u4(pair.ranges + 16 * stat_bin_of(u0, v0, cfg.binsize, d.ub, d.vb) + 4 * STAGE);
+    r = make_float4(__uint_as_float(rr.x), __uint_as_float(rr.y), __uint_as_float(rr.z), __uint_as_float(rr.w));
+  }
+  double u_ = -1, v_ = -1;
+  if (MAYPRED && jb.use_tr) {
+    if (STAGE == 1) {  // :1114-1126, contraction-free double arithmetic
+      double dd = (double)u0 - (double)q.u();
+      if (!(dd > 1.0)) dd = 1.0;
+      double x1p = ((double)u0 - cfg.cu) * cfg.base / dd;
+      double y1p = ((double)v0 - cfg.cv) * cfg.base / dd;
+      double z1p = cfg.f * cfg.base / dd;
+      double x2c = jb.t[0] * x1p + jb.t[1] * y1p + jb.t[2] * z1p + jb.t[3] - cfg.base;
+      double y2c = jb.t[4] * x1p + jb.t[5] * y1p + jb.t[6] * z1p + jb.t[7];
+      double z2c = jb.t[8] * x1p + jb.t[9] * y1p + jb.t[10] * z1p + jb.t[11];
+      u_ = cfg.f * x2c / z2c + cfg.cu;
+      v_ = cfg.f * y2c / z2c + cfg.cv;
+    } else {  // stage 4 predicts the chain's own start (:1134)
+      u_ = (double)u0;
+      v_ = (double)v0;
+    }
+  }
+  const int cq = q.c;
+  const uint32_t p = find_match<G, false>(q, B, d, cfg, prior, r.x, r.y, r.z, r.w, FLOW, MAYPRED ? u_ : -1.0, MAYPRED ? v_ : -1.0, lane);
+  if (!LAST) {
+    if (lane == 0) {
+      uint32_t w = p | ((uint32_t)cq << 30);
+      if (p == VSM_NONE) w = VSM_CHAIN_NONE | ((uint32_t)ldg_i32(B.feat + 3) << 30);  // feature 0 of B, class included
+      st[STAGE] = w;
+    }
+    return;
+  }
+  if (lane != 0) return;
+  const uint32_t last = p == VSM_NONE ? VSM_CHAIN_NONE : p;
+  bool ok = chain_index(B, last) == qi;
+  vsm_p_match m;
+  if (QUAD) {
+    if (ok) {
+      const uint32_t t0 = st[0], t1 = st[1], t2 = st[2];
+      const uint32_t w2p = chain_uv(s2p, t0), w2c = chain_uv(s2c, t1), w1c = chain_uv(s1c, t2);
+      const int u2p = (int)(w2p & 0xffffu), u2c = (int)(w2c & 0xffffu), u1c = (int)(w1c & 0xffffu);
+      ok = (u0 >= u2p) && (u1c >= u2c);
+      if (ok)
+        m = {(float)u0, (float)v0, qi, (float)u2p, (float)(int)(w2p >> 16), chain_index(s2p, t0), (float)u1c,
+             (float)(int)(w1c >> 16), chain_index(s1c, t2), (float)u2c, (float)(int)(w2c >> 16), chain_index(s2c, t1)};
+    }
+  } else if (ok) {
+    const uint32_t t0 = st[0];
+    const uint32_t w = chain_uv(P, t0);
+    const int uw = (int)(w & 0xffffu), vw = (int)(w >> 16), iw = chain_index(P, t0);
+    if (FLOWM) {
+      m = {(float)uw, (float)vw, iw, -1.f, -1.f, -1, (float)u0, (float)v0, qi, -1.f, -1.f, -1};
+    } else {
+      ok = u0 >= uw;
+      m = {-1.f, -1.f, -1, -1.f, -1.f, -1, (float)u0, (float)v0, qi, (float)uw, (float)vw, iw};
+    }
+  }
+  pair.flag[qi] = ok ? 1 : 0;
+  if (ok) pair.raw[qi] = m;
 }
 
 // ordered compaction of the accepted queries (push_back order = ascending query index) with the
@@ -1325,6 +1518,20 @@ __device__ __forceinline__ uint4 small_desc(const uint8_t *__restrict__ du, cons
   return r;
 }
 
+// the same descriptor from the tiled plane
+__device__ __forceinline__ uint4 small_desc_tiled(const uint8_t *__restrict__ t, int bpl, int u, int v) {
+#define TDU(x, y) ((uint32_t)t[vsm_tiled_at(bpl, (x), (y))])
+#define TDV(x, y) ((uint32_t)t[vsm_tiled_at(bpl, (x), (y)) + 8])
+  uint4 r;
+  r.x = TDU(u, v - 2) | (TDU(u - 2, v - 1) << 8) | (TDU(u, v - 1) << 16) | (TDU(u + 2, v - 1) << 24);
+  r.y = TDU(u - 1, v) | (TDU(u, v) << 8) | (TDU(u, v) << 16) | (TDU(u + 1, v) << 24);
+  r.z = TDU(u - 2, v + 1) | (TDU(u, v + 1) << 8) | (TDU(u + 2, v + 1) << 16) | (TDU(u, v + 2) << 24);
+  r.w = TDV(u, v - 1) | (TDV(u - 1, v) << 8) | (TDV(u + 1, v) << 16) | (TDV(u, v + 1) << 24);
+#undef TDU
+#undef TDV
+  return r;
+}
+
 __device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b) {
   uint32_t s = __builtin_amdgcn_sad_u8(a.x, b.x, 0u);
   s = __builtin_amdgcn_sad_u8(a.y, b.y, s);
@@ -1332,6 +1539,49 @@ __device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b) {
   return __builtin_amdgcn_sad_u8(a.w, b.w, s);
 }
 
+// reference descriptor at (u1c, v1c) of the current left image (computeSmallDescriptor, :479-506):
+// 5 du rows + 3 dv rows, columns u-2..u+2, each as two aligned dwords re-based with a funnel shift
+// (8 wide loads instead of 16 byte gathers)
+template <bool TILED>
+__device__ __forceinline__ uint4 refine_ref_desc(const VsmImage &ref, const VsmDims &dc, int ru, int rv) {
+  uint4 rd;
+  const int b0 = (ru - 2) & ~3, rsh = 8 * ((ru - 2) - b0);
+  uint64_t wu[5], wv[3];
+  if (TILED) {
+    // the two 4-pixel blocks holding columns ru-2 .. ru+2: block j of row y sits in tile j >> 1, half j & 1
+    const int j0 = b0 >> 2;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      const uint8_t *row = ref.duv_tiled;
+      const uint32_t lo = ldg_u32(row + vsm_tiled_at(dc.bpl, 4 * j0, rv - 2 + r)), hi = ldg_u32(row + vsm_tiled_at(dc.bpl, 4 * j0 + 4, rv - 2 + r));
+      wu[r] = ((((uint64_t)hi) << 32) | lo) >> rsh;
+      if (r >= 1 && r <= 3) {
+        const uint32_t lv = ldg_u32(row + vsm_tiled_at(dc.bpl, 4 * j0, rv - 2 + r) + 8), hv = ldg_u32(row + vsm_tiled_at(dc.bpl, 4 * j0 + 4, rv - 2 + r) + 8);
+        wv[r - 1] = ((((uint64_t)hv) << 32) | lv) >> rsh;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      const uint32_t *pr = (const uint32_t *)(ref.du_full + (size_t)(rv - 2 + r) * dc.bpl + b0);
+      wu[r] = ((((uint64_t)pr[1]) << 32) | pr[0]) >> rsh;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const uint32_t *pr = (const uint32_t *)(ref.dv_full + (size_t)(rv - 1 + r) * dc.bpl + b0);
+      wv[r] = ((((uint64_t)pr[1]) << 32) | pr[0]) >> rsh;
+    }
+  }
+#define WB(w, c) ((uint32_t)((w) >> (8 * (c))) & 0xffu)
+  rd.x = WB(wu[0], 2) | (WB(wu[1], 0) << 8) | (WB(wu[1], 2) << 16) | (WB(wu[1], 4) << 24);
+  rd.y = WB(wu[2], 1) | (WB(wu[2], 2) << 8) | (WB(wu[2], 2) << 16) | (WB(wu[2], 3) << 24);
+  rd.z = WB(wu[3], 0) | (WB(wu[3], 2) << 8) | (WB(wu[3], 4) << 16) | (WB(wu[4], 2) << 24);
+  rd.w = WB(wv[0], 2) | (WB(wv[1], 1) << 8) | (WB(wv[1], 3) << 16) | (WB(wv[2], 2) << 24);
+#undef WB
+  return rd;
+}
+
+template <bool TILED>
 __global__ void __launch_bounds__(256)
     k_refine(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
              VsmJob job0, VsmDims dp, VsmDims dc, int method, int nbx, int npairs) {
@@ -1347,12 +1597,30 @@ __global__ void __launch_bounds__(256)
   const VsmPair &pair = pairs[pj];
   const int g = bx * blockDim.x + threadIdx.x;
   const int mi = g / 3, step = g - mi * 3;
+  const VsmImage &ref = imgs[jb.img_curr];
+  // The reference descriptor of a match is the same for its three steps: lanes 0..21 of a wave compute those of the
+  // wave's (at most 22) matches, one each - a third of the lanes in contiguous quads, which is what the texture
+  // addresser's time goes by - and every lane picks its match's up with a cross-lane read.
+  uint4 rd;
+  {
+    const int lane = threadIdx.x & 63;
+    const int first_mi = (g - lane) / 3, rmi = first_mi + lane;
+    uint4 mine = make_uint4(0, 0, 0, 0);
+    if (lane < 22 && rmi < pair.count[1]) {
+      const vsm_p_match *rm = pair.list2 + rmi;
+      mine = refine_ref_desc<TILED>(ref, dc, (int)rm->u1c, (int)rm->v1c);
+    }
+    const int src = mi - first_mi;
+    rd.x = (uint32_t)__shfl((int)mine.x, src, 64);
+    rd.y = (uint32_t)__shfl((int)mine.y, src, 64);
+    rd.z = (uint32_t)__shfl((int)mine.z, src, 64);
+    rd.w = (uint32_t)__shfl((int)mine.w, src, 64);
+  }
   if (mi >= pair.count[1]) return;
   if (step == 0 && !(method == 0 || method == 2)) return;
   if (step == 1 && !(method == 1 || method == 2)) return;
   if (step == 2 && method != 2) return;
   vsm_p_match *m = pair.list2 + mi;  // refined in place (each step owns its two fields)
-  const VsmImage &ref = imgs[jb.img_curr];
   const VsmImage &tgt = step == 0 ? imgs[jb.img_prev] : (step == 1 ? imgs[jb.img_curr + 1] : imgs[jb.img_prev + 1]);
   const VsmDims &dt = step == 1 ? dc : dp;
   float *pu = step == 0 ? &m->u1p : (step == 1 ? &m->u2c : &m->u2p);
@@ -1361,49 +1629,44 @@ __global__ void __launch_bounds__(256)
   if (u2 - 2 < VSM_MARGIN || u2 + 2 > dt.w - 1 - VSM_MARGIN || v2 - 2 < VSM_MARGIN || v2 + 2 > dt.h - 1 - VSM_MARGIN)
     return;
   const int iu = (int)u2, iv = (int)v2;
-  const int a0 = (iu - 4) & ~3, sh = 8 * ((iu - 4) - a0);
   uint32_t U[9][3], V[9][3];
+  if (TILED) {
+    // tiled plane: the 9 columns iu-4 .. iu+4 start at byte o = (iu-4) & 7 of a tile row and end in the next tile; one
+    // 16-byte load per tile row brings 8 du + 8 dv bytes
+    const int o = (iu - 4) & 7, b = o >> 2;
+    const uint32_t sb = (uint32_t)(o & 3);
 #pragma unroll
-  for (int r = 0; r < 9; r++) {
-    const uint32_t *pr = (const uint32_t *)(tgt.du_full + (size_t)(iv - 4 + r) * dt.bpl + a0);
-    const uint32_t d0 = pr[0], d1 = pr[1], d2 = pr[2];
-    U[r][0] = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
-    U[r][1] = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
-    U[r][2] = d2 >> sh;
-    if (r >= 1 && r <= 7) {
-      const uint32_t *qr = (const uint32_t *)(tgt.dv_full + (size_t)(iv - 4 + r) * dt.bpl + a0);
-      const uint32_t e0 = qr[0], e1 = qr[1], e2 = qr[2];
-      V[r][0] = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
-      V[r][1] = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
-      V[r][2] = e2 >> sh;
-    } else {
-      V[r][0] = V[r][1] = V[r][2] = 0;
+    for (int r = 0; r < 9; r++) {
+      const uint8_t *pr = tgt.duv_tiled + vsm_tiled_at(dt.bpl, (iu - 4) & ~7, iv - 4 + r);
+      const uint4 t0 = ldg_u4(pr), t1 = ldg_u4(pr + 128);
+      const uint32_t d0 = b ? t0.y : t0.x, d1 = b ? t1.x : t0.y, d2 = b ? t1.y : t1.x;
+      U[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sb);
+      U[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sb);
+      U[r][2] = d2 >> (8 * sb);
+      const uint32_t e0 = b ? t0.w : t0.z, e1 = b ? t1.z : t0.w, e2 = b ? t1.w : t1.z;
+      V[r][0] = __builtin_amdgcn_alignbyte(e1, e0, sb);
+      V[r][1] = __builtin_amdgcn_alignbyte(e2, e1, sb);
+      V[r][2] = e2 >> (8 * sb);
     }
-  }
-  // reference descriptor at (u1c, v1c) of the current left image (computeSmallDescriptor, :479-506):
-  // 5 du rows + 3 dv rows, columns u-2..u+2, each as two aligned dwords re-based with a funnel shift
-  // (8 wide loads instead of 16 byte gathers)
-  uint4 rd;
-  {
-    const int ru = (int)m->u1c, rv = (int)m->v1c;
-    const int b0 = (ru - 2) & ~3, rsh = 8 * ((ru - 2) - b0);
-    uint64_t wu[5], wv[3];
+  } else {
+    const int a0 = (iu - 4) & ~3, sh = 8 * ((iu - 4) - a0);
 #pragma unroll
-    for (int r = 0; r < 5; r++) {
-      const uint32_t *pr = (const uint32_t *)(ref.du_full + (size_t)(rv - 2 + r) * dc.bpl + b0);
-      wu[r] = ((((uint64_t)pr[1]) << 32) | pr[0]) >> rsh;
+    for (int r = 0; r < 9; r++) {
+      const uint32_t *pr = (const uint32_t *)(tgt.du_full + (size_t)(iv - 4 + r) * dt.bpl + a0);
+      const uint32_t d0 = pr[0], d1 = pr[1], d2 = pr[2];
+      U[r][0] = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+      U[r][1] = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
+      U[r][2] = d2 >> sh;
+      if (r >= 1 && r <= 7) {
+        const uint32_t *qr = (const uint32_t *)(tgt.dv_full + (size_t)(iv - 4 + r) * dt.bpl + a0);
+        const uint32_t e0 = qr[0], e1 = qr[1], e2 = qr[2];
+        V[r][0] = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
+        V[r][1] = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
+        V[r][2] = e2 >> sh;
+      } else {
+        V[r][0] = V[r][1] = V[r][2] = 0;
+      }
     }
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const uint32_t *pr = (const uint32_t *)(ref.dv_full + (size_t)(rv - 1 + r) * dc.bpl + b0);
-      wv[r] = ((((uint64_t)pr[1]) << 32) | pr[0]) >> rsh;
-    }
-#define WB(w, c) ((uint32_t)((w) >> (8 * (c))) & 0xffu)
-    rd.x = WB(wu[0], 2) | (WB(wu[1], 0) << 8) | (WB(wu[1], 2) << 16) | (WB(wu[1], 4) << 24);
-    rd.y = WB(wu[2], 1) | (WB(wu[2], 2) << 8) | (WB(wu[2], 2) << 16) | (WB(wu[2], 3) << 24);
-    rd.z = WB(wu[3], 0) | (WB(wu[3], 2) << 8) | (WB(wu[3], 4) << 16) | (WB(wu[4], 2) << 24);
-    rd.w = WB(wv[0], 2) | (WB(wv[1], 1) << 8) | (WB(wv[1], 3) << 16) | (WB(wv[2], 2) << 24);
-#undef WB
   }
 #define UB(r, c) ((U[(r)][(c) >> 2] >> (8 * ((c)&3))) & 0xffu)
 #define VB(r, c) ((V[(r)][(c) >> 2] >> (8 * ((c)&3))) & 0xffu)
@@ -1459,12 +1722,15 @@ __global__ void __launch_bounds__(256)
     if (lane == 0) out[0] = 0;  // infeasible: match dropped (wave-uniform branch)
     return;
   }
-  const uint4 r = small_desc(ref.du_full, ref.dv_full, dc.bpl, (int)m->u1c, (int)m->v1c);
+  const bool tiled = ref.duv_tiled != nullptr;
+  const uint4 r = tiled ? small_desc_tiled(ref.duv_tiled, dc.bpl, (int)m->u1c, (int)m->v1c)
+                        : small_desc(ref.du_full, ref.dv_full, dc.bpl, (int)m->u1c, (int)m->v1c);
   uint32_t key = 0xffffffffu;
   int cost = 0;
   if (lane < 49) {
     const int ddv = lane / 7, ddu = lane - ddv * 7;
-    const uint4 t = small_desc(tgt.du_full, tgt.dv_full, dt.bpl, (int)u2 + ddu - 3, (int)v2 + ddv - 3);
+    const uint4 t = tiled ? small_desc_tiled(tgt.duv_tiled, dt.bpl, (int)u2 + ddu - 3, (int)v2 + ddv - 3)
+                          : small_desc(tgt.du_full, tgt.dv_full, dt.bpl, (int)u2 + ddu - 3, (int)v2 + ddv - 3);
     cost = (int)sad16(r, t);
     key = ((uint32_t)cost << 6) | (uint32_t)lane;
   }
@@ -1612,18 +1878,48 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
   const int pass = cfg.sparse ? 0 : 1;
   if (max_nq > 0) {
     pf.begin(cfg.sparse ? VSM_K_MATCH1 : VSM_K_MATCH2, s);
-    const int nbx = cdiv(max_nq * G, 256);
+    const int nbx = cdiv(max_nq * G, VSM_MATCH_BLOCK);
     const dim3 grid(((nbx * npairs + 7) / 8) * 8);
-    if (G == 1)
-      hipLaunchKernelGGL(k_match<1>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
+    // VSM_MATCH_STAGED=1: one kernel per stage (k_chain) - measured slower than the single launch, kept for experiments
+    static int staged_env = -1;
+    if (staged_env < 0) {
+      const char *e = getenv("VSM_MATCH_STAGED");
+      staged_env = e && atoi(e) ? 1 : 0;
+    }
+    const bool staged = staged_env == 1;
+    if (staged && (G == 2 || G == 4 || G == 8)) {
+#define VSM_CHAIN_LAUNCH(GG, KIND) \
+  hipLaunchKernelGGL((k_chain<GG, KIND>), grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs)
+#define VSM_CHAIN_ALL(GG)                                                           \
+  if (cfg.method == 2) {                                                            \
+    VSM_CHAIN_LAUNCH(GG, 0);                                                        \
+    VSM_CHAIN_LAUNCH(GG, 1);                                                        \
+    VSM_CHAIN_LAUNCH(GG, 2);                                                        \
+    VSM_CHAIN_LAUNCH(GG, 3);                                                        \
+  } else if (cfg.method == 0) {                                                     \
+    VSM_CHAIN_LAUNCH(GG, 4);                                                        \
+    VSM_CHAIN_LAUNCH(GG, 5);                                                        \
+  } else {                                                                          \
+    VSM_CHAIN_LAUNCH(GG, 6);                                                        \
+    VSM_CHAIN_LAUNCH(GG, 7);                                                        \
+  }
+      if (G == 2) {
+        VSM_CHAIN_ALL(2)
+      } else if (G == 4) {
+        VSM_CHAIN_ALL(4)
+      } else {
+        VSM_CHAIN_ALL(8)
+      }
+    } else if (G == 1)
+      hipLaunchKernelGGL(k_match<1>, grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
     else if (G == 2)
-      hipLaunchKernelGGL(k_match<2>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
+      hipLaunchKernelGGL(k_match<2>, grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
     else if (G == 4)
-      hipLaunchKernelGGL(k_match<4>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
+      hipLaunchKernelGGL(k_match<4>, grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
     else if (G == 16)
-      hipLaunchKernelGGL(k_match<16>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
+      hipLaunchKernelGGL(k_match<16>, grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
     else
-      hipLaunchKernelGGL(k_match<8>, grid, dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
+      hipLaunchKernelGGL(k_match<8>, grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
     pf.end(s);
   }
   const int nblk = max(cdiv(max_nq, 256), 1);
@@ -1652,7 +1948,10 @@ void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const
   else
   {
     const int nbx = cdiv(n_upper * 3, 256), tot = ((nbx * npairs + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_refine, dim3(tot), dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, dp, dc, method, nbx, npairs);
+    if (dc.scale == 2)
+      hipLaunchKernelGGL(k_refine<true>, dim3(tot), dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, dp, dc, method, nbx, npairs);
+    else
+      hipLaunchKernelGGL(k_refine<false>, dim3(tot), dim3(256), 0, s, d_imgs, d_pairs, d_jobs, job0, dp, dc, method, nbx, npairs);
   }
   pf.end(s);
 }

@@ -16,7 +16,7 @@ import sys
 
 NAMES = {"k_match<2>": "k_match<16>:pass2", "k_match<4>": "k_match<16>:pass1", "k_match<8>": "k_match<16>:pass1", "k_nms_tile": "k_nms:dense",
          "k_nms_tile8": "k_nms:sparse", "k_nms_fixed<3, 16, 8, 1>": "k_nms:dense", "k_nms_fixed<9, 4, 4, 8>": "k_nms:sparse",
-         "k_compact_write": "k_compact_matches"}
+         "k_compact_write": "k_compact_matches", "k_refine<true>": "k_refine", "k_refine<false>": "k_refine"}
 
 
 def agg(path, counter):
