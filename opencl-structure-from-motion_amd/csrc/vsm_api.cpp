@@ -1301,12 +1301,13 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
 
   // The GPU-resident form (vsm_seq2.inc) takes the run unless VSM_SEQ_V2=0 asks for the host-shared form below, or
   // it declines (lists beyond what its device-side vertex sort / kd order were written for).
-  // Which one is faster depends on how many host threads this rank has: the host-shared form lives off them (200 frames
-  // 1242x375: 8.0 ms with 16 threads, 11.6 with 8, 17 with 4, 24 with 2), the GPU-resident one does not care (9.4 ms with 16,
-  // 8, 4 or 2) - its triangulation kernels are chains of single-lane seam walks, at which a CPU core is much faster than a
-  // GPU lane.  VSM_SEQ_V2=0 / 1 decides otherwise.
+  // The host-shared form lives off the rank's host threads (200 frames 1242x375: 7.5-8.0 ms with 16 threads, 8.2 with 14,
+  // 9.6 with 12, 10.1 with 10, 17 with 4, 24 with 2); the GPU-resident one hardly cares (7.8-8.0 ms with 16 .. 6 threads,
+  // 8.8 with 4, 9.5 with 2, 9.9 with 1 - its host work is Triangle's vertex sort alone), so it is the default whatever the
+  // thread count: with 16 threads on an idle host the two are within a few per cent, and its time does not move with what
+  // else the host is doing.
   h->seq_v2_frames = 0;
-  const bool v2 = getenv("VSM_SEQ_V2") ? atoi(getenv("VSM_SEQ_V2")) != 0 : h->pool->size() <= 11;
+  const bool v2 = getenv("VSM_SEQ_V2") ? atoi(getenv("VSM_SEQ_V2")) != 0 : true;
   if (v2) {
     const int rc = sequence_run_v2(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
     if (rc != VSM_SEQ2_DECLINED) return rc;

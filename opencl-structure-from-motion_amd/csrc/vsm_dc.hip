@@ -887,6 +887,22 @@ __device__ inline bool dc2_walk(int32_t m, int depth, uint32_t path, int32_t &of
   return true;
 }
 
+#ifdef DC2_PHASE_TIMING  // experiments (tools/build_variant_dc.sh): cycles per phase, summed over blocks; [row][0] counts the blocks
+__device__ unsigned long long dc2_dbg[16][16];
+#define DC2_T(var) const long long var = clock64()
+#define DC2_ACC(row, col, a, b) atomicAdd(&dc2_dbg[row][col], (unsigned long long)((b) - (a)))
+extern "C" int vsm_debug_dc2_phases(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dc2_dbg), sizeof(dc2_dbg)) != hipSuccess) return -1;
+  if (reset) {
+    static unsigned long long z[16][16];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dc2_dbg), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define DC2_T(var)
+#define DC2_ACC(row, col, a, b)
+#endif
 // One wave per block sub-tree (<= VSM_DC_BLOCK_POINTS points) as k_dc_block, on the 16-bit local mesh: 22 KB of LDS per
 // wave instead of 40, so seven waves share a CU.
 __global__ void __launch_bounds__(64) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
@@ -921,6 +937,7 @@ __global__ void __launch_bounds__(64) k_dc2_block(const VsmDc2Job *__restrict__ 
   }
   if (d < depth && (path & ((1u << (depth - d)) - 1u)) != 0) return;
   const int lane = threadIdx.x;
+  DC2_T(c0);
   for (int i = lane; i < bn; i += 64) s_key[i] = j2.key[boff + i];
   {
     dc2_v4u ones;
@@ -934,12 +951,25 @@ __global__ void __launch_bounds__(64) k_dc2_block(const VsmDc2Job *__restrict__ 
   mesh.key = (DC2_AS3 uint64_t *)s_key;
   mesh.ptw = (DC2_AS3 uint32_t *)s_pt;
   mesh.gid = j2.id + boff;
+  DC2_T(c1);
   dc2_block_leaf_run(mesh, lane, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
   __syncthreads();
+  DC2_T(c2);
+#ifdef DC2_PHASE_TIMING
+  long long cl = c2;
+#endif
   for (int L = DC2_BLOCK_DEPTH - 1; L >= 0; L--) {
     dc2_block_merge_run(mesh, lane, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
     __syncthreads();
+#ifdef DC2_PHASE_TIMING
+    {
+      const long long cn = clock64();
+      if (lane == 0) DC2_ACC(0, 3 + (DC2_BLOCK_DEPTH - 1 - L), cl, cn);
+      cl = cn;
+    }
+#endif
   }
+  DC2_T(c3);
   // records out under global numbering
   int32_t *gt = j2.tri + (size_t)2 * boff * 8;
   for (int i = lane; i < 2 * bn * 8; i += 64) {
@@ -951,6 +981,16 @@ __global__ void __launch_bounds__(64) k_dc2_block(const VsmDc2Job *__restrict__ 
     const Dc2Hull16 hl = s_hull[1];
     j2.hulls[bidx] = VsmDcHull{hl.fl_t + 2 * boff, hl.fl_o, hl.fr_t + 2 * boff, hl.fr_o};
   }
+#ifdef DC2_PHASE_TIMING
+  if (lane == 0) {
+    const long long c4 = clock64();
+    atomicAdd(&dc2_dbg[0][0], 1ull);
+    DC2_ACC(0, 1, c0, c1);
+    DC2_ACC(0, 2, c1, c2);
+    DC2_ACC(0, 9, c3, c4);
+    DC2_ACC(0, 10, c0, c4);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1017,10 +1057,12 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
     s_cl = -1;
     s_cr = 1 << 30;
   }
+  DC2_T(m0);
   for (int i = t; i < n; i += DC2_MERGE_THREADS) s_pt[i] = jb.pt[off + i];
   if (whole) {
     for (int s = t; s < nslots; s += DC2_MERGE_THREADS) ((dc2_v4u *)s_rec)[s] = pack(grec[2 * s], grec[2 * s + 1]);
     __syncthreads();
+    DC2_T(m1);
     if (t == 0) {
       DcLdsMesh<false> mesh;
       mesh.rec = (DC2_AS3 dc2_word *)s_rec;
@@ -1029,6 +1071,14 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
       jb.hulls[idx] = VsmDcHull{fl.t + tbase, fl.o, fr.t + tbase, fr.o};
     }
     __syncthreads();
+#ifdef DC2_PHASE_TIMING
+    if (t == 0) {
+      const long long m2 = clock64();
+      atomicAdd(&dc2_dbg[1 + level][0], 1ull);
+      DC2_ACC(1 + level, 1, m0, m1);
+      DC2_ACC(1 + level, 2, m1, m2);
+    }
+#endif
     // everything back under global numbering (a record is two 16-byte stores)
     for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
       const dc2_v4u o = ((const dc2_v4u *)s_rec)[s];
@@ -1120,6 +1170,7 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
       }
   }
   __syncthreads();
+  DC2_T(m1);
   if (t == 0) {
     if (s_n > rec_cap) s_n = rec_cap;
     DcLdsMesh<true> mesh;
@@ -1133,6 +1184,13 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
     mesh.pbase = off;
     dc_merge_hulls(mesh, fl, il, ir, fr, axis, tcur);
     jb.hulls[idx] = VsmDcHull{fl.t + tbase, fl.o, fr.t + tbase, fr.o};
+#ifdef DC2_PHASE_TIMING
+    const long long m2 = clock64();
+    atomicAdd(&dc2_dbg[1 + level][0], 1ull);
+    DC2_ACC(1 + level, 1, m0, m1);
+    DC2_ACC(1 + level, 2, m1, m2);
+    atomicAdd(&dc2_dbg[1 + level][3], (unsigned long long)s_n);
+#endif
   }
 }
 

@@ -134,6 +134,29 @@ struct DcLdsMesh {
 #endif
   DC2_DEV inline int32_t px(int32_t p) const { DC2_NULL_PT(p); return (int32_t)(pt[p] & 0xffffu); }
   DC2_DEV inline int32_t py(int32_t p) const { DC2_NULL_PT(p); return (int32_t)(pt[p] >> 16); }
+  // the seam loop's form: coordinates in registers; differences < 2^15, so the 32-bit products are 24-bit multiplies
+  // (full rate; a 32-bit integer multiply is quarter rate)
+  DC2_DEV inline uint32_t P(int32_t p) const { DC2_NULL_PT(p); return pt[p]; }
+  DC2_DEV static inline int32_t mul24(int32_t a, int32_t b) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+  }
+  DC2_DEV static inline int32_t ccw_p(uint32_t pa, uint32_t pb, uint32_t pc) {
+    const int32_t cx = (int32_t)(pc & 0xffffu), cy = (int32_t)(pc >> 16);
+    return mul24((int32_t)(pa & 0xffffu) - cx, (int32_t)(pb >> 16) - cy) - mul24((int32_t)(pa >> 16) - cy, (int32_t)(pb & 0xffffu) - cx);
+  }
+  DC2_DEV static inline int64_t incircle_p(uint32_t pa, uint32_t pb, uint32_t pc, uint32_t pd) {
+    const int32_t dx = (int32_t)(pd & 0xffffu), dy = (int32_t)(pd >> 16);
+    const int32_t adx = (int32_t)(pa & 0xffffu) - dx, ady = (int32_t)(pa >> 16) - dy;
+    const int32_t bdx = (int32_t)(pb & 0xffffu) - dx, bdy = (int32_t)(pb >> 16) - dy;
+    const int32_t cdx = (int32_t)(pc & 0xffffu) - dx, cdy = (int32_t)(pc >> 16) - dy;
+    return (int64_t)(mul24(adx, adx) + mul24(ady, ady)) * (mul24(bdx, cdy) - mul24(cdx, bdy)) +
+           (int64_t)(mul24(bdx, bdx) + mul24(bdy, bdy)) * (mul24(cdx, ady) - mul24(adx, cdy)) +
+           (int64_t)(mul24(cdx, cdx) + mul24(cdy, cdy)) * (mul24(adx, bdy) - mul24(bdx, ady));
+  }
   DC2_DEV inline int32_t ccw(int32_t a, int32_t b, int32_t c) const {
     DC2_NULL_PT(a); DC2_NULL_PT(b); DC2_NULL_PT(c);
     const uint32_t pa = pt[a], pb = pt[b], pc = pt[c];

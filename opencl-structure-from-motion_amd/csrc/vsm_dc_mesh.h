@@ -76,6 +76,22 @@ struct DcMesh {
   }
   VSM_HD inline int32_t px(int32_t p) const { return (int32_t)(pt[p] & 0xffffu); }
   VSM_HD inline int32_t py(int32_t p) const { return (int32_t)(pt[p] >> 16); }
+  // the seam loop of merge_hulls keeps the packed coordinates of its four corner points beside their indices
+  VSM_HD inline uint32_t P(int32_t p) const { return pt[p]; }
+  VSM_HD static inline int32_t ccw_p(uint32_t pa, uint32_t pb, uint32_t pc) {
+    const int32_t cx = (int32_t)(pc & 0xffffu), cy = (int32_t)(pc >> 16);
+    return ((int32_t)(pa & 0xffffu) - cx) * ((int32_t)(pb >> 16) - cy) -
+           ((int32_t)(pa >> 16) - cy) * ((int32_t)(pb & 0xffffu) - cx);
+  }
+  VSM_HD static inline int64_t incircle_p(uint32_t pa, uint32_t pb, uint32_t pc, uint32_t pd) {
+    const int32_t dx = (int32_t)(pd & 0xffffu), dy = (int32_t)(pd >> 16);
+    const int32_t adx = (int32_t)(pa & 0xffffu) - dx, ady = (int32_t)(pa >> 16) - dy;
+    const int32_t bdx = (int32_t)(pb & 0xffffu) - dx, bdy = (int32_t)(pb >> 16) - dy;
+    const int32_t cdx = (int32_t)(pc & 0xffffu) - dx, cdy = (int32_t)(pc >> 16) - dy;
+    return (int64_t)(adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) +
+           (int64_t)(bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) +
+           (int64_t)(cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
+  }
   // coordinates < 2^14: the orientation determinant fits int32, the in-circle one int64
   VSM_HD inline int32_t ccw(int32_t a, int32_t b, int32_t c) const {
     const uint32_t pa = pt[a], pb = pt[b], pc = pt[c];
@@ -167,8 +183,10 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
   if (irorg == m.dest(farright)) farright = M::lprev(base);
   int32_t ll = ildest, lr = irorg;
   int32_t ul = m.apex(leftcand), ur = m.apex(rightcand);
+  // (packed coordinates of the four corners travel with their indices: every point is read once, when it becomes a corner)
+  uint32_t pll = m.P(ll), plr = m.P(lr), pul = m.P(ul), pur = m.P(ur);
   for (;;) {
-    const bool lfin = m.ccw(ul, ll, lr) <= 0, rfin = m.ccw(ur, ll, lr) <= 0;
+    const bool lfin = M::ccw_p(pul, pll, plr) <= 0, rfin = M::ccw_p(pur, pll, plr) <= 0;
 
     if (lfin && rfin) {  // close the seam with the top bounding triangle (:5771)
       OTri top = m.make(tcur);
@@ -201,7 +219,8 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
       OTri ne = m.sym(M::lprev(leftcand));
       int32_t na = m.apex(ne);
       if (na >= 0) {
-        bool bad = m.incircle(ll, lr, ul, na) > 0;
+        uint32_t pna = m.P(na);
+        bool bad = M::incircle_p(pll, plr, pul, pna) > 0;
         while (bad) {
           ne = M::lnext(ne);
           OTri topc = m.sym(ne);
@@ -220,9 +239,14 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
           m.set_dest(ne, ul);
           m.set_apex(ne, na);
           ul = na;
+          pul = pna;
           ne = sidec;
           na = m.apex(ne);
-          bad = na >= 0 && m.incircle(ll, lr, ul, na) > 0;
+          bad = false;
+          if (na >= 0) {
+            pna = m.P(na);
+            bad = M::incircle_p(pll, plr, pul, pna) > 0;
+          }
         }
       }
     }
@@ -230,7 +254,8 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
       OTri ne = m.sym(M::lnext(rightcand));
       int32_t na = m.apex(ne);
       if (na >= 0) {
-        bool bad = m.incircle(ll, lr, ur, na) > 0;
+        uint32_t pna = m.P(na);
+        bool bad = M::incircle_p(pll, plr, pur, pna) > 0;
         while (bad) {
           ne = M::lprev(ne);
           OTri topc = m.sym(ne);
@@ -249,26 +274,35 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
           m.set_dest(ne, -1);
           m.set_apex(ne, na);
           ur = na;
+          pur = pna;
           ne = sidec;
           na = m.apex(ne);
-          bad = na >= 0 && m.incircle(ll, lr, ur, na) > 0;
+          bad = false;
+          if (na >= 0) {
+            pna = m.P(na);
+            bad = M::incircle_p(pll, plr, pur, pna) > 0;
+          }
         }
       }
     }
-    if (lfin || (!rfin && m.incircle(ul, ll, lr, ur) > 0)) {  // new cross edge ll--ur (:5911)
+    if (lfin || (!rfin && M::incircle_p(pul, pll, plr, pur) > 0)) {  // new cross edge ll--ur (:5911)
       m.bond(base, rightcand);
       base = M::lprev(rightcand);
       m.set_dest(base, ll);
       lr = ur;
+      plr = pur;
       rightcand = m.sym(base);
       ur = m.apex(rightcand);
+      pur = m.P(ur);
     } else {  // new cross edge ul--lr (:5920)
       m.bond(base, leftcand);
       base = M::lnext(leftcand);
       m.set_org(base, lr);
       ll = ul;
+      pll = pul;
       leftcand = m.sym(base);
       ul = m.apex(leftcand);
+      pul = m.P(ul);
     }
   }
 }

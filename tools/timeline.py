@@ -8,14 +8,11 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("k_front", "k_ingest"))]
-# a call begins with a front/ingest kernel that follows a gap of > 300 µs without any kernel running
-calls = []
-end = 0
-for i, r in enumerate(rows):
-    if i in starts and int(r["Start_Timestamp"]) - end > 300e3:
-        calls.append(i)
-    end = max(end, int(r["End_Timestamp"]))
+fronts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("k_front", "k_ingest"))]
+# a call = one period of the front kernels' grid sizes (calls follow each other without a gap in a bench run)
+zs = [rows[i]["Grid_Size_Z"] for i in fronts]
+period = next(p for p in range(1, len(zs) + 1) if all(zs[k] == zs[k % p] for k in range(len(zs))))
+calls = fronts[::period]
 i0 = calls[-back]
 i1 = calls[-back + 1] if back > 1 else len(rows)
 t0 = int(rows[i0]["Start_Timestamp"])
