@@ -122,7 +122,7 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
   d.ub = (int32_t)ceilf((float)w / (float)p.match_binsize);
   d.vb = (int32_t)ceilf((float)hh / (float)p.match_binsize);
   const int nb = 4 * d.ub * d.vb;
-  if (p.match_binsize < 1 || nb > (1 << 22)) {
+  if (p.match_binsize < 1 || p.match_binsize > 32768 || nb > (1 << 22)) {
     fprintf(stderr, "visomatch: match_binsize %d is not usable (%d bins)\n", p.match_binsize, nb);
     return VSM_EARG;
   }
@@ -681,6 +681,7 @@ static VsmMatchCfg make_cfg(const vsm_params &p, int method) {
   memset(&cfg, 0, sizeof(cfg));
   cfg.method = method;
   cfg.binsize = p.match_binsize;
+  cfg.bin_magic = p.match_binsize >= 2 ? (uint32_t)(((1ull << 32) + (uint64_t)p.match_binsize - 1) / (uint64_t)p.match_binsize) : 0u;
   cfg.radius = p.match_radius;
   cfg.disp_tol = p.match_disp_tolerance;
   cfg.f = p.f;

@@ -61,6 +61,7 @@ struct VsmDims {
 struct VsmMatchCfg {  // common to all pairs of a launch
   int32_t method, use_prior, sparse;
   int32_t binsize, radius, disp_tol;
+  uint32_t bin_magic;  // ceil(2^32 / binsize): x / binsize == mulhi(x, bin_magic) for 0 <= x < 2^32 / binsize (binsize >= 2)
   double f, cu, cv, base;
 };
 

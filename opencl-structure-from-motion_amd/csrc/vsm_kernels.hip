@@ -32,6 +32,15 @@ __device__ __forceinline__ int4 ldg_i4(const void *p) {
   const vsm_i4 v = *(const VSM_AS1 vsm_i4 *)p;
   return make_int4(v.x, v.y, v.z, v.w);
 }
+// base + 32-bit byte offset: with a wave-uniform base the backend keeps the base in scalar registers and the offset in one
+// vector register (global_load ... v_off, s[base]) instead of building a 64-bit address per lane
+__device__ __forceinline__ uint4 ldg_u4_at(const void *base, uint32_t byte_off) {
+  const vsm_u4 v = *(const VSM_AS1 vsm_u4 *)((const VSM_AS1 char *)base + byte_off);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t ldg_u32_at(const void *base, uint32_t byte_off) {
+  return *(const VSM_AS1 uint32_t *)((const VSM_AS1 char *)base + byte_off);
+}
 __device__ __forceinline__ int32_t ldg_i32(const void *p) { return *(const VSM_AS1 int32_t *)p; }
 __device__ __forceinline__ uint32_t ldg_u32(const void *p) { return *(const VSM_AS1 uint32_t *)p; }
 
@@ -743,6 +752,17 @@ __device__ __forceinline__ int bin_of(int u, int v, int c, int binsize, int ub, 
   return (c * ub + ubin) * (vb * VSM_VSUB) + vfine_of(v, binsize, vb);
 }
 
+// the same with the division by the bin size as a multiply-high (cfg.bin_magic): k_match runs it several times per stage,
+// and an integer division by a run-time value costs ~20 instructions.  Exact for 0 <= x < 2^32 / binsize; the arguments
+// here are below 2^17 and the host refuses bin sizes above 32768.
+__device__ __forceinline__ int div_bin(int x, const VsmMatchCfg &cfg) {
+  return cfg.binsize == 1 ? x : (int)__umulhi((uint32_t)x, cfg.bin_magic);
+}
+__device__ __forceinline__ int vfine_fast(int v, const VsmMatchCfg &cfg, int vb) {
+  const int vbin = min(div_bin(v, cfg), vb - 1);
+  return vbin * VSM_VSUB + min(div_bin((v - vbin * cfg.binsize) * VSM_VSUB, cfg), VSM_VSUB - 1);
+}
+
 // Tile kernel: a block owns a rectangle of NMS cells (up to 128 x 32 matching-resolution pixels).
 // It first stages the Sobel responses of that rectangle plus the 5-pixel descriptor halo in LDS,
 // du and dv interleaved per pixel (coalesced dword row reads of both planes), then one thread per
@@ -969,21 +989,26 @@ __device__ __forceinline__ VsmQuery load_query(const VsmSet &A, int i) {
 #ifndef VSM_UVL
 #define VSM_UVL 2  // 16-byte coordinate loads in flight per lane
 #endif
-#ifndef VSM_JUDGE2
-#define VSM_JUDGE2 0
-#endif
 #ifndef VSM_MATCH_BLOCK
 #define VSM_MATCH_BLOCK 256  // threads per block of k_match
 #endif
-#ifndef VSM_RELOAD_WINNER
-#define VSM_RELOAD_WINNER 1  // 1: keep only the winner's position while scanning, fetch its record afterwards
+#ifdef VSM_MATCH_TIMING
+extern __device__ unsigned long long vsm_mt_acc[16];
+#endif
+#if defined(VSM_MATCH_TIMING) && VSM_MATCH_TIMING == 2
+#define VSM_MT_TRIP(k)                                                                       \
+  do {                                                                                       \
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&vsm_mt_acc[k], 1ull); \
+  } while (0)
+#else
+#define VSM_MT_TRIP(k)
 #endif
 typedef unsigned short vsm_us2 __attribute__((ext_vector_type(2)));
 
-template <int G, bool RELOAD = true>
+template <int G, bool RELOAD = true, bool MAYPRED = true>
 __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, const VsmDims &d, const VsmMatchCfg &cfg,
                                                bool prior, float r_umin, float r_umax, float r_vmin, float r_vmax,
-                                               bool flow, double u_, double v_, int lane) {
+                                               bool flow, double u_, double v_, int lane, long long *ph = nullptr) {
   float u_min, u_max, v_min, v_max;
   const int qu = q.u(), qv = q.v();
   if (prior) {
@@ -1001,9 +1026,6 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
     v_min = (float)(qv - cfg.disp_tol);
     v_max = (float)(qv + cfg.disp_tol);
   }
-  const float bs = (float)cfg.binsize;
-  const int ubmin = min(max((int)floorf(u_min / bs), 0), d.ub - 1);
-  const int ubmax = min(max((int)floorf(u_max / bs), 0), d.ub - 1);
   // The reference tests (float)u2 >= u_min && (float)u2 <= u_max (viso/matcher.cpp:943) on integer
   // coordinates: the same as lo <= u2 <= hi with lo = ceil(u_min), hi = floor(u_max).  Coordinates
   // are < 16384, so with both axes packed as 16-bit halves the whole window test is one wrapping
@@ -1011,20 +1033,19 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
   const int lo_u = max((int)ceilf(u_min), 0), hi_u = min((int)floorf(u_max), 65535);
   const int lo_v = max((int)ceilf(v_min), 0), hi_v = min((int)floorf(v_max), 65535);
   const bool empty = hi_u < lo_u || hi_v < lo_v;
+  // u-bins that can hold an in-window candidate: those of lo_u .. hi_u (a feature's bin is u / binsize, k_emit) - inside
+  // the reference's floor(u_min / binsize) .. floor(u_max / binsize) (:929-932), and every candidate takes the exact window
+  // test anyway; who wins a tie is settled by the candidates' ranks, not by the order of the visit
+  const int ubmin = min(div_bin(min(lo_u, 65535), cfg), d.ub - 1);
+  const int ubmax = min(div_bin(max(hi_u, 0), cfg), d.ub - 1);
   // fine rows that can hold an in-window candidate (a subset of the reference's v-bins vbmin..vbmax,
   // :933-934; every candidate still takes the exact window test below)
   const int vrows = d.vb * VSM_VSUB;
-  const int vfmin = vfine_of(min(lo_v, d.vb * cfg.binsize - 1), cfg.binsize, d.vb);
-  const int vfmax = vfine_of(min(max(hi_v, 0), d.vb * cfg.binsize - 1), cfg.binsize, d.vb);
+  const int vfmin = vfine_fast(min(lo_v, d.vb * cfg.binsize - 1), cfg, d.vb);
+  const int vfmax = vfine_fast(min(max(hi_v, 0), d.vb * cfg.binsize - 1), cfg, d.vb);
   const uint32_t lo_pk = (uint32_t)lo_u | ((uint32_t)lo_v << 16);
   const uint32_t rng_pk = (uint32_t)(hi_u - lo_u) | ((uint32_t)(hi_v - lo_v) << 16);
-  const bool pred = (u_ >= 0 && v_ >= 0);
-  double best = 10000000.0;
-  uint32_t bestq = VSM_NONE, brank = VSM_NONE;
-#if !VSM_RELOAD_WINNER
-  uint32_t buv = 0;
-  uint4 ba = make_uint4(0, 0, 0, 0), bb = make_uint4(0, 0, 0, 0);
-#endif
+  const bool pred = MAYPRED && (u_ >= 0 && v_ >= 0);
   // Two phases per stage.  (1) Walk the candidates: coordinates are packed (u | v << 16) and sorted
   // by fine bin, so one aligned 16-byte load brings 4 consecutive candidates of this lane
   // (VSM_UVL such loads in flight); the positions of the few that fall inside the window are parked
@@ -1034,73 +1055,39 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
   // runs phase 2 as many times as its busiest lane has candidates, not once per visited slot.
   // The reference keeps the FIRST minimum in its (u_bin, v_bin, index) visiting order (:937-958):
   // that is the minimum of (cost, rank), whatever order the candidates are judged in.
+  // A stage that cannot have a prediction (MAYPRED = false) compares one integer key, SAD << 32 | rank; the others keep
+  // the cost in double as the reference does.  The updates are selects, not branches.
+  double best = 10000000.0;
+  uint64_t bkey = ~0ull;
+  uint32_t bestq = VSM_NONE, brank = VSM_NONE;
   int nq = 0, q0p = 0, q1p = 0, q2p = 0, q3p = 0;
   auto judge = [&](int p) {
-    const uint4 a = ldg_u4(B.s_desc + 2 * p), b = ldg_u4(B.s_desc + 2 * p + 1);
-    const uint32_t rk = (uint32_t)ldg_i32(B.s_rank + p);
-    const uint32_t w = ldg_u32(B.s_uv + p);
-    double cost = (double)sad32(q.da, q.db, a, b);
-    if (cost <= best) {
-      if (pred) {
-        double du = (double)(int)(w & 0xffffu) - u_;
-        double dv = (double)(int)(w >> 16) - v_;
-        double dist = sqrt(du * du + dv * dv);
-        cost += 4 * dist;
-      }
-      if (cost < best || (cost == best && rk < brank)) {
-        best = cost;
-        brank = rk;
-        bestq = (uint32_t)p;
-#if !VSM_RELOAD_WINNER
-        buv = w;
-        ba = a;
-        bb = b;
-#endif
-      }
-    }
-  };
-#if VSM_JUDGE2
-  // two parked candidates per round trip: both records are requested before either is looked at
-  auto eval = [&](int p, const uint4 &a, const uint4 &b, uint32_t rk, uint32_t w) {
-    double cost = (double)sad32(q.da, q.db, a, b);
-    if (cost <= best) {
-      if (pred) {
-        double du = (double)(int)(w & 0xffffu) - u_;
-        double dv = (double)(int)(w >> 16) - v_;
-        double dist = sqrt(du * du + dv * dv);
-        cost += 4 * dist;
-      }
-      if (cost < best || (cost == best && rk < brank)) {
-        best = cost;
-        brank = rk;
-        bestq = (uint32_t)p;
+    VSM_MT_TRIP(2);
+    const uint4 a = ldg_u4_at(B.s_desc, (uint32_t)p * 32u), b = ldg_u4_at(B.s_desc, (uint32_t)p * 32u + 16u);
+    const uint32_t rk = ldg_u32_at(B.s_rank, (uint32_t)p * 4u);
+    const uint32_t sad = sad32(q.da, q.db, a, b);
+    if (!MAYPRED) {
+      const uint64_t key = ((uint64_t)sad << 32) | rk;
+      const bool better = key < bkey;
+      bkey = better ? key : bkey;
+      bestq = better ? (uint32_t)p : bestq;
+    } else {
+      double cost = (double)sad;
+      if (cost <= best) {
+        if (pred) {
+          const uint32_t w = ldg_u32_at(B.s_uv, (uint32_t)p * 4u);
+          double du = (double)(int)(w & 0xffffu) - u_;
+          double dv = (double)(int)(w >> 16) - v_;
+          double dist = sqrt(du * du + dv * dv);
+          cost += 4 * dist;
+        }
+        const bool better = cost < best || (cost == best && rk < brank);
+        best = better ? cost : best;
+        brank = better ? rk : brank;
+        bestq = better ? (uint32_t)p : bestq;
       }
     }
   };
-  auto pop_and_judge = [&]() {
-    if (nq > 0) {
-      const bool two = nq > 1;
-      const int pa = q0p, pb = two ? q1p : q0p;
-      const uint4 a0 = ldg_u4(B.s_desc + 2 * pa), a1 = ldg_u4(B.s_desc + 2 * pa + 1);
-      const uint4 b0 = ldg_u4(B.s_desc + 2 * pb), b1 = ldg_u4(B.s_desc + 2 * pb + 1);
-      const uint32_t rka = (uint32_t)ldg_i32(B.s_rank + pa), rkb = (uint32_t)ldg_i32(B.s_rank + pb);
-      uint32_t wa = 0, wb = 0;
-      if (pred) {
-        wa = ldg_u32(B.s_uv + pa);
-        wb = ldg_u32(B.s_uv + pb);
-      }
-      if (two) {
-        q0p = q2p;
-        q1p = q3p;
-        nq -= 2;
-      } else {
-        nq = 0;
-      }
-      eval(pa, a0, a1, rka, wa);
-      if (two) eval(pb, b0, b1, rkb, wb);
-    }
-  };
-#else
   auto pop_and_judge = [&]() {  // lanes with a parked candidate take their newest one
     if (nq > 0) {
       const int p = q0p;
@@ -1111,16 +1098,21 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
       judge(p);
     }
   };
+  VSM_MT_TRIP(3);
+#if defined(VSM_MATCH_TIMING) && VSM_MATCH_TIMING == 1
+  const long long ph0 = clock64();
 #endif
   for (int ubin = ubmin; ubin <= ubmax && !empty; ubin++) {
+    VSM_MT_TRIP(0);
     const int b0 = (q.c * d.ub + ubin) * vrows;
-    const int q0 = ldg_i32(B.bin_start + b0 + vfmin), q1 = ldg_i32(B.bin_start + b0 + vfmax + 1);
+    const int q0 = (int)ldg_u32_at(B.bin_start, (uint32_t)(b0 + vfmin) * 4u), q1 = (int)ldg_u32_at(B.bin_start, (uint32_t)(b0 + vfmax + 1) * 4u);
     for (int p0 = (q0 & ~3) + 4 * lane; p0 < q1; p0 += 4 * G * VSM_UVL) {
+      VSM_MT_TRIP(1);
       uint4 wk[VSM_UVL];
 #pragma unroll
       for (int j = 0; j < VSM_UVL; j++) {
         const int pj = p0 + j * 4 * G;
-        wk[j] = pj < q1 ? ldg_u4(B.s_uv + pj) : make_uint4(0, 0, 0, 0);
+        wk[j] = pj < q1 ? ldg_u4_at(B.s_uv, (uint32_t)pj * 4u) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int j = 0; j < VSM_UVL; j++) {
@@ -1146,19 +1138,33 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
       }
     }
   }
+#if defined(VSM_MATCH_TIMING) && VSM_MATCH_TIMING == 1
+  const long long ph1 = clock64();
+#endif
   while (__any(nq > 0)) pop_and_judge();
-#if !VSM_RELOAD_WINNER
-  const uint32_t myq = bestq;
+#if defined(VSM_MATCH_TIMING) && VSM_MATCH_TIMING == 1
+  const long long ph2 = clock64();
+  if (ph) {
+    ph[0] += ph1 - ph0;
+    ph[1] += ph2 - ph1;
+  }
 #endif
 #pragma unroll
   for (int m = G / 2; m >= 1; m >>= 1) {
-    double oc = __shfl_xor(best, m, G);
-    uint32_t oq = (uint32_t)__shfl_xor((int)bestq, m, G);
-    uint32_t ork = (uint32_t)__shfl_xor((int)brank, m, G);
-    if (oc < best || (oc == best && ork < brank)) {
-      best = oc;
-      bestq = oq;
-      brank = ork;
+    const uint32_t oq = (uint32_t)__shfl_xor((int)bestq, m, G);
+    if (!MAYPRED) {
+      const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)bkey, m, G), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(bkey >> 32), m, G);
+      const uint64_t ok = ((uint64_t)ohi << 32) | olo;
+      const bool better = ok < bkey;
+      bkey = better ? ok : bkey;
+      bestq = better ? oq : bestq;
+    } else {
+      const double oc = __shfl_xor(best, m, G);
+      const uint32_t ork = (uint32_t)__shfl_xor((int)brank, m, G);
+      const bool better = oc < best || (oc == best && ork < brank);
+      best = better ? oc : best;
+      bestq = better ? oq : bestq;
+      brank = better ? ork : brank;
     }
   }
   if (!RELOAD) return bestq;  // (the staged form: the next stage's kernel fetches the winner)
@@ -1166,40 +1172,48 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
     q = load_query(B, 0);
     return VSM_NONE;
   }
-#if VSM_RELOAD_WINNER
-  {  // every lane of the group fetches the winner's record (just touched, so it is in cache)
-    q.uv = ldg_u32(B.s_uv + bestq);
-    q.da = ldg_u4(B.s_desc + 2 * bestq);
-    q.db = ldg_u4(B.s_desc + 2 * bestq + 1);
-  }
-#else
-  // the winner's lane (unique: positions are distinct) hands its candidate to the whole group
-  int wl = (myq == bestq) ? lane : 0;
-#pragma unroll
-  for (int m = G / 2; m >= 1; m >>= 1) wl |= __shfl_xor(wl, m, G);
-  q.uv = (uint32_t)__shfl((int)buv, wl, G);
-  q.da.x = (uint32_t)__shfl((int)ba.x, wl, G);
-  q.da.y = (uint32_t)__shfl((int)ba.y, wl, G);
-  q.da.z = (uint32_t)__shfl((int)ba.z, wl, G);
-  q.da.w = (uint32_t)__shfl((int)ba.w, wl, G);
-  q.db.x = (uint32_t)__shfl((int)bb.x, wl, G);
-  q.db.y = (uint32_t)__shfl((int)bb.y, wl, G);
-  q.db.z = (uint32_t)__shfl((int)bb.z, wl, G);
-  q.db.w = (uint32_t)__shfl((int)bb.w, wl, G);
-#endif
+  // every lane of the group fetches the winner's record (just touched, so it is in cache; handing it over from the lane
+  // that judged it costs 20 registers and was measured 3 % quicker on pass 2, 15 % slower on pass 1)
+  q.uv = ldg_u32_at(B.s_uv, bestq * 4u);
+  q.da = ldg_u4_at(B.s_desc, bestq * 32u);
+  q.db = ldg_u4_at(B.s_desc, bestq * 32u + 16u);
   return bestq;
 }
 
-__device__ __forceinline__ int stat_bin_of(int u, int v, int binsize, int ub, int vb) {
-  int ubin = min((int)floorf((float)u / (float)binsize), ub - 1);
-  int vbin = min((int)floorf((float)v / (float)binsize), vb - 1);
-  return vbin * ub + ubin;
+// (floor((float)u / (float)binsize) of the reference, :1020-1022, is u / binsize for these integers: u < 2^14)
+__device__ __forceinline__ int stat_bin_of(int u, int v, const VsmMatchCfg &cfg, int ub, int vb) {
+  return min(div_bin(v, cfg), vb - 1) * ub + min(div_bin(u, cfg), ub - 1);
 }
 
 __device__ __forceinline__ int index_of(const VsmSet &B, uint32_t pos) { return pos == VSM_NONE ? 0 : ldg_i32(B.s_idx + pos); }
 
 #ifndef VSM_MATCH_WAVES
 #define VSM_MATCH_WAVES 4  // waves per SIMD the register allocator must leave room for
+#endif
+#ifdef VSM_MATCH_TIMING  // experiments (tools/build_variant.sh NAME -DVSM_MATCH_TIMING): life of every wave of the dense pass
+__device__ unsigned long long vsm_mt_acc[16];  // wave-level trip counts: [0] ubin iterations, [1] scan iterations, [2] judge rounds, [3] findMatch calls, [4..7] cycles of stage 1..4
+extern "C" int vsm_debug_match_acc(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vsm_mt_acc), sizeof(vsm_mt_acc)) != hipSuccess) return -1;
+  if (reset) {
+    static unsigned long long z[16];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vsm_mt_acc), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+__device__ unsigned int vsm_mt_n;
+__device__ unsigned int vsm_mt[1 << 18][8];  // life, stage 1..4, bins + scan, judging, start (low bits)
+extern "C" int vsm_debug_match_timing(unsigned int *out, unsigned int cap, int reset) {
+  unsigned int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(vsm_mt_n), 4) != hipSuccess) return -1;
+  if (n > (1u << 18)) n = 1u << 18;
+  if (n > cap) n = cap;
+  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(vsm_mt), (size_t)n * 32) != hipSuccess) return -1;
+  if (reset) {
+    const unsigned int z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vsm_mt_n), &z, 4) != hipSuccess) return -1;
+  }
+  return (int)n;
+}
 #endif
 template <int G>
 __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
@@ -1216,6 +1230,13 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
   const int qi = (bx * blockDim.x + threadIdx.x) / G;
   const int si = cfg.sparse ? 0 : 1;
   if (qi >= jb.nq[si]) return;
+#ifdef VSM_MATCH_TIMING
+  const long long mt0 = clock64();
+  long long mtph_[2] = {0, 0}, *mtph = mtph_;
+  unsigned int mtst[4] = {0, 0, 0, 0};
+#else
+  long long *mtph = nullptr;
+#endif
   const int img_prev = jb.img_prev, img_curr = jb.img_curr;
   const VsmSet &s1p = imgs[img_prev].set[si], &s2p = imgs[img_prev + 1].set[si];
   const VsmSet &s1c = imgs[img_curr].set[si], &s2c = imgs[img_curr + 1].set[si];
@@ -1226,7 +1247,7 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
   // per-stage boxes are fetched once
   VsmQuery q = load_query(cfg.method == 2 ? s1p : s1c, qi);
   // (stage-major on the device: one 16-byte load per stage, issued one stage ahead of its use)
-  const float *rg = pair.ranges + 16 * stat_bin_of(q.u(), q.v(), cfg.binsize, d.ub, d.vb);
+  const float *rg = pair.ranges + 16 * stat_bin_of(q.u(), q.v(), cfg, d.ub, d.vb);
   auto box = [&](int stage) {  // {u_min, u_max, v_min, v_max} offsets of a stage
     if (!prior) return make_float4(0, 0, 0, 0);
     const uint4 r = ldg_u4(rg + 4 * stage);
@@ -1236,17 +1257,17 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
   const int u0 = q.u(), v0 = q.v();
   if (cfg.method == 0) {  // flow, :1006-1041
     const float4 r0 = box(0), r1 = box(1);
-    const uint32_t p1 = find_match<G>(q, s1p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, true, -1, -1, lane);
+    const uint32_t p1 = find_match<G, true, false>(q, s1p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, true, -1, -1, lane);
     const int u1p = q.u(), v1p = q.v();
-    const uint32_t p2 = find_match<G>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, -1, -1, lane);
+    const uint32_t p2 = find_match<G, true, false>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, -1, -1, lane);
     const int i1p = index_of(s1p, p1), i1c2 = index_of(s1c, p2);
     ok = (i1c2 == qi);
     m = {(float)u1p, (float)v1p, i1p, -1.f, -1.f, -1, (float)u0, (float)v0, qi, -1.f, -1.f, -1};
   } else if (cfg.method == 1) {  // stereo, :1045-1084
     const float4 r0 = box(0), r1 = box(1);
-    const uint32_t p1 = find_match<G>(q, s2c, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane);
+    const uint32_t p1 = find_match<G, true, false>(q, s2c, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane);
     const int u2c = q.u(), v2c = q.v();
-    const uint32_t p2 = find_match<G>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, false, -1, -1, lane);
+    const uint32_t p2 = find_match<G, true, false>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, false, -1, -1, lane);
     const int i2c = index_of(s2c, p1), i1c2 = index_of(s1c, p2);
     ok = (i1c2 == qi) && (u0 >= u2c);
     m = {-1.f, -1.f, -1, -1.f, -1.f, -1, (float)u0, (float)v0, qi, (float)u2c, (float)v2c, i2c};
@@ -1254,8 +1275,11 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
     // (stage results stay packed u | v << 16 until the record is written: registers decide how many
     // chains a SIMD keeps in flight)
     const float4 r0 = box(0), r1 = box(1);
-    const uint32_t p1 = find_match<G>(q, s2p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane);
+    const uint32_t p1 = find_match<G, true, false>(q, s2p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane, mtph);
     const uint32_t w2p = q.uv;
+#ifdef VSM_MATCH_TIMING
+    const long long ms1 = clock64();
+#endif
     double u2c_ = -1, v2c_ = -1;
     if (jb.use_tr) {  // :1114-1126, contraction-free double arithmetic
       double dd = (double)u0 - (double)q.u();
@@ -1270,16 +1294,31 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
       v2c_ = cfg.f * y2c / z2c + cfg.cv;
     }
     const float4 r2 = box(2);
-    const uint32_t p2 = find_match<G>(q, s2c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, u2c_, v2c_, lane);
+    const uint32_t p2 = find_match<G>(q, s2c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, u2c_, v2c_, lane, mtph);
     const uint32_t w2c = q.uv;
+#ifdef VSM_MATCH_TIMING
+    const long long ms2 = clock64();
+#endif
     const float4 r3 = box(3);
-    const uint32_t p3 = find_match<G>(q, s1c, d, cfg, prior, r2.x, r2.y, r2.z, r2.w, false, -1, -1, lane);
+    const uint32_t p3 = find_match<G, true, false>(q, s1c, d, cfg, prior, r2.x, r2.y, r2.z, r2.w, false, -1, -1, lane, mtph);
     const uint32_t w1c = q.uv;
+#ifdef VSM_MATCH_TIMING
+    const long long ms3 = clock64();
+#endif
     // stage 4 predicts the chain's own start (:1134)
     const uint32_t p4 = find_match<G>(q, s1p, d, cfg, prior, r3.x, r3.y, r3.z, r3.w, true,
                                       jb.use_tr ? (double)(int)(w0 & 0xffffu) : -1.0,
-                                      jb.use_tr ? (double)(int)(w0 >> 16) : -1.0, lane);
+                                      jb.use_tr ? (double)(int)(w0 >> 16) : -1.0, lane, mtph);
     const int i1p2 = index_of(s1p, p4);
+#ifdef VSM_MATCH_TIMING
+    if (!cfg.sparse && (threadIdx.x & 63) == 0) {
+      const long long ms4 = clock64();
+      mtst[0] = (unsigned int)(ms1 - mt0);
+      mtst[1] = (unsigned int)(ms2 - ms1);
+      mtst[2] = (unsigned int)(ms3 - ms2);
+      mtst[3] = (unsigned int)(ms4 - ms3);
+    }
+#endif
     const int u2p = (int)(w2p & 0xffffu), u2c = (int)(w2c & 0xffffu), u1c = (int)(w1c & 0xffffu);
     ok = (i1p2 == qi) && (u0 >= u2p) && (u1c >= u2c);
     if (ok)
@@ -1290,6 +1329,22 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
     pair.flag[qi] = ok ? 1 : 0;
     if (ok) pair.raw[qi] = m;
   }
+#ifdef VSM_MATCH_TIMING
+  if (!cfg.sparse && (threadIdx.x & 63) == 0) {
+    const long long mt1 = clock64();
+    const unsigned int k = atomicAdd(&vsm_mt_n, 1u);
+    if (k < (1u << 18)) {
+      vsm_mt[k][0] = (unsigned int)(mt1 - mt0);
+      vsm_mt[k][1] = mtst[0];
+      vsm_mt[k][2] = mtst[1];
+      vsm_mt[k][3] = mtst[2];
+      vsm_mt[k][4] = mtst[3];
+      vsm_mt[k][5] = (unsigned int)mtph_[0];
+      vsm_mt[k][6] = (unsigned int)mtph_[1];
+      vsm_mt[k][7] = (unsigned int)mt0;
+    }
+  }
+#endif
 }
 
 // The same chains, one kernel per stage (VSM_MATCH_STAGED=1, an experiment): a stage keeps only its own query in registers
@@ -1363,7 +1418,7 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK)
   }
   float4 r = make_float4(0, 0, 0, 0);
   if (prior) {
-    const uint4 rr = ldg_u4(pair.ranges + 16 * stat_bin_of(u0, v0, cfg.binsize, d.ub, d.vb) + 4 * STAGE);
+    const uint4 rr = ldg_u4(pair.ranges + 16 * stat_bin_of(u0, v0, cfg, d.ub, d.vb) + 4 * STAGE);
     r = make_float4(__uint_as_float(rr.x), __uint_as_float(rr.y), __uint_as_float(rr.z), __uint_as_float(rr.w));
   }
   double u_ = -1, v_ = -1;
@@ -1385,7 +1440,7 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK)
     }
   }
   const int cq = q.c;
-  const uint32_t p = find_match<G, false>(q, B, d, cfg, prior, r.x, r.y, r.z, r.w, FLOW, MAYPRED ? u_ : -1.0, MAYPRED ? v_ : -1.0, lane);
+  const uint32_t p = find_match<G, false, MAYPRED>(q, B, d, cfg, prior, r.x, r.y, r.z, r.w, FLOW, MAYPRED ? u_ : -1.0, MAYPRED ? v_ : -1.0, lane);
   if (!LAST) {
     if (lane == 0) {
       uint32_t w = p | ((uint32_t)cq << 30);
