@@ -1754,7 +1754,12 @@ int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out,
     if (frame < 0 || frame >= h->seq_v2_frames) return 0;
     int32_t n = h->seq2->res_cnt[frame];
     if (n > cap) n = cap;
-    if (n > 0) memcpy(out, h->seq2->res + h->seq2->res_off[frame], (size_t)n * sizeof(vsm_p_match));
+    if (n > 0 && h->seq2->res_packed) {
+      const uint64_t *src = (const uint64_t *)(h->seq2->res + h->seq2->res_off[frame]);
+      for (int32_t i = 0; i < n; i++) vsm_unpack_match(src + 3 * (size_t)i, out[i]);
+    } else if (n > 0) {
+      memcpy(out, h->seq2->res + h->seq2->res_off[frame], (size_t)n * sizeof(vsm_p_match));
+    }
     return n;
   }
   if (frame < 0 || frame >= (int32_t)h->seq_matches.size()) return 0;

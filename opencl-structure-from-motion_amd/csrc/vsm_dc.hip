@@ -1285,6 +1285,24 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc2_compact(const VsmDc2Job *__r
     if (jb.h_out_count) *jb.h_out_count = s_total;
   }
   if (!jb.out) return;
+  if (jb.out_packed) {  // 24 bytes per survivor (the lists of a look-ahead chunk cross PCIe: that copy is what this kernel's time is)
+    uint64_t *dst = (uint64_t *)jb.out;
+    bool bad = false;
+    for (int32_t e = t; e < n; e += KD_THREADS) {
+      const int32_t d = jb.remap[e];
+      if (d < 0) continue;
+      uint64_t w[3];
+      if (vsm_pack_match(jb.list[e], w)) {
+        dst[3 * d] = w[0];
+        dst[3 * d + 1] = w[1];
+        dst[3 * d + 2] = w[2];
+      } else {
+        bad = true;
+      }
+    }
+    if (bad) *jb.error = 3;  // (a field that is not an integer in range: the caller runs the other form)
+    return;
+  }
   const uint4 *src = (const uint4 *)jb.list;
   uint4 *dst = (uint4 *)jb.out;
   for (int32_t p = t; p < 3 * n; p += KD_THREADS) {
