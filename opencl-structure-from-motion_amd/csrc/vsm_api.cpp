@@ -2122,6 +2122,18 @@ int32_t vsm_host_outliers_and_prior(const vsm_params *p, const vsm_p_match *list
   return (int32_t)m.size();
 }
 
+int32_t vsm_debug_pack_roundtrip(const vsm_p_match *in, int32_t n, vsm_p_match *out) {
+  int32_t rejected = 0;
+  for (int32_t i = 0; i < n; i++) {
+    uint64_t w[3];
+    if (vsm_pack_match(in[i], w))
+      vsm_unpack_match(w, out[i]);
+    else
+      rejected++;
+  }
+  return rejected;
+}
+
 int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, int32_t gpu_ties, int32_t copies,
                       vsm_p_match *out, int32_t cap, float *ranges, int32_t w, int32_t hh, double *kernel_us) {
   if (copies < 1) copies = 1;

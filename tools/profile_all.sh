@@ -9,11 +9,11 @@ cd /tmp && export TMPDIR=/tmp
 STAMP="# commit: ${VSM_COMMIT:-unknown}"$'\n'"# taken: $(date -u +%Y-%m-%dT%H:%MZ) on $(rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//') / $(grep -m1 'model name' /proc/cpuinfo | sed 's/.*: *//'), $(nproc) CPUs visible"
 B="python3 $R/bench.py --no-cpu-baseline --no-verify --no-per-frame"
 stamp() { { echo "$STAMP"; echo "# command: $2"; cat "$1"; } > "$3"; }
-# per-kernel time: default form of this box (host-shared with >= 11 host threads) and the GPU-resident form
+# per-kernel time: the default form (GPU-resident) and the host-shared form (VSM_SEQ_V2=0)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 3 --warmup 1 > $O/stats.log 2>&1 &&
 stamp $(ls $O/stats/*/*kernel_stats.csv) "rocprofv3 --kernel-trace --stats -- bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-per-frame" $O/${TAG}_lookahead_kernel_stats.csv &&
-VSM_SEQ_V2=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- $B --steps 3 --warmup 1 > $O/stats2.log 2>&1 &&
-stamp $(ls $O/stats2/*/*kernel_stats.csv) "VSM_SEQ_V2=1 (GPU-resident form) rocprofv3 --kernel-trace --stats -- bench.py --steps 3 --warmup 1 ..." $O/${TAG}_lookahead_gpu_resident_kernel_stats.csv &&
+VSM_SEQ_V2=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- $B --steps 3 --warmup 1 > $O/stats2.log 2>&1 &&
+stamp $(ls $O/stats2/*/*kernel_stats.csv) "VSM_SEQ_V2=0 (host-shared form) rocprofv3 --kernel-trace --stats -- bench.py --steps 3 --warmup 1 ..." $O/${TAG}_lookahead_host_shared_kernel_stats.csv &&
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/fetch.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > $O/write.log 2>&1 &&
@@ -25,5 +25,6 @@ python tools/pmc_table.py $O/sq > $O/sq_table.txt && stamp $O/sq_table.txt "rocp
 python tools/pmc_table.py $O/tcc > $O/tcc_table.txt && stamp $O/tcc_table.txt "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace -- bench.py ..." $O/${TAG}_lookahead_pmc_tcc.txt &&
 cp $O/${TAG}_lookahead_pmc_hbm.csv profiles/ &&
 timeout -k 10 500 python bench.py > $O/${TAG}_lookahead_bench.json 2> $O/bench.err &&
-for t in 8 4 2; do VSM_HOST_THREADS=$t timeout -k 10 300 python bench.py --no-cpu-baseline --no-per-frame > $O/${TAG}_lookahead_bench_${t}threads.json 2>> $O/bench.err; done
+for t in 8 4 2 1; do VSM_HOST_THREADS=$t timeout -k 10 300 python bench.py --no-cpu-baseline --no-per-frame > $O/${TAG}_lookahead_bench_${t}threads.json 2>> $O/bench.err; done
+VSM_SEQ_V2=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-per-frame > $O/${TAG}_lookahead_bench_host_shared_form.json 2>> $O/bench.err
 echo "exit $?"; ls $O | grep ${TAG}_
