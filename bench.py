@@ -48,6 +48,8 @@ def algorithmic_bytes(kernel, counts):
     P, Ph, Hh = counts["P"], counts["Ph"], counts["Hh"]
     if kernel == "k_filters<true>":      # read image, write du_full + dv_full
         return counts["imgs"] * (W * H + 2 * P * H)
+    if kernel == "k_front":              # read the caller's image once; write half image + the tiled du/dv plane (2 B / pixel)
+        return counts["imgs"] * (W * H + Ph * Hh + 2 * P * H)
     if kernel == "k_filters<false>":     # read half image, write du,dv (u8) + f1,f2 (i16)
         return counts["imgs"] * (Ph * Hh + 2 * Ph * Hh + 4 * Ph * Hh)
     if kernel.startswith("k_match"):      # 48 B/query record, 8 B/candidate, 32 B/SAD, 48 B/raw result
@@ -76,6 +78,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-per-frame", action="store_true", help="skip the per-frame API leg (profiling runs)")
+    ap.add_argument("--no-alone", action="store_true", help="skip the non-overlapped profiling pass (runs under rocprofv3: its launches would mix into the averages)")
     args = ap.parse_args()
 
     import torch
@@ -263,6 +266,21 @@ def main():
     torch.cuda.synchronize()
     stats = m.kernel_stats()
     m.set_profiling(False)
+    # ... and once more with nothing overlapping (VSM_SEQ_SERIAL=1: every group of launches drains before the next is
+    # enqueued): the same kernels on the same data with the GPU to themselves.  In the timed region the matching kernels
+    # share their SIMDs with the single-lane seam walks of the exact Delaunay chains, which take vector-issue cycles at the
+    # price of a full wavefront; "alone" is what the kernel itself does, "frac" what it gets in the pipeline.
+    stats_alone = None
+    if not args.no_alone:
+        os.environ["VSM_SEQ_SERIAL"] = "1"
+        try:
+            m.set_profiling(True)
+            run_sequence()
+            torch.cuda.synchronize()
+            stats_alone = m.kernel_stats()
+        finally:
+            m.set_profiling(False)
+            del os.environ["VSM_SEQ_SERIAL"]
     # The hot path proper (filter + match + refinement kernels on the main stream) and, announced beside it, whatever leads
     # over ALL streams - the exact Delaunay kernels run on streams of their own (k_export_list is a PCIe copy, not HBM)
     hot = [k for k in stats if stats[k][1] and not k.startswith("k_dc_") and k != "k_export_list"]
@@ -322,9 +340,15 @@ def main():
         if ab is None or nl == 0:
             return None
         achieved = ab / (ms / nl / 1e3) / 1e9
-        return dict(bound="hbm", kernel=kname, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=pmc.get(kname), avg_launch_us=round(ms / nl * 1e3, 3),
-                    algorithmic_bytes_per_launch=int(ab))
+        r = dict(bound="hbm", kernel=kname, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                 frac=round(achieved / HBM_PEAK_GBS, 6), traffic=pmc.get(kname), avg_launch_us=round(ms / nl * 1e3, 3),
+                 algorithmic_bytes_per_launch=int(ab))
+        if stats_alone and stats_alone.get(kname, (0, 0))[1]:
+            ms1, nl1 = stats_alone[kname]
+            a1 = ab * (nl / nl1) / (ms1 / nl1 / 1e3) / 1e9   # (same work per sequence; per-launch bytes follow the launch count)
+            r["alone"] = {"avg_launch_us": round(ms1 / nl1 * 1e3, 3), "achieved": round(a1, 3), "frac": round(a1 / HBM_PEAK_GBS, 6),
+                          "what": "same kernel, same data, nothing else on the GPU (VSM_SEQ_SERIAL=1 pass)"}
+        return r
 
     roof = roofline_of(dom)
     roof_all = {k: r for k in stats if stats[k][1] for r in [roofline_of(k)] if r}
@@ -363,7 +387,8 @@ def main():
         "vo_mono_egomotion": mono,
         "verified_bit_exact_vs_reference_hashes": verified,
         "roofline": roof,
-        "roofline_by_kernel": {k: {"achieved_GBps": r["achieved"], "frac": r["frac"], "avg_launch_us": r["avg_launch_us"]}
+        "roofline_by_kernel": {k: {"achieved_GBps": r["achieved"], "frac": r["frac"], "avg_launch_us": r["avg_launch_us"],
+                                   "alone_frac": (r.get("alone") or {}).get("frac"), "alone_us": (r.get("alone") or {}).get("avg_launch_us")}
                                for k, r in roof_all.items()},
         "cpu_baseline": cpu,
         "kernel_ms_per_frame": {k: round(v[0] / nf, 5) for k, v in stats.items() if v[1]},

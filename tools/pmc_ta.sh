@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2/ta
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-verify --no-per-frame --steps 1 --warmup 0"
+B="python3 $R/bench.py --no-cpu-baseline --no-verify --no-per-frame --no-alone --steps 1 --warmup 0"
 i=0
 for set in "TA_TA_BUSY_sum GRBM_GUI_ACTIVE" "TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TCP_GATE_EN1_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" "TD_TD_BUSY_sum TD_TC_STALL_sum" "TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_READ_WAVEFRONTS_sum"; do

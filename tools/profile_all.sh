@@ -7,7 +7,7 @@ O=$R/gpurun_out/prof
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 STAMP="# commit: ${VSM_COMMIT:-unknown}"$'\n'"# taken: $(date -u +%Y-%m-%dT%H:%MZ) on $(rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//') / $(grep -m1 'model name' /proc/cpuinfo | sed 's/.*: *//'), $(nproc) CPUs visible"
-B="python3 $R/bench.py --no-cpu-baseline --no-verify --no-per-frame"
+B="python3 $R/bench.py --no-cpu-baseline --no-verify --no-per-frame --no-alone"
 stamp() { { echo "$STAMP"; echo "# command: $2"; cat "$1"; } > "$3"; }
 # per-kernel time: the default form (GPU-resident) and the host-shared form (VSM_SEQ_V2=0)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 3 --warmup 1 > $O/stats.log 2>&1 &&

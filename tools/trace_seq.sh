@@ -5,5 +5,5 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2/$TAG
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --no-cpu-baseline --no-per-frame --no-verify --steps 2 --warmup 2 > $O.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --no-cpu-baseline --no-per-frame --no-verify --no-alone --steps 2 --warmup 2 > $O.log 2>&1
 echo "exit $?"
