@@ -1922,11 +1922,10 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
   // lanes per query: the chain is latency-bound per wavefront, so big batches want many
   // queries per wave (G = 2..4) and a lone frame pair wants more lanes per query (G = 8).
   // VSM_MATCH_G overrides (2, 4, 8, 16) for experiments.
-  static int Genv = -1;
-  if (Genv < 0) {
-    const char *e = getenv("VSM_MATCH_G");
-    Genv = e ? atoi(e) : 0;
-    if (Genv != 0 && Genv != 1 && Genv != 2 && Genv != 4 && Genv != 8 && Genv != 16) Genv = 0;
+  int Genv = 0;  // (read on every call: the tests switch it inside one process)
+  if (const char *e = getenv("VSM_MATCH_G")) {
+    Genv = atoi(e);
+    if (Genv != 1 && Genv != 2 && Genv != 4 && Genv != 8 && Genv != 16) Genv = 0;
   }
   const long total_q = (long)npairs * max_nq;
   const int G = Genv ? Genv : (total_q >= 200000 ? 2 : (total_q >= 30000 ? 4 : 8));
@@ -1936,12 +1935,8 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
     const int nbx = cdiv(max_nq * G, VSM_MATCH_BLOCK);
     const dim3 grid(((nbx * npairs + 7) / 8) * 8);
     // VSM_MATCH_STAGED=1: one kernel per stage (k_chain) - measured slower than the single launch, kept for experiments
-    static int staged_env = -1;
-    if (staged_env < 0) {
-      const char *e = getenv("VSM_MATCH_STAGED");
-      staged_env = e && atoi(e) ? 1 : 0;
-    }
-    const bool staged = staged_env == 1;
+    const char *se = getenv("VSM_MATCH_STAGED");
+    const bool staged = se && atoi(se) != 0;
     if (staged && (G == 2 || G == 4 || G == 8)) {
 #define VSM_CHAIN_LAUNCH(GG, KIND) \
   hipLaunchKernelGGL((k_chain<GG, KIND>), grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs)

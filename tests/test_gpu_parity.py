@@ -283,6 +283,34 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
     m.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"VSM_SEQ_SERIAL": "1"}, {"VSM_SEQ_PACK": "0"}, {"VSM_SEQ_DC_STREAMS": "1"}, {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNKS": "5,9,3"},
+                                 {"VSM_SEQ_TAPER": "1", "VSM_SEQ_CHUNK": "16"}, {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
+                                 {"VSM_MATCH_STAGED": "1"}, {"VSM_FRONT": "0"}, {"VSM_MATCH_G": "8"}])
+def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
+    """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), 48-byte result
+    records instead of the packed ones, one / four chain streams, explicit and tapered chunk sizes, the vertex sorts on the
+    device, one matching kernel per chain stage, the unfused front end, eight lanes per query: always the reference's lists,
+    and always this form (it must not quietly hand the run to the other one)."""
+    import torch
+    monkeypatch.setenv("VSM_SEQ_V2", "1")
+    monkeypatch.setenv("VSM_SEQ_CHUNK", "10")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = G.load("cfg2_seq200_tr")
+    w, h, nf = int(g["w"]), int(g["h"]), 36
+    cv = synth.canvas(int(g["seed"]), w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
+    left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
+    right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
+    m = vm.Matcher()
+    m.set_intrinsics(*[float(x) for x in g["intr"]])
+    got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
+    assert m.sequence_path() == 2, env
+    for f in range(nf):
+        assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), (env, f)
+    m.close()
+
+
 @pytest.mark.parametrize("env", [{"VSM_DC_GPU": "0"}, {"VSM_DC_FULL": "1"}, {"VSM_DC_FULL": "0"}, {"VSM_DC_FULL": "0", "VSM_DC_TIES": "1"}, {"VSM_DC_FULL": "1", "VSM_DC_KD": "0"},
                                  {"VSM_DC_BLOCK": "0"}, {"VSM_DC_BLOCK": "0", "VSM_DC_KD": "0"},
                                  {"VSM_DC_KD": "0"}, {"VSM_DC_BLOCK": "0", "VSM_DC_LEAF": "64", "VSM_DC_TOP": "0"},
