@@ -1828,15 +1828,15 @@ int32_t vsm_get_gradients(vsm_handle *h, int32_t which, int32_t full, uint8_t *d
   if (full && !h->param.half_resolution) return 0;
   const VsmImage &im = c.h_imgs[slot * 2 + side];
   const int32_t bytes = full ? c.dims.bpl * c.dims.h : c.dims.mbpl * c.dims.mh;
-  if (full) {  // the tiled plane (8 x 8 tiles: 8 du bytes, 8 dv bytes per tile row), un-tiled here
+  if (full) {  // the tiled plane (8 x 8 tiles; a tile row = du 0-3, dv 0-3, du 4-7, dv 4-7: vsm_tiled_at in vsm_kernels.hip), un-tiled here
     const int bpl = c.dims.bpl, hh = c.dims.h;
     std::vector<uint8_t> t((size_t)bpl * ((hh + 7) & ~7) * 2);
     if (hipMemcpy(t.data(), im.duv_tiled, t.size(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     for (int y = 0; y < hh; y++)
       for (int x = 0; x < bpl; x++) {
-        const size_t a = ((size_t)(y >> 3) * (size_t)(bpl >> 3) + (size_t)(x >> 3)) * 128 + (size_t)((y & 7) * 16 + (x & 7));
+        const size_t a = ((size_t)(y >> 3) * (size_t)(bpl >> 3) + (size_t)(x >> 3)) * 128 + (size_t)((y & 7) * 16 + ((x & 4) << 1) + (x & 3));
         if (du) du[(size_t)y * bpl + x] = t[a];
-        if (dv) dv[(size_t)y * bpl + x] = t[a + 8];
+        if (dv) dv[(size_t)y * bpl + x] = t[a + 4];
       }
     return bytes;
   }

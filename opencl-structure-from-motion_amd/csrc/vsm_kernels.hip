@@ -122,12 +122,14 @@ __global__ void __launch_bounds__(256) k_halve(const VsmImage *__restrict__ imgs
 // ---------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------
 // Full-resolution Sobel planes of half_resolution = 1 (read by the refinement only, as scattered 9 x 9 neighbourhoods):
-// ONE plane of 8 x 8-pixel tiles, 128 bytes each = one cache line: tile row = 8 du bytes then 8 dv bytes.  A refinement
+// ONE plane of 8 x 8-pixel tiles, 128 bytes each = one cache line; a tile row is 16 bytes: du of pixels 0-3, dv of pixels
+// 0-3, du of 4-7, dv of 4-7 (what a filter thread produces for its 4-pixel patch row is one 8-byte store).  A refinement
 // window (9 rows x 9 columns of both responses) lies in exactly 4 lines instead of 16, its row in two 16-byte loads.
-// du of pixel (x, y) at vsm_tiled_at(bpl, x, y), dv 8 bytes further.
+// du of pixel (x, y) at vsm_tiled_at(bpl, x, y), dv VSM_TILED_DV bytes further.
 // ---------------------------------------------------------------------------------------
+#define VSM_TILED_DV 4
 __host__ __device__ __forceinline__ size_t vsm_tiled_at(int bpl, int x, int y) {
-  return ((size_t)(y >> 3) * (size_t)(bpl >> 3) + (size_t)(x >> 3)) * 128 + (size_t)((y & 7) * 16 + (x & 7));
+  return ((size_t)(y >> 3) * (size_t)(bpl >> 3) + (size_t)(x >> 3)) * 128 + (size_t)((y & 7) * 16 + ((x & 4) << 1) + (x & 3));
 }
 
 #define FPB(r, i) ((int)((Wn[(r)][(i) >> 2] >> (8 * ((i)&3))) & 0xffu))
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(256)
   }
   const int lo = 2 * bpl, hi = (h - 2) * bpl;
   uint8_t *__restrict__ odu = FULL ? im.duv_tiled : im.du;
-  uint8_t *__restrict__ odv = FULL ? im.duv_tiled + 8 : im.dv;
+  uint8_t *__restrict__ odv = FULL ? im.duv_tiled + VSM_TILED_DV : im.dv;
   int16_t *f1 = FULL ? nullptr : f1base + (size_t)blockIdx.z * f_stride;
   int16_t *f2 = FULL ? nullptr : f2base + (size_t)blockIdx.z * f_stride;
 #pragma unroll
@@ -239,9 +241,11 @@ __global__ void __launch_bounds__(256)
   const int x0 = blockIdx.x * FRONT_TW, y0 = blockIdx.y * FRONT_TH;
   const int t = threadIdx.x;
   // ---- tile of the padded stream into LDS ----
-  for (int e = t; e < FRONT_LH * (FRONT_LW / 4); e += 256) {
-    const int r = e / (FRONT_LW / 4), c = e - r * (FRONT_LW / 4);
-    int y = y0 - 2 + r, x = x0 - 4 + 4 * c;  // stream position y * bpl + x; x may run into the neighbouring stream rows
+  // Items of four LDS dwords (16 stream bytes; the last item of a row has two).  An item that lies inside one image row
+  // takes ONE aligned 16-byte load plus one dword and four byte-aligns; the others (row ends, tile edges, rows outside the
+  // image) go dword by dword: two aligned dwords + an align each, bytes beyond the row's w and positions outside the
+  // image 0.  (Every 4-byte piece used to cost two loads: the kernel was bound by the texture addresser's lane rate.)
+  auto load_dword = [&](int y, int x) -> uint32_t {  // stream position y * bpl + x; x may run into the neighbouring stream rows
     if (x < 0) {
       x += bpl;
       y -= 1;
@@ -259,7 +263,25 @@ __global__ void __launch_bounds__(256)
       v = __builtin_amdgcn_alignbyte(hi, lo, sh);
       if (nvalid < 4) v &= (1u << (8 * nvalid)) - 1u;
     }
-    s_in[r][c] = v;
+    return v;
+  };
+  constexpr int kItems = (FRONT_LW / 4 + 3) / 4;  // per row
+  for (int e = t; e < FRONT_LH * kItems; e += 256) {
+    const int r = e / kItems, g = e - r * kItems;
+    const int y = y0 - 2 + r, x = x0 - 4 + 16 * g;
+    const int nd = min(4, FRONT_LW / 4 - 4 * g);
+    if (nd == 4 && y >= 0 && y < h && x >= 0 && x + 20 <= w) {
+      const uintptr_t a = (uintptr_t)(src + (size_t)y * src_bpl + x);
+      const uint32_t sh = (uint32_t)(a & 3);
+      const uint4 q = ldg_u4((const void *)(a - sh));
+      const uint32_t q4 = ldg_u32((const void *)(a - sh + 16));
+      s_in[r][4 * g] = __builtin_amdgcn_alignbyte(q.y, q.x, sh);
+      s_in[r][4 * g + 1] = __builtin_amdgcn_alignbyte(q.z, q.y, sh);
+      s_in[r][4 * g + 2] = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
+      s_in[r][4 * g + 3] = __builtin_amdgcn_alignbyte(q4, q.w, sh);
+    } else {
+      for (int k = 0; k < nd; k++) s_in[r][4 * g + k] = load_dword(y, x + 4 * k);
+    }
   }
   __syncthreads();
   // ---- padded copy (pad bytes 0), where asked for ----
@@ -298,6 +320,52 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int q = 0; q < 3; q++) Wn[r][q] = s_in[4 * ty + r][tx + q];
   }
+  if (yb >= 3 && yb + 3 <= h - 4) {
+    // Interior patch (every stream position of the 8 x 4 window lies in rows [2, h-3]: no zeroing): the same sums two
+    // pixels per instruction.  Bytes 2..9 of a window row become four pairs of 16-bit lanes; the 5-tap column sums
+    // (<= 4080 unsigned, +-765 signed) and the row passes (+-24480, +-12240) fit 16 bits, and (x >> 7) + 128 clamped to a
+    // byte is the same arithmetic shift as in 32 bits.
+    typedef short vsm_s2 __attribute__((ext_vector_type(2)));
+    vsm_s2 Pk[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      Pk[r][0] = __builtin_bit_cast(vsm_s2, __builtin_amdgcn_perm(0u, Wn[r][0], 0x0c030c02u));
+      Pk[r][1] = __builtin_bit_cast(vsm_s2, __builtin_amdgcn_perm(0u, Wn[r][1], 0x0c010c00u));
+      Pk[r][2] = __builtin_bit_cast(vsm_s2, __builtin_amdgcn_perm(0u, Wn[r][1], 0x0c030c02u));
+      Pk[r][3] = __builtin_bit_cast(vsm_s2, __builtin_amdgcn_perm(0u, Wn[r][2], 0x0c010c00u));
+    }
+    auto shl1 = [](vsm_s2 hi2, vsm_s2 lo2) -> vsm_s2 {  // (lo2.y, hi2.x): the pair one column further
+      return __builtin_bit_cast(vsm_s2, __builtin_amdgcn_alignbyte(__builtin_bit_cast(uint32_t, hi2), __builtin_bit_cast(uint32_t, lo2), 2u));
+    };
+    auto to_byte = [](vsm_s2 v) -> vsm_s2 {
+      const vsm_s2 c128 = {128, 128}, c0 = {0, 0}, c255 = {255, 255};
+      v = (v >> 7) + c128;
+      return __builtin_elementwise_min(__builtin_elementwise_max(v, c0), c255);
+    };
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int y = yb + rr;
+      vsm_s2 S[4], D[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const vsm_s2 a = Pk[rr][j], b = Pk[rr + 1][j], c = Pk[rr + 2][j], dd = Pk[rr + 3][j], e = Pk[rr + 4][j];
+        S[j] = (a + e) + (b + dd) * (short)4 + c * (short)6;
+        D[j] = (a - e) + (b - dd) * (short)2;
+      }
+      const vsm_s2 S12 = shl1(S[1], S[0]), S34 = shl1(S[2], S[1]), S56 = shl1(S[3], S[2]);
+      const vsm_s2 D12 = shl1(D[1], D[0]), D34 = shl1(D[2], D[1]), D56 = shl1(D[3], D[2]);
+      const vsm_s2 hu01 = (S[0] - S[2]) + (S12 - S34) * (short)2, hu23 = (S[1] - S[3]) + (S34 - S56) * (short)2;
+      const vsm_s2 hv01 = (D[0] + D[2]) + (D12 + D34) * (short)4 + D[1] * (short)6, hv23 = (D[1] + D[3]) + (D34 + D56) * (short)4 + D[2] * (short)6;
+      const uint32_t du = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, to_byte(hu23)), __builtin_bit_cast(uint32_t, to_byte(hu01)), 0x06040200u);
+      const uint32_t dv = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, to_byte(hv23)), __builtin_bit_cast(uint32_t, to_byte(hv01)), 0x06040200u);
+      typedef uint32_t vsm_u2 __attribute__((ext_vector_type(2)));
+      vsm_u2 o;
+      o.x = du;
+      o.y = dv;
+      *(VSM_AS1 vsm_u2 *)(im.duv_tiled + vsm_tiled_at(bpl, x4, y)) = o;
+    }
+    return;
+  }
 #define FPB(r, i) ((int)((Wn[(r)][(i) >> 2] >> (8 * ((i)&3))) & 0xffu))
   const int lo = 2 * bpl, hi = (h - 2) * bpl;
 #pragma unroll
@@ -325,7 +393,7 @@ __global__ void __launch_bounds__(256)
     }
     const size_t o0 = vsm_tiled_at(bpl, x4, y);
     *(VSM_AS1 uint32_t *)(im.duv_tiled + o0) = du;
-    *(VSM_AS1 uint32_t *)(im.duv_tiled + o0 + 8) = dv;
+    *(VSM_AS1 uint32_t *)(im.duv_tiled + o0 + VSM_TILED_DV) = dv;
   }
 #undef FPB
 }
@@ -1576,7 +1644,7 @@ __device__ __forceinline__ uint4 small_desc(const uint8_t *__restrict__ du, cons
 // the same descriptor from the tiled plane
 __device__ __forceinline__ uint4 small_desc_tiled(const uint8_t *__restrict__ t, int bpl, int u, int v) {
 #define TDU(x, y) ((uint32_t)t[vsm_tiled_at(bpl, (x), (y))])
-#define TDV(x, y) ((uint32_t)t[vsm_tiled_at(bpl, (x), (y)) + 8])
+#define TDV(x, y) ((uint32_t)t[vsm_tiled_at(bpl, (x), (y)) + VSM_TILED_DV])
   uint4 r;
   r.x = TDU(u, v - 2) | (TDU(u - 2, v - 1) << 8) | (TDU(u, v - 1) << 16) | (TDU(u + 2, v - 1) << 24);
   r.y = TDU(u - 1, v) | (TDU(u, v) << 8) | (TDU(u, v) << 16) | (TDU(u + 1, v) << 24);
@@ -1603,7 +1671,7 @@ __device__ __forceinline__ uint4 refine_ref_desc(const VsmImage &ref, const VsmD
   const int b0 = (ru - 2) & ~3, rsh = 8 * ((ru - 2) - b0);
   uint64_t wu[5], wv[3];
   if (TILED) {
-    // the two 4-pixel blocks holding columns ru-2 .. ru+2: block j of row y sits in tile j >> 1, half j & 1
+    // the two 4-pixel blocks holding columns ru-2 .. ru+2 (vsm_tiled_at of their first pixels)
     const int j0 = b0 >> 2;
 #pragma unroll
     for (int r = 0; r < 5; r++) {
@@ -1611,7 +1679,7 @@ __device__ __forceinline__ uint4 refine_ref_desc(const VsmImage &ref, const VsmD
       const uint32_t lo = ldg_u32(row + vsm_tiled_at(dc.bpl, 4 * j0, rv - 2 + r)), hi = ldg_u32(row + vsm_tiled_at(dc.bpl, 4 * j0 + 4, rv - 2 + r));
       wu[r] = ((((uint64_t)hi) << 32) | lo) >> rsh;
       if (r >= 1 && r <= 3) {
-        const uint32_t lv = ldg_u32(row + vsm_tiled_at(dc.bpl, 4 * j0, rv - 2 + r) + 8), hv = ldg_u32(row + vsm_tiled_at(dc.bpl, 4 * j0 + 4, rv - 2 + r) + 8);
+        const uint32_t lv = ldg_u32(row + vsm_tiled_at(dc.bpl, 4 * j0, rv - 2 + r) + VSM_TILED_DV), hv = ldg_u32(row + vsm_tiled_at(dc.bpl, 4 * j0 + 4, rv - 2 + r) + VSM_TILED_DV);
         wv[r - 1] = ((((uint64_t)hv) << 32) | lv) >> rsh;
       }
     }
@@ -1686,19 +1754,19 @@ __global__ void __launch_bounds__(256)
   const int iu = (int)u2, iv = (int)v2;
   uint32_t U[9][3], V[9][3];
   if (TILED) {
-    // tiled plane: the 9 columns iu-4 .. iu+4 start at byte o = (iu-4) & 7 of a tile row and end in the next tile; one
-    // 16-byte load per tile row brings 8 du + 8 dv bytes
+    // tiled plane: the 9 columns iu-4 .. iu+4 start at pixel o = (iu-4) & 7 of a tile row and end in the next tile; one
+    // 16-byte load per tile row brings du 0-3, dv 0-3, du 4-7, dv 4-7
     const int o = (iu - 4) & 7, b = o >> 2;
     const uint32_t sb = (uint32_t)(o & 3);
 #pragma unroll
     for (int r = 0; r < 9; r++) {
       const uint8_t *pr = tgt.duv_tiled + vsm_tiled_at(dt.bpl, (iu - 4) & ~7, iv - 4 + r);
       const uint4 t0 = ldg_u4(pr), t1 = ldg_u4(pr + 128);
-      const uint32_t d0 = b ? t0.y : t0.x, d1 = b ? t1.x : t0.y, d2 = b ? t1.y : t1.x;
+      const uint32_t d0 = b ? t0.z : t0.x, d1 = b ? t1.x : t0.z, d2 = b ? t1.z : t1.x;
       U[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sb);
       U[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sb);
       U[r][2] = d2 >> (8 * sb);
-      const uint32_t e0 = b ? t0.w : t0.z, e1 = b ? t1.z : t0.w, e2 = b ? t1.w : t1.z;
+      const uint32_t e0 = b ? t0.w : t0.y, e1 = b ? t1.y : t0.w, e2 = b ? t1.w : t1.y;
       V[r][0] = __builtin_amdgcn_alignbyte(e1, e0, sb);
       V[r][1] = __builtin_amdgcn_alignbyte(e2, e1, sb);
       V[r][2] = e2 >> (8 * sb);
