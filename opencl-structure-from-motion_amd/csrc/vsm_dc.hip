@@ -903,9 +903,12 @@ extern "C" int vsm_debug_dc2_phases(unsigned long long *out, int reset) {
 #define DC2_T(var)
 #define DC2_ACC(row, col, a, b)
 #endif
-// One wave per block sub-tree (<= VSM_DC_BLOCK_POINTS points) as k_dc_block, on the 16-bit local mesh: 22 KB of LDS per
-// wave instead of 40, so seven waves share a CU.
-__global__ void __launch_bounds__(64) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
+// One workgroup per block sub-tree (<= VSM_DC_BLOCK_POINTS points) as k_dc_block, on the 16-bit local mesh: 22 KB of LDS
+// instead of 40.  FOUR waves: lanes that walk different seams diverge, and a wave issues every diverging lane's path in
+// turn, so the quarter sub-trees of the block go to a wave each (they sit on the CU's four SIMDs) - 8 leaves instead of
+// 32 per wave, one merge node per wave from the third level up.  Measured alone, 50 lists of 7.4 k: 450 -> 330 us.
+#define DC2_BLOCK_THREADS 256
+__global__ void __launch_bounds__(DC2_BLOCK_THREADS) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
   __shared__ __attribute__((aligned(16))) dc2_word s_rec[2 * VSM_DC_BLOCK_POINTS * 8];
   __shared__ uint64_t s_key[VSM_DC_BLOCK_POINTS];
   __shared__ uint32_t s_pt[VSM_DC_BLOCK_POINTS];
@@ -937,12 +940,13 @@ __global__ void __launch_bounds__(64) k_dc2_block(const VsmDc2Job *__restrict__ 
   }
   if (d < depth && (path & ((1u << (depth - d)) - 1u)) != 0) return;
   const int lane = threadIdx.x;
+  const int wv = lane >> 6, wl = lane & 63;  // wave, lane in the wave
   DC2_T(c0);
-  for (int i = lane; i < bn; i += 64) s_key[i] = j2.key[boff + i];
+  for (int i = lane; i < bn; i += DC2_BLOCK_THREADS) s_key[i] = j2.key[boff + i];
   {
     dc2_v4u ones;
     ones.x = ones.y = ones.z = ones.w = 0xffffffffu;
-    for (int i = lane; i < 2 * bn * (int)sizeof(dc2_word) / 2; i += 64) ((dc2_v4u *)s_rec)[i] = ones;
+    for (int i = lane; i < 2 * bn * (int)sizeof(dc2_word) / 2; i += DC2_BLOCK_THREADS) ((dc2_v4u *)s_rec)[i] = ones;
   }
   __syncthreads();
   DcBlockMesh mesh;
@@ -952,14 +956,23 @@ __global__ void __launch_bounds__(64) k_dc2_block(const VsmDc2Job *__restrict__ 
   mesh.ptw = (DC2_AS3 uint32_t *)s_pt;
   mesh.gid = j2.id + boff;
   DC2_T(c1);
-  dc2_block_leaf_run(mesh, lane, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+  // leaf of virtual lane (wave << 4 | lane): the two top bits of a path - the quarter of the block - are the wave
+  if (wl < 16) dc2_block_leaf_run(mesh, (wv << 4) | wl, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
   __syncthreads();
   DC2_T(c2);
 #ifdef DC2_PHASE_TIMING
   long long cl = c2;
 #endif
   for (int L = DC2_BLOCK_DEPTH - 1; L >= 0; L--) {
-    dc2_block_merge_run(mesh, lane, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+    {  // node j of level L (2^L nodes): quarter = wave from the third level up; the two top levels on waves 0, 1 / wave 0
+      int j = -1;
+      if (L >= 2) {
+        if (wl < (1 << (L - 2))) j = (wv << (L - 2)) | wl;
+      } else if (wl == 0 && wv < (1 << L)) {
+        j = wv;
+      }
+      if (j >= 0) dc2_block_merge_run(mesh, j, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+    }
     __syncthreads();
 #ifdef DC2_PHASE_TIMING
     {
@@ -972,11 +985,11 @@ __global__ void __launch_bounds__(64) k_dc2_block(const VsmDc2Job *__restrict__ 
   DC2_T(c3);
   // records out under global numbering
   int32_t *gt = j2.tri + (size_t)2 * boff * 8;
-  for (int i = lane; i < 2 * bn * 8; i += 64) {
+  for (int i = lane; i < 2 * bn * 8; i += DC2_BLOCK_THREADS) {
     const uint32_t v = s_rec[i];
     gt[i] = v == DC2_NONE ? -1 : (int32_t)v + ((i & 4) ? boff : 8 * boff);
   }
-  for (int i = lane; i < bn; i += 64) j2.pt[boff + i] = s_pt[i];
+  for (int i = lane; i < bn; i += DC2_BLOCK_THREADS) j2.pt[boff + i] = s_pt[i];
   if (lane == 0) {
     const Dc2Hull16 hl = s_hull[1];
     j2.hulls[bidx] = VsmDcHull{hl.fl_t + 2 * boff, hl.fl_o, hl.fr_t + 2 * boff, hl.fr_o};
@@ -1397,7 +1410,7 @@ void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs) {
 }
 void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(k_dc2_block, dim3(1 << depth, njobs), dim3(64), 0, s, d_jobs, depth);
+  hipLaunchKernelGGL(k_dc2_block, dim3(1 << depth, njobs), dim3(DC2_BLOCK_THREADS), 0, s, d_jobs, depth);
 }
 void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth, int max_list) {
   if (njobs <= 0) return;
