@@ -38,6 +38,12 @@ __device__ __forceinline__ uint4 ldg_u4_at(const void *base, uint32_t byte_off) 
   const vsm_u4 v = *(const VSM_AS1 vsm_u4 *)((const VSM_AS1 char *)base + byte_off);
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+// 16 bytes at a dword-aligned (not 16-byte-aligned) offset: one global_load_dwordx4 all the same
+typedef uint32_t vsm_u4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ uint4 ldg_u4_at_dw(const void *base, uint32_t byte_off) {
+  const vsm_u4_a4 v = *(const VSM_AS1 vsm_u4_a4 *)((const VSM_AS1 char *)base + byte_off);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ uint32_t ldg_u32_at(const void *base, uint32_t byte_off) {
   return *(const VSM_AS1 uint32_t *)((const VSM_AS1 char *)base + byte_off);
 }
@@ -1060,6 +1066,9 @@ __device__ __forceinline__ VsmQuery load_query(const VsmSet &A, int i) {
 #ifndef VSM_MATCH_BLOCK
 #define VSM_MATCH_BLOCK 256  // threads per block of k_match
 #endif
+#ifndef VSM_SCAN_UNALIGNED
+#define VSM_SCAN_UNALIGNED 1  // coordinate loads start at the run's first candidate (dword-aligned 16-byte loads) instead of at the 16-byte line below it
+#endif
 #ifdef VSM_MATCH_TIMING
 extern __device__ unsigned long long vsm_mt_acc[16];
 #endif
@@ -1174,13 +1183,22 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
     VSM_MT_TRIP(0);
     const int b0 = (q.c * d.ub + ubin) * vrows;
     const int q0 = (int)ldg_u32_at(B.bin_start, (uint32_t)(b0 + vfmin) * 4u), q1 = (int)ldg_u32_at(B.bin_start, (uint32_t)(b0 + vfmax + 1) * 4u);
+#if VSM_SCAN_UNALIGNED
+    for (int p0 = q0 + 4 * lane; p0 < q1; p0 += 4 * G * VSM_UVL) {  // (the run's first candidate first: only the tail needs a bound)
+#else
+    const uint32_t qn = (uint32_t)(q1 - q0);
     for (int p0 = (q0 & ~3) + 4 * lane; p0 < q1; p0 += 4 * G * VSM_UVL) {
+#endif
       VSM_MT_TRIP(1);
       uint4 wk[VSM_UVL];
 #pragma unroll
       for (int j = 0; j < VSM_UVL; j++) {
         const int pj = p0 + j * 4 * G;
+#if VSM_SCAN_UNALIGNED
+        wk[j] = pj < q1 ? ldg_u4_at_dw(B.s_uv, (uint32_t)pj * 4u) : make_uint4(0, 0, 0, 0);
+#else
         wk[j] = pj < q1 ? ldg_u4_at(B.s_uv, (uint32_t)pj * 4u) : make_uint4(0, 0, 0, 0);
+#endif
       }
 #pragma unroll
       for (int j = 0; j < VSM_UVL; j++) {
@@ -1190,7 +1208,11 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
           const int p = p0 + j * 4 * G + k;
           const vsm_us2 off = __builtin_bit_cast(vsm_us2, w4[k]) - __builtin_bit_cast(vsm_us2, lo_pk);
           const vsm_us2 cl = __builtin_elementwise_min(off, __builtin_bit_cast(vsm_us2, rng_pk));
-          if (__builtin_bit_cast(uint32_t, cl) == __builtin_bit_cast(uint32_t, off) && p >= q0 && p < q1) {
+#if VSM_SCAN_UNALIGNED
+          if (__builtin_bit_cast(uint32_t, cl) == __builtin_bit_cast(uint32_t, off) && p < q1) {
+#else
+          if (__builtin_bit_cast(uint32_t, cl) == __builtin_bit_cast(uint32_t, off) && (uint32_t)(p - q0) < qn) {
+#endif
             if (nq == 4) {  // queue full (rare): make room first
               const int pf = q3p;
               nq = 3;
