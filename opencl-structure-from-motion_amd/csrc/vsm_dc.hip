@@ -908,7 +908,7 @@ extern "C" int vsm_debug_dc2_phases(unsigned long long *out, int reset) {
 // turn, so the quarter sub-trees of the block go to a wave each (they sit on the CU's four SIMDs) - 8 leaves instead of
 // 32 per wave, one merge node per wave from the third level up.  Measured alone, 50 lists of 7.4 k: 450 -> 330 us.
 #define DC2_BLOCK_THREADS 256
-__global__ void __launch_bounds__(DC2_BLOCK_THREADS) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
+__global__ void __launch_bounds__(DC2_BLOCK_THREADS, 7) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
   __shared__ __attribute__((aligned(16))) dc2_word s_rec[2 * VSM_DC_BLOCK_POINTS * 8];
   __shared__ uint64_t s_key[VSM_DC_BLOCK_POINTS];
   __shared__ uint32_t s_pt[VSM_DC_BLOCK_POINTS];
