@@ -284,7 +284,10 @@ def main():
     # The hot path proper (filter + match + refinement kernels on the main stream) and, announced beside it, whatever leads
     # over ALL streams - the exact Delaunay kernels run on streams of their own (k_export_list is a PCIe copy, not HBM)
     hot = [k for k in stats if stats[k][1] and not k.startswith("k_dc_") and k != "k_export_list"]
-    dom = max(hot, key=lambda k: stats[k][0])
+    # (dominant = the longest with the GPU to itself when that pass was made: in the pipeline two kernels of similar length
+    # swap places from run to run with how much of the chains happens to overlap them)
+    dom_by = stats_alone if stats_alone else stats
+    dom = max(hot, key=lambda k: dom_by.get(k, (0, 0))[0])
     dom_all = max((k for k in stats if stats[k][1] and k != "k_export_list"), key=lambda k: stats[k][0])
     gpu_total_ms = sum(v[0] for k, v in stats.items() if k != "k_export_list")
     dom_ms, dom_n = stats[dom]
