@@ -285,11 +285,12 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
 
 @pytest.mark.parametrize("env", [{}, {"VSM_SEQ_SERIAL": "1"}, {"VSM_SEQ_PACK": "0"}, {"VSM_SEQ_DC_STREAMS": "1"}, {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNKS": "5,9,3"},
                                  {"VSM_SEQ_TAPER": "1", "VSM_SEQ_CHUNK": "16"}, {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
-                                 {"VSM_MATCH_STAGED": "1"}, {"VSM_FRONT": "0"}, {"VSM_MATCH_G": "8"}])
+                                 {"VSM_MATCH_STAGED": "1"}, {"VSM_FRONT": "0"}, {"VSM_MATCH_G": "8"}, {"VSM_SEQ_HOST_SHARE": "35"}, {"VSM_SEQ_HOST_SHARE": "100"}])
 def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), 48-byte result
     records instead of the packed ones, one / four chain streams, explicit and tapered chunk sizes, the vertex sorts on the
-    device, one matching kernel per chain stage, the unfused front end, eight lanes per query: always the reference's lists,
+    device, one matching kernel per chain stage, the unfused front end, eight lanes per query, a share of the final stages (or
+    all of them) on the host pool: always the reference's lists,
     and always this form (it must not quietly hand the run to the other one)."""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1")
