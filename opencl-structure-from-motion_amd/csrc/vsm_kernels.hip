@@ -1082,7 +1082,7 @@ extern __device__ unsigned long long vsm_mt_acc[16];
 #endif
 typedef unsigned short vsm_us2 __attribute__((ext_vector_type(2)));
 
-template <int G, bool RELOAD = true, bool MAYPRED = true>
+template <int G, bool RELOAD = true, bool MAYPRED = true, bool BYBIN = false>
 __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, const VsmDims &d, const VsmMatchCfg &cfg,
                                                bool prior, float r_umin, float r_umax, float r_vmin, float r_vmax,
                                                bool flow, double u_, double v_, int lane, long long *ph = nullptr) {
@@ -1179,6 +1179,48 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
 #if defined(VSM_MATCH_TIMING) && VSM_MATCH_TIMING == 1
   const long long ph0 = clock64();
 #endif
+  if (BYBIN) {
+  // The lanes of a group take the window's u-bins in turn, each scanning its bin's run alone: a stereo stage's disparity
+  // range spans 2-3 bins and an unconstrained first-pass window nine, with a handful of candidates in each - the wave goes
+  // round ceil(bins / G) times instead of once per bin with most of a 16- or 32-slot sweep empty.  (BYBIN: the launches without prior
+  // boxes - 88 -> 70 us per 67 pairs; with them the windows are narrow and sharing a bin's run is 2 % quicker.)
+  for (int ubin = ubmin + lane; ubin <= ubmax && !empty; ubin += G) {
+    VSM_MT_TRIP(0);
+    const int b0 = (q.c * d.ub + ubin) * vrows;
+    const int q0 = (int)ldg_u32_at(B.bin_start, (uint32_t)(b0 + vfmin) * 4u), q1 = (int)ldg_u32_at(B.bin_start, (uint32_t)(b0 + vfmax + 1) * 4u);
+    for (int p0 = q0; p0 < q1; p0 += 4 * VSM_UVL) {
+      VSM_MT_TRIP(1);
+      uint4 wk[VSM_UVL];
+#pragma unroll
+      for (int j = 0; j < VSM_UVL; j++) {
+        const int pj = p0 + j * 4;
+        wk[j] = pj < q1 ? ldg_u4_at_dw(B.s_uv, (uint32_t)pj * 4u) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < VSM_UVL; j++) {
+        const uint32_t w4[4] = {wk[j].x, wk[j].y, wk[j].z, wk[j].w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int p = p0 + j * 4 + k;
+          const vsm_us2 off = __builtin_bit_cast(vsm_us2, w4[k]) - __builtin_bit_cast(vsm_us2, lo_pk);
+          const vsm_us2 cl = __builtin_elementwise_min(off, __builtin_bit_cast(vsm_us2, rng_pk));
+          if (__builtin_bit_cast(uint32_t, cl) == __builtin_bit_cast(uint32_t, off) && p < q1) {
+            if (nq == 4) {  // queue full (rare): make room first
+              const int pf = q3p;
+              nq = 3;
+              judge(pf);
+            }
+            q3p = q2p;
+            q2p = q1p;
+            q1p = q0p;
+            q0p = p;
+            nq++;
+          }
+        }
+      }
+    }
+  }
+  } else {
   for (int ubin = ubmin; ubin <= ubmax && !empty; ubin++) {
     VSM_MT_TRIP(0);
     const int b0 = (q.c * d.ub + ubin) * vrows;
@@ -1227,6 +1269,7 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
         }
       }
     }
+  }
   }
 #if defined(VSM_MATCH_TIMING) && VSM_MATCH_TIMING == 1
   const long long ph1 = clock64();
@@ -1305,7 +1348,7 @@ extern "C" int vsm_debug_match_timing(unsigned int *out, unsigned int cap, int r
   return (int)n;
 }
 #endif
-template <int G>
+template <int G, bool BYBIN = false>
 __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
     k_match(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
             VsmJob job0, VsmDims d, VsmMatchCfg cfg, int nbx, int npairs) {
@@ -1347,17 +1390,17 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
   const int u0 = q.u(), v0 = q.v();
   if (cfg.method == 0) {  // flow, :1006-1041
     const float4 r0 = box(0), r1 = box(1);
-    const uint32_t p1 = find_match<G, true, false>(q, s1p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, true, -1, -1, lane);
+    const uint32_t p1 = find_match<G, true, false, BYBIN>(q, s1p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, true, -1, -1, lane);
     const int u1p = q.u(), v1p = q.v();
-    const uint32_t p2 = find_match<G, true, false>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, -1, -1, lane);
+    const uint32_t p2 = find_match<G, true, false, BYBIN>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, -1, -1, lane);
     const int i1p = index_of(s1p, p1), i1c2 = index_of(s1c, p2);
     ok = (i1c2 == qi);
     m = {(float)u1p, (float)v1p, i1p, -1.f, -1.f, -1, (float)u0, (float)v0, qi, -1.f, -1.f, -1};
   } else if (cfg.method == 1) {  // stereo, :1045-1084
     const float4 r0 = box(0), r1 = box(1);
-    const uint32_t p1 = find_match<G, true, false>(q, s2c, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane);
+    const uint32_t p1 = find_match<G, true, false, BYBIN>(q, s2c, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane);
     const int u2c = q.u(), v2c = q.v();
-    const uint32_t p2 = find_match<G, true, false>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, false, -1, -1, lane);
+    const uint32_t p2 = find_match<G, true, false, BYBIN>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, false, -1, -1, lane);
     const int i2c = index_of(s2c, p1), i1c2 = index_of(s1c, p2);
     ok = (i1c2 == qi) && (u0 >= u2c);
     m = {-1.f, -1.f, -1, -1.f, -1.f, -1, (float)u0, (float)v0, qi, (float)u2c, (float)v2c, i2c};
@@ -1365,7 +1408,7 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
     // (stage results stay packed u | v << 16 until the record is written: registers decide how many
     // chains a SIMD keeps in flight)
     const float4 r0 = box(0), r1 = box(1);
-    const uint32_t p1 = find_match<G, true, false>(q, s2p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane, mtph);
+    const uint32_t p1 = find_match<G, true, false, BYBIN>(q, s2p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane, mtph);
     const uint32_t w2p = q.uv;
 #ifdef VSM_MATCH_TIMING
     const long long ms1 = clock64();
@@ -1384,19 +1427,19 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
       v2c_ = cfg.f * y2c / z2c + cfg.cv;
     }
     const float4 r2 = box(2);
-    const uint32_t p2 = find_match<G>(q, s2c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, u2c_, v2c_, lane, mtph);
+    const uint32_t p2 = find_match<G, true, true, BYBIN>(q, s2c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, u2c_, v2c_, lane, mtph);
     const uint32_t w2c = q.uv;
 #ifdef VSM_MATCH_TIMING
     const long long ms2 = clock64();
 #endif
     const float4 r3 = box(3);
-    const uint32_t p3 = find_match<G, true, false>(q, s1c, d, cfg, prior, r2.x, r2.y, r2.z, r2.w, false, -1, -1, lane, mtph);
+    const uint32_t p3 = find_match<G, true, false, BYBIN>(q, s1c, d, cfg, prior, r2.x, r2.y, r2.z, r2.w, false, -1, -1, lane, mtph);
     const uint32_t w1c = q.uv;
 #ifdef VSM_MATCH_TIMING
     const long long ms3 = clock64();
 #endif
     // stage 4 predicts the chain's own start (:1134)
-    const uint32_t p4 = find_match<G>(q, s1p, d, cfg, prior, r3.x, r3.y, r3.z, r3.w, true,
+    const uint32_t p4 = find_match<G, true, true, BYBIN>(q, s1p, d, cfg, prior, r3.x, r3.y, r3.z, r3.w, true,
                                       jb.use_tr ? (double)(int)(w0 & 0xffffu) : -1.0,
                                       jb.use_tr ? (double)(int)(w0 >> 16) : -1.0, lane, mtph);
     const int i1p2 = index_of(s1p, p4);
@@ -2024,6 +2067,14 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
     pf.begin(cfg.sparse ? VSM_K_MATCH1 : VSM_K_MATCH2, s);
     const int nbx = cdiv(max_nq * G, VSM_MATCH_BLOCK);
     const dim3 grid(((nbx * npairs + 7) / 8) * 8);
+    // without prior boxes (first pass, single-pass matching) the lanes of a group take whole u-bins
+#define VSM_MATCH_LAUNCH(GG)                                                                                                       \
+  do {                                                                                                                             \
+    if (cfg.use_prior)                                                                                                             \
+      hipLaunchKernelGGL((k_match<GG, false>), grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs); \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((k_match<GG, true>), grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);  \
+  } while (0)
     // VSM_MATCH_STAGED=1: one kernel per stage (k_chain) - measured slower than the single launch, kept for experiments
     const char *se = getenv("VSM_MATCH_STAGED");
     const bool staged = se && atoi(se) != 0;
@@ -2051,15 +2102,15 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
         VSM_CHAIN_ALL(8)
       }
     } else if (G == 1)
-      hipLaunchKernelGGL(k_match<1>, grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
+      VSM_MATCH_LAUNCH(1);
     else if (G == 2)
-      hipLaunchKernelGGL(k_match<2>, grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
+      VSM_MATCH_LAUNCH(2);
     else if (G == 4)
-      hipLaunchKernelGGL(k_match<4>, grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
+      VSM_MATCH_LAUNCH(4);
     else if (G == 16)
-      hipLaunchKernelGGL(k_match<16>, grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
+      VSM_MATCH_LAUNCH(16);
     else
-      hipLaunchKernelGGL(k_match<8>, grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);
+      VSM_MATCH_LAUNCH(8);
     pf.end(s);
   }
   const int nblk = max(cdiv(max_nq, 256), 1);
