@@ -1066,6 +1066,9 @@ __device__ __forceinline__ VsmQuery load_query(const VsmSet &A, int i) {
 #ifndef VSM_MATCH_BLOCK
 #define VSM_MATCH_BLOCK 256  // threads per block of k_match
 #endif
+#ifndef VSM_STEREO_BY_BIN
+#define VSM_STEREO_BY_BIN 1  // the stereo-type stages (window = a few rows x the disparity range: 2-3 bins, a few candidates each) scan by bin also under prior boxes: -3.5 %
+#endif
 #ifndef VSM_SCAN_UNALIGNED
 #define VSM_SCAN_UNALIGNED 1  // coordinate loads start at the run's first candidate (dword-aligned 16-byte loads) instead of at the 16-byte line below it
 #endif
@@ -1398,9 +1401,9 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
     m = {(float)u1p, (float)v1p, i1p, -1.f, -1.f, -1, (float)u0, (float)v0, qi, -1.f, -1.f, -1};
   } else if (cfg.method == 1) {  // stereo, :1045-1084
     const float4 r0 = box(0), r1 = box(1);
-    const uint32_t p1 = find_match<G, true, false, BYBIN>(q, s2c, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane);
+    const uint32_t p1 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN>(q, s2c, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane);
     const int u2c = q.u(), v2c = q.v();
-    const uint32_t p2 = find_match<G, true, false, BYBIN>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, false, -1, -1, lane);
+    const uint32_t p2 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, false, -1, -1, lane);
     const int i2c = index_of(s2c, p1), i1c2 = index_of(s1c, p2);
     ok = (i1c2 == qi) && (u0 >= u2c);
     m = {-1.f, -1.f, -1, -1.f, -1.f, -1, (float)u0, (float)v0, qi, (float)u2c, (float)v2c, i2c};
@@ -1408,7 +1411,7 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
     // (stage results stay packed u | v << 16 until the record is written: registers decide how many
     // chains a SIMD keeps in flight)
     const float4 r0 = box(0), r1 = box(1);
-    const uint32_t p1 = find_match<G, true, false, BYBIN>(q, s2p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane, mtph);
+    const uint32_t p1 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN>(q, s2p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane, mtph);
     const uint32_t w2p = q.uv;
 #ifdef VSM_MATCH_TIMING
     const long long ms1 = clock64();
@@ -1433,7 +1436,7 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
     const long long ms2 = clock64();
 #endif
     const float4 r3 = box(3);
-    const uint32_t p3 = find_match<G, true, false, BYBIN>(q, s1c, d, cfg, prior, r2.x, r2.y, r2.z, r2.w, false, -1, -1, lane, mtph);
+    const uint32_t p3 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN>(q, s1c, d, cfg, prior, r2.x, r2.y, r2.z, r2.w, false, -1, -1, lane, mtph);
     const uint32_t w1c = q.uv;
 #ifdef VSM_MATCH_TIMING
     const long long ms3 = clock64();
