@@ -55,9 +55,12 @@ bool VsmPool::work_one() {
 void VsmPool::worker() {
   for (;;) {
     if (stop_) return;
+    // (the post counter is read BEFORE the queue is looked at: a batch posted in between changes it, so the wait below
+    // returns at once - read afterwards, that batch would be slept through until the next post, and the look-ahead path's
+    // fire-and-forget batches have no waiting caller to run them instead)
+    const uint64_t seen = posted_.load(std::memory_order_acquire);
     if (work_one()) continue;
     // idle: spin on the post counter, then block
-    const uint64_t seen = posted_.load(std::memory_order_acquire);
     auto t0 = std::chrono::steady_clock::now();
     while (posted_.load(std::memory_order_acquire) == seen) {
       cpu_relax();
