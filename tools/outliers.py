@@ -1,0 +1,28 @@
+"""look-ahead call repeated: prints the library's per-chunk timeline (VSM_DEBUG_TIMING) of the slowest calls"""
+import importlib, os, sys, time, io, contextlib, subprocess
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["VSM_DEBUG_TIMING"] = "1"
+vm = importlib.import_module("opencl-structure-from-motion_amd.visomatch")
+synth = importlib.import_module("opencl-structure-from-motion_amd.synth")
+W, H, nf = 1242, 375, 200
+cv = synth.canvas(1234, W, H)
+host = np.stack([np.stack(synth.stereo_frame(cv, f, W, H)) for f in range(nf)])
+frames = torch.from_numpy(host).cuda()
+g = np.load(os.path.join(ROOT, "tests", "golden", "cfg4_seq200_tr_8seeds.npz"))
+tr12 = np.ascontiguousarray(g["s1234_tr_in"][:nf].reshape(nf, 16)[:, :12])
+trv = np.ascontiguousarray(g["s1234_tr_valid"][:nf].astype(np.uint8))
+m = vm.Matcher()
+m.set_intrinsics(*[float(x) for x in g["intr"]])
+L, R = frames[:, 0], frames[:, 1]
+times = []
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 80):
+    sys.stderr.write("RUN %d\n" % i)
+    sys.stderr.flush()
+    t0 = time.perf_counter()
+    m.run_sequence(L, R, 2, tr12, trv, fetch=False)
+    times.append((time.perf_counter() - t0) * 1e3)
+    sys.stderr.write("RUN %d took %.2f ms\n" % (i, times[-1]))
+print("median %.2f ms, max %.2f" % (float(np.median(times[3:])), max(times[3:])))
