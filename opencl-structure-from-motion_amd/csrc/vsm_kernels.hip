@@ -705,18 +705,39 @@ __global__ void __launch_bounds__(256)
   const int lim_i = d.mw - 1 - VSM_MARGIN - u0, lim_j = d.mh - 1 - VSM_MARGIN - v0;
   int wmn = 32767, wmx = -32768;  // extrema over this lane's share of the two windows
   if (lim_i >= TW - 1 && lim_j >= TH - 1) {  // block-uniform: no window of this tile is clipped
-    const int16_t *pn = &f[mnj - N][mni - N], *px = &f[mxj - N][mxi - N];
+    // A window row is W = 2N+1 values from column mi-N on: (W+1)/2 aligned dwords cover it whatever the parity of that
+    // column, with one value too many - the last one (even start) or the first (odd start) - which is replaced by the
+    // neutral element; then two values per v_pk_min_i16 / v_pk_max_i16.  (Half the LDS reads of the value-by-value walk:
+    // the kernels spend most of their time here.)
+    typedef short vsm_s2 __attribute__((ext_vector_type(2)));
+    constexpr int ND = (W + 1) / 2;
+    const int cn = mni - N, cx = mxi - N;
+    const bool pn1 = (cn & 1) != 0, px1 = (cx & 1) != 0;
+    const uint32_t *pn = (const uint32_t *)&f[mnj - N][cn & ~1], *px = (const uint32_t *)&f[mxj - N][cx & ~1];
+    vsm_s2 amn = {32767, 32767}, amx = {-32768, -32768};
 #pragma unroll
     for (int t = 0; t < (W + LANES - 1) / LANES; t++) {
       const int r = l8 + t * LANES;
       if (r < W) {
+        const uint32_t *rn = pn + r * (STR / 2), *rx = px + r * (STR / 2);
 #pragma unroll
-        for (int c = 0; c < W; c++) {
-          wmn = min(wmn, (int)pn[r * STR + c]);
-          wmx = max(wmx, (int)px[r * STR + c]);
+        for (int c = 0; c < ND; c++) {
+          uint32_t vn = rn[c], vx = rx[c];
+          if (c == 0) {
+            vn = pn1 ? ((vn & 0xffff0000u) | 0x00007fffu) : vn;
+            vx = px1 ? ((vx & 0xffff0000u) | 0x00008000u) : vx;
+          }
+          if (c == ND - 1) {
+            vn = pn1 ? vn : ((vn & 0x0000ffffu) | 0x7fff0000u);
+            vx = px1 ? vx : ((vx & 0x0000ffffu) | 0x80000000u);
+          }
+          amn = __builtin_elementwise_min(amn, __builtin_bit_cast(vsm_s2, vn));
+          amx = __builtin_elementwise_max(amx, __builtin_bit_cast(vsm_s2, vx));
         }
       }
     }
+    wmn = min((int)amn.x, (int)amn.y);
+    wmx = max((int)amx.x, (int)amx.y);
   } else {
     for (int r = l8; r < W; r += LANES) {
       if (mnj - N + r <= lim_j)
