@@ -807,17 +807,37 @@ __global__ void __launch_bounds__(1024) k_scan_cells(const VsmImage *__restrict_
   const int ncells = st.ncu * st.ncv;
   const int chunk = (ncells + 1023) / 1024;
   const int c0 = min((int)threadIdx.x * chunk, ncells), c1 = min(c0 + chunk, ncells);
-  int sum = 0;
-  for (int c = c0; c < c1; c++) {
-    const int4 v = *(const int4 *)(st.cand + (size_t)c * 4);
-    sum += (v.x < 0) + (v.y < 0) + (v.z < 0) + (v.w < 0);
-  }
-  int total;
-  int run = block_excl_scan_1024(sum, total, s_w);
-  for (int c = c0; c < c1; c++) {
-    const int4 v = *(const int4 *)(st.cand + (size_t)c * 4);
-    st.cell_off[c] = run;
-    run += (v.x < 0) + (v.y < 0) + (v.z < 0) + (v.w < 0);
+  int sum = 0, total, run;
+  if (chunk <= 8) {  // (the usual case: all of a thread's cells requested at once, their counts kept for the second sweep)
+    int cnt[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      cnt[k] = 0;
+      if (c0 + k < c1) {
+        const int4 v = ldg_i4(st.cand + (size_t)(c0 + k) * 4);
+        cnt[k] = (v.x < 0) + (v.y < 0) + (v.z < 0) + (v.w < 0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += cnt[k];
+    run = block_excl_scan_1024(sum, total, s_w);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (c0 + k < c1) {
+        st.cell_off[c0 + k] = run;
+        run += cnt[k];
+      }
+  } else {
+    for (int c = c0; c < c1; c++) {
+      const int4 v = *(const int4 *)(st.cand + (size_t)c * 4);
+      sum += (v.x < 0) + (v.y < 0) + (v.z < 0) + (v.w < 0);
+    }
+    run = block_excl_scan_1024(sum, total, s_w);
+    for (int c = c0; c < c1; c++) {
+      const int4 v = *(const int4 *)(st.cand + (size_t)c * 4);
+      st.cell_off[c] = run;
+      run += (v.x < 0) + (v.y < 0) + (v.z < 0) + (v.w < 0);
+    }
   }
   if (threadIdx.x == 0) {
     st.cell_off[ncells] = total;
