@@ -320,8 +320,15 @@ def main():
         rows = csv.DictReader(l for l in open(pmc_path) if not l.startswith("#"))
         for r in rows:
             pmc[r["bench_name"]] = int(float(r["traffic_bytes_per_launch"]))
+        # (taken from the same kernel sources as the library that runs now?  file times say nothing after a checkout)
+        import glob
+        csrc = os.path.join(ROOT, PKG, "csrc")
+        hsh = hashlib.sha256()
+        for pat in ("*.hip", "*.h", "*.inc", "*.cpp"):
+            for fn in sorted(glob.glob(os.path.join(csrc, pat))):
+                hsh.update(open(fn, "rb").read())
         pmc_src = {"file": "profiles/r02_lookahead_pmc_hbm.csv", "commit": meta.get("commit"), "taken": meta.get("taken"),
-                   "older_than_library": bool(os.path.getmtime(pmc_path) + 1 < os.path.getmtime(lib_path))}
+                   "same_kernel_sources": (meta.get("sources", "").split(" ")[0] == hsh.hexdigest()[:16]) if meta.get("sources") else None}
     except FileNotFoundError:
         pmc_src = {"file": None, "note": "no committed PMC summary"}
     except Exception as e:

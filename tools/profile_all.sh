@@ -6,7 +6,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-STAMP="# commit: ${VSM_COMMIT:-unknown}"$'\n'"# taken: $(date -u +%Y-%m-%dT%H:%MZ) on $(rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//') / $(grep -m1 'model name' /proc/cpuinfo | sed 's/.*: *//'), $(nproc) CPUs visible"
+SRC_SHA=$(cat $R/opencl-structure-from-motion_amd/csrc/*.hip $R/opencl-structure-from-motion_amd/csrc/*.h $R/opencl-structure-from-motion_amd/csrc/*.inc $R/opencl-structure-from-motion_amd/csrc/*.cpp | sha256sum | cut -c1-16)
+STAMP="# commit: ${VSM_COMMIT:-unknown}"$'\n'"# sources: $SRC_SHA (sha256 of csrc/*.hip *.h *.inc *.cpp, first 16 hex digits)"$'\n'"# taken: $(date -u +%Y-%m-%dT%H:%MZ) on $(rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//') / $(grep -m1 'model name' /proc/cpuinfo | sed 's/.*: *//'), $(nproc) CPUs visible"
 B="python3 $R/bench.py --no-cpu-baseline --no-verify --no-per-frame --no-alone"
 stamp() { { echo "$STAMP"; echo "# command: $2"; cat "$1"; } > "$3"; }
 # per-kernel time: the default form (GPU-resident) and the host-shared form (VSM_SEQ_V2=0)
