@@ -94,7 +94,15 @@ VsmPool::Ticket VsmPool::submit(int ntasks, std::function<void(int)> fn, bool ur
       queue_.push_back(b);
     posted_.fetch_add(1, std::memory_order_release);
   }
-  if (sleepers_.load() > 0) cv_.notify_all();
+  // (as many wake-ups as there are tasks: every woken worker that finds the queue empty spins for spin_us_ before it sleeps
+  // again, and sixteen of them spinning after every small batch is what pushes a rank over its CPU quota)
+  const int ns = sleepers_.load();
+  if (ns > 0) {
+    if (b->n >= ns)
+      cv_.notify_all();
+    else
+      for (int i = 0; i < b->n; i++) cv_.notify_one();
+  }
   return b;
 }
 

@@ -1,5 +1,18 @@
 """look-ahead call repeated: prints the library's per-chunk timeline (VSM_DEBUG_TIMING) of the slowest calls"""
-import importlib, os, sys, time, io, contextlib, subprocess
+import importlib, os, sys, time, re
+if len(sys.argv) > 2 and sys.argv[1] == "--show":
+    blocks = open(sys.argv[2]).read().split("RUN ")[1:]
+    runs = []
+    for b in blocks:
+        mt = re.search(r"TOOK ([0-9.]+) ms", b)
+        if mt:
+            runs.append((float(mt.group(1)), b))
+    runs = runs[3:]
+    runs.sort(key=lambda x: -x[0])
+    for tt, b in runs[:3] + runs[len(runs) // 2:len(runs) // 2 + 1]:
+        print("=====", tt, "ms")
+        print(b[:1800])
+    sys.exit(0)
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,5 +37,7 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 80):
     t0 = time.perf_counter()
     m.run_sequence(L, R, 2, tr12, trv, fetch=False)
     times.append((time.perf_counter() - t0) * 1e3)
-    sys.stderr.write("RUN %d took %.2f ms\n" % (i, times[-1]))
-print("median %.2f ms, max %.2f" % (float(np.median(times[3:])), max(times[3:])))
+    sys.stderr.write("TOOK %.2f ms\n" % times[-1])
+    sys.stderr.flush()
+print("median %.2f ms, max %.2f; calls over 9 ms: %d of %d" % (float(np.median(times[3:])), max(times[3:]), sum(1 for t in times[3:] if t > 9), len(times) - 3))
+# usage: python tools/outliers.py 300 2> log; then: python tools/outliers.py --show log
