@@ -117,9 +117,15 @@ struct DcLdsMesh {
   }
   DC2_DEV static inline OTri lnext(OTri a) { return OTri{a.t, a.o == 2 ? 0 : a.o + 1}; }
   DC2_DEV static inline OTri lprev(OTri a) { return OTri{a.t, a.o == 0 ? 2 : a.o - 1}; }
-  DC2_DEV inline int32_t org(OTri a) const { return ld(a.t, 4 + (a.o == 2 ? 0 : a.o + 1)); }
-  DC2_DEV inline int32_t dest(OTri a) const { return ld(a.t, 4 + (a.o == 0 ? 2 : a.o - 1)); }
-  DC2_DEV inline int32_t apex(OTri a) const { return ld(a.t, 4 + a.o); }
+  // vertex words: point numbers stay below 2^15 (at most DC2_CACHE_PTS local points), so the sign-extending 16-bit read
+  // turns the all-ones "no vertex" into -1 by itself - no compare and select behind every read of the seam walk
+  DC2_DEV inline int32_t ldv(int32_t t, int w) const {
+    if (MAPPED || sizeof(dc2_word) != 2) return ld(t, w);
+    return (int32_t)(int16_t)rec[t * 8 + w];
+  }
+  DC2_DEV inline int32_t org(OTri a) const { return ldv(a.t, 4 + (a.o == 2 ? 0 : a.o + 1)); }
+  DC2_DEV inline int32_t dest(OTri a) const { return ldv(a.t, 4 + (a.o == 0 ? 2 : a.o - 1)); }
+  DC2_DEV inline int32_t apex(OTri a) const { return ldv(a.t, 4 + a.o); }
   DC2_DEV inline void set_org(OTri a, int32_t v) const { st(a.t, 4 + (a.o == 2 ? 0 : a.o + 1), v); }
   DC2_DEV inline void set_dest(OTri a, int32_t v) const { st(a.t, 4 + (a.o == 0 ? 2 : a.o - 1), v); }
   DC2_DEV inline void set_apex(OTri a, int32_t v) const { st(a.t, 4 + a.o, v); }
