@@ -112,7 +112,9 @@ struct DcLdsMesh {
     return OTri{t, 0};
   }
   DC2_DEV inline OTri sym(OTri a) const {
-    const int32_t e = ld(a.t, a.o);
+    // (a neighbour word that is followed is never the "none" word - the walks only cross edges that have a triangle
+    // on the other side, tools/emulate counts the exceptions: zero - so the whole-node form reads it as it is)
+    const int32_t e = (MAPPED || sizeof(dc2_word) != 2) ? ld(a.t, a.o) : (int32_t)rec[a.t * 8 + a.o];
     return OTri{e >> 2, e & 3};
   }
   DC2_DEV static inline OTri lnext(OTri a) { return OTri{a.t, a.o == 2 ? 0 : a.o + 1}; }
