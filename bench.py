@@ -146,8 +146,8 @@ def main():
                 collect.append(m.get_matches())
 
     def run_sequence(collect=None):                         # look-ahead path
-        # like the per-frame loop above, the timed call leaves the lists inside the matcher
-        # (getMatches() copies are taken only by the verification pass)
+        # like the per-frame loop above, the timed call leaves the lists inside the matcher - in the reference's 48-byte
+        # p_match form, in host memory - (getMatches() copies are taken only by the verification pass)
         m.run_sequence(left_d, right_d, 2, tr12, trv, fetch=False)
         if collect is not None:
             collect.extend(m.sequence_matches(f) for f in range(nf))
@@ -276,7 +276,7 @@ def main():
     # price of a full wavefront; "alone" is what the kernel itself does, "frac" what it gets in the pipeline.
     stats_alone = None
     if not args.no_alone:
-        os.environ["VSM_SEQ_SERIAL"] = "1"
+        m.set_option("seq_serial", 1)
         try:
             m.set_profiling(True)
             run_sequence()
@@ -284,7 +284,7 @@ def main():
             stats_alone = m.kernel_stats()
         finally:
             m.set_profiling(False)
-            del os.environ["VSM_SEQ_SERIAL"]
+            m.set_option("seq_serial", 0)
     # The hot path proper (filter + match + refinement kernels on the main stream) and, announced beside it, whatever leads
     # over ALL streams - the exact Delaunay kernels run on streams of their own (k_export_list is a PCIe copy, not HBM)
     hot = [k for k in stats if stats[k][1] and not k.startswith("k_dc_") and k != "k_export_list"]
@@ -390,7 +390,10 @@ def main():
         "config": {"workload": f"KITTI-shaped synthetic stereo sequence 1242x375, {nf} frames per GPU, quad matching, "
                                "default parameters, replayed Tr_delta feedback, look-ahead C-ABI entry point "
                                f"vsm_sequence_run (chunks of {chunk} frames)",
-                   "frames_per_step": nf, "sequences": world, "inputs": "resident in HBM"},
+                   "frames_per_step": nf, "sequences": world, "inputs": "resident in HBM",
+                   "results": "when the timed call returns every frame's final list is in host memory as 48-byte p_match records "
+                              "(viso/matcher.h:86-100), as Matcher::matchFeatures leaves p_matched_2; the packed PCIe export is "
+                              "expanded by the host pool inside the call"},
         "per_frame_api": {"value": round(per_frame_value, 3) if per_frame_value else None, "unit": "frame-pairs/s",
                           "what": "same sequence through vsm_push_back_device + vsm_match per frame (drop-in "
                                   "Matcher::pushBack/matchFeatures path)"},
@@ -480,15 +483,12 @@ def secondary_configs(vm, synth, torch, dev):
         m = vm.Matcher()
         got = m.run_sequence(L[:gn], R[:gn], 2)
         ok = all(len(got[f]) == int(g["counts"][f][-1]) and sha(got[f]) == str(g["hashes"][f][-1]) for f in range(gn))
-        os.environ["VSM_SEQ_CHUNK"] = "12"
-        try:
-            m.run_sequence(L, R, 2, fetch=False)
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            m.run_sequence(L, R, 2, fetch=False)
-            dt = time.perf_counter() - t
-        finally:
-            del os.environ["VSM_SEQ_CHUNK"]
+        m.set_option("seq_chunk", 12)
+        m.run_sequence(L, R, 2, fetch=False)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        m.run_sequence(L, R, 2, fetch=False)
+        dt = time.perf_counter() - t
         form = m.sequence_path()
         t2 = time.perf_counter()
         for f in range(8):

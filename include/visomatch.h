@@ -111,7 +111,7 @@ float vsm_gain(vsm_handle *h, const int32_t *inliers, int32_t n);
  * Semantically identical to
  *     for f in 0..n_frames-1:  pushBack(left[f], right[f], dims, false);  matchFeatures(method, Tr[f])
  * on a fresh Matcher (viso/matcher.cpp:95, :183), but the frames of a chunk (VSM_SEQ_CHUNK, default
- * 50) go through every kernel in one launch and the host stages of the chunk's frame pairs run in
+ * 76) go through every kernel in one launch and the host stages of the chunk's frame pairs run in
  * parallel.  left/right: n_frames images frame_stride bytes apart (host or, with on_device != 0,
  * HBM); right == NULL (mono) and refinement == 2 fall back to the frame-by-frame path.
  * Tr_delta: NULL or n_frames x 12 doubles, Tr_valid: NULL (all valid) or n_frames flags.
@@ -130,6 +130,11 @@ void vsm_sequence_get_timings(vsm_handle *h, double *out4);
  * matching pass to the survivors; the host only runs Triangle's vertex sort), 1 = host-shared (VSM_SEQ_V2=0, or a list
  * the device chain declines) */
 int32_t vsm_sequence_path(vsm_handle *h);
+/* Measurement / test switches of a handle.  They are read from the environment once, by vsm_create (VSM_SEQ_V2,
+ * VSM_SEQ_CHUNK, VSM_SEQ_DC_STREAMS, VSM_SEQ_PACK, VSM_SEQ_SERIAL, VSM_SEQ_GPU_SORTS, VSM_FRONT); this call changes one
+ * afterwards: name = the variable's name without the VSM_ prefix, in lower case ("seq_serial", "seq_chunk", ...).
+ * None of them changes a result.  Returns VSM_OK, or VSM_EARG for an unknown name.  (No counterpart in the reference.) */
+int vsm_set_option(vsm_handle *h, const char *name, int32_t value);
 
 /* ---- stage-level views for parity tests (the reference's private members) ---- */
 

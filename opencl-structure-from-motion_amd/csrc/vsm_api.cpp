@@ -364,8 +364,45 @@ struct DcBank {
 };
 
 // ---------------------------------------------------------------------------------------
+// Measurement / test switches of a handle: read from the environment ONCE, at vsm_create (the calls themselves never
+// look at the environment), and settable afterwards through vsm_set_option (bench.py's "alone" pass, tools/).
+struct VsmSwitches {
+  int seq_v2 = 1;          // VSM_SEQ_V2: 0 = the host-shared look-ahead form
+  int seq_chunk = 0;       // VSM_SEQ_CHUNK: frames per look-ahead chunk (0 = by host threads)
+  int seq_dc_streams = 3;  // VSM_SEQ_DC_STREAMS: streams the final chains rotate over (1..4)
+  int seq_pack = 1;        // VSM_SEQ_PACK: survivors cross PCIe as 24-byte records
+  int seq_serial = 0;      // VSM_SEQ_SERIAL: nothing overlaps (every kernel's time alone)
+  int seq_gpu_sorts = -1;  // VSM_SEQ_GPU_SORTS: percent of a chunk's vertex sorts done on the device (-1 = by host threads)
+  int front = 1;           // VSM_FRONT: the fused front end
+  static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+  }
+  void from_environment() {
+    seq_v2 = env_int("VSM_SEQ_V2", 1) != 0;
+    seq_chunk = std::max(0, env_int("VSM_SEQ_CHUNK", 0));
+    seq_dc_streams = std::min(4, std::max(1, env_int("VSM_SEQ_DC_STREAMS", 3)));
+    seq_pack = env_int("VSM_SEQ_PACK", 1) != 0;
+    seq_serial = env_int("VSM_SEQ_SERIAL", 0) != 0;
+    seq_gpu_sorts = env_int("VSM_SEQ_GPU_SORTS", -1);
+    front = env_int("VSM_FRONT", 1) != 0;
+  }
+  bool set(const char *name, int v) {
+    if (!strcmp(name, "seq_v2")) seq_v2 = v != 0;
+    else if (!strcmp(name, "seq_chunk")) seq_chunk = std::max(0, v);
+    else if (!strcmp(name, "seq_dc_streams")) seq_dc_streams = std::min(4, std::max(1, v));
+    else if (!strcmp(name, "seq_pack")) seq_pack = v != 0;
+    else if (!strcmp(name, "seq_serial")) seq_serial = v != 0;
+    else if (!strcmp(name, "seq_gpu_sorts")) seq_gpu_sorts = v;
+    else if (!strcmp(name, "front")) front = v != 0;
+    else return false;
+    return true;
+  }
+};
+
 struct vsm_handle {
   vsm_params param;  // match_radius already halved for half_resolution (viso/matcher.cpp:59-60)
+  VsmSwitches sw;
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t input_ev = nullptr;   // vsm_wait_for_stream(): the producer stream's marker
@@ -467,6 +504,7 @@ vsm_handle *vsm_create(const vsm_params *p) {
   vsm_handle *h = new vsm_handle();
   h->param = *p;
   if (p->half_resolution) h->param.match_radius /= 2;
+  h->sw.from_environment();
   {
     // host threads (the caller's thread included): VSM_HOST_THREADS frame-parallel workers for
     // the look-ahead API, at most 8 of them for the sub-problems of one triangulation (streaming)
@@ -597,7 +635,7 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
   h->dims_c[2] = c.dims.bpl;
   const int n_img = I2 ? 2 : 1;
   // (VSM_FRONT=0: the three separate passes - ingest, halving, full-resolution Sobel - instead of the fused front end)
-  const bool fused_front = h->param.half_resolution && !(getenv("VSM_FRONT") && atoi(getenv("VSM_FRONT")) == 0);
+  const bool fused_front = h->param.half_resolution && h->sw.front;
   if (on_device) {
     if (fused_front)
       vsm_launch_front(h->stream, h->prof, c.d_imgs, slot * 2, I1, I2, 0, bpl, 1, c.dims, 1);
@@ -1242,7 +1280,7 @@ static int seq_ingest_host_frames(vsm_handle *h, VsmCtx &c, int first_img, const
     }
   });
   HIPCHK(hipMemcpyAsync(h->seq_stage_d[slot], dst, 2 * img * n, hipMemcpyHostToDevice, h->stream));
-  if (h->param.half_resolution && !(getenv("VSM_FRONT") && atoi(getenv("VSM_FRONT")) == 0))
+  if (h->param.half_resolution && h->sw.front)
     vsm_launch_front(h->stream, h->prof, c.d_imgs, first_img, h->seq_stage_d[slot], h->seq_stage_d[slot] + img * n, img, w, n, c.dims, 0);
   else
     vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first_img, h->seq_stage_d[slot], h->seq_stage_d[slot] + img * n, img, w, n, c.dims);
@@ -1295,6 +1333,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   const double t_entry = now_us();
   HIPCHK(hipSetDevice(h->device));
   const vsm_params &p = h->param;
+  h->seq_v2_frames = 0;
   h->seq_matches.resize(n_frames);  // keeps the capacity of earlier runs: no page-fault storm
   for (auto &v : h->seq_matches) v.clear();
   if (!right || p.refinement == 2)
@@ -1307,19 +1346,15 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   // 8.8 with 4, 9.5 with 2, 9.9 with 1 - its host work is Triangle's vertex sort alone), so it is the default whatever the
   // thread count: with 16 threads on an idle host the two are within a few per cent, and its time does not move with what
   // else the host is doing.
-  h->seq_v2_frames = 0;
-  const bool v2 = getenv("VSM_SEQ_V2") ? atoi(getenv("VSM_SEQ_V2")) != 0 : true;
-  if (v2) {
+  if (h->sw.seq_v2) {
     const int rc = sequence_run_v2(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
     if (rc != VSM_SEQ2_DECLINED) return rc;
     h->seq_v2_frames = 0;
   }
-  int C = 50;
-  if (const char *e = getenv("VSM_SEQ_CHUNK")) C = atoi(e);
-  if (C < 1) C = 1;
+  int C = h->sw.seq_chunk > 0 ? h->sw.seq_chunk : 50;
   if (C > n_frames) C = n_frames;
   VsmCtx &c = h->seq;
-  if (!c.ready || c.dims.w != w || c.dims.h != hh || h->seq_chunk != C || c.npairs != 2 * C) {
+  if (!c.ready || c.dims.w != w || c.dims.h != hh || h->seq_chunk != C || c.npairs != 2 * C || c.nframes != 3 * C) {
     (void)hipStreamSynchronize(h->stream);
     int rc = ctx_create(c, p, w, hh, 3 * C, 2 * C, h->stream);  // three banks of frames, two of pairs
     if (rc != VSM_OK) return rc;
@@ -1420,7 +1455,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     const int32_t f0 = chunk_start[k];
     const int n = chunk_start[k + 1] - f0;
     const int first_img = 2 * (k % 3) * C;
-    const bool fused_front = p.half_resolution && !(getenv("VSM_FRONT") && atoi(getenv("VSM_FRONT")) == 0);
+    const bool fused_front = p.half_resolution && h->sw.front;
     if (on_device) {
       if (fused_front)
         vsm_launch_front(h->stream, h->prof, c.d_imgs, first_img, left + (size_t)f0 * frame_stride, right + (size_t)f0 * frame_stride,
@@ -1744,24 +1779,11 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
 }
 
 int32_t vsm_sequence_num_matches(vsm_handle *h, int32_t frame) {
-  if (h->seq_v2_frames > 0 && frame >= 0 && frame < h->seq_v2_frames && h->seq2->frame_on_host[frame]) return (int32_t)h->seq_matches[frame].size();
-  if (h->seq_v2_frames > 0) return (frame >= 0 && frame < h->seq_v2_frames) ? h->seq2->res_cnt[frame] : 0;
   return (frame >= 0 && frame < (int32_t)h->seq_matches.size()) ? (int32_t)h->seq_matches[frame].size() : 0;
 }
 
+// (both look-ahead forms end with every frame's list in the reference's 48-byte p_match form in host memory)
 int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out, int32_t cap) {
-  if (h->seq_v2_frames > 0 && !(frame >= 0 && frame < h->seq_v2_frames && h->seq2->frame_on_host[frame])) {
-    if (frame < 0 || frame >= h->seq_v2_frames) return 0;
-    int32_t n = h->seq2->res_cnt[frame];
-    if (n > cap) n = cap;
-    if (n > 0 && h->seq2->res_packed) {
-      const uint64_t *src = (const uint64_t *)(h->seq2->res + h->seq2->res_off[frame]);
-      for (int32_t i = 0; i < n; i++) vsm_unpack_match(src + 3 * (size_t)i, out[i]);
-    } else if (n > 0) {
-      memcpy(out, h->seq2->res + h->seq2->res_off[frame], (size_t)n * sizeof(vsm_p_match));
-    }
-    return n;
-  }
   if (frame < 0 || frame >= (int32_t)h->seq_matches.size()) return 0;
   int32_t n = (int32_t)h->seq_matches[frame].size();
   if (n > cap) n = cap;
@@ -1771,6 +1793,7 @@ int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out,
 
 void vsm_sequence_get_timings(vsm_handle *h, double *out4) { memcpy(out4, h->seq_timings, sizeof(h->seq_timings)); }
 int32_t vsm_sequence_path(vsm_handle *h) { return h->seq_v2_frames > 0 ? 2 : 1; }
+int vsm_set_option(vsm_handle *h, const char *name, int32_t value) { return (h && name && h->sw.set(name, value)) ? VSM_OK : VSM_EARG; }
 
 // ---- stage-level views ----
 static bool which_set(vsm_handle *h, int32_t which, int &img, int &set, int32_t &n) {

@@ -33,7 +33,7 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
            "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
            "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_host_outliers_and_prior", "vsm_debug_dc2", "vsm_debug_pack_roundtrip", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
-           "vsm_sequence_get_timings", "vsm_sequence_path", "vsm_version",
+           "vsm_sequence_get_timings", "vsm_sequence_path", "vsm_set_option", "vsm_version",
            "vsm_vo_stereo_default_params", "vsm_vo_stereo_create", "vsm_vo_stereo_destroy", "vsm_vo_stereo_process",
            "vsm_vo_stereo_process_device", "vsm_vo_stereo_process_matches", "vsm_vo_stereo_get_motion",
            "vsm_vo_stereo_motion_valid", "vsm_vo_stereo_num_matches", "vsm_vo_stereo_get_matches",
@@ -132,6 +132,7 @@ def lib():
         L.vsm_sequence_get_matches.argtypes = [vp, i32, vp, i32]
         L.vsm_sequence_get_timings.argtypes = [vp, vp]
         L.vsm_sequence_path.argtypes = [vp]
+        L.vsm_set_option.argtypes = [vp, C.c_char_p, i32]
         vop = C.POINTER(VsmVoStereoParams)
         L.vsm_vo_stereo_default_params.argtypes = [vop]
         L.vsm_vo_stereo_create.restype = vp
@@ -533,6 +534,11 @@ class Matcher:
     def sequence_path(self):
         """2: the last run_sequence went through the GPU-resident form, 1: through the host-shared form"""
         return lib().vsm_sequence_path(self.h)
+
+    def set_option(self, name, value):
+        """measurement / test switch of this handle (vsm_set_option): "seq_serial", "seq_chunk", "seq_v2", ..."""
+        if lib().vsm_set_option(self.h, name.encode(), int(value)) != self.OK:
+            raise VisoMatchError(f"unknown option {name}")
 
     def sequence_timings(self):
         t = np.zeros(4, dtype=np.float64)

@@ -283,22 +283,21 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
     m.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"VSM_SEQ_SERIAL": "1"}, {"VSM_SEQ_PACK": "0"}, {"VSM_SEQ_DC_STREAMS": "1"}, {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNKS": "5,9,3"},
-                                 {"VSM_SEQ_TAPER": "1", "VSM_SEQ_CHUNK": "16"}, {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
-                                 {"VSM_MATCH_STAGED": "1"}, {"VSM_FRONT": "0"}, {"VSM_MATCH_G": "8"}, {"VSM_SEQ_HOST_SHARE": "35"}, {"VSM_SEQ_HOST_SHARE": "100"}])
+@pytest.mark.parametrize("env", [{}, {"VSM_SEQ_SERIAL": "1"}, {"VSM_SEQ_PACK": "0"}, {"VSM_SEQ_DC_STREAMS": "1"}, {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNK": "5"},
+                                 {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
+                                 {"VSM_MATCH_STAGED": "1"}, {"VSM_FRONT": "0"}, {"VSM_MATCH_G": "8"}])
 def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), 48-byte result
-    records instead of the packed ones, one / four chain streams, explicit and tapered chunk sizes, the vertex sorts on the
-    device, one matching kernel per chain stage, the unfused front end, eight lanes per query, a share of the final stages (or
-    all of them) on the host pool: always the reference's lists,
-    and always this form (it must not quietly hand the run to the other one)."""
+    records instead of the packed ones, one / four chain streams (eight chunks of five: every bank comes round twice), the
+    vertex sorts on the device, one matching kernel per chain stage, the unfused front end, eight lanes per query: always
+    the reference's lists, and always this form (it must not quietly hand the run to the other one)."""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1")
     monkeypatch.setenv("VSM_SEQ_CHUNK", "10")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     g = G.load("cfg2_seq200_tr")
-    w, h, nf = int(g["w"]), int(g["h"]), 36
+    w, h, nf = int(g["w"]), int(g["h"]), 38
     cv = synth.canvas(int(g["seed"]), w, h)
     fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
     left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
@@ -310,6 +309,77 @@ def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     for f in range(nf):
         assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), (env, f)
     m.close()
+
+
+def test_lookahead_as_shipped_200_frames(vm, synth, monkeypatch):
+    """What bench.py times, as it ships: config 2 (200 frames 1242x375 resident in HBM, replayed Tr_delta) through
+    vsm_sequence_run with NO VSM_* variable set - the GPU-resident form, chunks of 76, three chain streams, the default
+    host pool - every frame's final list against the reference's hash, twice on one handle (banks and slabs are reused)."""
+    import os
+    import torch
+    for k in [k for k in os.environ if k.startswith("VSM_")]:
+        monkeypatch.delenv(k)
+    g = G.load("cfg2_seq200_tr")
+    w, h, nf = int(g["w"]), int(g["h"]), 200
+    cv = synth.canvas(int(g["seed"]), w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
+    left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
+    right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
+    m = vm.Matcher()
+    m.set_intrinsics(*[float(x) for x in g["intr"]])
+    for rep in range(2):
+        got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
+        assert m.sequence_path() == 2
+        assert int(m.sequence_timings()["chunk"]) == 76
+        for f in range(nf):
+            assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), (rep, f)
+    m.close()
+
+
+@pytest.mark.parametrize("form", ["host-shared", "GPU-resident"])
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_sequence_api_single_stage(vm, B, synth, monkeypatch, method, form):
+    """multi_stage = 0 (one matching pass, no prior statistics: viso/matcher.cpp:217-221) through the look-ahead API in both
+    forms, flow / stereo / quad: the GPU-resident form then has no first-pass chain (and no first-pass slab) at all"""
+    monkeypatch.setenv("VSM_SEQ_CHUNK", "3")
+    monkeypatch.setenv("VSM_SEQ_V2", "1" if form == "GPU-resident" else "0")
+    monkeypatch.setenv("VSM_DC_GPU", "1")
+    seq = synth.stereo_sequence(33, 417, 163, 7, disparity=10, ramp=(1, 12))
+    left = np.stack([l for l, _ in seq])
+    right = np.stack([r for _, r in seq])
+    g = vm.Matcher(multi_stage=0)
+    got = g.run_sequence(left, right, method)   # (stereo input also for flow matching: mono input goes frame by frame)
+    assert g.sequence_path() == (2 if form == "GPU-resident" else 1)
+    c = B.CpuMatcher("oracle", multi_stage=0)
+    for f, (l, r) in enumerate(seq):
+        c.push_back(l, r)
+        c.match(method)
+        assert _same(got[f], c.matches()), (method, f, len(got[f]), len(c.matches()))
+    assert len(got[-1]) > 100
+    g.close()
+
+
+def test_sequence_forms_alternate_on_one_handle(vm, B, synth):
+    """a stereo run (GPU-resident form), then a mono run (frame by frame inside the call), then stereo again on ONE handle:
+    the getters always answer for the last run"""
+    seq = synth.stereo_sequence(35, 417, 163, 5, disparity=10, ramp=(1, 12))
+    left = np.stack([l for l, _ in seq])
+    right = np.stack([r for _, r in seq])
+    g = vm.Matcher()
+    ref = {}
+    for method, rgt in ((2, True), (0, False)):
+        c = B.CpuMatcher("oracle")
+        ref[method] = []
+        for l, r in seq:
+            c.push_back(l, r if rgt else None)
+            c.match(method)
+            ref[method].append(c.matches())
+    for method, rgt in ((2, True), (0, False), (2, True)):
+        got = g.run_sequence(left, right if rgt else None, method)
+        assert g.sequence_path() == (2 if rgt else 1)
+        for f in range(len(seq)):
+            assert _same(got[f], ref[method][f]), (method, f)
+    g.close()
 
 
 @pytest.mark.parametrize("env", [{"VSM_DC_GPU": "0"}, {"VSM_DC_FULL": "1"}, {"VSM_DC_FULL": "0"}, {"VSM_DC_FULL": "0", "VSM_DC_TIES": "1"}, {"VSM_DC_FULL": "1", "VSM_DC_KD": "0"},
