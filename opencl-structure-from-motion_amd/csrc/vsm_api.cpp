@@ -374,6 +374,9 @@ struct VsmSwitches {
   int seq_serial = 0;      // VSM_SEQ_SERIAL: nothing overlaps (every kernel's time alone)
   int seq_gpu_sorts = -1;  // VSM_SEQ_GPU_SORTS: percent of a chunk's vertex sorts done on the device (-1 = by host threads)
   int front = 1;           // VSM_FRONT: the fused front end
+  int seq_early_export = 1;  // VSM_SEQ_EARLY_EXPORT: the refined lists cross PCIe beside the triangulation, survivor bits follow
+  int seq_export_dma = 1;  // VSM_SEQ_EXPORT_DMA: early export packs into HBM, a DMA copy takes it to the host
+  int seq_chain_prio = 0;  // VSM_SEQ_CHAIN_PRIO: the Delaunay chains' streams at the device's highest priority (read when the streams are made)
   static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -386,6 +389,9 @@ struct VsmSwitches {
     seq_serial = env_int("VSM_SEQ_SERIAL", 0) != 0;
     seq_gpu_sorts = env_int("VSM_SEQ_GPU_SORTS", -1);
     front = env_int("VSM_FRONT", 1) != 0;
+    seq_chain_prio = env_int("VSM_SEQ_CHAIN_PRIO", 0) != 0;
+    seq_early_export = env_int("VSM_SEQ_EARLY_EXPORT", 1) != 0;
+    seq_export_dma = env_int("VSM_SEQ_EXPORT_DMA", 1) != 0;
   }
   bool set(const char *name, int v) {
     if (!strcmp(name, "seq_v2")) seq_v2 = v != 0;
@@ -395,6 +401,9 @@ struct VsmSwitches {
     else if (!strcmp(name, "seq_serial")) seq_serial = v != 0;
     else if (!strcmp(name, "seq_gpu_sorts")) seq_gpu_sorts = v;
     else if (!strcmp(name, "front")) front = v != 0;
+    else if (!strcmp(name, "seq_chain_prio")) seq_chain_prio = v != 0;
+    else if (!strcmp(name, "seq_early_export")) seq_early_export = v != 0;
+    else if (!strcmp(name, "seq_export_dma")) seq_export_dma = v != 0;
     else return false;
     return true;
   }

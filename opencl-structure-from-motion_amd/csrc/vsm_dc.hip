@@ -13,6 +13,7 @@
 #include <stdio.h>
 
 #include <algorithm>
+#include <cmath>
 
 #include "vsm_dc_gpu.h"
 #include "vsm_dc_mesh.h"
@@ -907,12 +908,14 @@ extern "C" int vsm_debug_dc2_phases(unsigned long long *out, int reset) {
 // instead of 40.  FOUR waves: lanes that walk different seams diverge, and a wave issues every diverging lane's path in
 // turn, so the quarter sub-trees of the block go to a wave each (they sit on the CU's four SIMDs) - 8 leaves instead of
 // 32 per wave, one merge node per wave from the third level up.  Measured alone, 50 lists of 7.4 k: 450 -> 330 us.
-#define DC2_BLOCK_THREADS 256
-__global__ void __launch_bounds__(DC2_BLOCK_THREADS, 7) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
-  __shared__ __attribute__((aligned(16))) dc2_word s_rec[2 * VSM_DC_BLOCK_POINTS * 8];
-  __shared__ uint64_t s_key[VSM_DC_BLOCK_POINTS];
+#ifndef DC2_BLOCK_WAVES
+#define DC2_BLOCK_WAVES 4
+#endif
+#define DC2_BLOCK_THREADS (64 * DC2_BLOCK_WAVES)
+__global__ void __launch_bounds__(DC2_BLOCK_THREADS, 5) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_w[2 * VSM_DC_BLOCK_POINTS * 4];  // edge words (vsm_dc_lds.h)
   __shared__ uint32_t s_pt[VSM_DC_BLOCK_POINTS];
-  __shared__ Dc2Hull16 s_hull[2 << DCB_DEPTH];
+  __shared__ Dc2Hull16 s_hull[2 << DC2_BLOCK_DEPTH];
   const VsmDc2Job j2 = jobs[blockIdx.y];
   const int32_t m = j2.mn[0];
   if (m < 2) return;
@@ -942,22 +945,24 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, 7) k_dc2_block(const VsmDc2
   const int lane = threadIdx.x;
   const int wv = lane >> 6, wl = lane & 63;  // wave, lane in the wave
   DC2_T(c0);
-  for (int i = lane; i < bn; i += DC2_BLOCK_THREADS) s_key[i] = j2.key[boff + i];
   {
     dc2_v4u ones;
     ones.x = ones.y = ones.z = ones.w = 0xffffffffu;
-    for (int i = lane; i < 2 * bn * (int)sizeof(dc2_word) / 2; i += DC2_BLOCK_THREADS) ((dc2_v4u *)s_rec)[i] = ones;
+    for (int i = lane; i < 2 * bn; i += DC2_BLOCK_THREADS) ((dc2_v4u *)s_w)[i] = ones;
   }
   __syncthreads();
   DcBlockMesh mesh;
-  mesh.rec = (DC2_AS3 dc2_word *)s_rec;
+  mesh.w = (DC2_AS3 dc2_u32a *)s_w;
   mesh.pt = (DC2_AS3 const uint32_t *)s_pt;
-  mesh.key = (DC2_AS3 uint64_t *)s_key;
+  mesh.key = j2.key + boff;  // (a leaf reads its two or three keys where they lie)
   mesh.ptw = (DC2_AS3 uint32_t *)s_pt;
   mesh.gid = j2.id + boff;
   DC2_T(c1);
-  // leaf of virtual lane (wave << 4 | lane): the two top bits of a path - the quarter of the block - are the wave
-  if (wl < 16) dc2_block_leaf_run(mesh, (wv << 4) | wl, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+  // leaf of virtual lane v: the two top bits of a path - the quarter of the block - are the wave
+  {
+    constexpr int kPerWave = (1 << DC2_BLOCK_DEPTH) / DC2_BLOCK_WAVES;
+    for (int v = wl; v < kPerWave; v += 64) dc2_block_leaf_run(mesh, wv * kPerWave + v, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+  }
   __syncthreads();
   DC2_T(c2);
 #ifdef DC2_PHASE_TIMING
@@ -965,29 +970,41 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, 7) k_dc2_block(const VsmDc2
 #endif
   for (int L = DC2_BLOCK_DEPTH - 1; L >= 0; L--) {
     {  // node j of level L (2^L nodes): quarter = wave from the third level up; the two top levels on waves 0, 1 / wave 0
-      int j = -1;
-      if (L >= 2) {
-        if (wl < (1 << (L - 2))) j = (wv << (L - 2)) | wl;
-      } else if (wl == 0 && wv < (1 << L)) {
-        j = wv;
+      const int nodes = 1 << L;
+      if (nodes >= DC2_BLOCK_WAVES) {
+        const int per_wave = nodes / DC2_BLOCK_WAVES;
+        for (int v = wl; v < per_wave; v += 64) dc2_block_merge_run(mesh, wv * per_wave + v, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+      } else if (wl == 0 && wv < nodes) {
+        dc2_block_merge_run(mesh, wv, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
       }
-      if (j >= 0) dc2_block_merge_run(mesh, j, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
     }
     __syncthreads();
 #ifdef DC2_PHASE_TIMING
     {
       const long long cn = clock64();
-      if (lane == 0) DC2_ACC(0, 3 + (DC2_BLOCK_DEPTH - 1 - L), cl, cn);
+      if (lane == 0) DC2_ACC(0, 3 + L, cl, cn);
       cl = cn;
     }
 #endif
   }
   DC2_T(c3);
-  // records out under global numbering
-  int32_t *gt = j2.tri + (size_t)2 * boff * 8;
-  for (int i = lane; i < 2 * bn * 8; i += DC2_BLOCK_THREADS) {
-    const uint32_t v = s_rec[i];
-    gt[i] = v == DC2_NONE ? -1 : (int32_t)v + ((i & 4) ? boff : 8 * boff);
+  // records out under global numbering: neighbour handles + 8 boff, vertices + boff (a record is two 16-byte stores)
+  dc2_v4i *gt = (dc2_v4i *)(j2.tri + (size_t)2 * boff * 8);
+  for (int t = lane; t < 2 * bn; t += DC2_BLOCK_THREADS) {
+    const dc2_v4u o = ((const dc2_v4u *)s_w)[t];
+    auto nb = [&](uint32_t v) -> int32_t { return (v & 0xffffu) == 0xffffu ? -1 : (int32_t)(v & 0xffffu) + 8 * boff; };
+    auto vx = [&](uint32_t v) -> int32_t { return (v >> 16) == 0xffffu ? -1 : (int32_t)(v >> 16) + boff; };
+    dc2_v4i a, b;
+    a.x = nb(o.x);
+    a.y = nb(o.y);
+    a.z = nb(o.z);
+    a.w = -1;
+    b.x = vx(o.x);
+    b.y = vx(o.y);
+    b.z = vx(o.z);
+    b.w = -1;
+    gt[2 * t] = a;
+    gt[2 * t + 1] = b;
   }
   for (int i = lane; i < bn; i += DC2_BLOCK_THREADS) j2.pt[boff + i] = s_pt[i];
   if (lane == 0) {
@@ -1000,36 +1017,84 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, 7) k_dc2_block(const VsmDc2
     atomicAdd(&dc2_dbg[0][0], 1ull);
     DC2_ACC(0, 1, c0, c1);
     DC2_ACC(0, 2, c1, c2);
-    DC2_ACC(0, 9, c3, c4);
-    DC2_ACC(0, 10, c0, c4);
+    DC2_ACC(0, 13, c3, c4);
+    DC2_ACC(0, 14, c0, c4);
   }
 #endif
 }
 
 // ---------------------------------------------------------------------------------------
 // Merge levels above the blocks.  mergehulls walks a seam: every step reads a few triangle records and points that
-// depend on the previous step, and in global memory each of those is an L2 round trip.  Here a workgroup takes one
-// merge node: all its threads first bring the node's points and the records the seam can touch into LDS -- the hull
-// (ghost) triangles of both halves, the triangles whose circumcircle reaches across the cut (only those can be
-// destroyed), their neighbours (read for their apex), the node's two new slots -- with a 16-bit slot -> LDS index map;
-// nodes small enough go in whole.  Then one lane zips the seam on the LDS copies (DcCachedMesh: stores also go through
-// to global memory, which therefore is always current; a record that was not foreseen is fetched on first use).
+// depend on the previous step, and in global memory each of those is an L2 round trip.  A workgroup takes one merge
+// node and brings into LDS ONLY what the seam can touch - the band:
+//   * the hull (ghost) triangles of both halves (the handles travel along them),
+//   * the triangles whose circumcircle reaches across the cut (only those can be dissolved: an edge goes when a point of
+//     the other half lies inside the circle through its triangle),
+//   * the neighbours of all of those (read for the apex across an edge, written when a bond changes),
+//   * the node's two new slots,
+// a few hundred records out of the node's 2 n (535 of 14 800 for the top merge of a 7.4 k list).  The band gets a
+// compact numbering of its own - line = number of band slots before it (rank in a bit mask), the points its records use
+// likewise - so the walk runs on the plain 16-bit whole-node accessors (DcLdsMesh<false>): 8-50 KB of LDS per node
+// instead of 36 bytes per point of the node (the top merges used to hold a compute unit's LDS each while one lane walked),
+// nothing to translate during the walk, and the node itself may be of any size.  One lane then zips the seam;
+// afterwards all lanes write the band's records back under global numbering.  A neighbour word that would lead out of the
+// band holds DC2_EXT; following it (it does not happen: the band is closed under the walk's accesses)
+// trips the mesh's guard, and the node is redone by one lane on the records in global memory, which are untouched until
+// the write-back.  The same happens to a node whose band does not fit the LDS the level was launched with.
 // ---------------------------------------------------------------------------------------
 #define DC2_MERGE_THREADS 256
-#define DC2_CACHE_PTS 8192   // mapped form: points + 16-bit map in LDS
-#define DC2_CACHE_RECS 4608  // ... and this many 16-byte record lines
-#define DC2_WHOLE_PTS 4416   // nodes up to this many points sit in LDS whole (36 bytes per point)
+#ifdef DC2_PHASE_TIMING
+#define DC2_BAND_STAT(level, col, v) atomicAdd(&dc2_dbg[1 + (level)][col], (unsigned long long)(v))
+#else
+#define DC2_BAND_STAT(level, col, v)
+#endif
 
-// dynamic LDS: [rec_cap][8] 16-bit records, [pts_cap] points, then for the mapped form [2 pts_cap / 32] claim bits and
-// [2 pts_cap] map entries - sized by the host for the largest node of the level, so the small nodes of the lower levels
-// leave room for several workgroups per CU
-__global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job *__restrict__ jobs, int level, int pts_cap, int rec_cap) {
+// exclusive prefix of the population counts of `words` mask words (256 threads; pre[w] = set bits before word w); returns the total
+__device__ inline uint32_t dc2_mask_prefix(const uint32_t *mask, uint16_t *pre, int words, uint32_t *tot) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int per = (words + DC2_MERGE_THREADS - 1) / DC2_MERGE_THREADS;
+  const int w0 = min(words, t * per), w1 = min(words, w0 + per);
+  uint32_t sum = 0;
+  for (int w = w0; w < w1; w++) sum += __popc(mask[w]);
+  uint32_t x = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) tot[wv] = x;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int k = 0; k < wv; k++) base += tot[k];
+  const uint32_t total = tot[0] + tot[1] + tot[2] + tot[3];
+  uint32_t run = base + x - sum;
+  for (int w = w0; w < w1; w++) {
+    pre[w] = (uint16_t)run;
+    run += __popc(mask[w]);
+  }
+  __syncthreads();
+  return total;
+}
+__device__ inline bool dc2_bit(const uint32_t *mask, int i) { return (mask[i >> 5] >> (i & 31)) & 1u; }
+__device__ inline int dc2_rank(const uint32_t *mask, const uint16_t *pre, int i) {
+  return (int)pre[i >> 5] + __popc(mask[i >> 5] & ((1u << (i & 31)) - 1u));
+}
+
+// dynamic LDS: [lines_cap][8] 16-bit records, [pts_cap] points, [lines_cap] line -> slot, [pts_cap] compact point -> point,
+// [words_cap] band mask, [words_cap] ring mask, [words_cap / 2] point mask, their prefixes (16-bit)
+__global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job *__restrict__ jobs, int level, int lines_cap, int pts_cap, int words_cap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dc2_lds[];
   uint16_t *s_rec = (uint16_t *)dc2_lds;
-  uint32_t *s_pt = (uint32_t *)(s_rec + (size_t)rec_cap * 8);
-  uint32_t *s_claim = s_pt + pts_cap;
-  uint16_t *s_map = (uint16_t *)(s_claim + (2 * pts_cap + 31) / 32);
-  __shared__ int32_t s_n, s_cl, s_cr;
+  uint32_t *s_pt = (uint32_t *)(s_rec + (size_t)lines_cap * 8);
+  uint32_t *s_l2s = s_pt + pts_cap;
+  uint32_t *s_c2p = s_l2s + lines_cap;
+  uint32_t *s_band = s_c2p + pts_cap;
+  uint32_t *s_ring = s_band + words_cap;
+  uint32_t *s_pmask = s_ring + words_cap;
+  uint16_t *s_bpre = (uint16_t *)(s_pmask + (words_cap + 1) / 2);
+  uint16_t *s_ppre = s_bpre + words_cap;
+  __shared__ int32_t s_cl, s_cr, s_fail;
+  __shared__ uint32_t s_tot[4];
   const VsmDc2Job jb = jobs[blockIdx.y];
   const int32_t m = jb.mn[0];
   if (m < 2) return;
@@ -1040,87 +1105,29 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
   const int t = threadIdx.x;
   const int32_t div = n >> 1;
   const VsmDcHull l = jb.hulls[2 * idx], r = jb.hulls[2 * idx + 1];
-  const int32_t tbase = 2 * off, nslots = 2 * n;
-  int32_t tcur = 2 * div - 2;  // local: the node's own two slots
-  const bool whole = nslots <= rec_cap && n <= pts_cap;
-  if (sizeof(dc2_word) != 2 || (!whole && (n > pts_cap || n > DC2_CACHE_PTS))) {  // too large for either form: the plain mesh in global memory
-    if (t == 0) {
-      DcOTri fl{l.fl_t, l.fl_o}, il{l.fr_t, l.fr_o}, ir{r.fl_t, r.fl_o}, fr{r.fr_t, r.fr_o};
-      int32_t tg = 2 * (off + div) - 2;
-      const DcMesh mesh{jb.tri, jb.pt, jb.id, jb.key};
-      mesh.merge_hulls(fl, il, ir, fr, axis, tg);
-      jb.hulls[idx] = VsmDcHull{fl.t, fl.o, fr.t, fr.o};
-    }
-    return;
-  }
-  DcOTri fl{l.fl_t - tbase, l.fl_o}, il{l.fr_t - tbase, l.fr_o}, ir{r.fl_t - tbase, r.fl_o}, fr{r.fr_t - tbase, r.fr_o};
+  const int32_t tbase = 2 * off, nslots = 2 * n, tbase4 = 4 * tbase;
+  const int bwords = (nslots + 31) >> 5, pwords = (n + 31) >> 5;
   int32_t *gnode = jb.tri + (size_t)tbase * 8;
   const dc2_v4i *grec = (const dc2_v4i *)gnode;
-  const int32_t tbase4 = 4 * tbase;
-  auto pack = [&](const dc2_v4i a, const dc2_v4i b) -> dc2_v4u {  // a global record as a local 16-bit one
-    dc2_v4u o;
-    o.x = (uint32_t)((a.x < 0 ? -1 : a.x - tbase4) & 0xffff) | ((uint32_t)(a.y < 0 ? -1 : a.y - tbase4) << 16);
-    o.y = (uint32_t)((a.z < 0 ? -1 : a.z - tbase4) & 0xffff) | 0xffff0000u;
-    o.z = (uint32_t)((b.x < 0 ? -1 : b.x - off) & 0xffff) | ((uint32_t)(b.y < 0 ? -1 : b.y - off) << 16);
-    o.w = (uint32_t)((b.z < 0 ? -1 : b.z - off) & 0xffff) | 0xffff0000u;
-    return o;
-  };
+  const uint32_t *gpt = jb.pt + off;
+  DC2_T(m0);
+  bool band_ok = bwords <= words_cap;
   if (t == 0) {
-    s_n = 0;
     s_cl = -1;
     s_cr = 1 << 30;
+    s_fail = 0;
   }
-  DC2_T(m0);
-  for (int i = t; i < n; i += DC2_MERGE_THREADS) s_pt[i] = jb.pt[off + i];
-  if (whole) {
-    for (int s = t; s < nslots; s += DC2_MERGE_THREADS) ((dc2_v4u *)s_rec)[s] = pack(grec[2 * s], grec[2 * s + 1]);
+  if (band_ok) {
+    for (int i = t; i < bwords; i += DC2_MERGE_THREADS) {
+      s_band[i] = 0;
+      s_ring[i] = 0;
+    }
+    for (int i = t; i < pwords; i += DC2_MERGE_THREADS) s_pmask[i] = 0;
     __syncthreads();
-    DC2_T(m1);
-    if (t == 0) {
-      DcLdsMesh<false> mesh;
-      mesh.rec = (DC2_AS3 dc2_word *)s_rec;
-      mesh.pt = (DC2_AS3 const uint32_t *)s_pt;
-      dc_merge_hulls(mesh, fl, il, ir, fr, axis, tcur);
-      jb.hulls[idx] = VsmDcHull{fl.t + tbase, fl.o, fr.t + tbase, fr.o};
-    }
-    __syncthreads();
-#ifdef DC2_PHASE_TIMING
-    if (t == 0) {
-      const long long m2 = clock64();
-      atomicAdd(&dc2_dbg[1 + level][0], 1ull);
-      DC2_ACC(1 + level, 1, m0, m1);
-      DC2_ACC(1 + level, 2, m1, m2);
-    }
-#endif
-    // everything back under global numbering (a record is two 16-byte stores)
-    for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
-      const dc2_v4u o = ((const dc2_v4u *)s_rec)[s];
-      auto nb = [&](uint32_t v) -> int32_t { return v == 0xffffu ? -1 : (int32_t)v + tbase4; };
-      auto vx = [&](uint32_t v) -> int32_t { return v == 0xffffu ? -1 : (int32_t)v + off; };
-      dc2_v4i a, b;
-      a.x = nb(o.x & 0xffffu);
-      a.y = nb(o.x >> 16);
-      a.z = nb(o.y & 0xffffu);
-      a.w = -1;
-      b.x = vx(o.z & 0xffffu);
-      b.y = vx(o.z >> 16);
-      b.z = vx(o.w & 0xffffu);
-      b.w = -1;
-      ((dc2_v4i *)gnode)[2 * s] = a;
-      ((dc2_v4i *)gnode)[2 * s + 1] = b;
-    }
-    return;
-  }
-  // ---- mapped form ----
-  for (int i = t; i < nslots; i += DC2_MERGE_THREADS) s_map[i] = 0xffff;
-  for (int i = t; i < (nslots + 31) / 32; i += DC2_MERGE_THREADS) s_claim[i] = 0;
-  __syncthreads();
-  {
-    // extent of the two halves along the cut axis: largest coordinate on the left, smallest on the right
-    {
+    {  // extent of the two halves along the cut axis: largest coordinate on the left, smallest on the right
       int32_t cl = -1, cr = 1 << 30;
       for (int i = t; i < n; i += DC2_MERGE_THREADS) {
-        const uint32_t p = s_pt[i];
+        const uint32_t p = gpt[i];
         const int32_t c = axis == 0 ? (int32_t)(p & 0xffffu) : (int32_t)(p >> 16);
         if (i < div)
           cl = max(cl, c);
@@ -1139,25 +1146,18 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
     }
     __syncthreads();
     const float fcl = (float)s_cl, fcr = (float)s_cr;
-    auto insert = [&](int s) {  // record of local slot s into the cache (the caller has claimed it)
-      const int k = atomicAdd(&s_n, 1);
-      if (k < rec_cap) {
-        ((dc2_v4u *)s_rec)[k] = pack(grec[2 * s], grec[2 * s + 1]);
-        s_map[s] = (uint16_t)k;
-      }
-    };
-    auto claim = [&](int s) -> bool { return ((atomicOr(&s_claim[s >> 5], 1u << (s & 31)) >> (s & 31)) & 1u) == 0; };
+    // the band's core: own slots, hull triangles, triangles whose circumcircle crosses the cut
     for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
       const dc2_v4i v = grec[2 * s + 1];
-      bool hot = false;
+      bool hot;
       if (s == 2 * div - 2 || s == 2 * div - 1) {
-        hot = true;  // the node's own two slots
+        hot = true;
       } else if ((v.x & v.y & v.z) < 0) {
         hot = false;  // unused slot
       } else if ((v.x | v.y | v.z) < 0) {
         hot = true;  // hull triangle
       } else {
-        const uint32_t pa = s_pt[v.x - off], pb = s_pt[v.y - off], pc = s_pt[v.z - off];
+        const uint32_t pa = gpt[v.x - off], pb = gpt[v.y - off], pc = gpt[v.z - off];
         const float ax = (float)(pa & 0xffffu), ay = (float)(pa >> 16);
         const float bx = (float)(pb & 0xffffu) - ax, by = (float)(pb >> 16) - ay;
         const float cx = (float)(pc & 0xffffu) - ax, cy = (float)(pc >> 16) - ay;
@@ -1169,40 +1169,134 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
         hot = s < 2 * div ? (cc + rad >= fcr) : (cc - rad <= fcl);
         hot = hot || !(d == d) || d == 0.f;
       }
-      if (hot && claim(s)) insert(s);
+      if (hot) atomicOr(&s_band[s >> 5], 1u << (s & 31));
     }
     __syncthreads();
-    const int nhot = min(s_n, rec_cap);
-    __syncthreads();
-    for (int k = t; k < nhot; k += DC2_MERGE_THREADS)  // their neighbours are read too (for the apex across an edge)
+    // ... and the neighbours of the core
+    for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
+      if (!dc2_bit(s_band, s)) continue;
+      const dc2_v4i e = grec[2 * s];
+      const int32_t nb[3] = {e.x, e.y, e.z};
+#pragma unroll
       for (int o = 0; o < 3; o++) {
-        const uint32_t e = s_rec[k * 8 + o];
-        if (e == 0xffffu) continue;
-        const int s2 = (int)(e >> 2);
-        if (s2 < nslots && claim(s2)) insert(s2);
+        if (nb[o] < 0) continue;
+        const int s2 = (nb[o] - tbase4) >> 2;
+        if (s2 >= 0 && s2 < nslots) atomicOr(&s_ring[s2 >> 5], 1u << (s2 & 31));
       }
-  }
-  __syncthreads();
-  DC2_T(m1);
-  if (t == 0) {
-    if (s_n > rec_cap) s_n = rec_cap;
-    DcLdsMesh<true> mesh;
-    mesh.rec = (DC2_AS3 dc2_word *)s_rec;
-    mesh.pt = (DC2_AS3 const uint32_t *)s_pt;
-    mesh.map = (DC2_AS3 uint16_t *)s_map;
-    mesh.nrec = (DC2_AS3 int32_t *)&s_n;
-    mesh.gtri = gnode;
-    mesh.rec_cap = rec_cap;
-    mesh.tbase4 = tbase4;
-    mesh.pbase = off;
-    dc_merge_hulls(mesh, fl, il, ir, fr, axis, tcur);
-    jb.hulls[idx] = VsmDcHull{fl.t + tbase, fl.o, fr.t + tbase, fr.o};
+    }
+    __syncthreads();
+    for (int i = t; i < bwords; i += DC2_MERGE_THREADS) s_band[i] |= s_ring[i];
+    __syncthreads();
+    const uint32_t nlines = dc2_mask_prefix(s_band, s_bpre, bwords, s_tot);
+    uint32_t npts = 0;
+    band_ok = nlines <= (uint32_t)lines_cap;
+    if (band_ok) {
+      // the points the band's records use
+      for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
+        if (!dc2_bit(s_band, s)) continue;
+        const dc2_v4i v = grec[2 * s + 1];
+        const int32_t vv[3] = {v.x, v.y, v.z};
+#pragma unroll
+        for (int o = 0; o < 3; o++)
+          if (vv[o] >= 0) atomicOr(&s_pmask[(vv[o] - off) >> 5], 1u << ((vv[o] - off) & 31));
+      }
+      __syncthreads();
+      npts = dc2_mask_prefix(s_pmask, s_ppre, pwords, s_tot);
+      band_ok = npts <= (uint32_t)pts_cap;
+      if (band_ok) {
+        for (int i = t; i < n; i += DC2_MERGE_THREADS)
+          if (dc2_bit(s_pmask, i)) {
+            const int c = dc2_rank(s_pmask, s_ppre, i);
+            s_pt[c] = gpt[i];
+            s_c2p[c] = (uint32_t)i;
+          }
+        for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
+          if (!dc2_bit(s_band, s)) continue;
+          const int line = dc2_rank(s_band, s_bpre, s);
+          const dc2_v4i e = grec[2 * s], v = grec[2 * s + 1];
+          auto nbw = [&](int32_t g) -> uint32_t {  // neighbour handle under the band's numbering
+            if (g < 0) return 0xffffu;
+            const int s2 = (g - tbase4) >> 2;
+            if (s2 < 0 || s2 >= nslots || !dc2_bit(s_band, s2)) return DC2_EXT;
+            return (uint32_t)(dc2_rank(s_band, s_bpre, s2) * 4 + (g & 3));
+          };
+          auto vxw = [&](int32_t g) -> uint32_t { return g < 0 ? 0xffffu : (uint32_t)dc2_rank(s_pmask, s_ppre, g - off); };
+          dc2_v4u o;  // edge words: neighbour | apex << 16 per edge
+          o.x = nbw(e.x) | (vxw(v.x) << 16);
+          o.y = nbw(e.y) | (vxw(v.y) << 16);
+          o.z = nbw(e.z) | (vxw(v.z) << 16);
+          o.w = 0xffffffffu;
+          ((dc2_v4u *)s_rec)[line] = o;
+          s_l2s[line] = (uint32_t)s;
+        }
+      }
+    }
+    __syncthreads();
+    DC2_T(m1);
+    if (band_ok) {
+      if (t == 0) {
+        DcBandMesh mesh;
+        mesh.w = (DC2_AS3 dc2_u32a *)s_rec;
+        mesh.pt = (DC2_AS3 const uint32_t *)s_pt;
+        auto ln = [&](int32_t gt) -> int32_t {
+          if (!dc2_bit(s_band, gt - tbase)) mesh.tripped = 1;  // (a hull handle is a hull triangle: in the band)
+          return dc2_rank(s_band, s_bpre, gt - tbase);
+        };
+        DcOTri fl{ln(l.fl_t), l.fl_o}, il{ln(l.fr_t), l.fr_o}, ir{ln(r.fl_t), r.fl_o}, fr{ln(r.fr_t), r.fr_o};
+        int32_t tcur = dc2_rank(s_band, s_bpre, 2 * div - 2);
+        if (mesh.ok()) dc_merge(mesh, fl, il, ir, fr, axis, tcur);
+        if (mesh.ok())
+          jb.hulls[idx] = VsmDcHull{(int32_t)s_l2s[fl.t] + tbase, fl.o, (int32_t)s_l2s[fr.t] + tbase, fr.o};
+        else
+          s_fail = 1;
+      }
+      __syncthreads();
+      band_ok = s_fail == 0;
 #ifdef DC2_PHASE_TIMING
-    const long long m2 = clock64();
-    atomicAdd(&dc2_dbg[1 + level][0], 1ull);
-    DC2_ACC(1 + level, 1, m0, m1);
-    DC2_ACC(1 + level, 2, m1, m2);
-    atomicAdd(&dc2_dbg[1 + level][3], (unsigned long long)s_n);
+      if (t == 0) {
+        const long long m2 = clock64();
+        atomicAdd(&dc2_dbg[1 + level][0], 1ull);
+        DC2_ACC(1 + level, 1, m0, m1);
+        DC2_ACC(1 + level, 2, m1, m2);
+        DC2_BAND_STAT(level, 3, nlines);
+        DC2_BAND_STAT(level, 4, band_ok ? 0 : 1);
+        atomicMax(&dc2_dbg[1 + level][6], (unsigned long long)nlines);
+        atomicMax(&dc2_dbg[1 + level][7], (unsigned long long)npts);
+      }
+#endif
+      if (band_ok) {  // the band's records back under global numbering (a record is two 16-byte stores)
+        for (uint32_t k = t; k < nlines; k += DC2_MERGE_THREADS) {
+          const dc2_v4u o = ((const dc2_v4u *)s_rec)[k];
+          auto nb = [&](uint32_t v) -> int32_t { return v == 0xffffu ? -1 : (int32_t)(s_l2s[v >> 2] * 4 + (v & 3)) + tbase4; };
+          auto vx = [&](uint32_t v) -> int32_t { return v == 0xffffu ? -1 : (int32_t)s_c2p[v] + off; };
+          // (a word that still says "out of the band" was never touched: the record in global memory has the neighbour)
+          const int32_t s = (int32_t)s_l2s[k];
+          const dc2_v4i old = grec[2 * s];
+          dc2_v4i a, b;
+          a.x = (o.x & 0xffffu) == DC2_EXT ? old.x : nb(o.x & 0xffffu);
+          a.y = (o.y & 0xffffu) == DC2_EXT ? old.y : nb(o.y & 0xffffu);
+          a.z = (o.z & 0xffffu) == DC2_EXT ? old.z : nb(o.z & 0xffffu);
+          a.w = -1;
+          b.x = vx(o.x >> 16);
+          b.y = vx(o.y >> 16);
+          b.z = vx(o.z >> 16);
+          b.w = -1;
+          ((dc2_v4i *)gnode)[2 * s] = a;
+          ((dc2_v4i *)gnode)[2 * s + 1] = b;
+        }
+        return;
+      }
+    }
+  }
+  // the band did not fit, or the walk left it: one lane on the plain mesh in global memory
+  if (t == 0) {
+    DcOTri fl{l.fl_t, l.fl_o}, il{l.fr_t, l.fr_o}, ir{r.fl_t, r.fl_o}, fr{r.fr_t, r.fr_o};
+    int32_t tg = 2 * (off + div) - 2;
+    const DcMesh mesh{jb.tri, jb.pt, jb.id, jb.key};
+    mesh.merge_hulls(fl, il, ir, fr, axis, tg);
+    jb.hulls[idx] = VsmDcHull{fl.t, fl.o, fr.t, fr.o};
+#ifdef DC2_PHASE_TIMING
+    atomicAdd(&dc2_dbg[1 + level][5], 1ull);
 #endif
   }
 }
@@ -1298,6 +1392,14 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc2_compact(const VsmDc2Job *__r
     if (jb.h_out_count) *jb.h_out_count = s_total;
   }
   if (!jb.out) return;
+  if (jb.out_packed == 2) {  // the records are on the host already: one bit per match says which of them stay
+    for (int32_t w = t; w < (n + 31) / 32; w += KD_THREADS) {
+      uint32_t bits = 0;
+      for (int b = 0; b < 32 && 32 * w + b < n; b++) bits |= jb.remap[32 * w + b] >= 0 ? (1u << b) : 0u;
+      jb.h_keep[w] = bits;
+    }
+    return;
+  }
   if (jb.out_packed) {  // 24 bytes per survivor (the lists of a look-ahead chunk cross PCIe: that copy is what this kernel's time is)
     uint64_t *dst = (uint64_t *)jb.out;
     bool bad = false;
@@ -1322,6 +1424,27 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc2_compact(const VsmDc2Job *__r
     const int32_t e = p / 3, d = jb.remap[e];
     if (d >= 0) dst[3 * d + (p - 3 * e)] = src[p];
   }
+}
+
+// the refined list as 24-byte records into the host-mapped result arena (out_packed == 2): behind the refinement, while
+// the triangulation runs - the PCIe copy of a chunk's lists takes a quarter of a millisecond and used to be the chain's last step
+__global__ void __launch_bounds__(256) k_dc2_export(const VsmDc2Job *__restrict__ jobs) {
+  const VsmDc2Job jb = jobs[blockIdx.y];
+  if (jb.out_packed != 2 || !jb.out) return;
+  const int n = min(*jb.count, jb.cap);
+  uint64_t *dst = (uint64_t *)jb.out;
+  bool bad = false;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    uint64_t w[3];
+    if (vsm_pack_match(jb.list[e], w)) {
+      dst[3 * e] = w[0];
+      dst[3 * e + 1] = w[1];
+      dst[3 * e + 2] = w[2];
+    } else {
+      bad = true;
+    }
+  }
+  if (bad) *jb.error = 3;  // (a field that is not an integer in range: the caller runs the other form)
 }
 
 // M4 computePriorStatistics (viso/matcher.cpp:734-868; host form: vsm_host_prior_statistics) over the survivors of
@@ -1400,55 +1523,64 @@ __global__ void __launch_bounds__(256) k_dc2_prior(const VsmDc2Job *__restrict__
   }
 }
 
+static int dc2_skip() {  // TEMPORARY ablation switch (timing experiments only: results are wrong with it)
+  static const int v = getenv("VSM_DC2_SKIP") ? atoi(getenv("VSM_DC2_SKIP")) : 0;
+  return v;
+}
 void vsm_dc2_launch_keys(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list) {
   if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_keys, dim3((std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs);
 }
 void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs) {
-  if (njobs <= 0) return;
+  if (njobs <= 0 || (dc2_skip() & 8)) return;
   hipLaunchKernelGGL(k_dc2_prepare, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs);
 }
 void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth) {
-  if (njobs <= 0) return;
+  if (njobs <= 0 || (dc2_skip() & 1)) return;
   hipLaunchKernelGGL(k_dc2_block, dim3(1 << depth, njobs), dim3(DC2_BLOCK_THREADS), 0, s, d_jobs, depth);
 }
 void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth, int max_list) {
-  if (njobs <= 0) return;
+  if (njobs <= 0 || (dc2_skip() & 2)) return;
   static const bool big_lds = hipFuncSetAttribute((const void *)k_dc2_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
   for (int level = depth - 1; level >= 0; level--) {
-    // the largest node of the level: ceil(max_list / 2^level) points
+    // the largest node of the level: ceil(max_list / 2^level) points.  A band is a few records per pixel of cut plus the
+    // two hulls, i.e. it grows like the square root of the node: 256 + 24 sqrt(n) lines cover it several times over
+    // (measured: 535 lines for the top merge of 7.4 k points), the points its records use are fewer than the lines.
     const int nmax = ((max_list + (1 << level) - 1) >> level) + 1;
-    int pts_cap = (nmax + 63) & ~63, rec_cap;
-    size_t bytes;
-    if (pts_cap <= DC2_WHOLE_PTS) {  // whole nodes: 2 records of 16 bytes + 4 bytes per point
-      rec_cap = 2 * pts_cap;
-      bytes = (size_t)rec_cap * 16 + (size_t)pts_cap * 4 + 64;
-    } else {  // mapped form (a node beyond DC2_CACHE_PTS points goes through global memory)
-      pts_cap = std::min(pts_cap, DC2_CACHE_PTS);
-      rec_cap = DC2_CACHE_RECS;
-      bytes = (size_t)rec_cap * 16 + (size_t)pts_cap * 4 + (size_t)((2 * pts_cap + 31) / 32) * 4 + (size_t)pts_cap * 4 + 64;
+    int lines_cap = (256 + (int)(24.0 * std::sqrt((double)nmax)) + 63) & ~63;
+    lines_cap = std::min(lines_cap, 16384);  // (16-bit line handles: line * 4 + edge below DC2_EXT)
+    int pts_cap = lines_cap;
+    int words_cap = ((2 * nmax + 31) >> 5) + 1;
+    auto bytes_of = [&]() {
+      return (size_t)lines_cap * 16 + (size_t)pts_cap * 4 + (size_t)lines_cap * 4 + (size_t)pts_cap * 4 + (size_t)words_cap * 4 * 2 +
+             (size_t)((words_cap + 1) / 2) * 4 + (size_t)words_cap * 2 * 2 + 64;
+    };
+    const size_t limit = big_lds ? 160 * 1024 - 1024 : 64 * 1024 - 1024;
+    while (bytes_of() > limit && lines_cap > 256) {  // (lists of several ten thousand points: what does not fit goes the slow way)
+      lines_cap -= 256;
+      pts_cap = lines_cap;
     }
-    if (!big_lds && bytes > 64 * 1024) {  // (not expected) within the default limit: the nodes that do not fit go through global memory
-      pts_cap = 1536;
-      rec_cap = 2 * pts_cap;
-      bytes = (size_t)rec_cap * 16 + (size_t)pts_cap * 4 + 64;
-    }
-    hipLaunchKernelGGL(k_dc2_merge, dim3(1 << level, njobs), dim3(DC2_MERGE_THREADS), bytes, s, d_jobs, level, pts_cap, rec_cap);
+    if (bytes_of() > limit) words_cap = 0;
+    hipLaunchKernelGGL(k_dc2_merge, dim3(1 << level, njobs), dim3(DC2_MERGE_THREADS), bytes_of(), s, d_jobs, level, lines_cap, pts_cap, words_cap);
   }
 }
 void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride) {
-  if (njobs <= 0) return;
+  if (njobs <= 0 || (dc2_skip() & 4)) return;
   hipLaunchKernelGGL(k_dc2_ties, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride);
 }
 void vsm_dc2_launch_support(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol, float disp_tol) {
-  if (njobs <= 0) return;
+  if (njobs <= 0 || (dc2_skip() & 16)) return;
   hipLaunchKernelGGL(k_dc2_apply_ties, dim3(njobs), dim3(64), 0, s, d_jobs);
   hipLaunchKernelGGL(k_dc2_flows, dim3((std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method);
   hipLaunchKernelGGL(k_dc2_support, dim3((2 * std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method, flow_tol, disp_tol);
 }
 void vsm_dc2_launch_compact(hipStream_t s, const VsmDc2Job *d_jobs, int njobs) {
-  if (njobs <= 0) return;
+  if (njobs <= 0 || (dc2_skip() & 32)) return;
   hipLaunchKernelGGL(k_dc2_compact, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs);
+}
+void vsm_dc2_launch_export(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(k_dc2_export, dim3(std::min(8, (std::max(max_list, 1) + 255) / 256), njobs), dim3(256), 0, s, d_jobs);
 }
 void vsm_dc2_launch_prior(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int method, int binsize, int radius, int w, int h, int ub,
                           int vb) {

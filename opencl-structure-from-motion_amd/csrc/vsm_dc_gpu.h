@@ -103,7 +103,10 @@ struct VsmDc2Job {
   int32_t *h_out_count;     // host-mapped, or null
   float *ranges;            // pass 1: the pair's prior boxes [ub*vb][16], device layout (k_dc2_prior)
   int32_t *error;           // host-mapped flag word: set when a pair cannot be handled on the device
-  int32_t out_packed;       // survivors leave as 24-byte records (vsm_pack_match) instead of 48-byte vsm_p_match: half the PCIe bytes
+  int32_t out_packed;       // 1: survivors leave as 24-byte records (vsm_pack_match) instead of 48-byte vsm_p_match: half the PCIe bytes;
+                            // 2: the WHOLE list left early as 24-byte records (k_dc2_export, behind the refinement, while the
+                            // triangulation runs) and only a survivor bit per match follows (h_keep): nothing PCIe-bound at the chain's end
+  uint32_t *h_keep;         // host-mapped: [ceil(cap / 32)] survivor bits (out_packed == 2)
 };
 // A match whose twelve fields are integers in range (coordinates 0..16382, indices 0..2^20-2, or -1) as 3 x 64 bits:
 // field triple k = (u, v, index) -> 48 bits u | v << 14 | index << 28 (-1 = all ones), triples 0..3 back to back.
@@ -148,6 +151,7 @@ void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int3
 void vsm_dc2_launch_support(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol,
                             float disp_tol);  // tie patches, flows, votes
 void vsm_dc2_launch_compact(hipStream_t s, const VsmDc2Job *d_jobs, int njobs);
+void vsm_dc2_launch_export(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list);  // out_packed == 2: the refined list, all of it
 void vsm_dc2_launch_prior(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int method, int binsize, int radius, int w, int h,
                           int ub, int vb);
 // smallest depth at which every sub-tree of a list of at most max_points points fits a block

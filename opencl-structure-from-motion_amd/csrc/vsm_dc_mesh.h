@@ -27,6 +27,18 @@ template <class M>
 VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft, DcOTri &innerright, DcOTri &farright,
                                   int axis, int32_t &tcur);
 
+// The seam walk a mesh view wants: views over the GPU's edge words (kFastZip, vsm_dc_lds.h) bring dc2_zip, a form of the
+// same walk written for them; everything else takes dc_merge_hulls.  Same decisions, same slots, same records either way.
+template <class M>
+VSM_HD inline void dc2_zip(const M &m, DcOTri &farleft, DcOTri &innerleft, DcOTri &innerright, DcOTri &farright, int axis, int32_t &tcur);
+template <class M>
+VSM_HD inline void dc_merge(const M &m, DcOTri &farleft, DcOTri &innerleft, DcOTri &innerright, DcOTri &farright, int axis, int32_t &tcur) {
+  if constexpr (M::kFastZip)
+    dc2_zip(m, farleft, innerleft, innerright, farright, axis, tcur);
+  else
+    dc_merge_hulls(m, farleft, innerleft, innerright, farright, axis, tcur);
+}
+
 // divconqrecurse + alternateaxes' leaf rule (viso/triangle.cpp:5963, :5596) over a mesh view M that additionally offers the
 // leaves' access to keys and points: key_at(i) (reference to the packed key at position i), put_point(i, x | y << 16, id)
 template <class M>
@@ -34,6 +46,11 @@ VSM_HD inline void dc_recurse(const M &m, int32_t off, int32_t n, int axis, DcOT
 
 struct DcMesh {
   typedef DcOTri OTri;
+  // a guarded view (the band cache of the GPU's merge levels, vsm_dc.hip) can refuse an access: dc_merge_hulls then
+  // leaves at the next loop head and the caller redoes the node another way; plain views never refuse
+  static constexpr bool kGuarded = false;
+  static constexpr bool kFastZip = false;
+  VSM_HD inline bool ok() const { return true; }
   // one 32-byte record per triangle: tri[t*8 + o] = neighbour handle across edge o,
   // tri[t*8 + 4 + o] = vertex o (-1 = ghost corner); pt[p] = x | y << 16 by sorted position
   int32_t *tri;
@@ -128,6 +145,7 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
     int32_t flpt = m.org(farleft), flapex = m.apex(farleft);
     int32_t frpt = m.dest(farright);
     while (m.py(flapex) < m.py(flpt)) {
+      if (M::kGuarded && !m.ok()) return;
       farleft = m.sym(M::lnext(farleft));
       flpt = flapex;
       flapex = m.apex(farleft);
@@ -135,6 +153,7 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
     OTri chk = m.sym(innerleft);
     int32_t cv = m.apex(chk);
     while (m.py(cv) > m.py(ildest)) {
+      if (M::kGuarded && !m.ok()) return;
       innerleft = M::lnext(chk);
       ilapex = ildest;
       ildest = cv;
@@ -142,6 +161,7 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
       cv = m.apex(chk);
     }
     while (m.py(irapex) < m.py(irorg)) {
+      if (M::kGuarded && !m.ok()) return;
       innerright = m.sym(M::lnext(innerright));
       irorg = irapex;
       irapex = m.apex(innerright);
@@ -149,6 +169,7 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
     chk = m.sym(farright);
     cv = m.apex(chk);
     while (m.py(cv) > m.py(frpt)) {
+      if (M::kGuarded && !m.ok()) return;
       farright = M::lnext(chk);
       frpt = cv;
       chk = m.sym(farright);
@@ -157,6 +178,7 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
   }
   bool changed;
   do {  // lower common tangent (:5704)
+    if (M::kGuarded && !m.ok()) return;
     changed = false;
     if (m.ccw(ildest, ilapex, irorg) > 0) {
       innerleft = m.sym(M::lprev(innerleft));
@@ -186,6 +208,7 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
   // (packed coordinates of the four corners travel with their indices: every point is read once, when it becomes a corner)
   uint32_t pll = m.P(ll), plr = m.P(lr), pul = m.P(ul), pur = m.P(ur);
   for (;;) {
+    if (M::kGuarded && !m.ok()) return;
     const bool lfin = M::ccw_p(pul, pll, plr) <= 0, rfin = M::ccw_p(pur, pll, plr) <= 0;
 
     if (lfin && rfin) {  // close the seam with the top bounding triangle (:5771)
@@ -202,12 +225,14 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
         OTri chk = m.sym(farleft);
         int32_t cv = m.apex(chk);
         while (m.px(cv) < m.px(flpt)) {
+          if (M::kGuarded && !m.ok()) return;
           farleft = M::lprev(chk);
           flpt = cv;
           chk = m.sym(farleft);
           cv = m.apex(chk);
         }
         while (m.px(frapex) > m.px(frpt)) {
+          if (M::kGuarded && !m.ok()) return;
           farright = m.sym(M::lprev(farright));
           frpt = frapex;
           frapex = m.apex(farright);
@@ -222,6 +247,7 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
         uint32_t pna = m.P(na);
         bool bad = M::incircle_p(pll, plr, pul, pna) > 0;
         while (bad) {
+          if (M::kGuarded && !m.ok()) return;
           ne = M::lnext(ne);
           OTri topc = m.sym(ne);
           ne = M::lnext(ne);
@@ -257,6 +283,7 @@ VSM_HD inline void dc_merge_hulls(const M &m, DcOTri &farleft, DcOTri &innerleft
         uint32_t pna = m.P(na);
         bool bad = M::incircle_p(pll, plr, pur, pna) > 0;
         while (bad) {
+          if (M::kGuarded && !m.ok()) return;
           ne = M::lprev(ne);
           OTri topc = m.sym(ne);
           ne = M::lprev(ne);
@@ -423,7 +450,7 @@ VSM_HD inline void dc_recurse(const M &m, int32_t off, int32_t n, int axis, DcOT
   dc_recurse(m, off, divider, 1 - axis, farleft, innerleft);
   dc_recurse(m, off + divider, n - divider, 1 - axis, innerright, farright);
   int32_t tcur = 2 * (off + divider) - 2;
-  dc_merge_hulls(m, farleft, innerleft, innerright, farright, axis, tcur);
+  dc_merge(m, farleft, innerleft, innerright, farright, axis, tcur);
 }
 
 VSM_HD inline void DcMesh::recurse(int32_t off, int32_t n, int axis, OTri &farleft, OTri &farright) const {
@@ -468,7 +495,7 @@ VSM_HD inline void dc_build_iter(const M &m, int32_t off0, int32_t n0, int axis0
     } else {
       OTri fl{s_flt[sp], s_flo[sp]}, il{s_ilt[sp], s_ilo[sp]}, ir = rl, fr = rr;
       int32_t tcur = 2 * (off + (n >> 1)) - 2;
-      dc_merge_hulls(m, fl, il, ir, fr, axis, tcur);
+      dc_merge(m, fl, il, ir, fr, axis, tcur);
       rl = fl;
       rr = fr;
     }
@@ -530,7 +557,7 @@ VSM_HD inline void dc_build_small(const M &m, int32_t off0, int32_t n0, int axis
       const uint64_t pk = d == 0 ? s0 : (d == 1 ? s1 : (d == 2 ? s2 : s3));
       OTri fl{(int32_t)(pk >> 34), (int32_t)((pk >> 32) & 3u)}, il{(int32_t)((pk >> 2) & 0x3fffffffu), (int32_t)(pk & 3u)}, ir = rl, fr = rr;
       int32_t tcur = 2 * (off + (n >> 1)) - 2;
-      dc_merge_hulls(m, fl, il, ir, fr, axis, tcur);
+      dc_merge(m, fl, il, ir, fr, axis, tcur);
       rl = fl;
       rr = fr;
     }

@@ -23,10 +23,12 @@ L.vsm_debug_dc2_phases(buf, 1)
 a = np.array(buf[:], dtype=np.float64).reshape(16, 16)
 MHZ = 100.0  # clock64() ticks per microsecond (s_memtime: constant 100 MHz on gfx9)
 print("k_dc2_block: blocks", int(a[0, 0]))
-names = ["init", "leaves", "L5", "L4", "L3", "L2", "L1", "L0", "write-out", "total"]
-for k, nm in enumerate(names):
-    print(f"  {nm:10s} {a[0, 1 + k] / max(a[0, 0], 1) / MHZ:9.2f} us per block")
+names = {1: "init", 2: "leaves", 13: "write-out", 14: "total"}
+names.update({3 + L: f"L{L}" for L in range(10)})
+for k in sorted(names):
+    if a[0, k]:
+        print(f"  {names[k]:10s} {a[0, k] / max(a[0, 0], 1) / MHZ:9.2f} ticks per block")
 for lv in range(0, 9):
     if a[1 + lv, 0]:
         c = a[1 + lv, 0]
-        print(f"k_dc2_merge level {lv}: nodes {int(c)}  load {a[1 + lv, 1] / c / MHZ:8.2f} us  zip {a[1 + lv, 2] / c / MHZ:8.2f} us  cached records {a[1 + lv, 3] / c:8.0f}")
+        print(f"k_dc2_merge level {lv}: nodes {int(c)}  load {a[1 + lv, 1] / c / MHZ:8.2f} us  zip {a[1 + lv, 2] / c / MHZ:8.2f} us  band lines {a[1 + lv, 3] / c:8.0f} (max {int(a[1 + lv, 6])}, points max {int(a[1 + lv, 7])})  walks that left the band {int(a[1 + lv, 4])}  nodes done in global memory {int(a[1 + lv, 5])}")
