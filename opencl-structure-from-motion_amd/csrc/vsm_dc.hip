@@ -1042,7 +1042,7 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, 5) k_dc2_block(const VsmDc2
 // trips the mesh's guard, and the node is redone by one lane on the records in global memory, which are untouched until
 // the write-back.  The same happens to a node whose band does not fit the LDS the level was launched with.
 // ---------------------------------------------------------------------------------------
-#define DC2_MERGE_THREADS 256
+#define DC2_MERGE_THREADS 1024  // (the band is gathered by all of them - dependent global loads, latency-bound; one lane then walks the seam)
 #ifdef DC2_PHASE_TIMING
 #define DC2_BAND_STAT(level, col, v) atomicAdd(&dc2_dbg[1 + (level)][col], (unsigned long long)(v))
 #else
@@ -1064,9 +1064,11 @@ __device__ inline uint32_t dc2_mask_prefix(const uint32_t *mask, uint16_t *pre, 
   }
   if (lane == 63) tot[wv] = x;
   __syncthreads();
-  uint32_t base = 0;
-  for (int k = 0; k < wv; k++) base += tot[k];
-  const uint32_t total = tot[0] + tot[1] + tot[2] + tot[3];
+  uint32_t base = 0, total = 0;
+  for (int k = 0; k < DC2_MERGE_THREADS / 64; k++) {
+    base += k < wv ? tot[k] : 0u;
+    total += tot[k];
+  }
   uint32_t run = base + x - sum;
   for (int w = w0; w < w1; w++) {
     pre[w] = (uint16_t)run;
@@ -1094,7 +1096,7 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
   uint16_t *s_bpre = (uint16_t *)(s_pmask + (words_cap + 1) / 2);
   uint16_t *s_ppre = s_bpre + words_cap;
   __shared__ int32_t s_cl, s_cr, s_fail;
-  __shared__ uint32_t s_tot[4];
+  __shared__ uint32_t s_tot[DC2_MERGE_THREADS / 64];
   const VsmDc2Job jb = jobs[blockIdx.y];
   const int32_t m = jb.mn[0];
   if (m < 2) return;
@@ -1189,7 +1191,7 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
     __syncthreads();
     const uint32_t nlines = dc2_mask_prefix(s_band, s_bpre, bwords, s_tot);
     uint32_t npts = 0;
-    band_ok = nlines <= (uint32_t)lines_cap;
+    band_ok = nlines + 1 <= (uint32_t)lines_cap;  // (+ the trap record)
     if (band_ok) {
       // the points the band's records use
       for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
@@ -1214,10 +1216,10 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
           if (!dc2_bit(s_band, s)) continue;
           const int line = dc2_rank(s_band, s_bpre, s);
           const dc2_v4i e = grec[2 * s], v = grec[2 * s + 1];
-          auto nbw = [&](int32_t g) -> uint32_t {  // neighbour handle under the band's numbering
-            if (g < 0) return 0xffffu;
+          auto nbw = [&](int32_t g) -> uint32_t {  // neighbour handle under the band's numbering; none / not in the band: the trap
+            if (g < 0) return 4 * nlines;
             const int s2 = (g - tbase4) >> 2;
-            if (s2 < 0 || s2 >= nslots || !dc2_bit(s_band, s2)) return DC2_EXT;
+            if (s2 < 0 || s2 >= nslots || !dc2_bit(s_band, s2)) return 4 * nlines;
             return (uint32_t)(dc2_rank(s_band, s_bpre, s2) * 4 + (g & 3));
           };
           auto vxw = [&](int32_t g) -> uint32_t { return g < 0 ? 0xffffu : (uint32_t)dc2_rank(s_pmask, s_ppre, g - off); };
@@ -1238,6 +1240,9 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
         DcBandMesh mesh;
         mesh.w = (DC2_AS3 dc2_u32a *)s_rec;
         mesh.pt = (DC2_AS3 const uint32_t *)s_pt;
+        mesh.rim = 4 * (int32_t)nlines;
+        mesh.budget = 8 * (int32_t)nlines + 64;
+        mesh.make_trap();
         auto ln = [&](int32_t gt) -> int32_t {
           if (!dc2_bit(s_band, gt - tbase)) mesh.tripped = 1;  // (a hull handle is a hull triangle: in the band)
           return dc2_rank(s_band, s_bpre, gt - tbase);
@@ -1245,7 +1250,7 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
         DcOTri fl{ln(l.fl_t), l.fl_o}, il{ln(l.fr_t), l.fr_o}, ir{ln(r.fl_t), r.fl_o}, fr{ln(r.fr_t), r.fr_o};
         int32_t tcur = dc2_rank(s_band, s_bpre, 2 * div - 2);
         if (mesh.ok()) dc_merge(mesh, fl, il, ir, fr, axis, tcur);
-        if (mesh.ok())
+        if (mesh.ok() && !mesh.trap_touched())
           jb.hulls[idx] = VsmDcHull{(int32_t)s_l2s[fl.t] + tbase, fl.o, (int32_t)s_l2s[fr.t] + tbase, fr.o};
         else
           s_fail = 1;
@@ -1269,13 +1274,14 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
           const dc2_v4u o = ((const dc2_v4u *)s_rec)[k];
           auto nb = [&](uint32_t v) -> int32_t { return v == 0xffffu ? -1 : (int32_t)(s_l2s[v >> 2] * 4 + (v & 3)) + tbase4; };
           auto vx = [&](uint32_t v) -> int32_t { return v == 0xffffu ? -1 : (int32_t)s_c2p[v] + off; };
-          // (a word that still says "out of the band" was never touched: the record in global memory has the neighbour)
+          // (a word that still points to the trap was never touched: the record in global memory has the neighbour, or none)
+          const uint32_t rimh = 4 * nlines;
           const int32_t s = (int32_t)s_l2s[k];
           const dc2_v4i old = grec[2 * s];
           dc2_v4i a, b;
-          a.x = (o.x & 0xffffu) == DC2_EXT ? old.x : nb(o.x & 0xffffu);
-          a.y = (o.y & 0xffffu) == DC2_EXT ? old.y : nb(o.y & 0xffffu);
-          a.z = (o.z & 0xffffu) == DC2_EXT ? old.z : nb(o.z & 0xffffu);
+          a.x = (o.x & 0xffffu) == rimh ? old.x : nb(o.x & 0xffffu);
+          a.y = (o.y & 0xffffu) == rimh ? old.y : nb(o.y & 0xffffu);
+          a.z = (o.z & 0xffffu) == rimh ? old.z : nb(o.z & 0xffffu);
           a.w = -1;
           b.x = vx(o.x >> 16);
           b.y = vx(o.y >> 16);

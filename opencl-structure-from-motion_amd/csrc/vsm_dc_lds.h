@@ -32,7 +32,12 @@ typedef uint32_t dc2_u32a __attribute__((may_alias));
 // 32-bit records of the host / global-memory form (DcMesh), ds_ instructions with the handle as address, nothing to
 // translate while a seam is walked: global numbering comes back when the records are written out.
 #define DC2_NONE16 0xffffu
-#define DC2_EXT 0xfffeu  // band form: the neighbour exists but is not in the band (following it trips the guard)
+// Band form (GUARDED): a neighbour that is not in the band - or does not exist - is the handle `rim` of a reserved TRAP
+// record behind the band's last line, whose own words point to itself.  Outside the seam loop following it trips the guard
+// at once (nb_of); inside the loop nothing is tested per access: a check that would need the triangle behind the rim
+// poisons itself (na = -2, looked at where the check is decided), and every other way onto the trap ends in a store
+// into it (bonds always write both sides), which the caller finds afterwards (trap_touched) - so the walk either stayed
+// inside the band or is redone on the records in global memory; a step budget bounds a walk that went astray.
 
 template <bool GUARDED>
 struct DcEdgeMesh {
@@ -42,7 +47,18 @@ struct DcEdgeMesh {
   DC2_AS3 dc2_u32a *w;         // edge words, 4 per triangle
   DC2_AS3 const uint32_t *pt;  // x | y << 16 by (local) point number
   mutable int32_t tripped = 0;
+  int32_t rim = 0xffff;        // GUARDED: handle of the trap record (4 * its line)
+  int32_t budget = 1 << 30;    // GUARDED: seam steps + dissolved edges a walk may take
   DC2_DEV inline bool ok() const { return !GUARDED || tripped == 0; }
+  DC2_DEV inline bool is_rim(uint32_t e) const { return GUARDED && (int32_t)e == rim; }
+  DC2_DEV inline void make_trap() const {  // (GUARDED) the trap record: three self-pointing edges, ghost corners
+    for (int o = 0; o < 4; o++) w[rim + o] = (uint32_t)rim | 0xffff0000u;
+  }
+  DC2_DEV inline bool trap_touched() const {
+    bool t = false;
+    for (int o = 0; o < 4; o++) t |= w[rim + o] != ((uint32_t)rim | 0xffff0000u);
+    return t;
+  }
 
   // ---- on handles (the seam walk's form) ----
   DC2_DEV inline uint32_t ldw(int32_t h) const { return w[h]; }
@@ -54,12 +70,13 @@ struct DcEdgeMesh {
   // neighbour part of a word that is going to be followed; a guarded mesh refuses the marker of the band's rim
   DC2_DEV inline int32_t nb_of(uint32_t word) const {
     const uint32_t e = word & 0xffffu;
-    if (GUARDED && e >= DC2_EXT) {
+    if (GUARDED && (int32_t)e == rim) {
       tripped = 1;
       return 0;
     }
     return (int32_t)e;
   }
+  DC2_DEV static inline int32_t nb_raw(uint32_t word) { return (int32_t)(word & 0xffffu); }  // (seam loop: see above)
   DC2_DEV static inline int32_t vx_of(uint32_t word) { return (int32_t)word >> 16; }  // (point numbers stay below 2^15: the ghost corner becomes -1 by itself)
   DC2_DEV inline uint32_t P(int32_t p) const { return pt[p]; }
 
@@ -147,7 +164,11 @@ struct DcEdgeMesh {
 };
 
 // the band form of the merge levels (k_dc2_merge): a guarded mesh
+#ifdef DC2_UNGUARDED_BAND
+typedef DcEdgeMesh<false> DcBandMesh;  // (measurement only)
+#else
 typedef DcEdgeMesh<true> DcBandMesh;
+#endif
 
 // the block form adds what the leaves need: their keys (read where they lie, in global memory), the point array
 // writable, ids straight to global memory
@@ -283,11 +304,11 @@ VSM_HD inline void dc2_zip(const M &m, DcOTri &farleft_, DcOTri &innerleft_, DcO
   // dissolving of edges: three in-circle signs and two orientations from registers, one select-driven advance, one chain
   // of four dependent LDS reads - and it is the same code whichever side moves, so lanes walking different seams stay
   // together.
-  int32_t lne, lna, rne, rna;
+  int32_t lne, lna, rne, rna, budget = m.budget;
   uint32_t lpna, rpna;
   {
     const uint32_t wl = m.ldw(M::hprev(leftcand)), wr = m.ldw(M::hnext(rightcand));
-    const bool xl = M::kGuarded && (wl & 0xffffu) >= DC2_EXT, xr = M::kGuarded && (wr & 0xffffu) >= DC2_EXT;
+    const bool xl = m.is_rim(wl & 0xffffu), xr = m.is_rim(wr & 0xffffu);
     lne = xl ? 0 : (int32_t)(wl & 0xffffu);
     rne = xr ? 0 : (int32_t)(wr & 0xffffu);
     lna = xl ? -2 : M::vx_of(m.ldw(lne));
@@ -300,22 +321,22 @@ VSM_HD inline void dc2_zip(const M &m, DcOTri &farleft_, DcOTri &innerleft_, DcO
     const bool lfin = M::ccw_p(pul, pll, plr) <= 0, rfin = M::ccw_p(pur, pll, plr) <= 0;
     const bool lin = M::incircle_in(pll, plr, pul, lpna), rin = M::incircle_in(pll, plr, pur, rpna);
     bool cin = M::incircle_in(pul, pll, plr, pur);
-    if (M::kGuarded) m.tripped |= (int32_t)((!lfin & (lna == -2)) | (!rfin & (rna == -2)));
+    if (M::kGuarded) m.tripped |= (int32_t)((!lfin & (lna == -2)) | (!rfin & (rna == -2)) | (--budget < 0));
     if ((lfin & rfin) | (M::kGuarded & !m.ok())) break;
     const bool lbad = !lfin & (lna >= 0) & lin, rbad = !rfin & (rna >= 0) & rin;
     if (lbad | rbad) {
       if (lbad) {  // dissolve non-Delaunay edges on the left (:5814)
         do {
-          if (M::kGuarded && !m.ok()) DC2_RET();
+          if (M::kGuarded && --budget < 0) break;
           const int32_t ne1 = M::hnext(lne), ne2 = M::hprev(lne);
-          const int32_t topc = m.nb_of(m.ldw(ne1)), sidec = m.nb_of(m.ldw(ne2));
+          const int32_t topc = M::nb_raw(m.ldw(ne1)), sidec = M::nb_raw(m.ldw(ne2));
           const int32_t lc1 = M::hnext(leftcand), lc2 = M::hprev(leftcand);
           // bond(ne2, topc), bond(leftcand, sidec) - then the outer neighbour is read, as the reference form does
           m.stw(ne2, (uint32_t)topc | 0xffff0000u);  // (its vertex becomes the ghost: set_org(ne1, -1))
           m.stn(topc, ne2);
           m.stw(leftcand, (uint32_t)sidec | 0xffff0000u);  // (set_dest(lc1, -1))
           m.stn(sidec, leftcand);
-          const int32_t outerc = m.nb_of(m.ldw(lc1));
+          const int32_t outerc = M::nb_raw(m.ldw(lc1));
           m.stw(ne1, (uint32_t)outerc | ((uint32_t)(uint16_t)lna << 16));  // bond(ne1, outerc), set_apex(ne1, na)
           m.stn(outerc, ne1);
           m.stv(lc2, ll);   // set_org(lc1, ll)
@@ -331,15 +352,15 @@ VSM_HD inline void dc2_zip(const M &m, DcOTri &farleft_, DcOTri &innerleft_, DcO
       }
       if (rbad) {  // ... and on the right (:5862)
         do {
-          if (M::kGuarded && !m.ok()) DC2_RET();
+          if (M::kGuarded && --budget < 0) break;
           const int32_t ne1 = M::hprev(rne), ne2 = M::hnext(rne);
-          const int32_t topc = m.nb_of(m.ldw(ne1)), sidec = m.nb_of(m.ldw(ne2));
+          const int32_t topc = M::nb_raw(m.ldw(ne1)), sidec = M::nb_raw(m.ldw(ne2));
           const int32_t rc1 = M::hprev(rightcand), rc2 = M::hnext(rightcand);
           m.stw(ne2, (uint32_t)topc | 0xffff0000u);  // bond(ne2, topc); set_dest(ne1, -1)
           m.stn(topc, ne2);
           m.stw(rightcand, (uint32_t)sidec | 0xffff0000u);  // bond(rightcand, sidec); set_org(rc1, -1)
           m.stn(sidec, rightcand);
-          const int32_t outerc = m.nb_of(m.ldw(rc1));
+          const int32_t outerc = M::nb_raw(m.ldw(rc1));
           m.stw(ne1, (uint32_t)outerc | ((uint32_t)(uint16_t)rna << 16));  // bond(ne1, outerc), set_apex(ne1, na)
           m.stn(outerc, ne1);
           m.stv(rc2, lr);   // set_dest(rc1, lr)
@@ -363,12 +384,10 @@ VSM_HD inline void dc2_zip(const M &m, DcOTri &farleft_, DcOTri &innerleft_, DcO
     m.stn(cand, base);
     base = M::hrot(cand, !take_r);                        // lprev(rightcand) / lnext(leftcand)
     m.stv(M::hrot(base, !take_r), take_r ? ll : lr);      // set_dest(base, ll) / set_org(base, lr)
-    const uint32_t wb = m.ldw(base);
-    if (M::kGuarded) m.tripped |= (int32_t)((wb & 0xffffu) >= DC2_EXT);
-    const int32_t ncand = (M::kGuarded && (wb & 0xffffu) >= DC2_EXT) ? 0 : (int32_t)(wb & 0xffffu);
+    const int32_t ncand = M::nb_raw(m.ldw(base));
     const uint32_t wc = m.ldw(ncand), wn = m.ldw(M::hrot(ncand, take_r));  // the check reads lnext(rightcand) / lprev(leftcand)
     const int32_t nup = M::vx_of(wc);
-    const bool xn = M::kGuarded & ((wn & 0xffffu) >= DC2_EXT);
+    const bool xn = m.is_rim(wn & 0xffffu);
     const int32_t nne = xn ? 0 : (int32_t)(wn & 0xffffu);
     const uint32_t pnup = m.P(nup);
     const int32_t nna = xn ? -2 : M::vx_of(m.ldw(nne));
