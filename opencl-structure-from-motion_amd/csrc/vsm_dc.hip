@@ -1042,7 +1042,9 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, 5) k_dc2_block(const VsmDc2
 // trips the mesh's guard, and the node is redone by one lane on the records in global memory, which are untouched until
 // the write-back.  The same happens to a node whose band does not fit the LDS the level was launched with.
 // ---------------------------------------------------------------------------------------
-#define DC2_MERGE_THREADS 1024  // (the band is gathered by all of them - dependent global loads, latency-bound; one lane then walks the seam)
+#ifndef DC2_MERGE_THREADS
+#define DC2_MERGE_THREADS 256
+#endif
 #ifdef DC2_PHASE_TIMING
 #define DC2_BAND_STAT(level, col, v) atomicAdd(&dc2_dbg[1 + (level)][col], (unsigned long long)(v))
 #else
@@ -1148,30 +1150,54 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
     }
     __syncthreads();
     const float fcl = (float)s_cl, fcr = (float)s_cr;
-    // the band's core: own slots, hull triangles, triangles whose circumcircle crosses the cut
-    for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
-      const dc2_v4i v = grec[2 * s + 1];
-      bool hot;
-      if (s == 2 * div - 2 || s == 2 * div - 1) {
-        hot = true;
-      } else if ((v.x & v.y & v.z) < 0) {
-        hot = false;  // unused slot
-      } else if ((v.x | v.y | v.z) < 0) {
-        hot = true;  // hull triangle
-      } else {
-        const uint32_t pa = gpt[v.x - off], pb = gpt[v.y - off], pc = gpt[v.z - off];
-        const float ax = (float)(pa & 0xffffu), ay = (float)(pa >> 16);
-        const float bx = (float)(pb & 0xffffu) - ax, by = (float)(pb >> 16) - ay;
-        const float cx = (float)(pc & 0xffffu) - ax, cy = (float)(pc >> 16) - ay;
-        const float d = 2.f * (bx * cy - by * cx);
-        const float b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
-        const float ux = (cy * b2 - by * c2) / d, uy = (bx * c2 - cx * b2) / d;  // circumcentre relative to a
-        const float rad = sqrtf(ux * ux + uy * uy) + 1.5f;
-        const float cc = axis == 0 ? ax + ux : ay + uy;
-        hot = s < 2 * div ? (cc + rad >= fcr) : (cc - rad <= fcl);
-        hot = hot || !(d == d) || d == 0.f;
+    // the band's core: own slots, hull triangles, triangles whose circumcircle crosses the cut.  Four slots per round: the
+    // vertex records first, then their twelve points, then the tests - the loop is a chain of dependent L2 round trips.
+    // (The circumcircle in double: vertices below 2^14 make every product exact, so "reaches the other half" is decided
+    // to a billionth of a pixel before the 1.5 pixels of margin - the band's closure rests on this test being conservative.)
+    for (int s0 = t; s0 < nslots; s0 += 4 * DC2_MERGE_THREADS) {
+      dc2_v4i v[4];
+      uint32_t pa[4], pb[4], pc[4];
+      int kind[4];  // 0 not in the core, 1 in the core, 2 decided by its circumcircle
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int s = s0 + k * DC2_MERGE_THREADS;
+        v[k] = s < nslots ? grec[2 * s + 1] : dc2_v4i{-1, -1, -1, -1};
       }
-      if (hot) atomicOr(&s_band[s >> 5], 1u << (s & 31));
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int s = s0 + k * DC2_MERGE_THREADS;
+        if (s >= nslots)
+          kind[k] = 0;
+        else if (s == 2 * div - 2 || s == 2 * div - 1)
+          kind[k] = 1;
+        else if ((v[k].x & v[k].y & v[k].z) < 0)
+          kind[k] = 0;  // unused slot
+        else if ((v[k].x | v[k].y | v[k].z) < 0)
+          kind[k] = 1;  // hull triangle
+        else
+          kind[k] = 2;
+        pa[k] = kind[k] == 2 ? gpt[v[k].x - off] : 0u;
+        pb[k] = kind[k] == 2 ? gpt[v[k].y - off] : 0u;
+        pc[k] = kind[k] == 2 ? gpt[v[k].z - off] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int s = s0 + k * DC2_MERGE_THREADS;
+        bool hot = kind[k] == 1;
+        if (kind[k] == 2) {
+          const double ax = (double)(pa[k] & 0xffffu), ay = (double)(pa[k] >> 16);
+          const double bx = (double)(pb[k] & 0xffffu) - ax, by = (double)(pb[k] >> 16) - ay;
+          const double cx = (double)(pc[k] & 0xffffu) - ax, cy = (double)(pc[k] >> 16) - ay;
+          const double d = 2.0 * (bx * cy - by * cx);
+          const double b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+          const double ux = (cy * b2 - by * c2) / d, uy = (bx * c2 - cx * b2) / d;  // circumcentre relative to a
+          const double rad = sqrt(ux * ux + uy * uy) + 1.5;
+          const double cc = axis == 0 ? ax + ux : ay + uy;
+          hot = s < 2 * div ? (cc + rad >= (double)fcr) : (cc - rad <= (double)fcl);
+          hot = hot || !(d == d) || d == 0.0 || !(rad == rad);
+        }
+        if (hot) atomicOr(&s_band[s >> 5], 1u << (s & 31));
+      }
     }
     __syncthreads();
     // ... and the neighbours of the core
