@@ -1555,24 +1555,20 @@ __global__ void __launch_bounds__(256) k_dc2_prior(const VsmDc2Job *__restrict__
   }
 }
 
-static int dc2_skip() {  // TEMPORARY ablation switch (timing experiments only: results are wrong with it)
-  static const int v = getenv("VSM_DC2_SKIP") ? atoi(getenv("VSM_DC2_SKIP")) : 0;
-  return v;
-}
 void vsm_dc2_launch_keys(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list) {
   if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_keys, dim3((std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs);
 }
 void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs) {
-  if (njobs <= 0 || (dc2_skip() & 8)) return;
+  if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_prepare, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs);
 }
 void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth) {
-  if (njobs <= 0 || (dc2_skip() & 1)) return;
+  if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_block, dim3(1 << depth, njobs), dim3(DC2_BLOCK_THREADS), 0, s, d_jobs, depth);
 }
 void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth, int max_list) {
-  if (njobs <= 0 || (dc2_skip() & 2)) return;
+  if (njobs <= 0) return;
   static const bool big_lds = hipFuncSetAttribute((const void *)k_dc2_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
   for (int level = depth - 1; level >= 0; level--) {
     // the largest node of the level: ceil(max_list / 2^level) points.  A band is a few records per pixel of cut plus the
@@ -1597,17 +1593,17 @@ void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, in
   }
 }
 void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride) {
-  if (njobs <= 0 || (dc2_skip() & 4)) return;
+  if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_ties, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride);
 }
 void vsm_dc2_launch_support(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol, float disp_tol) {
-  if (njobs <= 0 || (dc2_skip() & 16)) return;
+  if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_apply_ties, dim3(njobs), dim3(64), 0, s, d_jobs);
   hipLaunchKernelGGL(k_dc2_flows, dim3((std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method);
   hipLaunchKernelGGL(k_dc2_support, dim3((2 * std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method, flow_tol, disp_tol);
 }
 void vsm_dc2_launch_compact(hipStream_t s, const VsmDc2Job *d_jobs, int njobs) {
-  if (njobs <= 0 || (dc2_skip() & 32)) return;
+  if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_compact, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs);
 }
 void vsm_dc2_launch_export(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list) {

@@ -164,11 +164,7 @@ struct DcEdgeMesh {
 };
 
 // the band form of the merge levels (k_dc2_merge): a guarded mesh
-#ifdef DC2_UNGUARDED_BAND
-typedef DcEdgeMesh<false> DcBandMesh;  // (measurement only)
-#else
 typedef DcEdgeMesh<true> DcBandMesh;
-#endif
 
 // the block form adds what the leaves need: their keys (read where they lie, in global memory), the point array
 // writable, ids straight to global memory
