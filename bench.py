@@ -207,6 +207,14 @@ def main():
             ge = np.load(os.path.join(ROOT, "tests", "golden", "cfg2_seq200_ego.npz"))
             vo_ok = bool(trail.tobytes() == ge["tr_out"][:nf].tobytes())
 
+    # ---- K sequences in lock-step with live feedback (row f-3, multi-sequence per GPU) -----------------
+    multi = None
+    if rank == 0 and world == 1 and not args.no_per_frame:
+        try:
+            multi = multi_sequence_leg(vm, synth, torch, dev, W, H)
+        except Exception as e:  # informational leg: never takes the headline down with it
+            multi = {"error": repr(e)}
+
     # ---- monocular egomotion (row f-4): 2000 hypotheses on a synthetic 5000-match scene -----------
     mono = None
     if rank == 0 and not args.no_per_frame:
@@ -401,6 +409,7 @@ def main():
                            "tr_delta_trail_bit_exact_vs_reference": vo_ok,
                            "what": "vsm_vo_stereo_process_device per frame: pushBack + matchFeatures(2, live Tr_delta) + "
                                    "bucketFeatures + RANSAC/Gauss-Newton egomotion (VisualOdometryStereo::process)"},
+        "vo_multi_sequence": multi,
         "vo_mono_egomotion": mono,
         "verified_bit_exact_vs_reference_hashes": verified,
         "roofline": roof,
@@ -437,6 +446,44 @@ def cpu_model():
     except Exception:
         pass
     return None
+
+
+def multi_sequence_leg(vm, synth, torch, dev, W, H):
+    """K independent stereo sequences in lock-step with LIVE Tr_delta feedback (vsm_multi_process = VisualOdometryStereo::
+    process for the next pair of every sequence): config 4's eight seeds, repeated to K sequences; aggregate frames/s over
+    all sequences, and - for the frames the fixture covers - every sequence's Tr_delta trail against the reference's run of
+    that sequence in a process of its own."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cfg4_multi_8procs_32f.npz"))
+    seeds = [int(x) for x in g["seeds"]]
+    nfix, nf = int(g["n_frames"]), 48
+    canv = [synth.canvas(sd, W, H) for sd in seeds]
+    base = np.stack([np.stack([np.stack(synth.stereo_frame(cv, f, W, H)) for cv in canv]) for f in range(nf)])  # [F, 8, 2, H, W]
+    base_d = torch.from_numpy(base).to(dev)
+    out = {}
+    for K in (8, 32, 64):
+        idx = torch.arange(K, device=dev) % len(seeds)
+        frames = base_d[:, idx]                           # [F, K, 2, H, W], resident in HBM
+        left, right = frames[:, :, 0].contiguous(), frames[:, :, 1].contiguous()
+        best, exact = None, True
+        for rep in range(2):
+            vo = vm.MultiVisualOdometryStereo(K, *[float(x) for x in g["intr"]])
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for f in range(nf):
+                vo.process(left[f], right[f])
+                if rep == 0 and f < nfix:               # (rep 0 is the checked warm-up pass, rep 1 the timed one)
+                    for k in range(K):
+                        exact = exact and vo.get_motion(k).tobytes() == g[f"s{seeds[k % len(seeds)]}_tr_out"][f].tobytes()
+            dt = time.perf_counter() - t
+            tm = vo.timings()
+            vo.close()
+            if rep == 1:
+                best = dt
+        out[f"K{K}"] = {"value": round(K * nf / best, 1), "unit": "frames/s (all sequences)", "ms_per_step": round(best / nf * 1e3, 3),
+                        "tr_delta_trails_bit_exact_vs_reference": bool(exact), "last_step_us": {k: round(v, 1) for k, v in tm.items()}}
+    out["what"] = ("vsm_multi_process: pushBack + matchFeatures(2, live Tr_delta) + bucketFeatures + egomotion of K sequences per call, "
+                   "one launch per kernel over all K pairs; 48 frames per sequence, images resident in HBM")
+    return out
 
 
 def secondary_configs(vm, synth, torch, dev):

@@ -269,6 +269,31 @@ void vsm_vo_stereo_get_timings(vsm_vo_stereo *v, double *out4);
  * were recorded from a fresh process). */
 void vsm_vo_sampler_seed(uint32_t seed);
 
+/* ---- lock-step multi-sequence stereo visual odometry (multi-sequence per GPU) ----
+ * K independent sequences advance together: vsm_multi_process is VisualOdometryStereo::process (viso/viso_stereo.cpp:33-40)
+ * for the next stereo pair of EVERY sequence - pushBack, matchFeatures(2, live Tr_delta of that sequence), bucketFeatures,
+ * updateMotion - with one launch per kernel over all K pairs and the K egomotion estimates side by side on the host pool.
+ * Each sequence has the rand() stream (bucketing, srand(0) at construction, viso/viso.cpp:35) and the RANSAC sampler
+ * (viso/viso.cpp:93) that a process of its own would have, so sequence k's matches, inliers and Tr_delta equal what the
+ * reference gives for that sequence alone.  refinement == 2 is not taken here (one vsm_vo_stereo per sequence does it). */
+typedef struct vsm_multi vsm_multi;
+vsm_multi *vsm_multi_create(const vsm_vo_stereo_params *p, int32_t n_sequences);
+void vsm_multi_destroy(vsm_multi *m);
+/* left / right: n_sequences images seq_stride bytes apart (sequence k's pair at k * seq_stride), host memory or, with
+ * on_device != 0, HBM; ok_out: NULL or n_sequences flags = process()'s return value per sequence */
+int vsm_multi_process(vsm_multi *m, const uint8_t *left, const uint8_t *right, int64_t seq_stride, int on_device, int32_t width,
+                      int32_t height, int32_t bpl, int32_t *ok_out);
+int32_t vsm_multi_num_sequences(vsm_multi *m);
+void vsm_multi_get_motion(vsm_multi *m, int32_t seq, double *T16);   /* VisualOdometry::getMotion */
+int vsm_multi_motion_valid(vsm_multi *m, int32_t seq);
+/* bucketed = 0: Matcher::getMatches() as matchFeatures left it; 1: VisualOdometry::getMatches() (after bucketFeatures) */
+int32_t vsm_multi_num_matches(vsm_multi *m, int32_t seq, int bucketed);
+int32_t vsm_multi_get_matches(vsm_multi *m, int32_t seq, int bucketed, vsm_p_match *out, int32_t cap);
+int32_t vsm_multi_num_inliers(vsm_multi *m, int32_t seq);            /* VisualOdometry::getInlierIndices */
+int32_t vsm_multi_get_inliers(vsm_multi *m, int32_t seq, int32_t *out, int32_t cap);
+/* wall clock of the last step, microseconds: features, first pass + its chain, second pass + final chain, bucketing + egomotion */
+void vsm_multi_get_timings(vsm_multi *m, double *out4);
+
 /* ---- monocular visual odometry ----
  * class VisualOdometryMono, viso/viso_mono.h:28-90: process() = pushBack + matchFeatures(0) +
  * bucketFeatures + getMatches + updateMotion (viso/viso_mono.cpp:33-39); estimateMotion

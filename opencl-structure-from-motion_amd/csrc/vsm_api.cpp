@@ -1302,6 +1302,7 @@ static int seq_ingest_host_frames(vsm_handle *h, VsmCtx &c, int first_img, const
 
 }  // extern "C"
 #include "vsm_seq2.inc"
+#include "vsm_multi.inc"
 extern "C" {
 
 // ---------------------------------------------------------------------------------------

@@ -290,6 +290,7 @@ class EgoStereo {
 
   // estimateMotion (:42-146).  1 = success (tr6 set), 0 = failure, -1 = fewer than 6 matches
   // (the reference returns before clearing its inlier list in that case, so `inliers` is kept).
+  Sampler *sampler = &g_sampler;  // (the process's sampler; the lock-step multi-sequence API gives every sequence its own)
   template <class Runner>
   int estimate(const vsm_p_match *m, int count, Runner *pool, double *tr6, std::vector<int32_t> &inliers) {
     if (count < 6) return -1;
@@ -298,14 +299,14 @@ class EgoStereo {
     hyp.resize((size_t)iters);
     deck.resize((size_t)n);
     {
-      std::lock_guard<std::mutex> lock(g_sampler.mu);
+      std::lock_guard<std::mutex> lock(sampler->mu);
       const VsmDrawPlan plan[3] = {vsm_sampler_plan(0, (uint32_t)(n - 1)), vsm_sampler_plan(1, (uint32_t)(n - 1)),
                                    vsm_sampler_plan(2, (uint32_t)(n - 1))};
       for (int i = 0; i < n; i++) deck[i] = i;
       for (int k = 0; k < iters; k++) {  // partial shuffle of 0..n-1, first three (viso.cpp:96-105), undone afterwards
         int swapped[3];
         for (int i = 0; i < 3; i++) {
-          swapped[i] = (int)g_sampler.between(plan[i]);
+          swapped[i] = (int)sampler->between(plan[i]);
           std::swap(deck[i], deck[swapped[i]]);
         }
         for (int i = 0; i < 3; i++) hyp[k].pick[i] = deck[i];
@@ -424,6 +425,30 @@ static int after_push(vsm_vo_stereo *v) {  // viso/viso_stereo.cpp:35-39
   v->timings[2] = t3 - t2;
   v->timings[3] = t3 - t0;
   return ok;
+}
+
+// ---- one sequence of the lock-step multi-sequence API ----
+struct VsmEgoSeq {
+  EgoStereo ego;
+  Sampler sampler;    // seeded 71 like a fresh process of the reference
+  VsmRandStream rnd;  // srand(0), viso/viso.cpp:35
+};
+VsmEgoSeq *vsm_ego_seq_create(const vsm_vo_stereo_params *p) {
+  VsmEgoSeq *e = new VsmEgoSeq();
+  e->ego.par = *p;
+  e->ego.sampler = &e->sampler;
+  e->rnd.seed(0);
+  return e;
+}
+void vsm_ego_seq_destroy(VsmEgoSeq *e) { delete e; }
+int vsm_ego_seq_step(VsmEgoSeq *e, std::vector<vsm_p_match> &matches, double *T16, bool *valid, std::vector<int32_t> &inliers) {
+  vsm_host_bucket_with(matches, e->ego.par.bucket_max_features, (float)e->ego.par.bucket_width, (float)e->ego.par.bucket_height, e->rnd);
+  double tr[6];
+  const int rc = e->ego.estimate(matches.data(), (int)matches.size(), (VsmForkJoin *)nullptr, tr, inliers);
+  if (rc != 1) return 0;
+  pose_matrix(tr, T16);
+  *valid = true;
+  return 1;
 }
 
 extern "C" {

@@ -1181,7 +1181,8 @@ class LibcRandStream {
 alignas(8) char LibcRandStream::park_[128];
 }  // namespace
 
-void vsm_host_bucket(std::vector<vsm_p_match> &m, int max_features, float bw, float bh) {
+template <class Rnd>
+static void bucket_impl(std::vector<vsm_p_match> &m, int max_features, float bw, float bh, Rnd &rnd) {
   float u_max = 0, v_max = 0;
   for (const vsm_p_match &it : m) {
     if (it.u1c > u_max) u_max = it.u1c;
@@ -1210,7 +1211,6 @@ void vsm_host_bucket(std::vector<vsm_p_match> &m, int max_features, float bw, fl
     return t;
   }();
   {
-    LibcRandStream rnd;
     size_t lo = 0;
     for (size_t b = 0; b < nb; b++) {
       const size_t hi = start[b];
@@ -1227,6 +1227,14 @@ void vsm_host_bucket(std::vector<vsm_p_match> &m, int max_features, float bw, fl
     }
   }
   m.assign(kept.begin(), kept.end());
+}
+
+void vsm_host_bucket(std::vector<vsm_p_match> &m, int max_features, float bw, float bh) {
+  LibcRandStream rnd;  // the process's own rand() stream, read in bulk
+  bucket_impl(m, max_features, bw, bh, rnd);
+}
+void vsm_host_bucket_with(std::vector<vsm_p_match> &m, int max_features, float bw, float bh, VsmRandStream &rnd) {
+  bucket_impl(m, max_features, bw, bh, rnd);
 }
 
 // =======================================================================================

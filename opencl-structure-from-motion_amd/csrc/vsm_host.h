@@ -4,6 +4,8 @@
 #pragma once
 
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -266,6 +268,35 @@ bool vsm_host_parabolic_update(const int32_t *c9, int du, int dv, float &u2, flo
 
 // Matcher::bucketFeatures, viso/matcher.cpp:243-284
 void vsm_host_bucket(std::vector<vsm_p_match> &m, int max_features, float bucket_width, float bucket_height);
+// A rand() stream of one's own: the C library's generator (glibc: random()'s TYPE_3 additive feedback) behind the
+// reentrant interface, seeded like srand().  The lock-step multi-sequence API gives every sequence one, so that K
+// sequences in one process bucket exactly like K processes of the reference, each after its own srand(0) (viso/viso.cpp:35).
+struct VsmRandStream {
+  struct random_data rd;
+  char state[128];
+  VsmRandStream() { seed(0); }
+  void seed(unsigned s) {
+    memset(&rd, 0, sizeof(rd));
+    memset(state, 0, sizeof(state));
+    initstate_r(s, state, sizeof(state), &rd);
+  }
+  uint32_t next() {
+    int32_t v = 0;
+    random_r(&rd, &v);
+    return (uint32_t)v;
+  }
+};
+void vsm_host_bucket_with(std::vector<vsm_p_match> &m, int max_features, float bucket_width, float bucket_height, VsmRandStream &rnd);
+// One sequence's stereo egomotion state for the lock-step multi-sequence API (vsm_ego.cpp): estimateMotion's working
+// set, a RANSAC sampler of its own (the reference's is one std::default_random_engine per process, viso/viso.cpp:93) and
+// the rand() stream its bucketing draws from.
+struct VsmEgoSeq;
+VsmEgoSeq *vsm_ego_seq_create(const vsm_vo_stereo_params *p);
+void vsm_ego_seq_destroy(VsmEgoSeq *e);
+// VisualOdometryStereo::process behind the matcher (viso/viso_stereo.cpp:37-39, viso/viso.cpp:42-58): bucketFeatures on
+// `matches` (in: getMatches() after matchFeatures, out: the bucketed list), estimateMotion on one thread; on success T16
+// gets the new Tr_delta and *valid becomes true.  Returns 1 / 0 like process().
+int vsm_ego_seq_step(VsmEgoSeq *e, std::vector<vsm_p_match> &matches, double *T16, bool *valid, std::vector<int32_t> &inliers);
 
 // Matcher::getGain, viso/matcher.cpp:286-324
 float vsm_host_gain(const uint8_t *I1p, const uint8_t *I1c, const int32_t *dims_p, const int32_t *dims_c,

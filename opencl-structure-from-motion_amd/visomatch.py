@@ -34,6 +34,9 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
            "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_host_outliers_and_prior", "vsm_debug_dc2", "vsm_debug_pack_roundtrip", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
            "vsm_sequence_get_timings", "vsm_sequence_path", "vsm_set_option", "vsm_version",
+           "vsm_multi_create", "vsm_multi_destroy", "vsm_multi_process", "vsm_multi_num_sequences", "vsm_multi_get_motion",
+           "vsm_multi_motion_valid", "vsm_multi_num_matches", "vsm_multi_get_matches", "vsm_multi_num_inliers", "vsm_multi_get_inliers",
+           "vsm_multi_get_timings",
            "vsm_vo_stereo_default_params", "vsm_vo_stereo_create", "vsm_vo_stereo_destroy", "vsm_vo_stereo_process",
            "vsm_vo_stereo_process_device", "vsm_vo_stereo_process_matches", "vsm_vo_stereo_get_motion",
            "vsm_vo_stereo_motion_valid", "vsm_vo_stereo_num_matches", "vsm_vo_stereo_get_matches",
@@ -133,6 +136,18 @@ def lib():
         L.vsm_sequence_get_timings.argtypes = [vp, vp]
         L.vsm_sequence_path.argtypes = [vp]
         L.vsm_set_option.argtypes = [vp, C.c_char_p, i32]
+        L.vsm_multi_create.restype = vp
+        L.vsm_multi_create.argtypes = [C.POINTER(VsmVoStereoParams), i32]
+        L.vsm_multi_destroy.argtypes = [vp]
+        L.vsm_multi_process.argtypes = [vp, vp, vp, C.c_int64, C.c_int, i32, i32, i32, vp]
+        L.vsm_multi_num_sequences.argtypes = [vp]
+        L.vsm_multi_get_motion.argtypes = [vp, i32, vp]
+        L.vsm_multi_motion_valid.argtypes = [vp, i32]
+        L.vsm_multi_num_matches.argtypes = [vp, i32, C.c_int]
+        L.vsm_multi_get_matches.argtypes = [vp, i32, C.c_int, vp, i32]
+        L.vsm_multi_num_inliers.argtypes = [vp, i32]
+        L.vsm_multi_get_inliers.argtypes = [vp, i32, vp, i32]
+        L.vsm_multi_get_timings.argtypes = [vp, vp]
         vop = C.POINTER(VsmVoStereoParams)
         L.vsm_vo_stereo_default_params.argtypes = [vop]
         L.vsm_vo_stereo_create.restype = vp
@@ -567,6 +582,77 @@ class Matcher:
             self.close()
         except Exception:
             pass
+
+
+class MultiVisualOdometryStereo:
+    """K independent stereo sequences in lock-step (vsm_multi_*): process(left, right) is VisualOdometryStereo::process
+    for the next pair of every sequence, one launch per kernel over all of them; per sequence the results equal the
+    reference's for that sequence alone."""
+
+    def __init__(self, n_sequences, f, cu, cv, base, bucket=(2, 50.0, 50.0), ransac_iters=200, inlier_threshold=2.0,
+                 reweighting=True, **match):
+        self.params = vo_stereo_params(f, cu, cv, base, bucket, ransac_iters, inlier_threshold, reweighting, **match)
+        self.K = int(n_sequences)
+        h = lib().vsm_multi_create(C.byref(self.params), self.K)
+        if not h:
+            raise VisoMatchError("vsm_multi_create failed: no usable HIP device (there is no CPU path)")
+        self.h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().vsm_multi_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def process(self, left, right):
+        """left / right: [K,H,W] uint8, numpy (host) or CUDA torch tensors -> K success flags"""
+        L = lib()
+        ok = np.zeros(self.K, dtype=np.int32)
+        if _is_torch(left):
+            assert left.is_cuda and right.is_cuda and left.shape == right.shape and left.stride() == right.stride() and left.stride(2) == 1
+            K, h, w = left.shape
+            import torch
+            torch.cuda.current_stream(left.device).synchronize()   # (the library reads the images on its own stream)
+            rc = L.vsm_multi_process(self.h, C.c_void_p(left.data_ptr()), C.c_void_p(right.data_ptr()), left.stride(0), 1, w, h, left.stride(1),
+                                     ok.ctypes.data_as(C.c_void_p))
+        else:
+            left = np.ascontiguousarray(left, dtype=np.uint8)
+            right = np.ascontiguousarray(right, dtype=np.uint8)
+            K, h, w = left.shape
+            rc = L.vsm_multi_process(self.h, left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p), w * h, 0, w, h, w,
+                                     ok.ctypes.data_as(C.c_void_p))
+        assert K == self.K
+        if rc != 0:
+            raise VisoMatchError(f"vsm_multi_process failed with {rc}")
+        return ok.astype(bool)
+
+    def get_motion(self, k):
+        t = np.zeros(16)
+        lib().vsm_multi_get_motion(self.h, k, t.ctypes.data_as(C.c_void_p))
+        return t.reshape(4, 4)
+
+    def motion_valid(self, k):
+        return bool(lib().vsm_multi_motion_valid(self.h, k))
+
+    def get_matches(self, k, bucketed=True):
+        n = lib().vsm_multi_num_matches(self.h, k, int(bucketed))
+        out = np.zeros(n, dtype=P_MATCH)
+        if n:
+            lib().vsm_multi_get_matches(self.h, k, int(bucketed), out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def get_inlier_indices(self, k):
+        n = lib().vsm_multi_num_inliers(self.h, k)
+        out = np.zeros(n, dtype=np.int32)
+        if n:
+            lib().vsm_multi_get_inliers(self.h, k, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def timings(self):
+        t = np.zeros(4, dtype=np.float64)
+        lib().vsm_multi_get_timings(self.h, t.ctypes.data_as(C.c_void_p))
+        return dict(zip(("features_us", "pass1_us", "pass2_us", "egomotion_us"), t.tolist()))
 
 
 class VisualOdometryStereo:

@@ -545,6 +545,43 @@ def test_vo_stereo_vs_oracle_params_and_device_inputs(vm, B, synth):
     v.close()
 
 
+@pytest.mark.parametrize("K,device_inputs", [(8, True), (32, True), (3, False)])
+def test_multi_sequence_lockstep_live_feedback(vm, synth, K, device_inputs):
+    """vsm_multi_*: K independent stereo sequences stepped together with LIVE Tr_delta feedback (no recorded trail).  The
+    sequences are config 4's eight seeds (repeated for K = 32); the fixture is the reference's VisualOdometryStereo on each
+    of them in a process of its own (tests/golden/make_golden.py multi).  Per sequence and frame: what enters the matching
+    (Tr_valid, Tr_delta), matchFeatures' final list (count + sha), process()'s flag, the bucketed list, the inlier set and
+    the new Tr_delta."""
+    import torch
+    g = G.load("cfg4_multi_8procs_32f")
+    w, h, nf = int(g["w"]), int(g["h"]), int(g["n_frames"])
+    seeds = [int(s) for s in g["seeds"]][:min(K, 8)]
+    canv = {sd: synth.canvas(sd, w, h) for sd in seeds}
+    seq_seed = [seeds[k % len(seeds)] for k in range(K)]
+    vo = vm.MultiVisualOdometryStereo(K, *[float(x) for x in g["intr"]])
+    for f in range(nf if K <= 8 else 12):
+        fr = {sd: synth.stereo_frame(canv[sd], f, w, h) for sd in seeds}
+        left = np.stack([fr[sd][0] for sd in seq_seed])
+        right = np.stack([fr[sd][1] for sd in seq_seed])
+        tin = [(vo.motion_valid(k), vo.get_motion(k)) for k in range(K)]
+        if device_inputs:
+            ok = vo.process(torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda())
+        else:
+            ok = vo.process(left, right)
+        for k, sd in enumerate(seq_seed):
+            key = f"s{sd}_"
+            assert tin[k][0] == bool(g[key + "tr_valid"][f]), (f, k)
+            if tin[k][0]:
+                assert tin[k][1].tobytes() == g[key + "tr_in"][f].tobytes(), (f, k)
+            fin, b, i = vo.get_matches(k, bucketed=False), vo.get_matches(k), vo.get_inlier_indices(k)
+            assert len(fin) == int(g[key + "counts"][f]) and G.sha(fin) == str(g[key + "hashes"][f]), (f, k, len(fin))
+            assert bool(ok[k]) == bool(g[key + "ok"][f]), (f, k)
+            assert len(b) == int(g[key + "n_bucketed"][f]) and G.sha(b) == str(g[key + "bucketed_sha"][f]), (f, k)
+            assert len(i) == int(g[key + "n_inliers"][f]) and G.sha(i) == str(g[key + "inliers_sha"][f]), (f, k)
+            assert vo.get_motion(k).tobytes() == g[key + "tr_out"][f].tobytes(), (f, k)
+    vo.close()
+
+
 # ---- monocular egomotion (SURVEY.md section 8 row f-4): HIP inlier counting + plane vote ----------
 
 def test_vo_mono_cases_golden(vm):
