@@ -496,9 +496,9 @@ def secondary_configs(vm, synth, torch, dev):
     def sha(a):
         return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
-    # configs[2]: per-frame API, flow matching (the look-ahead entry point takes stereo input)
+    # configs[2]: mono input, flow matching - per frame and through the look-ahead entry point
     g = np.load(os.path.join(gdir, "cfg3_640x480_mono.npz"))
-    w, h, nfx = int(g["w"]), int(g["h"]), 60
+    w, h, nfx = int(g["w"]), int(g["h"]), 200
     seq = synth.mono_sequence(int(g["seed"]), w, h, nfx, blur=int(g["blur"]))
     fr = torch.from_numpy(np.stack(seq)).to(dev)
     m = vm.Matcher()
@@ -517,8 +517,21 @@ def secondary_configs(vm, synth, torch, dev):
         m.match_features(0)
     dt = time.perf_counter() - t
     m.close()
+    m = vm.Matcher()
+    got = m.run_sequence(fr[:int(g["n_frames"])], None, 0)
+    ok_la = all(len(got[f]) == int(g["counts"][f][-1]) and sha(got[f]) == str(g["hashes"][f][-1]) for f in range(int(g["n_frames"])))
+    m.run_sequence(fr, None, 0, fetch=False)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(3):
+        m.run_sequence(fr, None, 0, fetch=False)
+    dt_la = (time.perf_counter() - t) / 3
+    form = m.sequence_path()
+    m.close()
     out["cfg3_640x480_mono_flow"] = {"value": round(nfx / dt, 1), "unit": "frames/s", "api": "per frame (vsm_push_back_device + vsm_match(0))",
-                                     "bit_exact_vs_reference_hashes": bool(ok)}
+                                     "bit_exact_vs_reference_hashes": bool(ok),
+                                     "lookahead": {"value": round(nfx / dt_la, 1), "unit": "frames/s", "form": form, "frames": nfx,
+                                                   "bit_exact_vs_reference_hashes": bool(ok_la)}}
     # configs[4]
     for name, label in (("cfg5_2048x1024_quad_20k", "cfg5_2048x1024_20k_dense"), ("cfg5_2048x1024_quad", "cfg5_2048x1024_40k_dense")):
         g = np.load(os.path.join(gdir, name + ".npz"))

@@ -1281,8 +1281,9 @@ static int seq_ingest_host_frames(vsm_handle *h, VsmCtx &c, int first_img, const
   h->seq_stage_next ^= 1;
   HIPCHK(hipEventSynchronize(h->seq_stage_ev[slot]));  // its previous content has been ingested
   uint8_t *dst = h->seq_stage_h[slot];
-  h->pool->run(2 * n, [&](int t) {
-    const int i = t >> 1, side = t & 1;
+  const int sides = right ? 2 : 1;
+  h->pool->run(sides * n, [&](int t) {
+    const int i = right ? t >> 1 : t, side = right ? (t & 1) : 0;
     const uint8_t *src = (side ? right : left) + (size_t)(f0 + i) * frame_stride;
     uint8_t *d = dst + ((size_t)side * n + i) * img;
     if (bpl == w) {
@@ -1291,11 +1292,23 @@ static int seq_ingest_host_frames(vsm_handle *h, VsmCtx &c, int first_img, const
       for (int32_t v = 0; v < hh; v++) memcpy(d + (size_t)v * w, src + (size_t)v * bpl, w);
     }
   });
-  HIPCHK(hipMemcpyAsync(h->seq_stage_d[slot], dst, 2 * img * n, hipMemcpyHostToDevice, h->stream));
-  if (h->param.half_resolution && h->sw.front)
-    vsm_launch_front(h->stream, h->prof, c.d_imgs, first_img, h->seq_stage_d[slot], h->seq_stage_d[slot] + img * n, img, w, n, c.dims, 0);
-  else
-    vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first_img, h->seq_stage_d[slot], h->seq_stage_d[slot] + img * n, img, w, n, c.dims);
+  HIPCHK(hipMemcpyAsync(h->seq_stage_d[slot], dst, (size_t)sides * img * n, hipMemcpyHostToDevice, h->stream));
+  const uint8_t *d0 = h->seq_stage_d[slot];
+  const bool fused = h->param.half_resolution && h->sw.front;
+  // (the front kernels number their images first + 2 * frame + side: consecutive mono frames go through as (even, odd) pairs)
+  auto front = [&](int first, const uint8_t *s0, const uint8_t *s1, size_t stride, int frames) {
+    if (frames <= 0) return;
+    if (fused)
+      vsm_launch_front(h->stream, h->prof, c.d_imgs, first, s0, s1, stride, w, frames, c.dims, 0);
+    else
+      vsm_launch_ingest(h->stream, h->prof, c.d_imgs, first, s0, s1, stride, w, frames, c.dims);
+  };
+  if (right) {
+    front(first_img, d0, d0 + img * n, img, n);
+  } else {
+    front(first_img, d0, d0 + img, 2 * img, n / 2);
+    if (n & 1) front(first_img + n - 1, d0 + img * (size_t)(n - 1), nullptr, img, 1);
+  }
   HIPCHK(hipEventRecord(h->seq_stage_ev[slot], h->stream));
   return VSM_OK;
 }
@@ -1349,7 +1362,8 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   h->seq_v2_frames = 0;
   h->seq_matches.resize(n_frames);  // keeps the capacity of earlier runs: no page-fault storm
   for (auto &v : h->seq_matches) v.clear();
-  if (!right || p.refinement == 2)
+  // (sub-pixel refinement fits and drops matches on the host; mono input can only be flow-matched)
+  if (p.refinement == 2 || (!right && (method != 0 || !h->sw.seq_v2)))
     return sequence_fallback(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
 
   // The GPU-resident form (vsm_seq2.inc) takes the run unless VSM_SEQ_V2=0 asks for the host-shared form below, or
@@ -1363,6 +1377,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     const int rc = sequence_run_v2(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
     if (rc != VSM_SEQ2_DECLINED) return rc;
     h->seq_v2_frames = 0;
+    if (!right) return sequence_fallback(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
   }
   int C = h->sw.seq_chunk > 0 ? h->sw.seq_chunk : 50;
   if (C > n_frames) C = n_frames;

@@ -360,9 +360,45 @@ def test_sequence_api_single_stage(vm, B, synth, monkeypatch, method, form):
     g.close()
 
 
+@pytest.mark.parametrize("device_inputs", [False, True])
+@pytest.mark.parametrize("chunk", ["4", "5", "50"])
+def test_mono_flow_lookahead(vm, B, synth, monkeypatch, chunk, device_inputs):
+    """mono input (Matcher::pushBack(I1, dims, replace) + matchFeatures(0), viso/matcher.cpp:1006-1041) through the batched
+    GPU-resident look-ahead form: 13 frames in chunks of 4 (odd and even chunk lengths, four banks come round), 5 and one
+    chunk, host and device inputs, against the oracle frame by frame"""
+    import torch
+    monkeypatch.setenv("VSM_SEQ_CHUNK", chunk)
+    seq = synth.stereo_sequence(41, 417, 163, 13, disparity=10, ramp=(1, 12))
+    left = np.stack([l for l, _ in seq])
+    g = vm.Matcher()
+    got = g.run_sequence(torch.from_numpy(left).cuda() if device_inputs else left, None, 0)
+    assert g.sequence_path() == 2
+    c = B.CpuMatcher("oracle")
+    for f, (l, _) in enumerate(seq):
+        c.push_back(l, None)
+        c.match(0)
+        assert _same(got[f], c.matches()), (chunk, f, len(got[f]), len(c.matches()))
+    assert len(got[-1]) > 100
+    g.close()
+
+
+def test_golden_cfg3_mono_lookahead(vm, synth):
+    """config 3 (640x480 mono, flow matching) through the look-ahead API: the reference's final lists"""
+    g = G.load("cfg3_640x480_mono")
+    w, h, nf, method = int(g["w"]), int(g["h"]), int(g["n_frames"]), int(g["method"])
+    assert method == 0
+    seq = synth.mono_sequence(int(g["seed"]), w, h, nf, blur=int(g["blur"]))
+    m = vm.Matcher()
+    got = m.run_sequence(np.stack(seq), None, 0)
+    assert m.sequence_path() == 2
+    for f in range(nf):
+        assert len(got[f]) == int(g["counts"][f][-1]) and G.sha(got[f]) == str(g["hashes"][f][-1]), f
+    m.close()
+
+
 def test_sequence_forms_alternate_on_one_handle(vm, B, synth):
-    """a stereo run (GPU-resident form), then a mono run (frame by frame inside the call), then stereo again on ONE handle:
-    the getters always answer for the last run"""
+    """a stereo run, then a mono run, then stereo again on ONE handle (the frame banks change their numbering between
+    them): the getters always answer for the last run"""
     seq = synth.stereo_sequence(35, 417, 163, 5, disparity=10, ramp=(1, 12))
     left = np.stack([l for l, _ in seq])
     right = np.stack([r for _, r in seq])
@@ -377,7 +413,7 @@ def test_sequence_forms_alternate_on_one_handle(vm, B, synth):
             ref[method].append(c.matches())
     for method, rgt in ((2, True), (0, False), (2, True)):
         got = g.run_sequence(left, right if rgt else None, method)
-        assert g.sequence_path() == (2 if rgt else 1)
+        assert g.sequence_path() == 2
         for f in range(len(seq)):
             assert _same(got[f], ref[method][f]), (method, f)
     g.close()
@@ -444,12 +480,15 @@ def test_two_matchers_in_two_threads(vm, synth, monkeypatch):
 
 
 def test_sequence_api_fallbacks(vm, B, synth):
+    """what the look-ahead call takes frame by frame inside: sub-pixel refinement (fits and drops matches on the host), and
+    mono input asked for stereo / quad matching (the reference's matchFeatures returns early on every frame)"""
     seq = synth.stereo_sequence(8, 320, 128, 4)
     left = np.stack([l for l, _ in seq])
     right = np.stack([r for _, r in seq])
-    for kw, meth, rgt in ((dict(refinement=2), 2, right), (dict(), 0, None)):
+    for kw, meth, rgt in ((dict(refinement=2), 2, right), (dict(), 2, None), (dict(refinement=2), 0, None)):
         g = vm.Matcher(**kw)
         got = g.run_sequence(left, rgt, meth)
+        assert g.sequence_path() == 1
         c = B.CpuMatcher("oracle", **kw)
         for f, (l, r) in enumerate(seq):
             c.push_back(l, r if rgt is not None else None)
