@@ -912,7 +912,10 @@ extern "C" int vsm_debug_dc2_phases(unsigned long long *out, int reset) {
 #define DC2_BLOCK_WAVES 4
 #endif
 #define DC2_BLOCK_THREADS (64 * DC2_BLOCK_WAVES)
-__global__ void __launch_bounds__(DC2_BLOCK_THREADS, 5) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
+#ifndef DC2_BLOCK_OCC
+#define DC2_BLOCK_OCC 5
+#endif
+__global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
   __shared__ __attribute__((aligned(16))) uint32_t s_w[2 * VSM_DC_BLOCK_POINTS * 4];  // edge words (vsm_dc_lds.h)
   __shared__ uint32_t s_pt[VSM_DC_BLOCK_POINTS];
   __shared__ Dc2Hull16 s_hull[2 << DC2_BLOCK_DEPTH];
@@ -1596,11 +1599,53 @@ void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int3
   if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_ties, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride);
 }
+// the same votes with one workgroup per list and the counts in LDS (lists of up to DC2_SUPPORT_LDS matches): six integer
+// atomics per triangle that stay on the compute unit instead of going to L2 (398 -> ~60 us for 200 lists of 7.4 k matches)
+#define DC2_SUPPORT_LDS 12288
+__global__ void __launch_bounds__(1024) k_dc2_support_lds(const VsmDc2Job *__restrict__ jobs, int method, float ftol, float dtol) {
+  __shared__ int32_t s_sup[DC2_SUPPORT_LDS];
+  const VsmDc2Job jb = jobs[blockIdx.x];
+  const int32_t m = jb.mn[0], n = jb.mn[1];
+  if (m < 2) return;
+  const int t = threadIdx.x;
+  for (int i = t; i < n; i += 1024) s_sup[i] = 0;
+  __syncthreads();
+  const float *fua = (const float *)jb.kd_scratch, *fva = fua + jb.kd_stride, *dpa = fva + jb.kd_stride;
+  for (int s = t; s < 2 * m; s += 1024) {
+    const int4 v = *(const int4 *)(jb.tri + (size_t)s * 8 + 4);
+    if ((v.x | v.y | v.z) < 0) continue;
+    const int32_t q[3] = {jb.remap[jb.id[v.y]], jb.remap[jb.id[v.z]], jb.remap[jb.id[v.x]]};
+    float fu[3], fv[3], dp[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      fu[k] = fua[q[k]];
+      fv[k] = fva[q[k]];
+      dp[k] = dpa[q[k]];
+    }
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      const int a = e == 2 ? 0 : e, b = e == 0 ? 1 : 2;  // (0,1) (1,2) (0,2)
+      const bool flow_ok = fabsf(fu[a] - fu[b]) + fabsf(fv[a] - fv[b]) < ftol;
+      const bool disp_ok = fabsf(dp[a] - dp[b]) < dtol;
+      const bool ok = method == 0 ? flow_ok : (method == 1 ? disp_ok : (disp_ok && flow_ok));
+      if (ok) {
+        atomicAdd(&s_sup[q[a]], 1);
+        atomicAdd(&s_sup[q[b]], 1);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) jb.support[i] = s_sup[i];
+}
+
 void vsm_dc2_launch_support(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol, float disp_tol) {
   if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_apply_ties, dim3(njobs), dim3(64), 0, s, d_jobs);
   hipLaunchKernelGGL(k_dc2_flows, dim3((std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method);
-  hipLaunchKernelGGL(k_dc2_support, dim3((2 * std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method, flow_tol, disp_tol);
+  if (max_list <= DC2_SUPPORT_LDS)
+    hipLaunchKernelGGL(k_dc2_support_lds, dim3(njobs), dim3(1024), 0, s, d_jobs, method, flow_tol, disp_tol);
+  else
+    hipLaunchKernelGGL(k_dc2_support, dim3((2 * std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method, flow_tol, disp_tol);
 }
 void vsm_dc2_launch_compact(hipStream_t s, const VsmDc2Job *d_jobs, int njobs) {
   if (njobs <= 0) return;
