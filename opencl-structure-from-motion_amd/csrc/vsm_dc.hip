@@ -460,14 +460,14 @@ struct TieFromKeys {
   __device__ inline uint32_t idx(int i) const { return (uint32_t)(keys[i] & 0xfffffu); }
 };
 
-template <typename Src>
+template <int CAP, typename Src>
 __device__ inline void tie_sort(const Src src, const int n0, int32_t *__restrict__ tie_out) {
-  __shared__ uint32_t s_k[VSM_DC_TIE_POINTS], s_i[VSM_DC_TIE_POINTS];
-  __shared__ uint16_t s_L[VSM_DC_TIE_POINTS], s_R[VSM_DC_TIE_POINTS];
-  __shared__ uint64_t s_ge[VSM_DC_TIE_POINTS / 64], s_le[VSM_DC_TIE_POINTS / 64];
+  __shared__ uint32_t s_k[CAP], s_i[CAP];
+  __shared__ uint16_t s_L[CAP], s_R[CAP];
+  __shared__ uint64_t s_ge[CAP / 64], s_le[CAP / 64];
   __shared__ uint32_t s_stack[TIE_STACK * 2];
   const int lane = threadIdx.x;
-  if (n0 > VSM_DC_TIE_POINTS) {
+  if (n0 > CAP) {
     if (lane == 0) tie_out[0] = -1;
     return;
   }
@@ -689,7 +689,7 @@ __device__ inline void tie_sort(const Src src, const int n0, int32_t *__restrict
 __global__ void __launch_bounds__(64) k_dc_ties(const VsmDcJob *__restrict__ jobs, int njobs) {
   const VsmDcJob jb = jobs[blockIdx.x];
   if (!jb.tie_keys || !jb.tie_out) return;
-  tie_sort(TieFromKeys{jb.tie_keys}, jb.n_in, jb.tie_out);
+  tie_sort<VSM_DC_TIE_POINTS>(TieFromKeys{jb.tie_keys}, jb.n_in, jb.tie_out);
 }
 
 // The same for the pairs of a look-ahead chunk, as soon as their compacted pass-2 lists exist (refinement does
@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(64) k_dc_ties_of_keys(const uint64_t *__restri
     if (threadIdx.x == 0) out[0] = n < 2 ? 0 : -1;
     return;
   }
-  tie_sort(TieFromKeys{keys + (size_t)blockIdx.x * stride}, n, out);
+  tie_sort<VSM_DC_TIE_POINTS>(TieFromKeys{keys + (size_t)blockIdx.x * stride}, n, out);
 }
 
 // The support test of removeOutliers (viso/matcher.cpp:1266-1364; vsm_host_outliers_end is the host form):
@@ -1338,6 +1338,7 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
 
 // Triangle's vertex sort for the jobs of a chunk on the device (one wave each): the verdicts go to
 // tie_out + job * out_stride; lists the wave cannot take get -1 there
+template <int CAP>
 __global__ void __launch_bounds__(64) k_dc2_ties(const VsmDc2Job *__restrict__ jobs, int32_t *__restrict__ tie_out, int out_stride) {
   const VsmDc2Job jb = jobs[blockIdx.x];
   int32_t *out = tie_out + (size_t)blockIdx.x * out_stride;
@@ -1346,7 +1347,7 @@ __global__ void __launch_bounds__(64) k_dc2_ties(const VsmDc2Job *__restrict__ j
     if (threadIdx.x == 0) out[0] = n <= 3 ? 0 : -1;
     return;
   }
-  tie_sort(TieFromKeys{jb.keys_in}, n, out);
+  tie_sort<CAP>(TieFromKeys{jb.keys_in}, n, out);
 }
 
 // which match stands for a pixel that several share: remap[index carried] = index Triangle's sort puts first
@@ -1595,9 +1596,14 @@ void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, in
     hipLaunchKernelGGL(k_dc2_merge, dim3(1 << level, njobs), dim3(DC2_MERGE_THREADS), bytes_of(), s, d_jobs, level, lines_cap, pts_cap, words_cap);
   }
 }
-void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride) {
+void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride, int max_list) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(k_dc2_ties, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride);
+  // (the first-pass lists are a tenth of the second-pass ones: 25 KB of LDS per list instead of 141 - a list that turns out
+  // longer than the bound it was launched with reports -1 like one beyond VSM_DC_TIE_POINTS)
+  if (max_list > 0 && max_list <= 2048)
+    hipLaunchKernelGGL(k_dc2_ties<2048>, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride);
+  else
+    hipLaunchKernelGGL(k_dc2_ties<VSM_DC_TIE_POINTS>, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride);
 }
 // the same votes with one workgroup per list and the counts in LDS (lists of up to DC2_SUPPORT_LDS matches): six integer
 // atomics per triangle that stay on the compute unit instead of going to L2 (398 -> ~60 us for 200 lists of 7.4 k matches)

@@ -147,7 +147,7 @@ void vsm_dc2_launch_keys(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int 
 void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs);
 void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth);
 void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth, int max_list);  // levels depth-1 .. 0
-void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride);
+void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride, int max_list = 0);  // max_list: upper bound of the list lengths (0 = unknown)
 void vsm_dc2_launch_support(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol,
                             float disp_tol);  // tie patches, flows, votes
 void vsm_dc2_launch_compact(hipStream_t s, const VsmDc2Job *d_jobs, int njobs);
