@@ -138,13 +138,24 @@ struct DcEdgeMesh {
 #endif
   }
   DC2_DEV static inline int64_t incircle_p(uint32_t pa, uint32_t pb, uint32_t pc, uint32_t pd) { return incircle_s(pa, pb, pc, pd); }
-  // ... and only "is d strictly inside the circle through a, b, c" (what the seam walk asks)
+  // ... and only "is d strictly inside the circle through a, b, c" (what the seam walk asks): the three products as
+  // v_mad_i64_i32, one instruction each (the compiler's own 64-bit multiply of a known-non-negative by a signed 32-bit value
+  // comes out as two v_mad_u64_u32 plus moves; DC2_INCIRCLE_F64 selects the same sum in double, exact as well and 7 % slower).
   DC2_DEV static inline bool incircle_in(uint32_t pa, uint32_t pb, uint32_t pc, uint32_t pd) {
     const int32_t dx = (int32_t)(pd & 0xffffu), dy = (int32_t)(pd >> 16);
     const int32_t adx = (int32_t)(pa & 0xffffu) - dx, ady = (int32_t)(pa >> 16) - dy;
     const int32_t bdx = (int32_t)(pb & 0xffffu) - dx, bdy = (int32_t)(pb >> 16) - dy;
     const int32_t cdx = (int32_t)(pc & 0xffffu) - dx, cdy = (int32_t)(pc >> 16) - dy;
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DC2_INCIRCLE_F64)
+    const int32_t l1 = mul24(adx, adx) + mul24(ady, ady), l2 = mul24(bdx, bdx) + mul24(bdy, bdy), l3 = mul24(cdx, cdx) + mul24(cdy, cdy);
+    const int32_t c1 = mul24(bdx, cdy) - mul24(cdx, bdy), c2 = mul24(cdx, ady) - mul24(adx, cdy), c3 = mul24(adx, bdy) - mul24(bdx, ady);
+    int64_t det;
+    uint64_t carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(det), "=s"(carry) : "v"(l1), "v"(c1));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(det), "=s"(carry) : "v"(l2), "v"(c2), "v"(det));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(det), "=s"(carry) : "v"(l3), "v"(c3), "v"(det));
+    return det > 0;
+#elif defined(__HIP_DEVICE_COMPILE__)
     const double l1 = (double)(mul24(adx, adx) + mul24(ady, ady)), l2 = (double)(mul24(bdx, bdx) + mul24(bdy, bdy)), l3 = (double)(mul24(cdx, cdx) + mul24(cdy, cdy));
     const double c1 = (double)(mul24(bdx, cdy) - mul24(cdx, bdy)), c2 = (double)(mul24(cdx, ady) - mul24(adx, cdy)), c3 = (double)(mul24(adx, bdy) - mul24(bdx, ady));
     return __builtin_fma(l1, c1, __builtin_fma(l2, c2, l3 * c3)) > 0;
