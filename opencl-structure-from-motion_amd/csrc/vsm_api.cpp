@@ -370,7 +370,9 @@ struct VsmSwitches {
   int seq_v2 = 1;          // VSM_SEQ_V2: 0 = the host-shared look-ahead form
   int seq_chunk = 0;       // VSM_SEQ_CHUNK: frames per look-ahead chunk (0 = by host threads)
   int seq_dc_streams = 3;  // VSM_SEQ_DC_STREAMS: streams the final chains rotate over (1..4)
-  int seq_pack = 1;        // VSM_SEQ_PACK: survivors cross PCIe as 24-byte records
+  int seq_pack = 0;        // VSM_SEQ_PACK: 0 = the device writes the survivors as 48-byte p_match records, a DMA copy takes them into the
+                           // host-mapped arena and the getters read them there (no host copy inside the call); 1 = 24-byte packed
+                           // records cross PCIe early and the pool expands them (measured slower at every thread count)
   int seq_serial = 0;      // VSM_SEQ_SERIAL: nothing overlaps (every kernel's time alone)
   int seq_gpu_sorts = -1;  // VSM_SEQ_GPU_SORTS: percent of a chunk's vertex sorts done on the device (-1 = by host threads)
   int front = 1;           // VSM_FRONT: the fused front end
@@ -387,7 +389,7 @@ struct VsmSwitches {
     seq_v2 = env_int("VSM_SEQ_V2", 1) != 0;
     seq_chunk = std::max(0, env_int("VSM_SEQ_CHUNK", 0));
     seq_dc_streams = std::min(4, std::max(1, env_int("VSM_SEQ_DC_STREAMS", 3)));
-    seq_pack = env_int("VSM_SEQ_PACK", 1) != 0;
+    seq_pack = env_int("VSM_SEQ_PACK", 0);
     seq_serial = env_int("VSM_SEQ_SERIAL", 0) != 0;
     seq_gpu_sorts = env_int("VSM_SEQ_GPU_SORTS", -1);
     front = env_int("VSM_FRONT", 1) != 0;
@@ -401,7 +403,7 @@ struct VsmSwitches {
     if (!strcmp(name, "seq_v2")) seq_v2 = v != 0;
     else if (!strcmp(name, "seq_chunk")) seq_chunk = std::max(0, v);
     else if (!strcmp(name, "seq_dc_streams")) seq_dc_streams = std::min(4, std::max(1, v));
-    else if (!strcmp(name, "seq_pack")) seq_pack = v != 0;
+    else if (!strcmp(name, "seq_pack")) seq_pack = v;
     else if (!strcmp(name, "seq_serial")) seq_serial = v != 0;
     else if (!strcmp(name, "seq_gpu_sorts")) seq_gpu_sorts = v;
     else if (!strcmp(name, "front")) front = v != 0;
@@ -459,6 +461,13 @@ struct vsm_handle {
   std::vector<uint8_t> gainI[2];
   // results of the sequence API
   std::vector<std::vector<vsm_p_match>> seq_matches;
+  // ... or, per frame, a view of 48-byte records that the device wrote straight into the host-mapped result arena (the
+  // GPU-resident look-ahead form on hosts with few threads: no host copy inside the call at all)
+  struct SeqView {
+    const vsm_p_match *p = nullptr;
+    int32_t n = 0;
+  };
+  std::vector<SeqView> seq_view;
   double seq_timings[4] = {0, 0, 0, 0};
   bool dc_gpu_broken = false;    // a Delaunay stream reported a HIP error once: the host-shared form keeps off the GPU share from then on
   std::atomic<int> seq_hip_error{0};  // set by a chunk whose GPU share failed during the current vsm_sequence_run
@@ -1365,6 +1374,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   h->seq_v2_frames = 0;
   h->seq_matches.resize(n_frames);  // keeps the capacity of earlier runs: no page-fault storm
   for (auto &v : h->seq_matches) v.clear();
+  h->seq_view.assign(n_frames, vsm_handle::SeqView());
   // (sub-pixel refinement fits and drops matches on the host; mono input can only be flow-matched)
   if (p.refinement == 2 || (!right && (method != 0 || !h->sw.seq_v2)))
     return sequence_fallback(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
@@ -1810,15 +1820,18 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
 }
 
 int32_t vsm_sequence_num_matches(vsm_handle *h, int32_t frame) {
-  return (frame >= 0 && frame < (int32_t)h->seq_matches.size()) ? (int32_t)h->seq_matches[frame].size() : 0;
+  if (frame < 0 || frame >= (int32_t)h->seq_matches.size()) return 0;
+  if (frame < (int32_t)h->seq_view.size() && h->seq_view[frame].p) return h->seq_view[frame].n;
+  return (int32_t)h->seq_matches[frame].size();
 }
 
 // (both look-ahead forms end with every frame's list in the reference's 48-byte p_match form in host memory)
 int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out, int32_t cap) {
   if (frame < 0 || frame >= (int32_t)h->seq_matches.size()) return 0;
-  int32_t n = (int32_t)h->seq_matches[frame].size();
+  const bool view = frame < (int32_t)h->seq_view.size() && h->seq_view[frame].p;
+  int32_t n = view ? h->seq_view[frame].n : (int32_t)h->seq_matches[frame].size();
   if (n > cap) n = cap;
-  if (n > 0) memcpy(out, h->seq_matches[frame].data(), (size_t)n * sizeof(vsm_p_match));
+  if (n > 0) memcpy(out, view ? h->seq_view[frame].p : h->seq_matches[frame].data(), (size_t)n * sizeof(vsm_p_match));
   return n;
 }
 
