@@ -378,6 +378,7 @@ struct VsmSwitches {
   int front = 1;           // VSM_FRONT: the fused front end
   int seq_early_export = 1;  // VSM_SEQ_EARLY_EXPORT: the refined lists cross PCIe beside the triangulation, survivor bits follow
   int seq_group = 1;       // VSM_SEQ_GROUP: chunks per final chain (1..3; measured: one row of kernels per chunk overlaps the main stream's work better)
+  int seq_refine_lag = 0;  // VSM_SEQ_REFINE_LAG: groups between a second pass and its refinement on the main stream (0..2; measured: no difference)
   int seq_keys_dma = 1;    // VSM_SEQ_KEYS_DMA: the pass-2 keys reach the host's vertex sorts by a DMA copy instead of stores into host memory
   int seq_export_dma = 1;  // VSM_SEQ_EXPORT_DMA: early export packs into HBM, a DMA copy takes it to the host
   int seq_chain_prio = 0;  // VSM_SEQ_CHAIN_PRIO: the Delaunay chains' streams at the device's highest priority (read when the streams are made)
@@ -397,6 +398,7 @@ struct VsmSwitches {
     seq_early_export = env_int("VSM_SEQ_EARLY_EXPORT", 1) != 0;
     seq_export_dma = env_int("VSM_SEQ_EXPORT_DMA", 1) != 0;
     seq_keys_dma = env_int("VSM_SEQ_KEYS_DMA", 1) != 0;
+    seq_refine_lag = std::min(2, std::max(0, env_int("VSM_SEQ_REFINE_LAG", 0)));
     seq_group = std::min(3, std::max(1, env_int("VSM_SEQ_GROUP", 1)));
   }
   bool set(const char *name, int v) {
@@ -411,6 +413,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "seq_early_export")) seq_early_export = v != 0;
     else if (!strcmp(name, "seq_export_dma")) seq_export_dma = v != 0;
     else if (!strcmp(name, "seq_keys_dma")) seq_keys_dma = v != 0;
+    else if (!strcmp(name, "seq_refine_lag")) seq_refine_lag = std::min(2, std::max(0, (int)v));
     else if (!strcmp(name, "seq_group")) seq_group = std::min(3, std::max(1, (int)v));
     else return false;
     return true;

@@ -287,7 +287,8 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
                                  {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
                                  {"VSM_MATCH_STAGED": "1"}, {"VSM_FRONT": "0"}, {"VSM_MATCH_G": "8"}, {"VSM_SEQ_PACK": "1", "VSM_SEQ_EARLY_EXPORT": "0"},
                                  {"VSM_SEQ_CHAIN_PRIO": "1"}, {"VSM_SEQ_GROUP": "1"}, {"VSM_SEQ_GROUP": "2", "VSM_SEQ_CHUNK": "5"}, {"VSM_SEQ_KEYS_DMA": "0"},
-                                 {"VSM_SEQ_EXPORT_DMA": "0", "VSM_SEQ_GROUP": "2"}, {"VSM_SEQ_PACK": "1", "VSM_SEQ_GROUP": "3", "VSM_SEQ_CHUNK": "4"}])
+                                 {"VSM_SEQ_EXPORT_DMA": "0", "VSM_SEQ_GROUP": "2"}, {"VSM_SEQ_PACK": "1", "VSM_SEQ_GROUP": "3", "VSM_SEQ_CHUNK": "4"}, {"VSM_SEQ_REFINE_LAG": "0"},
+                                 {"VSM_SEQ_REFINE_LAG": "1", "VSM_SEQ_CHUNK": "3"}, {"VSM_SEQ_REFINE_LAG": "2", "VSM_SEQ_CHUNK": "2", "VSM_SEQ_GROUP": "2"}])
 def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), 48-byte result
     records instead of the packed ones, one / four chain streams (eight chunks of five: every bank comes round twice), the
