@@ -1719,6 +1719,42 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Quad matching keeps every accepted query (no pixel de-dup, viso/matcher.cpp:1139-1151): a block finds its base by
+// summing the acceptance flags in front of it itself - at most 8 k flags, 32 KB out of L2 - and the count kernel, a second
+// launch that the lists behind it (and the Delaunay chain behind those) wait for, is gone.
+__global__ void __launch_bounds__(256)
+    k_compact_quad(const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs, VsmJob job0, int pass) {
+  __shared__ int s_red[4];
+  __shared__ int s_cnt[4];
+  const VsmPair &pair = pairs[blockIdx.y];
+  const int n_query = (jobs ? jobs[blockIdx.y] : job0).nq[pass];
+  const int nblk = max((n_query + 255) / 256, 1);  // blocks that hold queries of this pair
+  if ((int)blockIdx.x >= nblk) return;
+  vsm_p_match *__restrict__ list = pass ? pair.list2 : pair.list1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int part = 0;
+  for (int q = threadIdx.x; q < (int)blockIdx.x * 256; q += 256) part += pair.flag[q] ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool keep = i < n_query && pair.flag[i];
+  const unsigned long long bal = __ballot(keep);
+  if (lane == 0) {
+    s_red[wv] = part;
+    s_cnt[wv] = __popcll(bal);
+  }
+  __syncthreads();
+  int pos = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  for (int w = 0; w < wv; w++) pos += s_cnt[w];
+  pos += __popcll(bal & ((1ull << lane) - 1ull));
+  if (keep) list[pos] = pair.raw[i];
+  if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 255) {
+    const int total = pos + (keep ? 1 : 0);
+    pair.count[pass] = total;
+    pair.hcount[pass] = total;
+  }
+}
+
 // wide copy of a finished list into host-mapped pinned memory (16 bytes per lane over PCIe):
 // the host reads it after the stream sync, no D2H copy call and no second round trip
 __global__ void __launch_bounds__(256)
@@ -2159,8 +2195,12 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
   }
   const int nblk = max(cdiv(max_nq, 256), 1);
   pf.begin(cfg.sparse ? VSM_K_COMPACT1 : VSM_K_COMPACT2, s);
-  hipLaunchKernelGGL(k_compact_count, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);
-  hipLaunchKernelGGL(k_compact_write, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);
+  if (cfg.method == 2) {
+    hipLaunchKernelGGL(k_compact_quad, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, pass);
+  } else {
+    hipLaunchKernelGGL(k_compact_count, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);
+    hipLaunchKernelGGL(k_compact_write, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);
+  }
   pf.end(s);
 }
 
