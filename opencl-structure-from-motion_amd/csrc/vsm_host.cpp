@@ -88,10 +88,16 @@ VsmPool::Ticket VsmPool::submit(int ntasks, std::function<void(int)> fn, bool ur
   }
   {
     std::lock_guard<std::mutex> lk(mu_);
-    if (urgent)
-      queue_.push_front(b);  // a blocking caller is waiting: ahead of background batches
-    else
+    if (urgent) {
+      // ahead of the background batches, but behind the urgent ones that are already waiting: first come, first served among
+      // them (the look-ahead path's vertex sorts of chunk k must not be overtaken by those of chunk k + 1)
+      auto it = queue_.begin();
+      while (it != queue_.end() && (*it)->urgent) ++it;
+      b->urgent = true;
+      queue_.insert(it, b);
+    } else {
       queue_.push_back(b);
+    }
     posted_.fetch_add(1, std::memory_order_release);
   }
   // (as many wake-ups as there are tasks: every woken worker that finds the queue empty spins for spin_us_ before it sleeps

@@ -29,6 +29,7 @@ class VsmPool {
   struct Batch {
     std::function<void(int)> fn;
     int n = 0;
+    bool urgent = false;
     std::atomic<int> next{0}, done{0};
   };
   typedef std::shared_ptr<Batch> Ticket;
