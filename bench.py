@@ -400,8 +400,9 @@ def main():
                                f"vsm_sequence_run (chunks of {chunk} frames)",
                    "frames_per_step": nf, "sequences": world, "inputs": "resident in HBM",
                    "results": "when the timed call returns every frame's final list is in host memory as 48-byte p_match records "
-                              "(viso/matcher.h:86-100), as Matcher::matchFeatures leaves p_matched_2; the packed PCIe export is "
-                              "expanded by the host pool inside the call"},
+                              "(viso/matcher.h:86-100), as Matcher::matchFeatures leaves p_matched_2: the refined lists cross PCIe by DMA as they "
+                              "are, the device sends one survivor bit per match behind them, the host pool closes the gaps in "
+                              "place - all inside the timed call; vsm_sequence_get_matches copies from there"},
         "per_frame_api": {"value": round(per_frame_value, 3) if per_frame_value else None, "unit": "frame-pairs/s",
                           "what": "same sequence through vsm_push_back_device + vsm_match per frame (drop-in "
                                   "Matcher::pushBack/matchFeatures path)"},

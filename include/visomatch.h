@@ -131,7 +131,7 @@ void vsm_sequence_get_timings(vsm_handle *h, double *out4);
  * the device chain declines) */
 int32_t vsm_sequence_path(vsm_handle *h);
 /* Measurement / test switches of a handle.  They are read from the environment once, by vsm_create (VSM_SEQ_V2,
- * VSM_SEQ_CHUNK, VSM_SEQ_DC_STREAMS, VSM_SEQ_PACK, VSM_SEQ_SERIAL, VSM_SEQ_GPU_SORTS, VSM_FRONT); this call changes one
+ * VSM_SEQ_CHUNK, VSM_SEQ_DC_STREAMS, VSM_SEQ_SERIAL, VSM_SEQ_GPU_SORTS, VSM_SEQ_EARLY_EXPORT, VSM_FRONT); this call changes one
  * afterwards: name = the variable's name without the VSM_ prefix, in lower case ("seq_serial", "seq_chunk", ...).
  * None of them changes a result.  Returns VSM_OK, or VSM_EARG for an unknown name.  (No counterpart in the reference.) */
 int vsm_set_option(vsm_handle *h, const char *name, int32_t value);
@@ -216,11 +216,6 @@ int32_t vsm_host_outliers_and_prior(const vsm_params *p, const vsm_p_match *list
                                     int32_t cap, float *ranges, int32_t w, int32_t h);
 int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, int32_t gpu_ties, int32_t copies,
                       vsm_p_match *out, int32_t cap, float *ranges, int32_t w, int32_t h, double *kernel_us);
-
-/* The 24-byte form in which the look-ahead path sends its final lists through PCIe (integer-valued fields: coordinates
- * 0..16382 or -1, indices 0..2^20-2 or -1; vsm_sequence_get_matches unpacks): packs `n` matches and unpacks them again
- * into `out`; returns how many did not fit the form (those are left untouched in `out`).  Test hook, no GPU involved. */
-int32_t vsm_debug_pack_roundtrip(const vsm_p_match *in, int32_t n, vsm_p_match *out);
 
 /* ---- stereo visual odometry on top of the matcher ----
  * class VisualOdometryStereo, viso/viso_stereo.h:28-88 + viso/viso.h:28-131: process() =

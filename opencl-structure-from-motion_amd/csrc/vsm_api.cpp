@@ -370,18 +370,11 @@ struct VsmSwitches {
   int seq_v2 = 1;          // VSM_SEQ_V2: 0 = the host-shared look-ahead form
   int seq_chunk = 0;       // VSM_SEQ_CHUNK: frames per look-ahead chunk (0 = by host threads)
   int seq_dc_streams = 3;  // VSM_SEQ_DC_STREAMS: streams the final chains rotate over (1..4)
-  int seq_pack = 0;        // VSM_SEQ_PACK: 0 = the device writes the survivors as 48-byte p_match records, a DMA copy takes them into the
-                           // host-mapped arena and the getters read them there (no host copy inside the call); 1 = 24-byte packed
-                           // records cross PCIe early and the pool expands them (measured slower at every thread count)
   int seq_serial = 0;      // VSM_SEQ_SERIAL: nothing overlaps (every kernel's time alone)
   int seq_gpu_sorts = -1;  // VSM_SEQ_GPU_SORTS: percent of a chunk's vertex sorts done on the device (-1 = by host threads)
   int front = 1;           // VSM_FRONT: the fused front end
-  int seq_early_export = 1;  // VSM_SEQ_EARLY_EXPORT: the refined lists cross PCIe beside the triangulation, survivor bits follow
-  int seq_group = 1;       // VSM_SEQ_GROUP: chunks per final chain (1..3; measured: one row of kernels per chunk overlaps the main stream's work better)
-  int seq_refine_lag = 0;  // VSM_SEQ_REFINE_LAG: groups between a second pass and its refinement on the main stream (0..2; measured: no difference)
-  int seq_keys_dma = 1;    // VSM_SEQ_KEYS_DMA: the pass-2 keys reach the host's vertex sorts by a DMA copy instead of stores into host memory
-  int seq_export_dma = 1;  // VSM_SEQ_EXPORT_DMA: early export packs into HBM, a DMA copy takes it to the host
-  int seq_chain_prio = 0;  // VSM_SEQ_CHAIN_PRIO: the Delaunay chains' streams at the device's highest priority (read when the streams are made)
+  int seq_early_export = -1;  // VSM_SEQ_EARLY_EXPORT: the refined lists cross PCIe beside the triangulation, survivor bits follow, the pool
+                              // closes the gaps (1); survivors compacted on the device, one DMA copy at the chain's end (0); -1: by pool size
   static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -390,31 +383,19 @@ struct VsmSwitches {
     seq_v2 = env_int("VSM_SEQ_V2", 1) != 0;
     seq_chunk = std::max(0, env_int("VSM_SEQ_CHUNK", 0));
     seq_dc_streams = std::min(4, std::max(1, env_int("VSM_SEQ_DC_STREAMS", 3)));
-    seq_pack = env_int("VSM_SEQ_PACK", 0);
     seq_serial = env_int("VSM_SEQ_SERIAL", 0) != 0;
     seq_gpu_sorts = env_int("VSM_SEQ_GPU_SORTS", -1);
     front = env_int("VSM_FRONT", 1) != 0;
-    seq_chain_prio = env_int("VSM_SEQ_CHAIN_PRIO", 0) != 0;
-    seq_early_export = env_int("VSM_SEQ_EARLY_EXPORT", 1) != 0;
-    seq_export_dma = env_int("VSM_SEQ_EXPORT_DMA", 1) != 0;
-    seq_keys_dma = env_int("VSM_SEQ_KEYS_DMA", 1) != 0;
-    seq_refine_lag = std::min(2, std::max(0, env_int("VSM_SEQ_REFINE_LAG", 0)));
-    seq_group = std::min(3, std::max(1, env_int("VSM_SEQ_GROUP", 1)));
+    seq_early_export = env_int("VSM_SEQ_EARLY_EXPORT", -1);
   }
   bool set(const char *name, int v) {
     if (!strcmp(name, "seq_v2")) seq_v2 = v != 0;
     else if (!strcmp(name, "seq_chunk")) seq_chunk = std::max(0, v);
     else if (!strcmp(name, "seq_dc_streams")) seq_dc_streams = std::min(4, std::max(1, v));
-    else if (!strcmp(name, "seq_pack")) seq_pack = v;
     else if (!strcmp(name, "seq_serial")) seq_serial = v != 0;
     else if (!strcmp(name, "seq_gpu_sorts")) seq_gpu_sorts = v;
     else if (!strcmp(name, "front")) front = v != 0;
-    else if (!strcmp(name, "seq_chain_prio")) seq_chain_prio = v != 0;
-    else if (!strcmp(name, "seq_early_export")) seq_early_export = v != 0;
-    else if (!strcmp(name, "seq_export_dma")) seq_export_dma = v != 0;
-    else if (!strcmp(name, "seq_keys_dma")) seq_keys_dma = v != 0;
-    else if (!strcmp(name, "seq_refine_lag")) seq_refine_lag = std::min(2, std::max(0, (int)v));
-    else if (!strcmp(name, "seq_group")) seq_group = std::min(3, std::max(1, (int)v));
+    else if (!strcmp(name, "seq_early_export")) seq_early_export = v;
     else return false;
     return true;
   }
@@ -2190,18 +2171,6 @@ int32_t vsm_host_outliers_and_prior(const vsm_params *p, const vsm_p_match *list
   }
   for (size_t i = 0; i < m.size() && (int32_t)i < cap; i++) out[i] = m[i];
   return (int32_t)m.size();
-}
-
-int32_t vsm_debug_pack_roundtrip(const vsm_p_match *in, int32_t n, vsm_p_match *out) {
-  int32_t rejected = 0;
-  for (int32_t i = 0; i < n; i++) {
-    uint64_t w[3];
-    if (vsm_pack_match(in[i], w))
-      vsm_unpack_match(w, out[i]);
-    else
-      rejected++;
-  }
-  return rejected;
 }
 
 int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, int32_t gpu_ties, int32_t copies,

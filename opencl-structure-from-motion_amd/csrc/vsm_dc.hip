@@ -904,10 +904,14 @@ extern "C" int vsm_debug_dc2_phases(unsigned long long *out, int reset) {
 #define DC2_T(var)
 #define DC2_ACC(row, col, a, b)
 #endif
-// One workgroup per block sub-tree (<= VSM_DC_BLOCK_POINTS points) as k_dc_block, on the 16-bit local mesh: 22 KB of LDS
-// instead of 40.  FOUR waves: lanes that walk different seams diverge, and a wave issues every diverging lane's path in
-// turn, so the quarter sub-trees of the block go to a wave each (they sit on the CU's four SIMDs) - 8 leaves instead of
-// 32 per wave, one merge node per wave from the third level up.  Measured alone, 50 lists of 7.4 k: 450 -> 330 us.
+// One workgroup per block sub-tree (<= VSM_DC_BLOCK_POINTS points) on the edge-word LDS mesh (vsm_dc_lds.h): 15 KB of words,
+// 2 KB of points, 4 KB of hull handles.  The block is cut down to Triangle's own leaves of two or three points
+// (DC2_BLOCK_DEPTH = 8 halvings, the same rule as the host's tree): 256 lanes build a leaf each - a handful of stores, no
+// walk - and the eight levels above are merged level by level, a node per lane: a quarter of the block per wave (the four
+// waves sit on the CU's four SIMDs), the two top levels on waves 0, 1 / wave 0.  The seam loop (dc2_zip) is straight-line
+// code under selects, so the lanes of a wave that walk different seams mostly execute the same instructions; what is left
+// of the divergence is the trip count.  Measured alone, 67 lists of 7.4 k: ~340 us (round 2's form - 64 leaves of <= 14
+// points by a per-lane recursion, six levels - took 466).
 #ifndef DC2_BLOCK_WAVES
 #define DC2_BLOCK_WAVES 4
 #endif
@@ -1037,13 +1041,14 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
 //   * the node's two new slots,
 // a few hundred records out of the node's 2 n (535 of 14 800 for the top merge of a 7.4 k list).  The band gets a
 // compact numbering of its own - line = number of band slots before it (rank in a bit mask), the points its records use
-// likewise - so the walk runs on the plain 16-bit whole-node accessors (DcLdsMesh<false>): 8-50 KB of LDS per node
-// instead of 36 bytes per point of the node (the top merges used to hold a compute unit's LDS each while one lane walked),
-// nothing to translate during the walk, and the node itself may be of any size.  One lane then zips the seam;
-// afterwards all lanes write the band's records back under global numbering.  A neighbour word that would lead out of the
-// band holds DC2_EXT; following it (it does not happen: the band is closed under the walk's accesses)
-// trips the mesh's guard, and the node is redone by one lane on the records in global memory, which are untouched until
-// the write-back.  The same happens to a node whose band does not fit the LDS the level was launched with.
+// likewise - so the walk runs on the edge-word mesh of vsm_dc_lds.h (DcBandMesh): 8-50 KB of LDS per node instead of 36
+// bytes per point of the node (the top merges used to hold a compute unit's LDS each while one lane walked), nothing to
+// translate during the walk, and the node itself may be of any size.  One lane then zips the seam (dc2_zip); afterwards
+// all lanes write the band's records back under global numbering.  A neighbour that is not in the band is the handle of
+// the band's TRAP record (vsm_dc_lds.h): a walk that would need what lies behind it - it does not happen on the test
+// sets: the band is closed under the walk's accesses, DESIGN.md section 6b - poisons its own check or leaves a store in
+// the trap, and the node is then redone by one lane on the records in global memory, which are untouched until the
+// write-back.  The same happens to a node whose band does not fit the LDS the level was launched with.
 // ---------------------------------------------------------------------------------------
 #ifndef DC2_MERGE_THREADS
 #define DC2_MERGE_THREADS 256
@@ -1428,30 +1433,12 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc2_compact(const VsmDc2Job *__r
     if (jb.h_out_count) *jb.h_out_count = s_total;
   }
   if (!jb.out) return;
-  if (jb.out_packed == 2) {  // the records are on the host already: one bit per match says which of them stay
+  if (jb.h_keep) {  // the records are on the host already: one bit per match says which of them stay
     for (int32_t w = t; w < (n + 31) / 32; w += KD_THREADS) {
       uint32_t bits = 0;
       for (int b = 0; b < 32 && 32 * w + b < n; b++) bits |= jb.remap[32 * w + b] >= 0 ? (1u << b) : 0u;
       jb.h_keep[w] = bits;
     }
-    return;
-  }
-  if (jb.out_packed) {  // 24 bytes per survivor (the lists of a look-ahead chunk cross PCIe: that copy is what this kernel's time is)
-    uint64_t *dst = (uint64_t *)jb.out;
-    bool bad = false;
-    for (int32_t e = t; e < n; e += KD_THREADS) {
-      const int32_t d = jb.remap[e];
-      if (d < 0) continue;
-      uint64_t w[3];
-      if (vsm_pack_match(jb.list[e], w)) {
-        dst[3 * d] = w[0];
-        dst[3 * d + 1] = w[1];
-        dst[3 * d + 2] = w[2];
-      } else {
-        bad = true;
-      }
-    }
-    if (bad) *jb.error = 3;  // (a field that is not an integer in range: the caller runs the other form)
     return;
   }
   const uint4 *src = (const uint4 *)jb.list;
@@ -1460,27 +1447,6 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc2_compact(const VsmDc2Job *__r
     const int32_t e = p / 3, d = jb.remap[e];
     if (d >= 0) dst[3 * d + (p - 3 * e)] = src[p];
   }
-}
-
-// the refined list as 24-byte records into the host-mapped result arena (out_packed == 2): behind the refinement, while
-// the triangulation runs - the PCIe copy of a chunk's lists takes a quarter of a millisecond and used to be the chain's last step
-__global__ void __launch_bounds__(256) k_dc2_export(const VsmDc2Job *__restrict__ jobs) {
-  const VsmDc2Job jb = jobs[blockIdx.y];
-  if (jb.out_packed != 2 || !jb.out) return;
-  const int n = min(*jb.count, jb.cap);
-  uint64_t *dst = (uint64_t *)jb.out;
-  bool bad = false;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    uint64_t w[3];
-    if (vsm_pack_match(jb.list[e], w)) {
-      dst[3 * e] = w[0];
-      dst[3 * e + 1] = w[1];
-      dst[3 * e + 2] = w[2];
-    } else {
-      bad = true;
-    }
-  }
-  if (bad) *jb.error = 3;  // (a field that is not an integer in range: the caller runs the other form)
 }
 
 // M4 computePriorStatistics (viso/matcher.cpp:734-868; host form: vsm_host_prior_statistics) over the survivors of
@@ -1580,7 +1546,7 @@ void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, in
     // (measured: 535 lines for the top merge of 7.4 k points), the points its records use are fewer than the lines.
     const int nmax = ((max_list + (1 << level) - 1) >> level) + 1;
     int lines_cap = (256 + (int)(24.0 * std::sqrt((double)nmax)) + 63) & ~63;
-    lines_cap = std::min(lines_cap, 16384);  // (16-bit line handles: line * 4 + edge below DC2_EXT)
+    lines_cap = std::min(lines_cap, 16384);  // (16-bit line handles: line * 4 + edge, the trap record included, below 0xffff)
     int pts_cap = lines_cap;
     int words_cap = ((2 * nmax + 31) >> 5) + 1;
     auto bytes_of = [&]() {
@@ -1656,10 +1622,6 @@ void vsm_dc2_launch_support(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, i
 void vsm_dc2_launch_compact(hipStream_t s, const VsmDc2Job *d_jobs, int njobs) {
   if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_compact, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs);
-}
-void vsm_dc2_launch_export(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list) {
-  if (njobs <= 0) return;
-  hipLaunchKernelGGL(k_dc2_export, dim3(std::min(8, (std::max(max_list, 1) + 255) / 256), njobs), dim3(256), 0, s, d_jobs);
 }
 void vsm_dc2_launch_prior(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int method, int binsize, int radius, int w, int h, int ub,
                           int vb) {

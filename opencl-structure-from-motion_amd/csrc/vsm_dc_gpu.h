@@ -103,46 +103,9 @@ struct VsmDc2Job {
   int32_t *h_out_count;     // host-mapped, or null
   float *ranges;            // pass 1: the pair's prior boxes [ub*vb][16], device layout (k_dc2_prior)
   int32_t *error;           // host-mapped flag word: set when a pair cannot be handled on the device
-  int32_t out_packed;       // 1: survivors leave as 24-byte records (vsm_pack_match) instead of 48-byte vsm_p_match: half the PCIe bytes;
-                            // 2: the WHOLE list left early as 24-byte records (k_dc2_export, behind the refinement, while the
-                            // triangulation runs) and only a survivor bit per match follows (h_keep): nothing PCIe-bound at the chain's end
-  uint32_t *h_keep;         // host-mapped: [ceil(cap / 32)] survivor bits (out_packed == 2)
+  uint32_t *h_keep;         // host-mapped, or null: [ceil(cap / 32)] survivor bits - the list itself is on the host already (DMA copy behind the
+                            // refinement, while the triangulation runs), k_dc2_compact only says which of its matches stay
 };
-// A match whose twelve fields are integers in range (coordinates 0..16382, indices 0..2^20-2, or -1) as 3 x 64 bits:
-// field triple k = (u, v, index) -> 48 bits u | v << 14 | index << 28 (-1 = all ones), triples 0..3 back to back.
-// vsm_unpack_match is the exact inverse; vsm_pack_match returns false when a field does not fit (nothing is written then).
-static inline
-#ifdef __HIPCC__
-    __host__ __device__
-#endif
-    bool
-    vsm_pack_match(const vsm_p_match &m, uint64_t out[3]) {
-  const float f[12] = {m.u1p, m.v1p, (float)0, m.u2p, m.v2p, (float)0, m.u1c, m.v1c, (float)0, m.u2c, m.v2c, (float)0};
-  const int32_t idx[4] = {m.i1p, m.i2p, m.i1c, m.i2c};
-  uint64_t t[4];
-  for (int k = 0; k < 4; k++) {
-    const float u = f[3 * k], v = f[3 * k + 1];
-    const int32_t iu = (int32_t)u, iv = (int32_t)v, ii = idx[k];
-    if ((float)iu != u || (float)iv != v || iu < -1 || iu > 16382 || iv < -1 || iv > 16382 || ii < -1 || ii > (1 << 20) - 2) return false;
-    t[k] = ((uint64_t)((uint32_t)iu & 0x3fffu)) | ((uint64_t)((uint32_t)iv & 0x3fffu) << 14) | ((uint64_t)((uint32_t)ii & 0xfffffu) << 28);
-  }
-  out[0] = t[0] | (t[1] << 48);
-  out[1] = (t[1] >> 16) | (t[2] << 32);
-  out[2] = (t[2] >> 32) | (t[3] << 16);
-  return true;
-}
-static inline void vsm_unpack_match(const uint64_t in[3], vsm_p_match &m) {
-  const uint64_t t[4] = {in[0] & 0xffffffffffffull, ((in[0] >> 48) | (in[1] << 16)) & 0xffffffffffffull,
-                         ((in[1] >> 32) | (in[2] << 32)) & 0xffffffffffffull, in[2] >> 16};
-  float *f[4][2] = {{&m.u1p, &m.v1p}, {&m.u2p, &m.v2p}, {&m.u1c, &m.v1c}, {&m.u2c, &m.v2c}};
-  int32_t *ix[4] = {&m.i1p, &m.i2p, &m.i1c, &m.i2c};
-  for (int k = 0; k < 4; k++) {
-    const uint32_t u = (uint32_t)(t[k] & 0x3fffu), v = (uint32_t)((t[k] >> 14) & 0x3fffu), i = (uint32_t)(t[k] >> 28) & 0xfffffu;
-    *f[k][0] = u == 0x3fffu ? -1.f : (float)u;
-    *f[k][1] = v == 0x3fffu ? -1.f : (float)v;
-    *ix[k] = i == 0xfffffu ? -1 : (int32_t)i;
-  }
-}
 void vsm_dc2_launch_keys(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list);
 void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs);
 void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth);
@@ -151,7 +114,6 @@ void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int3
 void vsm_dc2_launch_support(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol,
                             float disp_tol);  // tie patches, flows, votes
 void vsm_dc2_launch_compact(hipStream_t s, const VsmDc2Job *d_jobs, int njobs);
-void vsm_dc2_launch_export(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list);  // out_packed == 2: the refined list, all of it
 void vsm_dc2_launch_prior(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int method, int binsize, int radius, int w, int h,
                           int ub, int vb);
 // smallest depth at which every sub-tree of a list of at most max_points points fits a block

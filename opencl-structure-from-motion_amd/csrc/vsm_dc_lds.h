@@ -25,7 +25,7 @@ typedef uint32_t dc2_u32a __attribute__((may_alias));
 
 // A sub-triangulation in LDS under LOCAL numbering (positions and slots count from the node's - or the band's - first
 // one), 16 bytes per triangle, as EDGE WORDS: dword o (0..2) of triangle t describes the oriented triangle (t, o) -
-//     bits  0..15  the neighbour across edge o as a handle t' * 4 + o'   (0xffff: none; DC2_EXT: outside the band)
+//     bits  0..15  the neighbour across edge o as a handle t' * 4 + o'   (0xffff: none; band form: the trap handle `rim` = outside the band)
 //     bits 16..31  the apex of (t, o), i.e. vertex o of the triangle       (0xffff: the ghost corner)
 // dword 3 is unused.  A handle h = t * 4 + o IS the word's index, so sym() and apex() of a handle are one 32-bit read at
 // h * 4 with nothing to compute, a rotation is an add on the handle, a bond is a 16-bit store.  Half the bytes of the

@@ -55,40 +55,3 @@ def test_product_does_not_touch_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "viso_oracle" not in txt and "libvisoref" not in txt, f
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f
-
-
-def test_packed_result_records_round_trip():
-    """The look-ahead path sends its final lists through PCIe as 24-byte records (csrc/vsm_dc_gpu.h, vsm_pack_match):
-    every list the path produces (integer fields in range, -1 for the fields a matching method leaves out) must come
-    back bit for bit, and anything else must be refused, not mangled.  Host code only: no GPU call."""
-    import ctypes as C
-
-    import numpy as np
-    vm = _ensure_built()
-    L = vm.lib()
-    rng = np.random.default_rng(7)
-    n = 20000
-    m = np.zeros(n, dtype=vm.P_MATCH)
-    for k in ("1p", "2p", "1c", "2c"):
-        m["u" + k] = rng.integers(0, 16383, n)
-        m["v" + k] = rng.integers(0, 16383, n)
-        m["i" + k] = rng.integers(0, (1 << 20) - 1, n)
-    # the extremes, and the -1 triples of flow / stereo lists
-    m[0] = tuple([0.0, 0.0, 0] * 4)
-    m[1] = tuple([16382.0, 16382.0, (1 << 20) - 2] * 4)
-    m[2] = tuple([-1.0, -1.0, -1] * 2 + [5.0, 7.0, 3] * 2)
-    m[3] = tuple([1241.0, 374.0, 99999, -1.0, -1.0, -1, 0.0, 16382.0, 0, -1.0, -1.0, -1])
-    out = np.zeros_like(m)
-    L.vsm_debug_pack_roundtrip.restype = C.c_int32
-    assert L.vsm_debug_pack_roundtrip(m.ctypes.data_as(C.c_void_p), C.c_int32(n), out.ctypes.data_as(C.c_void_p)) == 0
-    assert out.tobytes() == m.tobytes()
-    # not representable: a sub-pixel coordinate, 16383, an index of 2^20 - 1, -2
-    bad = m[:4].copy()
-    bad["u1c"][0] = 10.5
-    bad["v2p"][1] = 16383.0
-    bad["i2c"][2] = (1 << 20) - 1
-    bad["u1p"][3] = -2.0
-    sentinel = np.full(4, 0x5A, dtype=np.uint8).tobytes() * 48
-    out4 = np.frombuffer(bytearray(sentinel), dtype=vm.P_MATCH).copy()
-    assert L.vsm_debug_pack_roundtrip(bad.ctypes.data_as(C.c_void_p), C.c_int32(4), out4.ctypes.data_as(C.c_void_p)) == 4
-    assert out4.tobytes() == sentinel

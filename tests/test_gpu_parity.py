@@ -283,16 +283,15 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
     m.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"VSM_SEQ_SERIAL": "1"}, {"VSM_SEQ_PACK": "1"}, {"VSM_SEQ_PACK": "1", "VSM_SEQ_EXPORT_DMA": "0"}, {"VSM_SEQ_DC_STREAMS": "1"}, {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNK": "5"},
+@pytest.mark.parametrize("env", [{}, {"VSM_SEQ_SERIAL": "1"}, {"VSM_SEQ_EARLY_EXPORT": "0"}, {"VSM_SEQ_EARLY_EXPORT": "1"},
+                                 {"VSM_SEQ_EARLY_EXPORT": "1", "VSM_HOST_THREADS": "2"}, {"VSM_SEQ_DC_STREAMS": "1"},
+                                 {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNK": "5"}, {"VSM_SEQ_CHUNK": "2", "VSM_SEQ_EARLY_EXPORT": "0"},
                                  {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
-                                 {"VSM_MATCH_STAGED": "1"}, {"VSM_FRONT": "0"}, {"VSM_MATCH_G": "8"}, {"VSM_SEQ_PACK": "1", "VSM_SEQ_EARLY_EXPORT": "0"},
-                                 {"VSM_SEQ_CHAIN_PRIO": "1"}, {"VSM_SEQ_GROUP": "1"}, {"VSM_SEQ_GROUP": "2", "VSM_SEQ_CHUNK": "5"}, {"VSM_SEQ_KEYS_DMA": "0"},
-                                 {"VSM_SEQ_EXPORT_DMA": "0", "VSM_SEQ_GROUP": "2"}, {"VSM_SEQ_PACK": "1", "VSM_SEQ_GROUP": "3", "VSM_SEQ_CHUNK": "4"}, {"VSM_SEQ_REFINE_LAG": "0"},
-                                 {"VSM_SEQ_REFINE_LAG": "1", "VSM_SEQ_CHUNK": "3"}, {"VSM_SEQ_REFINE_LAG": "2", "VSM_SEQ_CHUNK": "2", "VSM_SEQ_GROUP": "2"}])
+                                 {"VSM_MATCH_STAGED": "1"}, {"VSM_FRONT": "0"}, {"VSM_MATCH_G": "8"}])
 def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
-    """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), 48-byte result
-    records instead of the packed ones, one / four chain streams (eight chunks of five: every bank comes round twice), the
-    vertex sorts on the device, one matching kernel per chain stage, the unfused front end, eight lanes per query: always
+    """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), both ways of
+    result delivery at both ends of the pool size, one / four chain streams (eight chunks of five, twenty of two: every bank
+    comes round), the vertex sorts on the device, one matching kernel per chain stage, the unfused front end, eight lanes per query: always
     the reference's lists, and always this form (it must not quietly hand the run to the other one)."""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1")
@@ -832,9 +831,10 @@ def test_delaunay_subtrees_on_gpu(vm):
 
 def test_gpu_resident_remove_outliers_chain(vm):
     """the device chain of the GPU-resident look-ahead form (keys, (x,y) sort + duplicates + kd order, block sub-trees on the
-    16-bit LDS mesh, merge levels whole in LDS / through the mapped cache, tie patches from the device's or the host's
-    vertex sort, support votes, survivors, prior statistics) against the host code of the per-frame path: survivors and
-    prior boxes byte for byte, list lengths around every structural boundary (3 | 4, one block | two, whole | mapped merge)"""
+    edge-word LDS mesh, merge levels through the band cache, tie patches from the device's or the host's vertex sort,
+    support votes, survivors, prior statistics) against the host code of the per-frame path: survivors and prior boxes byte
+    for byte, list lengths around every structural boundary (3 | 4, five points - the case the vectorizers once broke -,
+    one block | two, small | large bands)"""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("dc2_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dc2_check.py"))
