@@ -135,7 +135,7 @@ __device__ inline void kd_levels(T *X0, T *X1, T *Y0, T *Y1, T *PX, T *PY, uint3
 // scratch = VSM_DC_KD_SCRATCH arrays of `stride` uint32, hist / tot = the workgroup's LDS (KD_DIGITS * KD_CHUNKS and
 // KD_THREADS / 64 + 1 words); key_out gets the keys in kd order
 __device__ inline void kd_order_body(const uint64_t *__restrict__ ks, const int32_t m, uint32_t *scratch, const int32_t stride,
-                                     uint64_t *__restrict__ key_out, uint32_t *hist, uint32_t *tot) {
+                                     uint64_t *__restrict__ key_out, uint32_t *hist, uint32_t *tot, long long *stamp = nullptr) {
   uint32_t *X0 = scratch, *X1 = X0 + stride, *Y0 = X1 + stride, *Y1 = Y0 + stride;
   uint32_t *PX = Y1 + stride, *PY = PX + stride, *P = PY + stride;
   const int t = threadIdx.x;
@@ -180,6 +180,7 @@ __device__ inline void kd_order_body(const uint64_t *__restrict__ ks, const int3
     }
     __syncthreads();
   }
+  if (stamp) *stamp = clock64();
   if (m <= KD_LDS_POINTS) {
     // the lists move into LDS, over the histogram (no longer needed): a dependent access there costs an LDS round
     // trip instead of one through L2
@@ -829,13 +830,33 @@ __device__ inline void dc2_radix_pass(const uint64_t *__restrict__ src, uint64_t
   __syncthreads();
 }
 
+#ifdef DC2_PHASE_TIMING  // experiments (tools/build_variant_dc.sh): cycles per phase, summed over blocks; [row][0] counts the blocks
+__device__ unsigned long long dc2_dbg[16][16];
+#define DC2_T(var) const long long var = clock64()
+#define DC2_ACC(row, col, a, b) atomicAdd(&dc2_dbg[row][col], (unsigned long long)((b) - (a)))
+__device__ void dc2_prepare_stat(long long a, long long b, long long c, long long d) {
+  atomicAdd(&dc2_dbg[12][0], 1ull);
+  atomicAdd(&dc2_dbg[12][1], (unsigned long long)a);
+  atomicAdd(&dc2_dbg[12][2], (unsigned long long)b);
+  atomicAdd(&dc2_dbg[12][3], (unsigned long long)c);
+  atomicAdd(&dc2_dbg[12][4], (unsigned long long)d);
+}
+extern "C" int vsm_debug_dc2_phases(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dc2_dbg), sizeof(dc2_dbg)) != hipSuccess) return -1;
+  if (reset) {
+    static unsigned long long z[16][16];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dc2_dbg), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define DC2_T(var)
+#define DC2_ACC(row, col, a, b)
+#endif
 // ExactDelaunay::prepare(defer_ties) on the device: stable sort of the keys by (x, y), the first key of every pixel
 // stays (it carries the smallest input index; the vertex sort's verdict is patched in later), kd order.
-__global__ void __launch_bounds__(KD_THREADS) k_dc2_prepare(const VsmDc2Job *__restrict__ jobs) {
-  __shared__ uint32_t hist[KD_DIGITS * KD_CHUNKS];
-  __shared__ uint32_t tot[KD_THREADS / 64 + 1];
+__device__ inline void dc2_prepare_global(const VsmDc2Job &jb, uint32_t *hist, uint32_t *tot) {  // KD_THREADS threads, KD_DIGITS * KD_CHUNKS words of hist
   __shared__ int32_t s_m;
-  const VsmDc2Job jb = jobs[blockIdx.x];
   const int t = threadIdx.x;
   const int32_t nl = *jb.count;
   int32_t n = min(nl, jb.cap), m = 0;
@@ -843,12 +864,19 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc2_prepare(const VsmDc2Job *__r
     if (t == 0) *jb.error = 1;
     n = 0;
   }
+#ifdef DC2_PHASE_TIMING
+  const long long p0 = clock64();
+  long long p1 = p0, p2 = p0, p3 = p0;
+#endif
   if (n > 3) {  // the reference leaves lists of up to three matches alone (viso/matcher.cpp:1210)
     uint64_t *T0 = (uint64_t *)jb.kd_scratch, *T1 = T0 + jb.kd_stride;
     dc2_radix_pass(jb.keys_in, T0, n, 20, hist, tot);
     dc2_radix_pass(T0, T1, n, 27, hist, tot);
     dc2_radix_pass(T1, T0, n, 34, hist, tot);
     dc2_radix_pass(T0, T1, n, 41, hist, tot);
+#ifdef DC2_PHASE_TIMING
+    p1 = clock64();
+#endif
     const int32_t per = (n + KD_THREADS - 1) / KD_THREADS;
     const int32_t i0 = min(n, t * per), i1 = min(n, i0 + per);
     uint32_t cnt = 0;
@@ -864,7 +892,312 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc2_prepare(const VsmDc2Job *__r
     jb.mn[0] = m;
     jb.mn[1] = n;
   }
+#ifdef DC2_PHASE_TIMING
+  p2 = p3 = clock64();
+  if (m >= 2) kd_order_body(jb.key_sorted, m, jb.kd_scratch, jb.kd_stride, jb.key, hist, tot, &p3);
+  if (t == 0) {
+    const long long p4 = clock64();
+    dc2_prepare_stat(p1 - p0, p2 - p1, p3 - p2, p4 - p3);
+  }
+#else
   if (m >= 2) kd_order_body(jb.key_sorted, m, jb.kd_scratch, jb.kd_stride, jb.key, hist, tot);
+#endif
+}
+
+__global__ void __launch_bounds__(KD_THREADS) k_dc2_prepare(const VsmDc2Job *__restrict__ jobs) {
+  __shared__ uint32_t hist[KD_DIGITS * KD_CHUNKS];
+  __shared__ uint32_t tot[KD_THREADS / 64 + 1];
+  dc2_prepare_global(jobs[blockIdx.x], hist, tot);
+}
+
+// ---------------------------------------------------------------------------------------
+// The same preparation for lists of up to DC2_PREP_LDS matches, entirely inside LDS and sized by the launch's longest
+// list (cap2 = a power of two >= it; 16 bytes of LDS per entry: 16 KB for a first-pass list of 700 matches, 128 KB for
+// 8192).  The histogram form above runs 256 of its 1024 threads through global scratch six times (four 7-bit passes by
+// (x, y), two by y) and its kd levels recompute every position's node from the root at every level; here
+//   * the (x, y, input index) order is ONE bitonic sort of the 64-bit keys (the index in the low bits makes it the
+//     stable order), stages whose partner lies inside a thread's own E entries run in registers,
+//   * the y order of the distinct points is a second one over 32-bit words y << 13 | rank,
+//   * a thread keeps the kd node (offset, size) of its E positions in registers and halves it once per level.
+// Same output as k_dc2_prepare (mn, key_sorted, key): the block and merge kernels do not care which one ran.
+// ---------------------------------------------------------------------------------------
+#define DC2_PREP_LDS 8192
+extern __shared__ __attribute__((aligned(16))) uint8_t dc2_prep_lds[];
+
+__device__ inline uint32_t dc2_scan(uint32_t v, uint32_t *tot, int nwaves) {  // exclusive prefix over the workgroup
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) tot[wv] = x;
+  __syncthreads();
+  if (wv == 0) {
+    const uint32_t t = lane < nwaves ? tot[lane] : 0;
+    uint32_t s = t;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const uint32_t y = __shfl_up(s, d, 64);
+      if (lane >= d) s += y;
+    }
+    if (lane < nwaves) tot[lane] = s - t;
+  }
+  __syncthreads();
+  const uint32_t r = x - v + tot[wv];
+  __syncthreads();
+  return r;
+}
+
+// the same with ONE barrier: every wave adds up the other waves' totals itself; tot2 = two rows of 16 words used in turn
+// (`par` alternates from call to call, and the caller has a barrier of its own between two calls)
+__device__ inline uint32_t dc2_scan1(uint32_t v, uint32_t *tot2, int par, int nwaves) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  uint32_t *tot = tot2 + 16 * par;
+  if (lane == 63) tot[wv] = x;
+  __syncthreads();
+  const uint32_t w = lane < nwaves ? tot[lane] : 0;
+  uint32_t s = w;
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+    const uint32_t y = __shfl_up(s, d, 64);
+    if (lane >= d) s += y;
+  }
+  return x - v + __shfl(s - w, wv, 64);
+}
+__device__ inline void dc2_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// One stable LSD pass (7 bits at `sh`) over the cap = E * blockDim.x entries of a[] in LDS, in place: every thread takes E
+// entries into registers - wave w the entries [64 E w, 64 E (w + 1)), 64 consecutive ones per batch -, ranks them inside the
+// wave (the lanes that share a digit find each other with seven ballots; the wave's count per digit lives in
+// hist[digit][wave]), one exclusive scan over hist in (digit, wave) order gives every wave its start per digit, and the
+// entries go back to their new places.  No atomics, no second buffer; the order inside a digit is the order of the source.
+template <typename K, int E>
+__device__ inline void dc2_radix_lds(K *a, const int sh, uint32_t *hist, uint32_t *tot) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, nw = (int)blockDim.x >> 6;
+  hist[2 * t] = 0;
+  hist[2 * t + 1] = 0;  // 128 digits x nw waves = 2 x blockDim.x counters
+  __syncthreads();
+  K key[E];
+  uint32_t place[E];  // digit * nw + wave, and the entry's number among the wave's entries of that digit so far
+  uint32_t rank[E];
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    key[r] = a[wv * 64 * E + 64 * r + lane];
+    const uint32_t d = (uint32_t)(key[r] >> sh) & 127u;
+    uint64_t same = ~0ull;
+#pragma unroll
+    for (int bit = 0; bit < 7; bit++) {
+      const bool on = (d >> bit) & 1u;
+      const uint64_t bal = __builtin_amdgcn_ballot_w64(on);
+      same &= on ? bal : ~bal;
+    }
+    place[r] = d * (uint32_t)nw + (uint32_t)wv;
+    const uint32_t before = (uint32_t)__popcll(same & lt);
+    const uint32_t prior = hist[place[r]];
+    dc2_wave_sync();
+    if (before == 0) hist[place[r]] = prior + (uint32_t)__popcll(same);
+    dc2_wave_sync();
+    rank[r] = prior + before;
+  }
+  __syncthreads();
+  {
+    const uint32_t v0 = hist[2 * t], v1 = hist[2 * t + 1];
+    const uint32_t run = dc2_scan(v0 + v1, tot, nw);
+    hist[2 * t] = run;
+    hist[2 * t + 1] = run + v0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < E; r++) a[hist[place[r]] + rank[r]] = key[r];
+  __syncthreads();
+}
+
+template <int E>
+__global__ void __launch_bounds__(1024) k_dc2_prepare_lds(const VsmDc2Job *__restrict__ jobs, int cap2, int big_too) {
+  __shared__ uint32_t tot[33];
+  __shared__ int32_t s_m;
+  const VsmDc2Job jb = jobs[blockIdx.x];
+  const int t = threadIdx.x, nwaves = (int)blockDim.x >> 6;
+  const int32_t nl = *jb.count;
+  if (big_too && nl > cap2) {  // a list of a launch that may hold longer ones (the host only knows the query counts): the form above,
+    dc2_prepare_global(jb, (uint32_t *)dc2_prep_lds, tot);  // on this kernel's LDS (the launch is KD_THREADS wide and 128 KB deep then)
+    return;
+  }
+  int32_t n = min(nl, jb.cap), m = 0;
+  if (nl > jb.cap || nl > cap2) {  // (not expected: the host sizes slabs and launches from the query counts)
+    if (t == 0) *jb.error = 1;
+    n = 0;
+  }
+  uint64_t *K = (uint64_t *)dc2_prep_lds;                        // [cap2] keys
+  uint32_t *YK = (uint32_t *)(dc2_prep_lds + 8 * (size_t)cap2);  // [cap2] y << 13 | rank
+  uint32_t *hist = (uint32_t *)(dc2_prep_lds + 14 * (size_t)cap2);  // [2 blockDim.x] the radix passes' counters
+  DC2_T(p0);
+  if (n > 3) {  // the reference leaves lists of up to three matches alone (viso/matcher.cpp:1210)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int i = E * t + e;
+      K[i] = i < n ? jb.keys_in[i] : ~0ull;
+    }
+    __syncthreads();
+    for (int sh = 20; sh < 48; sh += 7) dc2_radix_lds<uint64_t, E>(K, sh, hist, tot);
+    DC2_T(p1);
+    if (t == 0) DC2_ACC(12, 1, p0, p1);
+    // the first key of every pixel stays
+    uint64_t r[E];
+    uint32_t first = 0, cnt = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int i = E * t + e;
+      r[e] = K[i];
+      const uint64_t prev = e > 0 ? r[e - 1] : (i > 0 ? K[i - 1] : 0);
+      if (i < n && (i == 0 || VSM_KXY(r[e]) != VSM_KXY(prev))) {
+        first |= 1u << e;
+        cnt++;
+      }
+    }
+    uint32_t pos = dc2_scan(cnt, tot, nwaves);
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      if (first & (1u << e)) {
+        jb.key_sorted[pos] = r[e];
+        YK[pos] = ((uint32_t)(r[e] >> 20) & 0x3fffu) << 13 | pos;
+        pos++;
+      }
+    }
+    if (t == (int)blockDim.x - 1) s_m = (int32_t)pos;
+    __syncthreads();
+    m = s_m;
+  }
+  if (t == 0) {
+    jb.mn[0] = m;
+    jb.mn[1] = n;
+  }
+  if (m < 2) return;
+  DC2_T(p2);
+  // ---- y order ----
+  for (int i = m + t; i < cap2; i += (int)blockDim.x) YK[i] = 0xffffffffu;
+  __syncthreads();
+  dc2_radix_lds<uint32_t, E>(YK, 13, hist, tot);
+  dc2_radix_lds<uint32_t, E>(YK, 20, hist, tot);
+  DC2_T(p3);
+  // ---- kd lists: X (x order), Y (y order), their inverses, double buffers, the scan words ----
+  uint32_t yk[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) yk[e] = E * t + e < m ? (YK[E * t + e] & 0x1fffu) : 0;
+  __syncthreads();
+  uint16_t *l16 = (uint16_t *)dc2_prep_lds;
+  uint16_t *X0 = l16, *X1 = X0 + cap2, *Y0 = X1 + cap2, *Y1 = Y0 + cap2, *PX = Y1 + cap2, *PY = PX + cap2, *P = PY + cap2;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int q = E * t + e;
+    if (q < m) {
+      X0[q] = (uint16_t)q;
+      PX[q] = (uint16_t)q;
+      Y0[q] = (uint16_t)yk[e];
+      PY[yk[e]] = (uint16_t)q;
+    }
+  }
+  __syncthreads();
+  // ---- kd levels (kd_levels above), the node of each of the thread's positions carried along ----
+  int32_t off[E], nn[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    off[e] = 0;
+    nn[e] = m;
+  }
+  uint16_t *X = X0, *Xn = X1, *Y = Y0, *Yn = Y1;
+  for (int depth = 0; ((m + (1 << depth) - 1) >> depth) > 3; depth++) {
+    const bool cut_x = (depth & 1) == 0;
+    const uint16_t *S = cut_x ? Y : X;  // the list to partition
+    uint16_t *D = cut_x ? Yn : Xn;
+    const uint16_t *PO = cut_x ? PX : PY;  // position in the list that is cut in place
+    uint16_t *PS = cut_x ? PY : PX;
+    typedef uint16_t DcRow __attribute__((ext_vector_type(E), may_alias));
+    uint32_t left = 0, sum = 0;
+    uint32_t el[E];
+    {
+      const DcRow row = *(const DcRow *)(S + E * t);  // the thread's E entries in one read
+#pragma unroll
+      for (int e = 0; e < E; e++) el[e] = E * t + e < m ? row[e] : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int q = E * t + e;
+      if (q < m && (nn[e] <= 3 || (int32_t)PO[el[e]] < off[e] + (nn[e] >> 1))) {
+        left |= 1u << e;
+        sum++;
+      }
+    }
+    uint32_t run = dc2_scan1(sum, tot, depth & 1, nwaves);
+    uint32_t mine[E];  // flags before each of the thread's positions
+    {
+      DcRow row;
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        mine[e] = run;
+        row[e] = (uint16_t)run;
+        run += (left >> e) & 1u;
+      }
+      *(DcRow *)(P + E * t) = row;
+    }
+    __syncthreads();
+    uint32_t at_off = 0;  // flags before the node's first position (consecutive positions mostly share their node)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int q = E * t + e;
+      if (e == 0 || off[e] != off[e - 1]) at_off = P[off[e]];
+      if (q < m) {
+        const uint32_t before = mine[e] - at_off;
+        const uint32_t np = ((left >> e) & 1u) ? off[e] + before : off[e] + (nn[e] >> 1) + ((q - off[e]) - before);
+        D[np] = (uint16_t)el[e];
+        PS[el[e]] = (uint16_t)np;
+      }
+      // the node of position q one level down (kd_node_at)
+      const int32_t div = nn[e] >> 1;
+      if (q < off[e] + div) {
+        nn[e] = div;
+      } else {
+        off[e] += div;
+        nn[e] -= div;
+      }
+    }
+    __syncthreads();
+    if (cut_x) {
+      uint16_t *w = Y;
+      Y = Yn;
+      Yn = w;
+    } else {
+      uint16_t *w = X;
+      X = Xn;
+      Xn = w;
+    }
+  }
+  DC2_T(p4);
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int q = E * t + e;
+    if (q < m) jb.key[q] = jb.key_sorted[X[q]];
+  }
+#ifdef DC2_PHASE_TIMING
+  if (t == 0) {
+    const long long p5 = clock64();
+    atomicAdd(&dc2_dbg[12][0], 1ull);
+    DC2_ACC(12, 3, p2, p3);
+    DC2_ACC(12, 4, p3, p4);
+    DC2_ACC(12, 2, p4, p5);
+  }
+#endif
 }
 
 // The divide-and-conquer tree is ExactDelaunay::build_tree's: [off, off+n) splits at n >> 1 while n > block points.
@@ -888,22 +1221,6 @@ __device__ inline bool dc2_walk(int32_t m, int depth, uint32_t path, int32_t &of
   return true;
 }
 
-#ifdef DC2_PHASE_TIMING  // experiments (tools/build_variant_dc.sh): cycles per phase, summed over blocks; [row][0] counts the blocks
-__device__ unsigned long long dc2_dbg[16][16];
-#define DC2_T(var) const long long var = clock64()
-#define DC2_ACC(row, col, a, b) atomicAdd(&dc2_dbg[row][col], (unsigned long long)((b) - (a)))
-extern "C" int vsm_debug_dc2_phases(unsigned long long *out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dc2_dbg), sizeof(dc2_dbg)) != hipSuccess) return -1;
-  if (reset) {
-    static unsigned long long z[16][16];
-    if (hipMemcpyToSymbol(HIP_SYMBOL(dc2_dbg), z, sizeof(z)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#else
-#define DC2_T(var)
-#define DC2_ACC(row, col, a, b)
-#endif
 // One workgroup per block sub-tree (<= VSM_DC_BLOCK_POINTS points) on the edge-word LDS mesh (vsm_dc_lds.h): 15 KB of words,
 // 2 KB of points, 4 KB of hull handles.  The block is cut down to Triangle's own leaves of two or three points
 // (DC2_BLOCK_DEPTH = 8 halvings, the same rule as the host's tree): 256 lanes build a leaf each - a handful of stores, no
@@ -964,6 +1281,25 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
   mesh.key = j2.key + boff;  // (a leaf reads its two or three keys where they lie)
   mesh.ptw = (DC2_AS3 uint32_t *)s_pt;
   mesh.gid = j2.id + boff;
+#ifdef DC2_BLOCK_ROT
+  __shared__ int s_simd[4];
+  {
+    uint32_t hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if (wl == 0) s_simd[wv] = (int)(((hwid >> 4) & 3u) | ((hwid & 15u) << 4));  // SIMD, wave slot on it
+  }
+  __syncthreads();
+  // top_simd = the wave's SIMD (its number in the workgroup if the four waves do not sit on four SIMDs); top_rot = the
+  // workgroup's wave slot (successive workgroups of a compute unit get successive slots)
+  int top_simd, top_rot;
+  {
+    int seen = 0;
+    for (int w = 0; w < 4; w++) seen |= 1 << (s_simd[w] & 3);
+    const bool perm = seen == 15;
+    top_simd = perm ? (s_simd[wv] & 3) : wv;
+    top_rot = perm ? ((s_simd[0] >> 4) & 3) : 0;
+  }
+#endif
   DC2_T(c1);
   // leaf of virtual lane v: the two top bits of a path - the quarter of the block - are the wave
   {
@@ -978,12 +1314,23 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
   for (int L = DC2_BLOCK_DEPTH - 1; L >= 0; L--) {
     {  // node j of level L (2^L nodes): quarter = wave from the third level up; the two top levels on waves 0, 1 / wave 0
       const int nodes = 1 << L;
+#ifdef DC2_BLOCK_COMPACT
+      if (lane < nodes) dc2_block_merge_run(mesh, lane, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+#else
       if (nodes >= DC2_BLOCK_WAVES) {
         const int per_wave = nodes / DC2_BLOCK_WAVES;
         for (int v = wl; v < per_wave; v += 64) dc2_block_merge_run(mesh, wv * per_wave + v, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
-      } else if (wl == 0 && wv < nodes) {
-        dc2_block_merge_run(mesh, wv, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+      } else if (wl == 0) {
+#ifdef DC2_BLOCK_ROT
+        // the top nodes on the wave whose SIMD this workgroup's place on the compute unit points at: the workgroups of a
+        // compute unit reach these levels together, and with node 0 always on wave 0 they would all walk on one SIMD
+        const int node = (top_simd - top_rot) & 3;  // nodes == 2: waves rot, rot + 2; nodes == 1: wave rot
+        if (nodes == 2 ? (node & 1) == 0 : node == 0) dc2_block_merge_run(mesh, node >> 1, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+#else
+        if (wv < nodes) dc2_block_merge_run(mesh, wv, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
+#endif
       }
+#endif
     }
     __syncthreads();
 #ifdef DC2_PHASE_TIMING
@@ -1529,8 +1876,25 @@ void vsm_dc2_launch_keys(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int 
   if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_keys, dim3((std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs);
 }
-void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs) {
+void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list) {
   if (njobs <= 0) return;
+#ifndef DC2_PREP_OLD
+  if (max_list > 0) {  // (0: the caller does not know how long the lists are)
+    static const bool big8 = hipFuncSetAttribute((const void *)k_dc2_prepare_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * DC2_PREP_LDS) == hipSuccess;
+    static const bool big4 = hipFuncSetAttribute((const void *)k_dc2_prepare_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * DC2_PREP_LDS / 2) == hipSuccess;
+    int cap2 = 256;
+    while (cap2 < max_list && cap2 < DC2_PREP_LDS) cap2 <<= 1;
+    static_assert(DC2_PREP_LDS / 8 == KD_THREADS && 16 * DC2_PREP_LDS >= 4 * KD_DIGITS * KD_CHUNKS, "the long lists of a launch run k_dc2_prepare's body on this kernel's threads and LDS");
+    if (cap2 == DC2_PREP_LDS && big8) {  // (max_list counts queries: most lists of such a launch are shorter than 8192 matches, whoever is not takes the first form)
+      hipLaunchKernelGGL(k_dc2_prepare_lds<8>, dim3(njobs), dim3(cap2 / 8), (size_t)16 * cap2, s, d_jobs, cap2, max_list > cap2 ? 1 : 0);
+      return;
+    }
+    if (cap2 < DC2_PREP_LDS && (big4 || 16 * cap2 <= 64 * 1024)) {
+      hipLaunchKernelGGL(k_dc2_prepare_lds<4>, dim3(njobs), dim3(cap2 / 4), (size_t)14 * cap2 + 8 * (cap2 / 4), s, d_jobs, cap2, 0);
+      return;
+    }
+  }
+#endif
   hipLaunchKernelGGL(k_dc2_prepare, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs);
 }
 void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth) {

@@ -107,7 +107,7 @@ struct VsmDc2Job {
                             // refinement, while the triangulation runs), k_dc2_compact only says which of its matches stay
 };
 void vsm_dc2_launch_keys(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list);
-void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs);
+void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list = 0);  // max_list: upper bound of the list lengths (0 = unknown)
 void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth);
 void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth, int max_list);  // levels depth-1 .. 0
 void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride, int max_list = 0);  // max_list: upper bound of the list lengths (0 = unknown)

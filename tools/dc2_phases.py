@@ -32,3 +32,6 @@ for lv in range(0, 9):
     if a[1 + lv, 0]:
         c = a[1 + lv, 0]
         print(f"k_dc2_merge level {lv}: nodes {int(c)}  load {a[1 + lv, 1] / c / MHZ:8.2f} us  zip {a[1 + lv, 2] / c / MHZ:8.2f} us  band lines {a[1 + lv, 3] / c:8.0f} (max {int(a[1 + lv, 6])}, points max {int(a[1 + lv, 7])})  walks that left the band {int(a[1 + lv, 4])}  nodes done in global memory {int(a[1 + lv, 5])}")
+if a[12, 0]:
+    c = a[12, 0]
+    print(f"k_dc2_prepare: lists {int(c)}  (x,y) radix sort {a[12, 1] / c:9.0f}  duplicates {a[12, 2] / c:9.0f}  y order {a[12, 3] / c:9.0f}  kd levels {a[12, 4] / c:9.0f}  clock64 ticks per list")
