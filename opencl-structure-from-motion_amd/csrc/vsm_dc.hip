@@ -1221,6 +1221,42 @@ __device__ inline bool dc2_walk(int32_t m, int depth, uint32_t path, int32_t &of
   return true;
 }
 
+// REACH WORDS.  A merge level brings into LDS the triangles whose circumcircle reaches across its cut; whoever writes a
+// triangle record to global memory therefore leaves the circle's extent with it, in the two words of the 32-byte record
+// that are otherwise unused: word 7 = x extent, word 3 = y extent, each lo | hi << 16 as signed 16-bit pixels, rounded
+// outward with 1.5 pixels of margin.  Vertices below 2^14 make every product of the circumcentre exact in double, so the
+// extent is right to a billionth of a pixel before the margin: the band's closure rests on it being conservative.  A hull
+// triangle (ghost corner) reaches everywhere, an unused slot nowhere; a level then decides a slot from ONE word.
+#define DC2_REACH_ALL 0x7fff8000u   // lo = -32768, hi = 32767
+#define DC2_REACH_NONE 0x80007fffu  // lo = 32767, hi = -32768
+__device__ inline uint32_t dc2_reach_word(double c, double rad) {
+  const double lo = floor(c - rad), hi = ceil(c + rad);
+  if (!(lo == lo) || !(hi == hi)) return DC2_REACH_ALL;
+  const int32_t l = lo < -32768.0 ? -32768 : (lo > 32767.0 ? 32767 : (int32_t)lo);
+  const int32_t h = hi > 32767.0 ? 32767 : (hi < -32768.0 ? -32768 : (int32_t)hi);
+  return ((uint32_t)l & 0xffffu) | ((uint32_t)h << 16);
+}
+// pa, pb, pc = x | y << 16
+__device__ inline void dc2_reach(uint32_t pa, uint32_t pb, uint32_t pc, uint32_t &wx, uint32_t &wy) {
+  const double ax = (double)(pa & 0xffffu), ay = (double)(pa >> 16);
+  const double bx = (double)(pb & 0xffffu) - ax, by = (double)(pb >> 16) - ay;
+  const double cx = (double)(pc & 0xffffu) - ax, cy = (double)(pc >> 16) - ay;
+  const double d = 2.0 * (bx * cy - by * cx);
+  const double b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+  const double ux = (cy * b2 - by * c2) / d, uy = (bx * c2 - cx * b2) / d;  // circumcentre relative to a
+  const double rad = sqrt(ux * ux + uy * uy) + 1.5;
+  if (!(d == d) || d == 0.0 || !(rad == rad)) {
+    wx = wy = DC2_REACH_ALL;
+    return;
+  }
+  wx = dc2_reach_word(ax + ux, rad);
+  wy = dc2_reach_word(ay + uy, rad);
+}
+__device__ inline bool dc2_reaches(uint32_t w, bool left_half, int32_t cl, int32_t cr) {
+  const int32_t lo = (int32_t)(int16_t)(w & 0xffffu), hi = (int32_t)(int16_t)(w >> 16);
+  return left_half ? hi >= cr : lo <= cl;
+}
+
 // One workgroup per block sub-tree (<= VSM_DC_BLOCK_POINTS points) on the edge-word LDS mesh (vsm_dc_lds.h): 15 KB of words,
 // 2 KB of points, 4 KB of hull handles.  The block is cut down to Triangle's own leaves of two or three points
 // (DC2_BLOCK_DEPTH = 8 halvings, the same rule as the host's tree): 256 lanes build a leaf each - a handful of stores, no
@@ -1352,11 +1388,18 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
     a.x = nb(o.x);
     a.y = nb(o.y);
     a.z = nb(o.z);
-    a.w = -1;
     b.x = vx(o.x);
     b.y = vx(o.y);
     b.z = vx(o.z);
-    b.w = -1;
+    uint32_t wx, wy;  // reach words (above)
+    if ((b.x & b.y & b.z) < 0)
+      wx = wy = DC2_REACH_NONE;
+    else if ((b.x | b.y | b.z) < 0)
+      wx = wy = DC2_REACH_ALL;
+    else
+      dc2_reach(s_pt[o.x >> 16], s_pt[o.y >> 16], s_pt[o.z >> 16], wx, wy);
+    a.w = (int32_t)wy;
+    b.w = (int32_t)wx;
     gt[2 * t] = a;
     gt[2 * t + 1] = b;
   }
@@ -1504,54 +1547,24 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
       }
     }
     __syncthreads();
-    const float fcl = (float)s_cl, fcr = (float)s_cr;
-    // the band's core: own slots, hull triangles, triangles whose circumcircle crosses the cut.  Four slots per round: the
-    // vertex records first, then their twelve points, then the tests - the loop is a chain of dependent L2 round trips.
-    // (The circumcircle in double: vertices below 2^14 make every product exact, so "reaches the other half" is decided
-    // to a billionth of a pixel before the 1.5 pixels of margin - the band's closure rests on this test being conservative.)
-    for (int s0 = t; s0 < nslots; s0 += 4 * DC2_MERGE_THREADS) {
-      dc2_v4i v[4];
-      uint32_t pa[4], pb[4], pc[4];
-      int kind[4];  // 0 not in the core, 1 in the core, 2 decided by its circumcircle
+    const int32_t cl = s_cl, cr = s_cr;
+    // the band's core: own slots, hull triangles, triangles whose circumcircle crosses the cut - one reach word per slot
+    // (above; whoever wrote the record left it there), four independent loads in flight per thread
+    {
+      const int32_t *gw = gnode + (axis == 0 ? 7 : 3);
+      for (int s0 = t; s0 < nslots; s0 += 4 * DC2_MERGE_THREADS) {
+        uint32_t w[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int s = s0 + k * DC2_MERGE_THREADS;
-        v[k] = s < nslots ? grec[2 * s + 1] : dc2_v4i{-1, -1, -1, -1};
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int s = s0 + k * DC2_MERGE_THREADS;
-        if (s >= nslots)
-          kind[k] = 0;
-        else if (s == 2 * div - 2 || s == 2 * div - 1)
-          kind[k] = 1;
-        else if ((v[k].x & v[k].y & v[k].z) < 0)
-          kind[k] = 0;  // unused slot
-        else if ((v[k].x | v[k].y | v[k].z) < 0)
-          kind[k] = 1;  // hull triangle
-        else
-          kind[k] = 2;
-        pa[k] = kind[k] == 2 ? gpt[v[k].x - off] : 0u;
-        pb[k] = kind[k] == 2 ? gpt[v[k].y - off] : 0u;
-        pc[k] = kind[k] == 2 ? gpt[v[k].z - off] : 0u;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int s = s0 + k * DC2_MERGE_THREADS;
-        bool hot = kind[k] == 1;
-        if (kind[k] == 2) {
-          const double ax = (double)(pa[k] & 0xffffu), ay = (double)(pa[k] >> 16);
-          const double bx = (double)(pb[k] & 0xffffu) - ax, by = (double)(pb[k] >> 16) - ay;
-          const double cx = (double)(pc[k] & 0xffffu) - ax, cy = (double)(pc[k] >> 16) - ay;
-          const double d = 2.0 * (bx * cy - by * cx);
-          const double b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
-          const double ux = (cy * b2 - by * c2) / d, uy = (bx * c2 - cx * b2) / d;  // circumcentre relative to a
-          const double rad = sqrt(ux * ux + uy * uy) + 1.5;
-          const double cc = axis == 0 ? ax + ux : ay + uy;
-          hot = s < 2 * div ? (cc + rad >= (double)fcr) : (cc - rad <= (double)fcl);
-          hot = hot || !(d == d) || d == 0.0 || !(rad == rad);
+        for (int k = 0; k < 4; k++) {
+          const int s = s0 + k * DC2_MERGE_THREADS;
+          w[k] = s < nslots ? (uint32_t)gw[(size_t)s * 8] : DC2_REACH_NONE;
         }
-        if (hot) atomicOr(&s_band[s >> 5], 1u << (s & 31));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int s = s0 + k * DC2_MERGE_THREADS;
+          const bool hot = s < nslots && (s == 2 * div - 2 || s == 2 * div - 1 || dc2_reaches(w[k], s < 2 * div, cl, cr));
+          if (hot) atomicOr(&s_band[s >> 5], 1u << (s & 31));
+        }
       }
     }
     __syncthreads();
@@ -1663,11 +1676,18 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
           a.x = (o.x & 0xffffu) == rimh ? old.x : nb(o.x & 0xffffu);
           a.y = (o.y & 0xffffu) == rimh ? old.y : nb(o.y & 0xffffu);
           a.z = (o.z & 0xffffu) == rimh ? old.z : nb(o.z & 0xffffu);
-          a.w = -1;
           b.x = vx(o.x >> 16);
           b.y = vx(o.y >> 16);
           b.z = vx(o.z >> 16);
-          b.w = -1;
+          uint32_t wx, wy;  // reach words of the record as it is now
+          if ((b.x & b.y & b.z) < 0)
+            wx = wy = DC2_REACH_NONE;
+          else if ((b.x | b.y | b.z) < 0)
+            wx = wy = DC2_REACH_ALL;
+          else
+            dc2_reach(s_pt[o.x >> 16], s_pt[o.y >> 16], s_pt[o.z >> 16], wx, wy);
+          a.w = (int32_t)wy;
+          b.w = (int32_t)wx;
           ((dc2_v4i *)gnode)[2 * s] = a;
           ((dc2_v4i *)gnode)[2 * s + 1] = b;
         }
@@ -1685,6 +1705,24 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
 #ifdef DC2_PHASE_TIMING
     atomicAdd(&dc2_dbg[1 + level][5], 1ull);
 #endif
+  }
+  __threadfence();
+  __syncthreads();
+  // the plain mesh knows nothing of reach words: every record of the node gets them afresh (rare path)
+  for (int sl = t; sl < nslots; sl += DC2_MERGE_THREADS) {
+    // (lane 0 has just rewritten these records: loads that go to L2, not to a line this compute unit may still hold)
+    const int32_t vx0 = __hip_atomic_load(gnode + (size_t)sl * 8 + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t vx1 = __hip_atomic_load(gnode + (size_t)sl * 8 + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t vx2 = __hip_atomic_load(gnode + (size_t)sl * 8 + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t wx, wy;
+    if ((vx0 & vx1 & vx2) < 0)
+      wx = wy = DC2_REACH_NONE;
+    else if ((vx0 | vx1 | vx2) < 0)
+      wx = wy = DC2_REACH_ALL;
+    else
+      dc2_reach(jb.pt[vx0], jb.pt[vx1], jb.pt[vx2], wx, wy);
+    gnode[(size_t)sl * 8 + 3] = (int32_t)wy;
+    gnode[(size_t)sl * 8 + 7] = (int32_t)wx;
   }
 }
 
