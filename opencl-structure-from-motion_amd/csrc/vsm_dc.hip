@@ -1269,6 +1269,9 @@ __device__ inline bool dc2_reaches(uint32_t w, bool left_half, int32_t cl, int32
 #define DC2_BLOCK_WAVES 4
 #endif
 #define DC2_BLOCK_THREADS (64 * DC2_BLOCK_WAVES)
+#ifndef DC2_BLOCK_PACKED
+#define DC2_BLOCK_PACKED 16  // levels with at least this many nodes run lane by lane through the workgroup
+#endif
 #ifndef DC2_BLOCK_OCC
 #define DC2_BLOCK_OCC 5
 #endif
@@ -1317,25 +1320,6 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
   mesh.key = j2.key + boff;  // (a leaf reads its two or three keys where they lie)
   mesh.ptw = (DC2_AS3 uint32_t *)s_pt;
   mesh.gid = j2.id + boff;
-#ifdef DC2_BLOCK_ROT
-  __shared__ int s_simd[4];
-  {
-    uint32_t hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    if (wl == 0) s_simd[wv] = (int)(((hwid >> 4) & 3u) | ((hwid & 15u) << 4));  // SIMD, wave slot on it
-  }
-  __syncthreads();
-  // top_simd = the wave's SIMD (its number in the workgroup if the four waves do not sit on four SIMDs); top_rot = the
-  // workgroup's wave slot (successive workgroups of a compute unit get successive slots)
-  int top_simd, top_rot;
-  {
-    int seen = 0;
-    for (int w = 0; w < 4; w++) seen |= 1 << (s_simd[w] & 3);
-    const bool perm = seen == 15;
-    top_simd = perm ? (s_simd[wv] & 3) : wv;
-    top_rot = perm ? ((s_simd[0] >> 4) & 3) : 0;
-  }
-#endif
   DC2_T(c1);
   // leaf of virtual lane v: the two top bits of a path - the quarter of the block - are the wave
   {
@@ -1348,25 +1332,22 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
   long long cl = c2;
 #endif
   for (int L = DC2_BLOCK_DEPTH - 1; L >= 0; L--) {
-    {  // node j of level L (2^L nodes): quarter = wave from the third level up; the two top levels on waves 0, 1 / wave 0
+    {
+      // node j of level L (2^L nodes).  The short seams of the lower levels side by side in as few waves as possible (the lanes
+      // of a wave mostly execute the same instructions, and a wave costs a SIMD the same issue slots whether one lane walks
+      // or sixty-four: 16 nodes on one wave take 0.7 of the time they take as 4 x 4, and leave the other SIMDs to whatever
+      // else runs on the compute unit); from 8 nodes up the seams are long, differ in length, and go one or two to a wave.
       const int nodes = 1 << L;
-#ifdef DC2_BLOCK_COMPACT
-      if (lane < nodes) dc2_block_merge_run(mesh, lane, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
-#else
-      if (nodes >= DC2_BLOCK_WAVES) {
+      int node = -1;  // (one call site: the seam walk is a lot of code, and the instruction cache is shared)
+      if (nodes >= DC2_BLOCK_PACKED) {
+        node = lane < nodes ? lane : -1;
+      } else if (nodes >= DC2_BLOCK_WAVES) {
         const int per_wave = nodes / DC2_BLOCK_WAVES;
-        for (int v = wl; v < per_wave; v += 64) dc2_block_merge_run(mesh, wv * per_wave + v, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
-      } else if (wl == 0) {
-#ifdef DC2_BLOCK_ROT
-        // the top nodes on the wave whose SIMD this workgroup's place on the compute unit points at: the workgroups of a
-        // compute unit reach these levels together, and with node 0 always on wave 0 they would all walk on one SIMD
-        const int node = (top_simd - top_rot) & 3;  // nodes == 2: waves rot, rot + 2; nodes == 1: wave rot
-        if (nodes == 2 ? (node & 1) == 0 : node == 0) dc2_block_merge_run(mesh, node >> 1, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
-#else
-        if (wv < nodes) dc2_block_merge_run(mesh, wv, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
-#endif
+        node = wl < per_wave ? wv * per_wave + wl : -1;
+      } else {
+        node = wl == 0 && wv < nodes ? wv : -1;
       }
-#endif
+      if (node >= 0) dc2_block_merge_run(mesh, node, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
     }
     __syncthreads();
 #ifdef DC2_PHASE_TIMING
