@@ -40,6 +40,7 @@ class VsmPool {
   void run(int ntasks, const std::function<void(int)> &fn);  // blocking
   Ticket submit(int ntasks, std::function<void(int)> fn, bool urgent = false);  // asynchronous
   void wait(const Ticket &t);                                // helps until the batch is done
+  bool help() { return work_one(); }                         // a thread with nothing else to do runs one queued task; false if there is none
 
  private:
   void worker();
