@@ -1954,56 +1954,130 @@ void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int3
   else
     hipLaunchKernelGGL(k_dc2_ties<VSM_DC_TIE_POINTS>, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride);
 }
-// the same votes with one workgroup per list and the counts in LDS (lists of up to DC2_SUPPORT_LDS matches): six integer
-// atomics per triangle that stay on the compute unit instead of going to L2 (398 -> ~60 us for 200 lists of 7.4 k matches)
 #define DC2_SUPPORT_LDS 12288
-__global__ void __launch_bounds__(1024) k_dc2_support_lds(const VsmDc2Job *__restrict__ jobs, int method, float ftol, float dtol) {
+// The end of a chain in ONE kernel for lists of up to DC2_SUPPORT_LDS matches (k_dc2_apply_ties + k_dc2_support_lds +
+// k_dc2_compact): the tie patches go into a 16-bit remap table in LDS, the votes count in LDS, the survivors' places come
+// from a scan over the counts where they lie - three launches and two trips through global memory less at the tail of
+// every chain, and the votes take four slots per thread and round (each is a chain of dependent loads: record -> input
+// index -> flow).  One workgroup per list.
+__global__ void __launch_bounds__(1024) k_dc2_finish(const VsmDc2Job *__restrict__ jobs, int method, float ftol, float dtol) {
   __shared__ int32_t s_sup[DC2_SUPPORT_LDS];
+  __shared__ uint16_t s_map[DC2_SUPPORT_LDS];  // remap (tie patches), later: the survivor's place, 0xffff = dropped
+  __shared__ uint32_t tot[33];
+  __shared__ int32_t s_total;
   const VsmDc2Job jb = jobs[blockIdx.x];
   const int32_t m = jb.mn[0], n = jb.mn[1];
-  if (m < 2) return;
   const int t = threadIdx.x;
-  for (int i = t; i < n; i += 1024) s_sup[i] = 0;
-  __syncthreads();
-  const float *fua = (const float *)jb.kd_scratch, *fva = fua + jb.kd_stride, *dpa = fva + jb.kd_stride;
-  for (int s = t; s < 2 * m; s += 1024) {
-    const int4 v = *(const int4 *)(jb.tri + (size_t)s * 8 + 4);
-    if ((v.x | v.y | v.z) < 0) continue;
-    const int32_t q[3] = {jb.remap[jb.id[v.y]], jb.remap[jb.id[v.z]], jb.remap[jb.id[v.x]]};
-    float fu[3], fv[3], dp[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      fu[k] = fua[q[k]];
-      fv[k] = fva[q[k]];
-      dp[k] = dpa[q[k]];
-    }
-#pragma unroll
-    for (int e = 0; e < 3; e++) {
-      const int a = e == 2 ? 0 : e, b = e == 0 ? 1 : 2;  // (0,1) (1,2) (0,2)
-      const bool flow_ok = fabsf(fu[a] - fu[b]) + fabsf(fv[a] - fv[b]) < ftol;
-      const bool disp_ok = fabsf(dp[a] - dp[b]) < dtol;
-      const bool ok = method == 0 ? flow_ok : (method == 1 ? disp_ok : (disp_ok && flow_ok));
-      if (ok) {
-        atomicAdd(&s_sup[q[a]], 1);
-        atomicAdd(&s_sup[q[b]], 1);
-      }
-    }
+  for (int i = t; i < n; i += 1024) {
+    s_sup[i] = 0;
+    s_map[i] = (uint16_t)i;
   }
   __syncthreads();
-  for (int i = t; i < n; i += 1024) jb.support[i] = s_sup[i];
+  if (m >= 2) {
+    const int32_t c = jb.tie_out[0];
+    if (c < 0) {  // (the vertex sort could not take the list)
+      if (t == 0) *jb.error = 3;
+    } else {
+      for (int k = t; k < c; k += 1024) {
+        const int32_t rep = jb.tie_out[1 + 2 * k], first = jb.tie_out[2 + 2 * k];
+        if (rep >= 0 && rep < n && first >= 0 && first < n) s_map[rep] = (uint16_t)first;
+      }
+    }
+    __syncthreads();
+    const float *fua = (const float *)jb.kd_scratch, *fva = fua + jb.kd_stride, *dpa = fva + jb.kd_stride;
+    for (int s0 = t; s0 < 2 * m; s0 += 4 * 1024) {
+      int4 v[4];
+      int32_t id[4][3];
+      bool live[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int s = s0 + k * 1024;
+        v[k] = s < 2 * m ? *(const int4 *)(jb.tri + (size_t)s * 8 + 4) : int4{-1, -1, -1, -1};
+        live[k] = (v[k].x | v[k].y | v[k].z) >= 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        id[k][0] = live[k] ? jb.id[v[k].y] : 0;
+        id[k][1] = live[k] ? jb.id[v[k].z] : 0;
+        id[k][2] = live[k] ? jb.id[v[k].x] : 0;
+      }
+      int32_t q[4][3];
+      float fu[4][3], fv[4][3], dp[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          q[k][j] = live[k] ? (int32_t)s_map[min(max(id[k][j], 0), n - 1)] : 0;
+          fu[k][j] = fua[q[k][j]];
+          fv[k][j] = fva[q[k][j]];
+          dp[k][j] = dpa[q[k][j]];
+        }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (!live[k]) continue;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+          const int a = e == 2 ? 0 : e, b = e == 0 ? 1 : 2;  // (0,1) (1,2) (0,2)
+          const bool flow_ok = fabsf(fu[k][a] - fu[k][b]) + fabsf(fv[k][a] - fv[k][b]) < ftol;
+          const bool disp_ok = fabsf(dp[k][a] - dp[k][b]) < dtol;
+          const bool ok = method == 0 ? flow_ok : (method == 1 ? disp_ok : (disp_ok && flow_ok));
+          if (ok) {
+            atomicAdd(&s_sup[q[k][a]], 1);
+            atomicAdd(&s_sup[q[k][b]], 1);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // survivors (support >= 4, viso/matcher.cpp:1369-1371; lists of up to three matches unchanged, :1210) in list order
+  const int32_t per = (n + 1023) / 1024;
+  const int32_t i0 = min(n, t * per), i1 = min(n, i0 + per);
+  uint32_t cnt = 0;
+  for (int32_t i = i0; i < i1; i++) {
+    const int32_t sup = s_sup[i];
+    jb.support[i] = sup;  // (k_dc2_prior looks at it)
+    cnt += (n <= 3 || sup >= 4) ? 1u : 0u;
+  }
+  uint32_t pos = dc2_scan(cnt, tot, 16);
+  for (int32_t i = i0; i < i1; i++) s_map[i] = (n <= 3 || s_sup[i] >= 4) ? (uint16_t)pos++ : (uint16_t)0xffffu;
+  if (t == 1023) s_total = (int32_t)pos;
+  __syncthreads();
+  if (t == 0) {
+    *jb.out_count = s_total;
+    if (jb.h_out_count) *jb.h_out_count = s_total;
+  }
+  if (!jb.out) return;
+  if (jb.h_keep) {  // the records are on the host already: one bit per match says which of them stay
+    for (int32_t w = t; w < (n + 31) / 32; w += 1024) {
+      uint32_t bits = 0;
+      for (int b = 0; b < 32 && 32 * w + b < n; b++) bits |= s_map[32 * w + b] != 0xffffu ? (1u << b) : 0u;
+      jb.h_keep[w] = bits;
+    }
+    return;
+  }
+  const uint4 *src = (const uint4 *)jb.list;
+  uint4 *dst = (uint4 *)jb.out;
+  for (int32_t p = t; p < 3 * n; p += 1024) {
+    const int32_t e = p / 3;
+    const uint32_t d = s_map[e];
+    if (d != 0xffffu) dst[3 * d + (p - 3 * e)] = src[p];
+  }
 }
 
-void vsm_dc2_launch_support(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol, float disp_tol) {
+void vsm_dc2_launch_flows(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(k_dc2_apply_ties, dim3(njobs), dim3(64), 0, s, d_jobs);
   hipLaunchKernelGGL(k_dc2_flows, dim3((std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method);
-  if (max_list <= DC2_SUPPORT_LDS)
-    hipLaunchKernelGGL(k_dc2_support_lds, dim3(njobs), dim3(1024), 0, s, d_jobs, method, flow_tol, disp_tol);
-  else
-    hipLaunchKernelGGL(k_dc2_support, dim3((2 * std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method, flow_tol, disp_tol);
 }
-void vsm_dc2_launch_compact(hipStream_t s, const VsmDc2Job *d_jobs, int njobs) {
+// tie patches, votes, survivors (k_dc2_flows has run)
+void vsm_dc2_launch_votes(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol, float disp_tol) {
   if (njobs <= 0) return;
+  if (max_list <= DC2_SUPPORT_LDS && max_list < 0xffff) {
+    hipLaunchKernelGGL(k_dc2_finish, dim3(njobs), dim3(1024), 0, s, d_jobs, method, flow_tol, disp_tol);
+    return;
+  }
+  hipLaunchKernelGGL(k_dc2_apply_ties, dim3(njobs), dim3(64), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_dc2_support, dim3((2 * std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs, method, flow_tol, disp_tol);
   hipLaunchKernelGGL(k_dc2_compact, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs);
 }
 void vsm_dc2_launch_prior(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int method, int binsize, int radius, int w, int h, int ub,

@@ -111,9 +111,8 @@ void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, i
 void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth);
 void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth, int max_list);  // levels depth-1 .. 0
 void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride, int max_list = 0);  // max_list: upper bound of the list lengths (0 = unknown)
-void vsm_dc2_launch_support(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol,
-                            float disp_tol);  // tie patches, flows, votes
-void vsm_dc2_launch_compact(hipStream_t s, const VsmDc2Job *d_jobs, int njobs);
+void vsm_dc2_launch_flows(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method);  // per match: flow, disparity (needs the refined list)
+void vsm_dc2_launch_votes(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, int method, float flow_tol, float disp_tol);  // tie patches, votes, survivors
 void vsm_dc2_launch_prior(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int method, int binsize, int radius, int w, int h,
                           int ub, int vb);
 // smallest depth at which every sub-tree of a list of at most max_points points fits a block
