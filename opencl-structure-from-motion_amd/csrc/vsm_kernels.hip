@@ -1719,39 +1719,87 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// Quad matching keeps every accepted query (no pixel de-dup, viso/matcher.cpp:1139-1151): a block finds its base by
-// summing the acceptance flags in front of it itself - at most 8 k flags, 32 KB out of L2 - and the count kernel, a second
-// launch that the lists behind it (and the Delaunay chain behind those) wait for, is gone.
-__global__ void __launch_bounds__(256)
-    k_compact_quad(const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs, VsmJob job0, int pass) {
-  __shared__ int s_red[4];
-  __shared__ int s_cnt[4];
+// Quad matching keeps every accepted query (no pixel de-dup, viso/matcher.cpp:1139-1151): ordered compaction of raw[] into
+// the list in ONE launch (the lists behind it, and the Delaunay chain behind those, wait for it).  QUAD_PARTS workgroups of
+// 1024 threads per pair: a workgroup counts the acceptance flags in front of its part itself (a few independent loads per
+// thread), scans its own - a run of consecutive queries per thread - and moves the records.  Records move as 16-byte pieces, consecutive lanes consecutive pieces.  35 us per 67 pairs of 10 k
+// queries with the GPU to itself - and 80-90 us in the pipeline whatever the kernel's form (even with its loads and stores
+// taken out): what it waits for there is not in the kernel.
+#define QUAD_PARTS 4
+#define QUAD_RUN 4  // queries per thread at most: QUAD_PARTS * 1024 * QUAD_RUN queries per pair in this form
+__global__ void __launch_bounds__(1024)
+    k_compact_quad(const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs, VsmJob job0, int pass, int parts) {
+  __shared__ int s_w[17];
+  __shared__ int s_base[16];
+  __shared__ int s_dst[1024 * QUAD_RUN];  // place of every query of the part in the list, -1 = not accepted
   const VsmPair &pair = pairs[blockIdx.y];
   const int n_query = (jobs ? jobs[blockIdx.y] : job0).nq[pass];
-  const int nblk = max((n_query + 255) / 256, 1);  // blocks that hold queries of this pair
-  if ((int)blockIdx.x >= nblk) return;
+  const int per_part = ((n_query + parts - 1) / parts + 1023) & ~1023;  // whole rounds of the workgroup
+  const int q0 = (int)blockIdx.x * per_part, q1 = min(n_query, q0 + per_part);
+  if (q0 >= n_query && !(blockIdx.x == 0 && n_query == 0)) {
+    return;
+  }
   vsm_p_match *__restrict__ list = pass ? pair.list2 : pair.list1;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  // accepted queries in front of this part
   int part = 0;
-  for (int q = threadIdx.x; q < (int)blockIdx.x * 256; q += 256) part += pair.flag[q] ? 1 : 0;
+  {
+    int f[QUAD_PARTS * QUAD_RUN];
+#pragma unroll
+    for (int k = 0; k < QUAD_PARTS * QUAD_RUN; k++) {
+      const int q = t + 1024 * k;
+      f[k] = q < q0 ? pair.flag[q] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < QUAD_PARTS * QUAD_RUN; k++) part += f[k] ? 1 : 0;
+  }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool keep = i < n_query && pair.flag[i];
-  const unsigned long long bal = __ballot(keep);
-  if (lane == 0) {
-    s_red[wv] = part;
-    s_cnt[wv] = __popcll(bal);
+  if (lane == 0) s_base[wv] = part;
+  // own flags: thread t owns queries q0 + t * run .. + run - 1
+  const int run = per_part >> 10;  // <= QUAD_RUN
+  int keep[QUAD_RUN], cnt = 0;
+#pragma unroll
+  for (int k = 0; k < QUAD_RUN; k++) {
+    const int i = q0 + t * run + k;
+    keep[k] = (k < run && i < q1) ? (pair.flag[i] ? 1 : 0) : 0;
+    cnt += keep[k];
   }
+  int total;
+  int pos = block_excl_scan_1024(cnt, total, s_w);  // (its barriers also publish s_base)
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) base += s_base[w];
+  pos += base;
+  // the records move as 16-byte pieces, consecutive lanes consecutive pieces of raw[] (a 48-byte record per lane would be
+  // twelve dword accesses 48 - 192 bytes apart: a cache line per lane and instruction)
+#pragma unroll
+  for (int k = 0; k < QUAD_RUN; k++)
+    if (k < run) s_dst[t * run + k] = keep[k] ? pos++ : -1;
   __syncthreads();
-  int pos = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-  for (int w = 0; w < wv; w++) pos += s_cnt[w];
-  pos += __popcll(bal & ((1ull << lane) - 1ull));
-  if (keep) list[pos] = pair.raw[i];
-  if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 255) {
-    const int total = pos + (keep ? 1 : 0);
-    pair.count[pass] = total;
-    pair.hcount[pass] = total;
+  {
+    const uint4 *src = (const uint4 *)(pair.raw + q0);
+    uint4 *dst = (uint4 *)list;
+    const int pieces = 3 * (q1 - q0);
+    for (int p0 = t; p0 < pieces; p0 += 4 * 1024) {
+      uint4 v[4];
+      int d[4], part[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int p = p0 + 1024 * k;
+        const int e = p / 3;
+        part[k] = p - 3 * e;
+        d[k] = p < pieces ? s_dst[e] : -1;
+        if (d[k] >= 0) v[k] = src[p];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (d[k] >= 0) dst[3 * (size_t)d[k] + part[k]] = v[k];
+    }
+  }
+  if (q1 == n_query && t == 1023) {  // the part that holds the last query
+    pair.count[pass] = base + total;
+    pair.hcount[pass] = base + total;
   }
 }
 
@@ -2195,8 +2243,9 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
   }
   const int nblk = max(cdiv(max_nq, 256), 1);
   pf.begin(cfg.sparse ? VSM_K_COMPACT1 : VSM_K_COMPACT2, s);
-  if (cfg.method == 2) {
-    hipLaunchKernelGGL(k_compact_quad, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, pass);
+  if (cfg.method == 2 && max_nq <= QUAD_PARTS * 1024 * QUAD_RUN) {
+    const int parts = std::min(QUAD_PARTS, std::max(1, cdiv(max_nq, 2048)));  // (short lists: fewer, fuller workgroups)
+    hipLaunchKernelGGL(k_compact_quad, dim3(parts, npairs), dim3(1024), 0, s, d_pairs, d_jobs, job0, pass, parts);
   } else {
     hipLaunchKernelGGL(k_compact_count, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);
     hipLaunchKernelGGL(k_compact_write, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);

@@ -8,7 +8,7 @@ for v in $1; do
 import json,sys
 d=json.loads(sys.stdin.read())
 k=d['kernel_avg_launch_us']
-print('$v', d['value'], d['ms_per_step'], sorted(d['step_ms_rank0'])[:3], d['verified_bit_exact_vs_reference_hashes'], 'block', k.get('k_dc_block'), 'merge', k.get('k_dc_merge'), 'match2', k.get('k_match<16>:pass2'))
+print('$v', d['value'], d['ms_per_step'], sorted(d['step_ms_rank0'])[:3], d['verified_bit_exact_vs_reference_hashes'], 'block', k.get('k_dc_block'), 'merge', k.get('k_dc_merge'), 'match2', k.get('k_match<16>:pass2'), 'compact2', k.get('k_compact_matches:pass2'), 'refine', k.get('k_refine'))
 "
 done
 done
