@@ -195,7 +195,7 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
     po[j].l1 = take((size_t)c.cap_set[0] * 48);
     po[j].l2 = take(qcap * 48);
     po[j].cnt = take(16);
-    po[j].pf = (p.refinement == 2 && npairs == 1) ? take(qcap * 3 * 12 * 4) : 0;
+    po[j].pf = p.refinement == 2 ? take(qcap * 3 * 12 * 4) : 0;  // (per-frame ring: one pair; look-ahead banks: every pair)
   }
   const size_t o_rng = take(c.ranges_stride * 4 * npairs);
   const size_t o_imgs = take((size_t)nimg * sizeof(VsmImage));
@@ -1359,8 +1359,9 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   h->seq_matches.resize(n_frames);  // keeps the capacity of earlier runs: no page-fault storm
   for (auto &v : h->seq_matches) v.clear();
   h->seq_view.assign(n_frames, vsm_handle::SeqView());
-  // (sub-pixel refinement fits and drops matches on the host; mono input can only be flow-matched)
-  if (p.refinement == 2 || (!right && (method != 0 || !h->sw.seq_v2)))
+  // (mono input can only be flow-matched; the host-shared form below has no sub-pixel refinement - its fits and dropped matches
+  // are the GPU-resident form's, or the per-frame code's)
+  if ((!right && (method != 0 || !h->sw.seq_v2)) || (p.refinement == 2 && !h->sw.seq_v2))
     return sequence_fallback(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
 
   // The GPU-resident form (vsm_seq2.inc) takes the run unless VSM_SEQ_V2=0 asks for the host-shared form below, or
@@ -1374,7 +1375,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     const int rc = sequence_run_v2(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
     if (rc != VSM_SEQ2_DECLINED) return rc;
     h->seq_v2_frames = 0;
-    if (!right) return sequence_fallback(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
+    if (!right || p.refinement == 2) return sequence_fallback(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
   }
   int C = h->sw.seq_chunk > 0 ? h->sw.seq_chunk : 50;
   if (C > n_frames) C = n_frames;

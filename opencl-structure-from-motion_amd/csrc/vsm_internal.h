@@ -153,6 +153,8 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
 void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
                       const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq);
 void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair *d_pairs, int npairs, int pass, int n_upper);
+#define VSM_PARA_MAX_LIST 16384  // matches per pair the batched tail of refinement==2 takes
+void vsm_launch_parabolic_apply(hipStream_t s, const VsmPair *d_pairs, int npairs);
 void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
                        const VsmJob &job0, int npairs, const VsmDims &dp, const VsmDims &dc, int method, int refinement,
                        int n_upper);

@@ -2074,6 +2074,123 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// refinement==2 in the batched (look-ahead) path: the least-squares tail of parabolicFitting (viso/matcher.cpp:1425-1453;
+// host form: vsm_host_parabolic_update, vsm_host.cpp) and the removal of the matches whose fit fails (:1541-1581), on the
+// device.  Matrix::operator* and Matrix::solve (Gauss-Jordan with full pivoting, viso/matrix.cpp) are + - * / and
+// comparisons in double, evaluated here in the reference's order: IEEE arithmetic on either side, contraction off, so the
+// same bits.  One workgroup per pair: every thread fits its matches and parks the updated records in raw[], a scan over
+// the verdicts gives the survivors their places, the records move back into the list as 16-byte pieces.
+// ---------------------------------------------------------------------------------------
+__device__ inline bool dev_gauss_jordan6(double A[6][6], double B[6]) {
+  int ipiv[6] = {0, 0, 0, 0, 0, 0};
+  int icol = 0, irow = 0;
+  for (int i = 0; i < 6; i++) {
+    double big = 0.0;
+    for (int j = 0; j < 6; j++)
+      if (ipiv[j] != 1)
+        for (int k = 0; k < 6; k++)
+          if (ipiv[k] == 0 && fabs(A[j][k]) >= big) {
+            big = fabs(A[j][k]);
+            irow = j;
+            icol = k;
+          }
+    ++ipiv[icol];
+    if (irow != icol) {
+      for (int l = 0; l < 6; l++) {
+        const double t = A[irow][l];
+        A[irow][l] = A[icol][l];
+        A[icol][l] = t;
+      }
+      const double t = B[irow];
+      B[irow] = B[icol];
+      B[icol] = t;
+    }
+    if (fabs(A[icol][icol]) < 1e-20) return false;
+    const double pivinv = 1.0 / A[icol][icol];
+    A[icol][icol] = 1.0;
+    for (int l = 0; l < 6; l++) A[icol][l] *= pivinv;
+    B[icol] *= pivinv;
+    for (int ll = 0; ll < 6; ll++)
+      if (ll != icol) {
+        const double dum = A[ll][icol];
+        A[ll][icol] = 0.0;
+        for (int l = 0; l < 6; l++) A[ll][l] -= A[icol][l] * dum;
+        B[ll] -= B[icol] * dum;
+      }
+  }
+  return true;
+}
+__device__ inline bool dev_parabolic_update(const int32_t *c9, int du, int dv, float &u2, float &v2) {
+  const double kA[9][6] = {{1, 1, 1, -1, -1, 1}, {0, 1, 0, 0, -1, 1}, {1, 1, -1, 1, -1, 1}, {1, 0, 0, -1, 0, 1}, {0, 0, 0, 0, 0, 1},
+                           {1, 0, 0, 1, 0, 1},   {1, 1, -1, -1, 1, 1}, {0, 1, 0, 0, 1, 1},  {1, 1, 1, 1, 1, 1}};
+  double b[6], AtA[6][6];
+  for (int i = 0; i < 6; i++) {
+    double s = 0;
+    for (int k = 0; k < 9; k++) s += kA[k][i] * (double)c9[k];
+    b[i] = s;
+    for (int j = 0; j < 6; j++) {
+      double t = 0;
+      for (int k = 0; k < 9; k++) t += kA[k][i] * kA[k][j];
+      AtA[i][j] = t;
+    }
+  }
+  if (!dev_gauss_jordan6(AtA, b)) return false;
+  const float divisor = (float)(b[2] * b[2] - 4.0 * b[0] * b[1]);
+  if ((double)fabsf(divisor) < 1e-8 || fabs(b[2]) < 1e-8) return false;
+  const float ddv = (float)((2.0 * b[0] * b[4] - b[2] * b[3]) / (double)divisor);
+  const float ddu = (float)(-(b[4] + 2.0 * b[1] * (double)ddv) / b[2]);
+  if ((double)fabsf(ddu) >= 1.0 || (double)fabsf(ddv) >= 1.0) return false;
+  u2 = (float)((double)u2 + ((double)(float)du - 3.0 + (double)ddu));
+  v2 = (float)((double)v2 + ((double)(float)dv - 3.0 + (double)ddv));
+  return true;
+}
+#define PARA_MAX_LIST 16384  // matches per pair this kernel takes (16-bit places in LDS)
+__global__ void __launch_bounds__(1024) k_parabolic_apply(const VsmPair *__restrict__ pairs) {
+  __shared__ uint16_t s_dst[PARA_MAX_LIST];  // the match's place among the survivors, 0xffff = dropped
+  __shared__ int s_w[17];
+  const VsmPair &pair = pairs[blockIdx.x];
+  const int n = min(pair.count[1], PARA_MAX_LIST);
+  const int t = threadIdx.x;
+  // thread t owns the run of matches [t * run, t * run + run)
+  const int run = (n + 1023) / 1024;
+  int cnt = 0;
+  for (int k = 0; k < run; k++) {
+    const int i = t * run + k;
+    if (i >= n) break;
+    vsm_p_match m = pair.list2[i];
+    bool ok = true;
+    float *tu[3] = {&m.u1p, &m.u2c, &m.u2p}, *tv[3] = {&m.v1p, &m.v2c, &m.v2p};
+    for (int st = 0; st < 3 && ok; st++) {
+      const int32_t *r = pair.pf + ((size_t)i * 3 + st) * 12;
+      if (r[0] == 2) continue;  // step not applicable to the matching method
+      ok = r[0] == 1 && dev_parabolic_update(r + 3, r[1], r[2], *tu[st], *tv[st]);
+    }
+    pair.raw[i] = m;
+    s_dst[i] = ok ? 1 : 0;
+    cnt += ok ? 1 : 0;
+  }
+  int total;
+  int pos = block_excl_scan_1024(cnt, total, s_w);
+  for (int k = 0; k < run; k++) {
+    const int i = t * run + k;
+    if (i >= n) break;
+    s_dst[i] = s_dst[i] ? (uint16_t)pos++ : (uint16_t)0xffffu;
+  }
+  __syncthreads();  // (raw[] written above is read below by other threads of this workgroup, and only by them)
+  const uint4 *src = (const uint4 *)pair.raw;
+  uint4 *dst = (uint4 *)pair.list2;
+  for (int p = t; p < 3 * n; p += 1024) {
+    const int e = p / 3;
+    const uint32_t d = s_dst[e];
+    if (d != 0xffffu) dst[3 * (size_t)d + (p - 3 * e)] = src[p];
+  }
+  if (t == 0) {
+    pair.count[1] = total;
+    pair.hcount[1] = total;
+  }
+}
+
 // =======================================================================================
 // launchers
 // =======================================================================================
@@ -2258,6 +2375,12 @@ void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair *d_pairs, int n
   hipLaunchKernelGGL(k_export_list, dim3(max(min(cdiv(n_upper * 3, 256), 256), 1), npairs), dim3(256), 0, s, d_pairs,
                      pass);
   pf.end(s);
+}
+
+// the batched tail of refinement==2 (behind vsm_launch_refine): fits, dropped matches, the lists closed up again
+void vsm_launch_parabolic_apply(hipStream_t s, const VsmPair *d_pairs, int npairs) {
+  if (npairs <= 0) return;
+  hipLaunchKernelGGL(k_parabolic_apply, dim3(npairs), dim3(1024), 0, s, d_pairs);
 }
 
 void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,

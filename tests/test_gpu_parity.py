@@ -480,13 +480,15 @@ def test_two_matchers_in_two_threads(vm, synth, monkeypatch):
             assert len(out[k][f]) == int(g["counts"][f]) and G.sha(out[k][f]) == str(g["hashes"][f]), (k, f)
 
 
-def test_sequence_api_fallbacks(vm, B, synth):
-    """what the look-ahead call takes frame by frame inside: sub-pixel refinement (fits and drops matches on the host), and
-    mono input asked for stereo / quad matching (the reference's matchFeatures returns early on every frame)"""
+def test_sequence_api_fallbacks(vm, B, synth, monkeypatch):
+    """what the look-ahead call takes frame by frame inside: mono input asked for stereo / quad matching (the reference's
+    matchFeatures returns early on every frame), and sub-pixel refinement when the host-shared form is asked for"""
     seq = synth.stereo_sequence(8, 320, 128, 4)
     left = np.stack([l for l, _ in seq])
     right = np.stack([r for _, r in seq])
-    for kw, meth, rgt in ((dict(refinement=2), 2, right), (dict(), 2, None), (dict(refinement=2), 0, None)):
+    for kw, meth, rgt, env in ((dict(refinement=2), 2, right, {"VSM_SEQ_V2": "0"}), (dict(), 2, None, {}), (dict(refinement=2), 1, right, {"VSM_SEQ_V2": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         g = vm.Matcher(**kw)
         got = g.run_sequence(left, rgt, meth)
         assert g.sequence_path() == 1
@@ -496,6 +498,37 @@ def test_sequence_api_fallbacks(vm, B, synth):
             c.match(meth)
             assert _same(got[f], c.matches()), (kw, f)
         g.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+@pytest.mark.parametrize("method,mono", [(2, False), (1, False), (0, False), (0, True)])
+def test_subpixel_refinement_in_the_batched_form(vm, B, synth, monkeypatch, method, mono):
+    """refinement = 2 (parabolicFitting, viso/matcher.cpp:1379-1454: 7 x 7 costs, a 6 x 6 least-squares fit in double per
+    match and step, matches whose fit fails dropped, :1541-1581) through the GPU-resident look-ahead form - fits, removal
+    and the closing of the lists on the device, chunks of three so that chunk borders are crossed - against the oracle
+    frame by frame, and against the per-frame path of the library"""
+    monkeypatch.setenv("VSM_SEQ_CHUNK", "3")
+    seq = synth.stereo_sequence(21, 480, 160, 8)
+    left = np.stack([l for l, _ in seq])
+    right = None if mono else np.stack([r for _, r in seq])
+    g = vm.Matcher(refinement=2)
+    got = g.run_sequence(left, right, method)
+    assert g.sequence_path() == 2
+    c = B.CpuMatcher("oracle", refinement=2)
+    p = vm.Matcher(refinement=2)
+    dropped = 0
+    for f, (l, r) in enumerate(seq):
+        c.push_back(l, None if mono else r)
+        c.match(method)
+        p.push_back(l, None if mono else r)
+        p.match_features(method)
+        assert _same(got[f], c.matches()), f
+        assert _same(got[f], p.get_matches()), f
+        dropped += 1 if f and len(got[f]) else 0
+    assert dropped > 3   # (lists that are not empty: the test means something)
+    g.close()
+    p.close()
 
 
 def test_degenerate_inputs(vm, B, synth):
