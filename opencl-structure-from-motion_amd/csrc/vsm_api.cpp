@@ -803,11 +803,17 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
                           h->stream));
   if (p.refinement > 0)
     vsm_launch_refine(h->stream, h->prof, c.d_imgs, c.d_pairs, nullptr, job, 1, dp, dc, method, p.refinement, nq2);
+  // sub-pixel refinement: the fits' least-squares tail and the removal of failed matches on the device too (as in the look-ahead
+  // path; 7 k matches x 3 fits were 3 ms of one host thread) - unless the stage views are wanted, which show the list in between
+  const bool fits_on_device = p.refinement == 2 && !h->capture_stage2 && nq2 <= VSM_PARA_MAX_LIST;
+  if (fits_on_device) vsm_launch_parabolic_apply(h->stream, c.d_pairs, 1);
   vsm_launch_export(h->stream, h->prof, c.d_pairs, 1, 1, nq2);
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
   const int32_t n2 = c.hm_lcount[1];
-  if (p.refinement == 1) {
+  if (fits_on_device) {
+    h->stage[3].assign(c.hm_list2[0], c.hm_list2[0] + n2);
+  } else if (p.refinement == 1) {
     h->stage[3].assign(c.hm_list2[0], c.hm_list2[0] + n2);
     if (h->capture_stage2) {
       h->stage[2].resize(n2);

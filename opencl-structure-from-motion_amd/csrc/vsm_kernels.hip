@@ -2082,9 +2082,29 @@ __global__ void __launch_bounds__(256)
 // same bits.  One workgroup per pair: every thread fits its matches and parks the updated records in raw[], a scan over
 // the verdicts gives the survivors their places, the records move back into the list as 16-byte pieces.
 // ---------------------------------------------------------------------------------------
-__device__ inline bool dev_gauss_jordan6(double A[6][6], double B[6]) {
+// The system matrix At*A is the same for every fit, so the elimination's pivots, row swaps and multipliers are too: the
+// host runs Gauss-Jordan on it ONCE (same IEEE double arithmetic, contraction off) and records, per step, what the
+// reference does to the right-hand side - swap B[irow], B[icol]; B[icol] *= pivinv; B[ll] -= B[icol] * dum[ll] - and the
+// device replays exactly those operations on every fit's b: the same bits as solving the whole system each time, without
+// a 6 x 6 matrix per thread.
+struct VsmParaPlan {
+  int32_t ok, irow[6], icol[6];
+  double pivinv[6], dum[6][6];
+};
+static const double kParaA[9][6] = {{1, 1, 1, -1, -1, 1}, {0, 1, 0, 0, -1, 1}, {1, 1, -1, 1, -1, 1}, {1, 0, 0, -1, 0, 1}, {0, 0, 0, 0, 0, 1},
+                                    {1, 0, 0, 1, 0, 1},   {1, 1, -1, -1, 1, 1}, {0, 1, 0, 0, 1, 1},  {1, 1, 1, 1, 1, 1}};
+static VsmParaPlan make_para_plan() {  // Matrix::solve (viso/matrix.cpp) on At*A, the right-hand side's share recorded
+  VsmParaPlan pl = VsmParaPlan();
+  double A[6][6];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      double t = 0;
+      for (int k = 0; k < 9; k++) t += kParaA[k][i] * kParaA[k][j];
+      A[i][j] = t;
+    }
   int ipiv[6] = {0, 0, 0, 0, 0, 0};
   int icol = 0, irow = 0;
+  pl.ok = 1;
   for (int i = 0; i < 6; i++) {
     double big = 0.0;
     for (int j = 0; j < 6; j++)
@@ -2096,46 +2116,61 @@ __device__ inline bool dev_gauss_jordan6(double A[6][6], double B[6]) {
             icol = k;
           }
     ++ipiv[icol];
-    if (irow != icol) {
-      for (int l = 0; l < 6; l++) {
-        const double t = A[irow][l];
-        A[irow][l] = A[icol][l];
-        A[icol][l] = t;
-      }
-      const double t = B[irow];
-      B[irow] = B[icol];
-      B[icol] = t;
+    pl.irow[i] = irow;
+    pl.icol[i] = icol;
+    if (irow != icol)
+      for (int l = 0; l < 6; l++) std::swap(A[irow][l], A[icol][l]);
+    if (fabs(A[icol][icol]) < 1e-20) {
+      pl.ok = 0;
+      return pl;
     }
-    if (fabs(A[icol][icol]) < 1e-20) return false;
     const double pivinv = 1.0 / A[icol][icol];
+    pl.pivinv[i] = pivinv;
     A[icol][icol] = 1.0;
     for (int l = 0; l < 6; l++) A[icol][l] *= pivinv;
-    B[icol] *= pivinv;
     for (int ll = 0; ll < 6; ll++)
       if (ll != icol) {
         const double dum = A[ll][icol];
+        pl.dum[i][ll] = dum;
         A[ll][icol] = 0.0;
         for (int l = 0; l < 6; l++) A[ll][l] -= A[icol][l] * dum;
-        B[ll] -= B[icol] * dum;
       }
   }
-  return true;
+  return pl;
 }
-__device__ inline bool dev_parabolic_update(const int32_t *c9, int du, int dv, float &u2, float &v2) {
-  const double kA[9][6] = {{1, 1, 1, -1, -1, 1}, {0, 1, 0, 0, -1, 1}, {1, 1, -1, 1, -1, 1}, {1, 0, 0, -1, 0, 1}, {0, 0, 0, 0, 0, 1},
-                           {1, 0, 0, 1, 0, 1},   {1, 1, -1, -1, 1, 1}, {0, 1, 0, 0, 1, 1},  {1, 1, 1, 1, 1, 1}};
-  double b[6], AtA[6][6];
-  for (int i = 0; i < 6; i++) {
+__device__ inline double para_get(const double b[6], int i) {
+  return i == 0 ? b[0] : (i == 1 ? b[1] : (i == 2 ? b[2] : (i == 3 ? b[3] : (i == 4 ? b[4] : b[5]))));
+}
+__device__ inline void para_set(double b[6], int i, double v) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) b[k] = k == i ? v : b[k];
+}
+__device__ inline bool dev_parabolic_update(const VsmParaPlan &pl, const int32_t *c9, int du, int dv, float &u2, float &v2) {
+  constexpr double kA[9][6] = {{1, 1, 1, -1, -1, 1}, {0, 1, 0, 0, -1, 1}, {1, 1, -1, 1, -1, 1}, {1, 0, 0, -1, 0, 1}, {0, 0, 0, 0, 0, 1},
+                               {1, 0, 0, 1, 0, 1},   {1, 1, -1, -1, 1, 1}, {0, 1, 0, 0, 1, 1},  {1, 1, 1, 1, 1, 1}};
+  double b[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {  // b = At * c (Matrix::operator*: the sum over k in order, zero terms included)
     double s = 0;
+#pragma unroll
     for (int k = 0; k < 9; k++) s += kA[k][i] * (double)c9[k];
     b[i] = s;
-    for (int j = 0; j < 6; j++) {
-      double t = 0;
-      for (int k = 0; k < 9; k++) t += kA[k][i] * kA[k][j];
-      AtA[i][j] = t;
-    }
   }
-  if (!dev_gauss_jordan6(AtA, b)) return false;
+  if (!pl.ok) return false;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const int irow = pl.irow[i], icol = pl.icol[i];
+    if (irow != icol) {
+      const double x = para_get(b, irow), y = para_get(b, icol);
+      para_set(b, irow, y);
+      para_set(b, icol, x);
+    }
+    const double bc = para_get(b, icol) * pl.pivinv[i];
+    para_set(b, icol, bc);
+#pragma unroll
+    for (int ll = 0; ll < 6; ll++)
+      if (ll != icol) b[ll] -= bc * pl.dum[i][ll];
+  }
   const float divisor = (float)(b[2] * b[2] - 4.0 * b[0] * b[1]);
   if ((double)fabsf(divisor) < 1e-8 || fabs(b[2]) < 1e-8) return false;
   const float ddv = (float)((2.0 * b[0] * b[4] - b[2] * b[3]) / (double)divisor);
@@ -2146,7 +2181,7 @@ __device__ inline bool dev_parabolic_update(const int32_t *c9, int du, int dv, f
   return true;
 }
 #define PARA_MAX_LIST 16384  // matches per pair this kernel takes (16-bit places in LDS)
-__global__ void __launch_bounds__(1024) k_parabolic_apply(const VsmPair *__restrict__ pairs) {
+__global__ void __launch_bounds__(1024) k_parabolic_apply(const VsmPair *__restrict__ pairs, VsmParaPlan pl) {
   __shared__ uint16_t s_dst[PARA_MAX_LIST];  // the match's place among the survivors, 0xffff = dropped
   __shared__ int s_w[17];
   const VsmPair &pair = pairs[blockIdx.x];
@@ -2164,7 +2199,7 @@ __global__ void __launch_bounds__(1024) k_parabolic_apply(const VsmPair *__restr
     for (int st = 0; st < 3 && ok; st++) {
       const int32_t *r = pair.pf + ((size_t)i * 3 + st) * 12;
       if (r[0] == 2) continue;  // step not applicable to the matching method
-      ok = r[0] == 1 && dev_parabolic_update(r + 3, r[1], r[2], *tu[st], *tv[st]);
+      ok = r[0] == 1 && dev_parabolic_update(pl, r + 3, r[1], r[2], *tu[st], *tv[st]);
     }
     pair.raw[i] = m;
     s_dst[i] = ok ? 1 : 0;
@@ -2380,7 +2415,8 @@ void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair *d_pairs, int n
 // the batched tail of refinement==2 (behind vsm_launch_refine): fits, dropped matches, the lists closed up again
 void vsm_launch_parabolic_apply(hipStream_t s, const VsmPair *d_pairs, int npairs) {
   if (npairs <= 0) return;
-  hipLaunchKernelGGL(k_parabolic_apply, dim3(npairs), dim3(1024), 0, s, d_pairs);
+  static const VsmParaPlan plan = make_para_plan();
+  hipLaunchKernelGGL(k_parabolic_apply, dim3(npairs), dim3(1024), 0, s, d_pairs, plan);
 }
 
 void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
