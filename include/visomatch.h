@@ -113,7 +113,7 @@ float vsm_gain(vsm_handle *h, const int32_t *inliers, int32_t n);
  * on a fresh Matcher (viso/matcher.cpp:95, :183), but the frames of a chunk (VSM_SEQ_CHUNK, default
  * 76) go through every kernel in one launch and the host stages of the chunk's frame pairs run in
  * parallel.  left/right: n_frames images frame_stride bytes apart (host or, with on_device != 0,
- * HBM); right == NULL (mono) and refinement == 2 fall back to the frame-by-frame path.
+ * HBM); right == NULL (mono) with stereo / quad matching goes frame by frame (the reference's matchFeatures returns early).
  * Tr_delta: NULL or n_frames x 12 doubles, Tr_valid: NULL (all valid) or n_frames flags.
  * The streaming ring buffer (vsm_push_back / vsm_match) is not touched except by the fallback. */
 int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, int64_t frame_stride, int on_device,
@@ -270,7 +270,7 @@ void vsm_vo_sampler_seed(uint32_t seed);
  * updateMotion - with one launch per kernel over all K pairs and the K egomotion estimates side by side on the host pool.
  * Each sequence has the rand() stream (bucketing, srand(0) at construction, viso/viso.cpp:35) and the RANSAC sampler
  * (viso/viso.cpp:93) that a process of its own would have, so sequence k's matches, inliers and Tr_delta equal what the
- * reference gives for that sequence alone.  refinement == 2 is not taken here (one vsm_vo_stereo per sequence does it). */
+ * reference gives for that sequence alone. */
 typedef struct vsm_multi vsm_multi;
 vsm_multi *vsm_multi_create(const vsm_vo_stereo_params *p, int32_t n_sequences);
 void vsm_multi_destroy(vsm_multi *m);

@@ -655,6 +655,43 @@ def test_multi_sequence_lockstep_live_feedback(vm, synth, K, device_inputs):
     vo.close()
 
 
+def test_multi_sequence_with_subpixel_refinement(vm, synth):
+    """refinement = 2 inside vsm_multi_process: per sequence and frame, matchFeatures' final list equals what the per-frame
+    matcher gives for the same images and the Tr_delta the multi-sequence step actually used (that path is checked against
+    the oracle elsewhere); two sequences fed the same images stay identical to each other and to a run with K = 1"""
+    w, h, nf, K = 640, 192, 6, 3
+    canv = [synth.canvas(77, w, h), synth.canvas(78, w, h)]
+    which = [0, 1, 0]
+    intr = (645.24, 635.96, 194.13, 0.5707)
+    vo = vm.MultiVisualOdometryStereo(K, *intr, refinement=2)
+    solo = vm.MultiVisualOdometryStereo(1, *intr, refinement=2)
+    per = [vm.Matcher(refinement=2) for _ in range(K)]
+    for m in per:
+        m.set_intrinsics(*intr)
+    n_matched = 0
+    for f in range(nf):
+        fr = [synth.stereo_frame(cv, f, w, h) for cv in canv]
+        left = np.stack([fr[i][0] for i in which])
+        right = np.stack([fr[i][1] for i in which])
+        tin = [(vo.motion_valid(k), vo.get_motion(k)) for k in range(K)]
+        vo.process(left, right)
+        solo.process(left[:1], right[:1])
+        for k in range(K):
+            per[k].push_back(left[k], right[k])
+            per[k].match_features(2, tin[k][1] if tin[k][0] else None)
+            fin = vo.get_matches(k, bucketed=False)
+            assert _same(fin, per[k].get_matches()), (f, k)
+            n_matched += len(fin)
+        assert _same(vo.get_matches(0, bucketed=False), vo.get_matches(2, bucketed=False)), f
+        assert vo.get_motion(0).tobytes() == vo.get_motion(2).tobytes() == solo.get_motion(0).tobytes(), f
+        assert _same(vo.get_matches(0), solo.get_matches(0)), f
+    assert n_matched > 1000
+    vo.close()
+    solo.close()
+    for m in per:
+        m.close()
+
+
 # ---- monocular egomotion (SURVEY.md section 8 row f-4): HIP inlier counting + plane vote ----------
 
 def test_vo_mono_cases_golden(vm):
