@@ -1372,11 +1372,10 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
 
   // The GPU-resident form (vsm_seq2.inc) takes the run unless VSM_SEQ_V2=0 asks for the host-shared form below, or
   // it declines (lists beyond what its device-side vertex sort / kd order were written for).
-  // The host-shared form lives off the rank's host threads (200 frames 1242x375: 7.5-8.0 ms with 16 threads, 8.2 with 14,
-  // 9.6 with 12, 10.1 with 10, 17 with 4, 24 with 2); the GPU-resident one hardly cares (7.8-8.0 ms with 16 .. 6 threads,
-  // 8.8 with 4, 9.5 with 2, 9.9 with 1 - its host work is Triangle's vertex sort alone), so it is the default whatever the
-  // thread count: with 16 threads on an idle host the two are within a few per cent, and its time does not move with what
-  // else the host is doing.
+  // The host-shared form lives off the rank's host threads (200 frames 1242x375, round 3: 7.6 ms with 14 pool threads, 15 with 8,
+  // 24 with 2); the GPU-resident one keeps only Triangle's vertex sort and the closing of the result lists on the host (5.0-5.2 ms
+  // with 14 threads, 6.3 with 8, 8.0 with 4, 8.9 with 2, 9.1 with 1 - results in host memory included), so it is the default
+  // whatever the thread count.
   if (h->sw.seq_v2) {
     const int rc = sequence_run_v2(h, left, right, frame_stride, on_device, n_frames, w, hh, bpl, method, Tr, Tr_valid);
     if (rc != VSM_SEQ2_DECLINED) return rc;
