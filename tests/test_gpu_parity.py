@@ -928,6 +928,26 @@ def test_gpu_resident_remove_outliers_chain(vm):
     assert _same(vm.remove_outliers(lst, 2, 1242, 375, gpu=True)[0], vm.remove_outliers(lst, 2, 1242, 375)[0])
 
 
+def test_device_chain_at_the_capacity_steps_of_its_lds_kernels(vm):
+    """the LDS preparation kernel (sort, duplicates, kd order) is launched with a power-of-two capacity and capacity / 4 or / 8
+    threads, the chain's last kernel keeps its tables in LDS up to 12288 matches: list lengths on both sides of every step,
+    heavy duplicates included, against the host code"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("dc2_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dc2_check.py"))
+    dc2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dc2)
+    for n in (255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 4095, 4096, 4097, 8191, 8192, 8193, 12287, 12288, 12289):
+        for grid in (False, True):
+            lst = dc2.make_list(n, grid=grid)
+            hs, hr, _ = vm.remove_outliers(lst, 2, 1242, 375)
+            for gt in (False, True):
+                if gt and n > 8192:
+                    continue
+                gs, gr, _ = vm.remove_outliers(lst, 2, 1242, 375, gpu=True, gpu_ties=gt, copies=3)
+                assert _same(hs, gs) and np.array_equal(hr, gr), (n, grid, gt, len(hs), len(gs))
+
+
 @pytest.mark.parametrize("form", ["host-shared", "GPU-resident"])
 def test_all_eight_sequences_of_config_4_on_one_gpu(vm, synth, monkeypatch, form):
     """config 4 = eight independent sequences, one per GPU.  Without the 8-GPU node every rank's sequence still has to go
