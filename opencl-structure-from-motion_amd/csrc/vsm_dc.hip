@@ -1275,6 +1275,9 @@ __device__ inline bool dc2_reaches(uint32_t w, bool left_half, int32_t cl, int32
 #ifndef DC2_BLOCK_OCC
 #define DC2_BLOCK_OCC 5
 #endif
+#ifndef DC2_BLOCK_TAIL
+#define DC2_BLOCK_TAIL 1  // waves that carry the levels below DC2_BLOCK_PACKED nodes (and the write-back); the others end early
+#endif
 __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
   __shared__ __attribute__((aligned(16))) uint32_t s_w[2 * VSM_DC_BLOCK_POINTS * 4];  // edge words (vsm_dc_lds.h)
   __shared__ uint32_t s_pt[VSM_DC_BLOCK_POINTS];
@@ -1340,11 +1343,19 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
       const int nodes = 1 << L;
       int node = -1;  // (one call site: the seam walk is a lot of code, and the instruction cache is shared)
       if (nodes >= DC2_BLOCK_PACKED) {
+        // a wave that has no node at this level has none at any level above it: it ENDS here.  Its registers and its wave
+        // slot go back to the compute unit at once (the workgroup's LDS stays until the last wave is through) and
+        // s_barrier counts the surviving waves only.  What this is for is not this kernel: five resident workgroups of
+        // four waves hold 5 x 96 of a SIMD's 512 vector registers, and a k_match wave (104) then has nowhere to go on that
+        // compute unit for as long as the block's single-lane upper levels take.
+        if (DC2_BLOCK_TAIL < DC2_BLOCK_WAVES && wv >= DC2_BLOCK_TAIL && wv * 64 >= nodes) return;
         node = lane < nodes ? lane : -1;
-      } else if (nodes >= DC2_BLOCK_WAVES) {
-        const int per_wave = nodes / DC2_BLOCK_WAVES;
+      } else if (nodes >= DC2_BLOCK_TAIL) {
+        const int per_wave = nodes / DC2_BLOCK_TAIL;
+        if (wv >= DC2_BLOCK_TAIL) return;
         node = wl < per_wave ? wv * per_wave + wl : -1;
       } else {
+        if (wv >= nodes && DC2_BLOCK_TAIL < DC2_BLOCK_WAVES) return;
         node = wl == 0 && wv < nodes ? wv : -1;
       }
       if (node >= 0) dc2_block_merge_run(mesh, node, L, bn, baxis, (DC2_AS3 Dc2Hull16 *)s_hull);
@@ -1361,7 +1372,8 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
   DC2_T(c3);
   // records out under global numbering: neighbour handles + 8 boff, vertices + boff (a record is two 16-byte stores)
   dc2_v4i *gt = (dc2_v4i *)(j2.tri + (size_t)2 * boff * 8);
-  for (int t = lane; t < 2 * bn; t += DC2_BLOCK_THREADS) {
+  constexpr int kLive = DC2_BLOCK_TAIL < DC2_BLOCK_WAVES ? 64 : DC2_BLOCK_THREADS;  // (with early exits only wave 0 gets here)
+  for (int t = lane; t < 2 * bn; t += kLive) {
     const dc2_v4u o = ((const dc2_v4u *)s_w)[t];
     auto nb = [&](uint32_t v) -> int32_t { return (v & 0xffffu) == 0xffffu ? -1 : (int32_t)(v & 0xffffu) + 8 * boff; };
     auto vx = [&](uint32_t v) -> int32_t { return (v >> 16) == 0xffffu ? -1 : (int32_t)(v >> 16) + boff; };
@@ -1384,7 +1396,7 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
     gt[2 * t] = a;
     gt[2 * t + 1] = b;
   }
-  for (int i = lane; i < bn; i += DC2_BLOCK_THREADS) j2.pt[boff + i] = s_pt[i];
+  for (int i = lane; i < bn; i += kLive) j2.pt[boff + i] = s_pt[i];
   if (lane == 0) {
     const Dc2Hull16 hl = s_hull[1];
     j2.hulls[bidx] = VsmDcHull{hl.fl_t + 2 * boff, hl.fl_o, hl.fr_t + 2 * boff, hl.fr_o};

@@ -1409,6 +1409,9 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
   if (qi >= jb.nq[si]) return;
 #ifdef VSM_MATCH_TIMING
   const long long mt0 = clock64();
+#if VSM_MATCH_TIMING == 3
+  const long long mtw0 = wall_clock64();
+#endif
   long long mtph_[2] = {0, 0}, *mtph = mtph_;
   unsigned int mtst[4] = {0, 0, 0, 0};
 #else
@@ -1517,8 +1520,13 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
       vsm_mt[k][3] = mtst[2];
       vsm_mt[k][4] = mtst[3];
       vsm_mt[k][5] = (unsigned int)mtph_[0];
+#if VSM_MATCH_TIMING == 3  // wall clock (100 MHz, one counter for the whole device: s_memtime runs per XCD): life and start
+      vsm_mt[k][6] = (unsigned int)(wall_clock64() - mtw0);
+      vsm_mt[k][7] = (unsigned int)mtw0;
+#else
       vsm_mt[k][6] = (unsigned int)mtph_[1];
       vsm_mt[k][7] = (unsigned int)mt0;
+#endif
     }
   }
 #endif

@@ -609,20 +609,24 @@ class MultiVisualOdometryStereo:
         """left / right: [K,H,W] uint8, numpy (host) or CUDA torch tensors -> K success flags"""
         L = lib()
         ok = np.zeros(self.K, dtype=np.int32)
+        # (checked BEFORE the call: the library reads K images per side from these pointers)
         if _is_torch(left):
-            assert left.is_cuda and right.is_cuda and left.shape == right.shape and left.stride() == right.stride() and left.stride(2) == 1
-            K, h, w = left.shape
             import torch
+            if not (_is_torch(right) and left.is_cuda and right.is_cuda and left.dtype == torch.uint8 and right.dtype == torch.uint8 and left.dim() == 3
+                    and left.shape == right.shape and left.shape[0] == self.K and left.stride() == right.stride() and left.stride(2) == 1):
+                raise VisoMatchError(f"process: left / right must be uint8 CUDA tensors [K={self.K},H,W] of equal shape and strides, unit stride along W")
+            K, h, w = left.shape
             torch.cuda.current_stream(left.device).synchronize()   # (the library reads the images on its own stream)
             rc = L.vsm_multi_process(self.h, C.c_void_p(left.data_ptr()), C.c_void_p(right.data_ptr()), left.stride(0), 1, w, h, left.stride(1),
                                      ok.ctypes.data_as(C.c_void_p))
         else:
             left = np.ascontiguousarray(left, dtype=np.uint8)
             right = np.ascontiguousarray(right, dtype=np.uint8)
+            if left.ndim != 3 or left.shape != right.shape or left.shape[0] != self.K:
+                raise VisoMatchError(f"process: left / right must be uint8 arrays [K={self.K},H,W] of equal shape, got {left.shape} / {right.shape}")
             K, h, w = left.shape
             rc = L.vsm_multi_process(self.h, left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p), w * h, 0, w, h, w,
                                      ok.ctypes.data_as(C.c_void_p))
-        assert K == self.K
         if rc != 0:
             raise VisoMatchError(f"vsm_multi_process failed with {rc}")
         return ok.astype(bool)

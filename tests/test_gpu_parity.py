@@ -692,6 +692,83 @@ def test_multi_sequence_with_subpixel_refinement(vm, synth):
         m.close()
 
 
+def test_multi_sequence_blank_frame_follows_the_reference(vm, B, synth):
+    """A frame without features makes matchFeatures return early (viso/matcher.cpp:190-216): p_matched_2 keeps what the
+    previous step's bucketFeatures left in it, process() buckets THAT list again (drawing from rand()) and hands it to
+    updateMotion.  One of two lock-step sequences gets such a frame; both must follow the oracle's VisualOdometryStereo (run
+    once per sequence, with the generators of a fresh process) through it and afterwards."""
+    w, h, nf, K = 480, 200, 9, 2
+    intr = (420.0, w / 2.0, h / 2.0, 0.45)
+    seqs = [synth.stereo_sequence(41, w, h, nf, disparity=14), synth.stereo_sequence(42, w, h, nf, disparity=14)]
+    blank = np.full((h, w), 90, dtype=np.uint8)
+    seqs[0][4] = (blank, blank)
+    seqs[0][5] = (blank, blank)   # two in a row: the list that is bucketed again has already been bucketed twice
+    ref = []
+    for k in range(K):
+        B.oracle_sampler_seed(71)   # the state of viso/viso.cpp:88's function-local generator in a process of its own
+        o = B.OracleStereoVO(*intr)
+        rows = []
+        for l, r in seqs[k]:
+            ok, _, _, T = o.process(l, r)
+            rows.append((ok, T.copy(), o.bucketed().copy(), o.inliers().copy()))
+        ref.append(rows)
+        o.close()
+    assert len(ref[0][3][2]) > 20 and _same(ref[0][4][2], ref[0][4][2])
+    vo = vm.MultiVisualOdometryStereo(K, *intr)
+    for f in range(nf):
+        ok = vo.process(np.stack([seqs[k][f][0] for k in range(K)]), np.stack([seqs[k][f][1] for k in range(K)]))
+        for k in range(K):
+            assert bool(ok[k]) == ref[k][f][0], (f, k)
+            assert vo.get_motion(k).tobytes() == ref[k][f][1].tobytes(), (f, k)
+            assert _same(vo.get_matches(k), ref[k][f][2]), (f, k, len(vo.get_matches(k)), len(ref[k][f][2]))
+            assert np.array_equal(vo.get_inlier_indices(k), ref[k][f][3]), (f, k)
+    vo.close()
+
+
+def test_multi_sequence_failed_step_changes_nothing(vm, synth):
+    """vsm_multi_process promises that a step which fails has advanced no sequence.  The late failure there is: sub-pixel
+    refinement with more queries than its batched tail takes (VSM_PARA_MAX_LIST = 16384 dense features in the previous
+    frame) - found only after the frame's features have gone through the kernels.  The failed call must leave motion, lists
+    and the previous frame as they were, fail the same way when repeated, and a twin that is fed the frames again after a
+    change of size (which restarts every sequence) must agree with a fresh object."""
+    w, h = 1344, 720
+    cv = synth.canvas(5, w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(3)]
+    intr = (700.0, w / 2.0, h / 2.0, 0.5)
+    vo = vm.MultiVisualOdometryStereo(1, *intr, refinement=2)
+    one = lambda im: im[None]
+    vo.process(one(fr[0][0]), one(fr[0][1]))
+    state = lambda: (vo.motion_valid(0), vo.get_motion(0).tobytes(), vo.get_matches(0).tobytes(), vo.get_matches(0, bucketed=False).tobytes(),
+                     vo.get_inlier_indices(0).tobytes())
+    before = state()
+    for _ in range(2):
+        with pytest.raises(vm.VisoMatchError):
+            vo.process(one(fr[1][0]), one(fr[1][1]))
+        assert state() == before
+    # a smaller image restarts the sequences; from there on the object behaves like a new one
+    ws, hs = 480, 200
+    seq = synth.stereo_sequence(43, ws, hs, 4, disparity=14)
+    fresh = vm.MultiVisualOdometryStereo(1, *intr, refinement=2)
+    for l, r in seq:
+        a, b = vo.process(one(l), one(r)), fresh.process(one(l), one(r))
+        assert bool(a[0]) == bool(b[0])
+        assert vo.get_motion(0).tobytes() == fresh.get_motion(0).tobytes()
+        assert _same(vo.get_matches(0), fresh.get_matches(0)) and _same(vo.get_matches(0, bucketed=False), fresh.get_matches(0, bucketed=False))
+    assert len(vo.get_matches(0, bucketed=False)) > 100
+    vo.close()
+    fresh.close()
+
+
+def test_multi_sequence_rejects_wrong_shapes_before_the_call(vm):
+    vo = vm.MultiVisualOdometryStereo(3, 400.0, 100.0, 50.0, 0.5)
+    im = np.zeros((2, 64, 96), dtype=np.uint8)   # K' = 2 < K = 3: the library would read a third image past the end
+    with pytest.raises(vm.VisoMatchError):
+        vo.process(im, im)
+    with pytest.raises(vm.VisoMatchError):
+        vo.process(np.zeros((3, 64, 96), dtype=np.uint8), np.zeros((3, 64, 80), dtype=np.uint8))
+    vo.close()
+
+
 # ---- monocular egomotion (SURVEY.md section 8 row f-4): HIP inlier counting + plane vote ----------
 
 def test_vo_mono_cases_golden(vm):
@@ -876,9 +953,10 @@ def test_emulated_vertex_sort_on_gpu(vm):
     assert checked > 30
 
 
-def test_delaunay_subtrees_on_gpu(vm):
+def test_delaunay_subtrees_on_gpu(vm, B):
     """the shared form of the exact Delaunay: sub-trees triangulated by GPU threads (vsm_dc.hip), the
-    host continues on the same arrays; triangle sets equal the host-only run for every split"""
+    host continues on the same arrays; triangle sets equal the ORACLE's Triangle restatement (viso/triangle.cpp:6161
+    as the oracle restates it; the reference's own where oracle/_ref is present) for every split"""
     import time
     rs = np.random.RandomState(3)
 
@@ -890,21 +968,38 @@ def test_delaunay_subtrees_on_gpu(vm):
     g = np.stack(np.meshgrid(np.arange(0, 60, 2), np.arange(0, 40, 2)), -1).reshape(-1, 2)
     cases += [g, np.concatenate([g, g[::3]]), np.stack([np.arange(0, 300, 2), np.full(150, 8)], 1)]
     big = np.stack([rs.randint(0, 1024, 20000) * 2, rs.randint(0, 512, 20000) * 2], 1)   # > 16384 distinct points
-    assert np.array_equal(canon(vm.host_delaunay(big, 1)), canon(vm.delaunay_gpu_split(big, 480, -1, True)))
+    def oracle_tris(p):
+        t = canon(B.delaunay("oracle", p.astype(np.float32)))
+        if B.have_ref():
+            assert np.array_equal(t, canon(B.delaunay("ref", p.astype(np.float32))))
+        return t
+
+    assert np.array_equal(oracle_tris(big), canon(vm.delaunay_gpu_split(big, 480, -1, True)))
     for p in cases:
-        whole = canon(vm.host_delaunay(p, 1))
+        whole = oracle_tris(p)
+        assert np.array_equal(whole, canon(vm.host_delaunay(p, 1))), len(p)
         for leaf, top in ((3, 0), (14, 0), (56, 0), (500, 0), (3, 12), (14, 120), (16, 240), (56, 480), (30, 900),
                           (480, -1), (100, -1), (14, -1), (5000, -1)):
             for kd in (False, True):
                 assert np.array_equal(whole, canon(vm.delaunay_gpu_split(p, leaf, top, kd))), (len(p), leaf, top, kd)
 
 
-def test_gpu_resident_remove_outliers_chain(vm):
+def _oracle_survivors(B, lst, method):
+    """Matcher::removeOutliers (viso/matcher.cpp:1207-1377) of the CPU oracle - and of the reference itself where its library
+    travelled with the snapshot - on a match list"""
+    want = B.remove_outliers("oracle", lst, method)
+    if B.have_ref():
+        assert _same(want, B.remove_outliers("ref", lst, method)), (len(lst), method)
+    return want
+
+
+def test_gpu_resident_remove_outliers_chain(vm, B):
     """the device chain of the GPU-resident look-ahead form (keys, (x,y) sort + duplicates + kd order, block sub-trees on the
     edge-word LDS mesh, merge levels through the band cache, tie patches from the device's or the host's vertex sort,
-    support votes, survivors, prior statistics) against the host code of the per-frame path: survivors and prior boxes byte
-    for byte, list lengths around every structural boundary (3 | 4, five points - the case the vectorizers once broke -,
-    one block | two, small | large bands)"""
+    support votes, survivors, prior statistics): the survivors against the ORACLE's removeOutliers (and the reference's own,
+    where oracle/_ref is present), byte for byte; the prior boxes against the host code of the per-frame path (whose boxes
+    the stage goldens pin).  List lengths around every structural boundary (3 | 4, five points - the case the vectorizers
+    once broke -, one block | two, small | large bands)"""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("dc2_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dc2_check.py"))
@@ -914,24 +1009,26 @@ def test_gpu_resident_remove_outliers_chain(vm):
         for method in (0, 1, 2):
             for grid in (False, True):
                 lst = dc2.make_list(n, grid=grid)
+                want = _oracle_survivors(B, lst, method)
                 hs, hr, _ = vm.remove_outliers(lst, method, 1242, 375)
+                assert _same(want, hs), (n, method, grid, len(want), len(hs))
                 for gt in (False, True):
                     if gt and n > 8192:
                         continue
                     gs, gr, _ = vm.remove_outliers(lst, method, 1242, 375, gpu=True, gpu_ties=gt, copies=2)
-                    assert _same(hs, gs) and np.array_equal(hr, gr), (n, method, grid, gt, len(hs), len(gs))
+                    assert _same(want, gs) and np.array_equal(hr, gr), (n, method, grid, gt, len(want), len(gs))
     lst = dc2.make_list(60, dup=0)
     lst["u1c"], lst["v1c"] = 100, 50                       # every match at one pixel: no triangulation, nothing survives
-    assert len(vm.remove_outliers(lst, 2, 1242, 375, gpu=True)[0]) == len(vm.remove_outliers(lst, 2, 1242, 375)[0]) == 0
+    assert len(vm.remove_outliers(lst, 2, 1242, 375, gpu=True)[0]) == len(_oracle_survivors(B, lst, 2)) == 0
     lst = dc2.make_list(300, dup=0)
     lst["v1c"] = 40                                          # collinear
-    assert _same(vm.remove_outliers(lst, 2, 1242, 375, gpu=True)[0], vm.remove_outliers(lst, 2, 1242, 375)[0])
+    assert _same(vm.remove_outliers(lst, 2, 1242, 375, gpu=True)[0], _oracle_survivors(B, lst, 2))
 
 
-def test_device_chain_at_the_capacity_steps_of_its_lds_kernels(vm):
+def test_device_chain_at_the_capacity_steps_of_its_lds_kernels(vm, B):
     """the LDS preparation kernel (sort, duplicates, kd order) is launched with a power-of-two capacity and capacity / 4 or / 8
     threads, the chain's last kernel keeps its tables in LDS up to 12288 matches: list lengths on both sides of every step,
-    heavy duplicates included, against the host code"""
+    heavy duplicates included - survivors against the oracle's removeOutliers, prior boxes against the host code"""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("dc2_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dc2_check.py"))
@@ -940,12 +1037,14 @@ def test_device_chain_at_the_capacity_steps_of_its_lds_kernels(vm):
     for n in (255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 4095, 4096, 4097, 8191, 8192, 8193, 12287, 12288, 12289):
         for grid in (False, True):
             lst = dc2.make_list(n, grid=grid)
+            want = _oracle_survivors(B, lst, 2)
             hs, hr, _ = vm.remove_outliers(lst, 2, 1242, 375)
+            assert _same(want, hs), (n, grid, len(want), len(hs))
             for gt in (False, True):
                 if gt and n > 8192:
                     continue
                 gs, gr, _ = vm.remove_outliers(lst, 2, 1242, 375, gpu=True, gpu_ties=gt, copies=3)
-                assert _same(hs, gs) and np.array_equal(hr, gr), (n, grid, gt, len(hs), len(gs))
+                assert _same(want, gs) and np.array_equal(hr, gr), (n, grid, gt, len(want), len(gs))
 
 
 @pytest.mark.parametrize("form", ["host-shared", "GPU-resident"])
