@@ -159,3 +159,24 @@ def test_error_paths(B, synth):
     mo = B.CpuMatcher("oracle")
     assert mo.L.vo_push_back(mo.h, None, None, 128, 64, 128, 0) == -1
     assert mo.L.vo_push_back(mo.h, l.ctypes.data_as(B._p_u8), None, 128, 64, 100, 0) == -1
+
+
+def test_remove_outliers_on_the_chain_test_lists(B):
+    """Matcher::removeOutliers (viso/matcher.cpp:1207-1377) on the match lists the GPU suite feeds the device chain
+    (tools/dc2_check.py make_list: random and grid-shaped point sets with shared pixels, list lengths around the chain's
+    structural boundaries): the oracle's survivors against the reference's own.  The GPU tests then compare the device
+    chain with the oracle only (the reference's library is not loaded beside the HIP runtime)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("dc2_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dc2_check.py"))
+    dc2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dc2)
+    n_checked = 0
+    for n in (0, 3, 4, 5, 17, 100, 480, 481, 961, 2000, 4500, 7400, 9000, 12289):
+        for method in (0, 1, 2):
+            for grid in (False, True):
+                lst = dc2.make_list(n, grid=grid)
+                a, b = B.remove_outliers("oracle", lst, method), B.remove_outliers("ref", lst, method)
+                assert len(a) == len(b) and a.tobytes() == b.tobytes(), (n, method, grid, len(a), len(b))
+                n_checked += len(a)
+    assert n_checked > 100000
