@@ -1728,73 +1728,82 @@ __global__ void __launch_bounds__(256)
 }
 
 // Quad matching keeps every accepted query (no pixel de-dup, viso/matcher.cpp:1139-1151): ordered compaction of raw[] into
-// the list in ONE launch (the lists behind it, and the Delaunay chain behind those, wait for it).  QUAD_PARTS workgroups of
-// 1024 threads per pair: a workgroup counts the acceptance flags in front of its part itself (a few independent loads per
-// thread), scans its own - a run of consecutive queries per thread - and moves the records.  Records move as 16-byte pieces, consecutive lanes consecutive pieces.  35 us per 67 pairs of 10 k
-// queries with the GPU to itself - and 80-90 us in the pipeline whatever the kernel's form (even with its loads and stores
-// taken out): what it waits for there is not in the kernel.
-#define QUAD_PARTS 4
-#define QUAD_RUN 4  // queries per thread at most: QUAD_PARTS * 1024 * QUAD_RUN queries per pair in this form
-__global__ void __launch_bounds__(1024)
-    k_compact_quad(const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs, VsmJob job0, int pass, int parts) {
-  __shared__ int s_w[17];
-  __shared__ int s_base[16];
-  __shared__ int s_dst[1024 * QUAD_RUN];  // place of every query of the part in the list, -1 = not accepted
+// the list in ONE launch (the lists behind it, and the Delaunay chain behind those, wait for it).  A workgroup of 256
+// threads takes QUAD_SPAN consecutive queries of a pair: it counts the acceptance flags in front of its span itself (every
+// workgroup reads the pair's flags up to its own - a few KB out of L2 - so no workgroup waits for another), scans its own and
+// moves the records as 16-byte pieces, consecutive lanes consecutive pieces of raw[].  Round 3's form - four workgroups of
+// 1024 threads and 16 KB of LDS per pair - took 35 us per 67 pairs with the GPU to itself and 100-170 us in the pipeline,
+// whatever was in it: a 16-wave workgroup needs four free wave slots on every SIMD of one compute unit plus its LDS at the
+// same moment, and beside the Delaunay chains it waits for that.  Four waves and 4 KB find a place at once.
+#define QUAD_SPAN 1024
+__global__ void __launch_bounds__(256)
+    k_compact_quad(const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs, VsmJob job0, int pass) {
+  __shared__ int s_w[5];
+  __shared__ int s_base[4];
+  __shared__ int s_dst[QUAD_SPAN];  // place of every query of the span in the list, -1 = not accepted
   const VsmPair &pair = pairs[blockIdx.y];
   const int n_query = (jobs ? jobs[blockIdx.y] : job0).nq[pass];
-  const int per_part = ((n_query + parts - 1) / parts + 1023) & ~1023;  // whole rounds of the workgroup
-  const int q0 = (int)blockIdx.x * per_part, q1 = min(n_query, q0 + per_part);
-  if (q0 >= n_query && !(blockIdx.x == 0 && n_query == 0)) {
-    return;
-  }
+  const int q0 = (int)blockIdx.x * QUAD_SPAN, q1 = min(n_query, q0 + QUAD_SPAN);
+  if (q0 >= n_query && !(blockIdx.x == 0 && n_query == 0)) return;
   vsm_p_match *__restrict__ list = pass ? pair.list2 : pair.list1;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  // accepted queries in front of this part
-  int part = 0;
+  // accepted queries in front of this span: four flags per thread and load
+  int before = 0;
   {
-    int f[QUAD_PARTS * QUAD_RUN];
+    const int4 *f4 = (const int4 *)pair.flag;  // (flag[] is 16-byte aligned, q0 a multiple of 4)
+    for (int i0 = t; i0 < q0 / 4; i0 += 4 * 256) {
+      int4 f[4];
 #pragma unroll
-    for (int k = 0; k < QUAD_PARTS * QUAD_RUN; k++) {
-      const int q = t + 1024 * k;
-      f[k] = q < q0 ? pair.flag[q] : 0;
+      for (int k = 0; k < 4; k++) {
+        const int i = i0 + 256 * k;
+        f[k] = i < q0 / 4 ? f4[i] : make_int4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) before += (f[k].x ? 1 : 0) + (f[k].y ? 1 : 0) + (f[k].z ? 1 : 0) + (f[k].w ? 1 : 0);
     }
-#pragma unroll
-    for (int k = 0; k < QUAD_PARTS * QUAD_RUN; k++) part += f[k] ? 1 : 0;
   }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
-  if (lane == 0) s_base[wv] = part;
-  // own flags: thread t owns queries q0 + t * run .. + run - 1
-  const int run = per_part >> 10;  // <= QUAD_RUN
-  int keep[QUAD_RUN], cnt = 0;
+  for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (lane == 0) s_base[wv] = before;
+  // own flags: thread t owns queries q0 + 4 t .. q0 + 4 t + 3
+  constexpr int RUN = QUAD_SPAN / 256;
+  int keep[RUN], cnt = 0;
 #pragma unroll
-  for (int k = 0; k < QUAD_RUN; k++) {
-    const int i = q0 + t * run + k;
-    keep[k] = (k < run && i < q1) ? (pair.flag[i] ? 1 : 0) : 0;
+  for (int k = 0; k < RUN; k++) {
+    const int i = q0 + t * RUN + k;
+    keep[k] = i < q1 ? (pair.flag[i] ? 1 : 0) : 0;
     cnt += keep[k];
   }
-  int total;
-  int pos = block_excl_scan_1024(cnt, total, s_w);  // (its barriers also publish s_base)
-  int base = 0;
+  // exclusive scan over the 256 threads
+  int incl = cnt;
 #pragma unroll
-  for (int w = 0; w < 16; w++) base += s_base[w];
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) s_w[wv] = incl;
+  __syncthreads();
+  int pos = incl - cnt, total = 0, base = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    pos += w < wv ? s_w[w] : 0;
+    total += s_w[w];
+    base += s_base[w];
+  }
   pos += base;
-  // the records move as 16-byte pieces, consecutive lanes consecutive pieces of raw[] (a 48-byte record per lane would be
-  // twelve dword accesses 48 - 192 bytes apart: a cache line per lane and instruction)
 #pragma unroll
-  for (int k = 0; k < QUAD_RUN; k++)
-    if (k < run) s_dst[t * run + k] = keep[k] ? pos++ : -1;
+  for (int k = 0; k < RUN; k++) s_dst[t * RUN + k] = keep[k] ? pos++ : -1;
   __syncthreads();
   {
     const uint4 *src = (const uint4 *)(pair.raw + q0);
     uint4 *dst = (uint4 *)list;
     const int pieces = 3 * (q1 - q0);
-    for (int p0 = t; p0 < pieces; p0 += 4 * 1024) {
+    for (int p0 = t; p0 < pieces; p0 += 4 * 256) {
       uint4 v[4];
       int d[4], part[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int p = p0 + 1024 * k;
+        const int p = p0 + 256 * k;
         const int e = p / 3;
         part[k] = p - 3 * e;
         d[k] = p < pieces ? s_dst[e] : -1;
@@ -1805,7 +1814,7 @@ __global__ void __launch_bounds__(1024)
         if (d[k] >= 0) dst[3 * (size_t)d[k] + part[k]] = v[k];
     }
   }
-  if (q1 == n_query && t == 1023) {  // the part that holds the last query
+  if (q1 == n_query && t == 255) {  // the span that holds the last query
     pair.count[pass] = base + total;
     pair.hcount[pass] = base + total;
   }
@@ -2403,9 +2412,8 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
   }
   const int nblk = max(cdiv(max_nq, 256), 1);
   pf.begin(cfg.sparse ? VSM_K_COMPACT1 : VSM_K_COMPACT2, s);
-  if (cfg.method == 2 && max_nq <= QUAD_PARTS * 1024 * QUAD_RUN) {
-    const int parts = std::min(QUAD_PARTS, std::max(1, cdiv(max_nq, 2048)));  // (short lists: fewer, fuller workgroups)
-    hipLaunchKernelGGL(k_compact_quad, dim3(parts, npairs), dim3(1024), 0, s, d_pairs, d_jobs, job0, pass, parts);
+  if (cfg.method == 2) {
+    hipLaunchKernelGGL(k_compact_quad, dim3(std::max(1, cdiv(max_nq, QUAD_SPAN)), npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, pass);
   } else {
     hipLaunchKernelGGL(k_compact_count, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);
     hipLaunchKernelGGL(k_compact_write, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);
