@@ -246,10 +246,13 @@ def main():
             verified = None
 
     # ---- the same look-ahead call fed from host memory (PCIe inclusive: the reference's pushBack takes host images) ----
-    host_in_value = None
+    host_in_value, host_in_verified = None, None
     if not args.no_per_frame:
         hl, hr = np.ascontiguousarray(host[:, 0]), np.ascontiguousarray(host[:, 1])
         m.run_sequence(hl, hr, 2, tr12, trv, fetch=False)
+        if not args.no_verify:   # (outside the timed region, like the headline's check)
+            if key == f"s{seed}":
+                host_in_verified = bool(all(sha(m.sequence_matches(f)) == str(g[key + "_hashes"][f]) for f in range(nf)))
         shard.barrier(dmod, comm_dev)
         th = time.perf_counter()
         for _ in range(3):
@@ -428,7 +431,10 @@ def main():
         "lookahead_form": {2: "GPU-resident (lists stay in HBM; host only runs Triangle's vertex sort)",
                            1: "host-shared (prior statistics and the top of the exact Delaunay on the host pool)"}.get(lookahead_form),
         "lookahead_host_inputs": {"value": round(host_in_value, 3) if host_in_value else None, "unit": "frame-pairs/s",
-                                  "what": "the same look-ahead call fed from pageable host memory (on_device = 0): PCIe inclusive"},
+                                  "of_resident": round(host_in_value / value, 3) if host_in_value else None,
+                                  "bit_exact_vs_reference_hashes": host_in_verified if host_in_value else None,
+                                  "what": "the same look-ahead call fed from pageable host memory (on_device = 0): PCIe inclusive; the frames cross "
+                                          "in pieces of 8 (pool gathers into pinned memory, DMA on a stream of its own) beside the GPU's work"},
         "secondary_configs": secondary,
         "verified_ranks": n_verified,
         "step_ms_rank0": step_ms,

@@ -1,17 +1,24 @@
 import importlib, os, sys
-sys.path.insert(0, os.getcwd())
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12"); os.environ.setdefault("VSM_HOST_THREADS", "14"); os.environ["VSM_DEBUG_TIMING"] = "1"
 import numpy as np, torch
 vm = importlib.import_module("opencl-structure-from-motion_amd.visomatch")
 synth = importlib.import_module("opencl-structure-from-motion_amd.synth")
-g = np.load("tests/golden/cfg4_seq200_tr_8seeds.npz")
+g = np.load(os.path.join(ROOT, "tests/golden/cfg4_seq200_tr_8seeds.npz"))
 W, H, nf = 1242, 375, 200
 cv = synth.canvas(1234, W, H)
 fr = torch.from_numpy(np.stack([np.stack(synth.stereo_frame(cv, f, W, H)) for f in range(nf)])).cuda()
 tr = np.ascontiguousarray(g["s1234_tr_in"][:nf].reshape(nf, 16)[:, :12]); trv = np.ascontiguousarray(g["s1234_tr_valid"][:nf].astype(np.uint8))
 m = vm.Matcher(); m.set_intrinsics(*[float(x) for x in g["intr"]])
 import time
+host = os.environ.get("SEQ_HOST_INPUTS")   # SEQ_HOST_INPUTS=1: the frames in pageable host memory
+if host:
+    hl, hr = np.ascontiguousarray(fr[:, 0].cpu().numpy()), np.ascontiguousarray(fr[:, 1].cpu().numpy())
 for i in range(6):
     t = time.perf_counter()
-    m.run_sequence(fr[:, 0], fr[:, 1], 2, tr, trv, fetch=False)
+    if host:
+        m.run_sequence(hl, hr, 2, tr, trv, fetch=False)
+    else:
+        m.run_sequence(fr[:, 0], fr[:, 1], 2, tr, trv, fetch=False)
     print("call ms", round((time.perf_counter() - t) * 1e3, 3), flush=True)
