@@ -133,6 +133,8 @@ int32_t vsm_sequence_path(vsm_handle *h);
 /* Measurement / test switches of a handle.  They are read from the environment once, by vsm_create (VSM_SEQ_V2,
  * VSM_SEQ_CHUNK, VSM_SEQ_DC_STREAMS, VSM_SEQ_SERIAL, VSM_SEQ_GPU_SORTS, VSM_SEQ_EARLY_EXPORT, VSM_FRONT); this call changes one
  * afterwards: name = the variable's name without the VSM_ prefix, in lower case ("seq_serial", "seq_chunk", ...).
+ * Option-only names (never read from the environment): "dc_gpu", "dc_full", "dc_watchdog_ms", "dc_fault_inject" - the GPU's
+ * share of the final stage in the host-shared form.
  * None of them changes a result.  Returns VSM_OK, or VSM_EARG for an unknown name.  (No counterpart in the reference.) */
 int vsm_set_option(vsm_handle *h, const char *name, int32_t value);
 

@@ -375,6 +375,11 @@ struct VsmSwitches {
   int front = 1;           // VSM_FRONT: the fused front end
   int seq_early_export = -1;  // VSM_SEQ_EARLY_EXPORT: the refined lists cross PCIe beside the triangulation, survivor bits follow, the pool
                               // closes the gaps (1); survivors compacted on the device, one DMA copy at the chain's end (0); -1: by pool size
+  // settable through vsm_set_option only (tests, tools); none of them is read from the environment:
+  int dc_gpu = -1;           // host-shared look-ahead form: the GPU's share of the final stage: -1 = chunks with at least as many pairs as host threads, 0 = never, 1 = always
+  int dc_full = -1;          // ... everything after the vertex sort on the GPU: -1 = with six host threads or fewer, 0 / 1
+  int dc_fault_inject = 0;   // ... tests: the completion callback of the GPU share is "lost" (dc_wait()'s watchdog has to notice)
+  int dc_watchdog_ms = 20000;  // ... how long dc_wait() listens for that callback before it asks the stream itself
   static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -396,6 +401,10 @@ struct VsmSwitches {
     else if (!strcmp(name, "seq_gpu_sorts")) seq_gpu_sorts = v;
     else if (!strcmp(name, "front")) front = v != 0;
     else if (!strcmp(name, "seq_early_export")) seq_early_export = v;
+    else if (!strcmp(name, "dc_gpu")) dc_gpu = v;
+    else if (!strcmp(name, "dc_full")) dc_full = v;
+    else if (!strcmp(name, "dc_fault_inject")) dc_fault_inject = v;
+    else if (!strcmp(name, "dc_watchdog_ms")) dc_watchdog_ms = std::max(1, v);
     else return false;
     return true;
   }
@@ -522,8 +531,7 @@ vsm_handle *vsm_create(const vsm_params *p) {
     // (the look-ahead caller sleeps in a blocking event wait while the GPU works, so all nt budgeted
     // CPUs go to pool workers: nt workers + the caller's thread)
     h->pool = new VsmPool(nt + 1);
-    int fjt = nt < 8 ? nt : 8;
-    if (const char *e = getenv("VSM_FJ_THREADS")) fjt = std::max(1, std::min(atoi(e), nt));
+    const int fjt = nt < 8 ? nt : 8;
     h->fj = new VsmForkJoin(fjt);
     h->work.pool = h->fj;
     h->work.async = h->pool;
@@ -1119,8 +1127,8 @@ static void dc_enqueue_gpu(DcChunk *ch, bool wait_here = false) {
     }
     return;
   }
-  // (VSM_DC_FAULT_INJECT=1, tests only: the completion callback is "lost" - dc_wait()'s watchdog has to notice)
-  const bool lose_callback = getenv("VSM_DC_FAULT_INJECT") && atoi(getenv("VSM_DC_FAULT_INJECT")) == 1;
+  // (option dc_fault_inject = 1, tests only: the completion callback is "lost" - dc_wait()'s watchdog has to notice)
+  const bool lose_callback = ch->h->sw.dc_fault_inject == 1;
   if (ok && maxt > 0 && lose_callback) return;
   if (ok && maxt > 0 && hipLaunchHostFunc(s2, dc_after_gpu, ch) == hipSuccess) return;
   // nothing for the GPU, or it could not be used: the host solves the sub-trees too
@@ -1205,15 +1213,15 @@ static void dc_submit_a(DcChunk *ch) {
 }
 
 // Until the chunk's final lists are in seq_matches.  The GPU's part normally takes a millisecond or two and reports back
-// through a host function on its stream.  If nothing has been heard after the watchdog time (VSM_DC_WATCHDOG_MS, default
+// through a host function on its stream.  If nothing has been heard after the watchdog time (option dc_watchdog_ms, default
 // 20 s) the stream itself is asked: hipStreamSynchronize() either returns an error - the device faulted; that is logged
 // with HIP's own message, remembered in the handle (no GPU share from then on) and reported by vsm_sequence_run as
 // VSM_EHIP - or it returns success, in which case the device's results are complete and only the callback went missing.
 // Either way nothing on the device can touch the chunk's slabs any more when the host takes over, and the chunk and
 // its bank stay alive until then (they are owned by vsm_sequence_run, which calls this for every chunk before it returns).
 static void dc_wait(DcChunk *ch) {
-  const double watchdog_us = (getenv("VSM_DC_WATCHDOG_MS") ? atof(getenv("VSM_DC_WATCHDOG_MS")) : 20000.0) * 1e3;
   vsm_handle *h = ch->h;
+  const double watchdog_us = (double)h->sw.dc_watchdog_ms * 1e3;
   if (!ch->submitted) {  // (left early, between setting it up and submitting it: only its vertex sorts may be in flight)
     const double t0 = vsm_now_us();
     while (!ch->ties_done.load(std::memory_order_acquire)) {
@@ -1400,26 +1408,45 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   std::vector<VsmPool::Ticket> tickets;  // final stages that stay on the host ...
   std::vector<int> ticket_chunk;         // ... and the chunk each belongs to
   // final stage: see DcChunk above
-  const bool dc_env = !(getenv("VSM_DC_GPU") && atoi(getenv("VSM_DC_GPU")) == 0);
-  const bool dc_forced = getenv("VSM_DC_GPU") && atoi(getenv("VSM_DC_GPU")) != 0;
-  const int dc_leaf = getenv("VSM_DC_LEAF") ? std::max(3, atoi(getenv("VSM_DC_LEAF"))) : 16;
-  const bool dc_kd = !(getenv("VSM_DC_KD") && atoi(getenv("VSM_DC_KD")) == 0);  // kd order of the keys on the GPU too
-  const bool dc_block = !(getenv("VSM_DC_BLOCK") && atoi(getenv("VSM_DC_BLOCK")) == 0);  // k_dc_block instead of leaf / top
+  // (options dc_gpu / dc_full, vsm_set_option.  Round 1's sub-variants of this form - per-lane sub-trees of VSM_DC_LEAF points
+  // with merge levels up to VSM_DC_TOP points in global memory, the kd order on the host, the vertex sort on one wave of
+  // the device - are compile-time choices now: tools/build_variant.sh NAME "-DVSM_DC_BLOCK_FORM=0 -DVSM_DC_LEAF=64 ...")
+#ifndef VSM_DC_LEAF
+#define VSM_DC_LEAF 16
+#endif
+#ifndef VSM_DC_KD_ON_GPU
+#define VSM_DC_KD_ON_GPU 1
+#endif
+#ifndef VSM_DC_BLOCK_FORM
+#define VSM_DC_BLOCK_FORM 1
+#endif
+#ifndef VSM_DC_TOP
+#define VSM_DC_TOP 240
+#endif
+#ifndef VSM_DC_TIES_ON_GPU
+#define VSM_DC_TIES_ON_GPU 0
+#endif
+  const VsmSwitches &sw = h->sw;
+  const bool dc_env = sw.dc_gpu != 0;
+  const bool dc_forced = sw.dc_gpu > 0;
+  const int dc_leaf = std::max(3, VSM_DC_LEAF);
+  const bool dc_kd = VSM_DC_KD_ON_GPU != 0;      // kd order of the keys on the GPU too
+  const bool dc_block = VSM_DC_BLOCK_FORM != 0;  // k_dc_block instead of leaf / top
   // (with block) the merges above the sub-trees and the support test on the GPU too: a third less host work per
   // pair, but the large merges are slow there (a dependent L2 round trip per step), so it pays when the host has
   // few cores for this rank (200 frames 1242x375, ms: 16 threads 9.1 shared / 14.2 full, 8: 12.9 / 14.9, 4: 21.5 / 18.6,
-  // 2: 33.1 / 25.8; host only: 14.0, 25.3, 43.4, 70.8); VSM_DC_FULL=0/1 decides otherwise
-  const bool dc_full = getenv("VSM_DC_FULL") ? atoi(getenv("VSM_DC_FULL")) != 0 : h->pool->size() <= 6;
-  const int dc_top = getenv("VSM_DC_TOP") ? atoi(getenv("VSM_DC_TOP")) : 240;  // merge nodes up to this size follow on the GPU
+  // 2: 33.1 / 25.8; host only: 14.0, 25.3, 43.4, 70.8); option dc_full = 0 / 1 decides otherwise
+  const bool dc_full = sw.dc_full >= 0 ? sw.dc_full != 0 : h->pool->size() <= 6;
+  const int dc_top = VSM_DC_TOP;  // merge nodes up to this size follow on the GPU
   bool dc_gpu = dc_env && !h->dc_gpu_broken;
   h->seq_hip_error.store(0);
   for (hipStream_t &st : h->dc_stream)
     if (dc_gpu && !st) dc_gpu = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;  // (stream priorities make no measurable difference)
-  // VSM_DC_TIES=1: Triangle's randomised vertex sort on the GPU too (k_dc_ties_of_keys, one wave per pair, started right
+  // -DVSM_DC_TIES_ON_GPU=1: Triangle's randomised vertex sort on the GPU too (k_dc_ties_of_keys, one wave per pair, started right
   // behind the pass-2 compaction).  Exact, and it takes 150 us per pair off the host, but one wave needs 3.2 ms for a
   // 7.4 k list (0.65 us per partition, all dependent scalar work) - longer than everything else of a chunk together, so
   // the B stage ends up waiting for it: 13.4 ms per 200 frames against 9.0.  Off unless asked for.
-  const bool dc_ties = dc_gpu && getenv("VSM_DC_TIES") && atoi(getenv("VSM_DC_TIES")) != 0;
+  const bool dc_ties = dc_gpu && VSM_DC_TIES_ON_GPU != 0;
   if (dc_ties) {
     bool ok = true;
     for (hipStream_t &st : h->tie_stream)
@@ -1461,7 +1488,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   // host pool has nothing to do until the first chunk's lists exist, and nothing overlaps the last chunk's final stage
   std::vector<int32_t> chunk_start;
   {
-    const bool taper = !(getenv("VSM_SEQ_TAPER") && atoi(getenv("VSM_SEQ_TAPER")) == 0);
+    const bool taper = true;
     const int32_t half = C / 2;
     int32_t f = 0;
     if (taper && half >= 8 && n_frames >= 3 * C) {
@@ -2223,7 +2250,9 @@ int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, i
     if (kernel_us) *kernel_us = ms * 1e3;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (const char *dump = getenv("VSM_DC2_DUMP")) {  // debugging aid: the first job's triangulation as the device left it
+#ifdef VSM_DC2_DUMP_FILE  // debugging aid (tools/dc2_dump.py on a -DVSM_DC2_DUMP_FILE=\"path\" build): the first job's triangulation as the device left it
+    {
+      const char *dump = VSM_DC2_DUMP_FILE;  // debugging aid: the first job's triangulation as the device left it
       int32_t mn[2] = {0, 0};
       (void)hipMemcpy(mn, B.pp[0].mn, 8, hipMemcpyDeviceToHost);
       const int32_t mm = std::max(mn[0], 0);
@@ -2240,6 +2269,7 @@ int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, i
         fclose(f);
       }
     }
+#endif
     if (ok && *B.h_error) {
       result = -2;
     } else if (ok) {

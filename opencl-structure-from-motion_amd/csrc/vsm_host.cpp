@@ -9,6 +9,12 @@
 #include <chrono>
 #if defined(__x86_64__)
 #include <immintrin.h>
+
+// VSM_DEBUG_TIMING: phase times on stderr (read once)
+static bool vsm_host_debug_timing() {
+  static const bool on = getenv("VSM_DEBUG_TIMING") != nullptr;
+  return on;
+}
 #endif
 
 // =======================================================================================
@@ -22,7 +28,6 @@ static inline void cpu_relax() {
 
 VsmPool::VsmPool(int threads) : nthreads_(threads < 1 ? 1 : threads) {
   spin_us_ = 100;  // millisecond-sized tasks: a wake-up is cheap next to them, spinning burns quota
-  if (const char *e = getenv("VSM_POOL_SPIN_US")) spin_us_ = atoi(e);
   for (int i = 1; i < nthreads_; i++) threads_.emplace_back([this] { worker(); });
 }
 
@@ -132,7 +137,6 @@ void VsmPool::run(int ntasks, const std::function<void(int)> &fn) {
 // VsmForkJoin: lock-free fork-join for the fine-grained phases inside one Delaunay
 // ---------------------------------------------------------------------------------------
 VsmForkJoin::VsmForkJoin(int threads) : nthreads_(threads < 1 ? 1 : threads) {
-  if (const char *e = getenv("VSM_HOST_SPIN_US")) spin_us_ = atoi(e);
   for (int i = 1; i < nthreads_; i++) threads_.emplace_back([this] { worker(); });
 }
 
@@ -680,8 +684,11 @@ void ExactDelaunay::solve_merges() {
 
 void ExactDelaunay::solve_tasks(VsmForkJoin *pool) {
   const DcMesh mesh = this->mesh();
-  // (VSM_DC_ITER=1: the explicit-stack form the GPU lanes use, dc_build_iter - a test switch, same result)
-  static const bool iter = getenv("VSM_DC_ITER") && atoi(getenv("VSM_DC_ITER")) != 0;
+  // (-DVSM_DC_ITER=1: the explicit-stack form the GPU lanes use, dc_build_iter - same result)
+#ifndef VSM_DC_ITER
+#define VSM_DC_ITER 0
+#endif
+  constexpr bool iter = VSM_DC_ITER != 0;
   auto one = [&](int t) {
     Node &nd = nodes_[tasks_[t].node];
     if (iter)
@@ -772,7 +779,7 @@ void ExactDelaunay::apply_ties() {
 }
 
 void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJoin *pool, VsmPool *async) {
-  static const bool dbg = getenv("VSM_DEBUG_TIMING") != nullptr;
+  static const bool dbg = vsm_host_debug_timing();
   const int nthreads = pool ? pool->size() : 1;
   // one task (the whole array) when single-threaded, about one sub-tree per thread otherwise
   int32_t max_task = n;
@@ -957,7 +964,7 @@ void vsm_host_remove_outliers_from(VsmHostWork &w, const vsm_params &p, const vs
     return;
   }
   vsm_host_outliers_begin(w, in, n, method);
-  static const bool dbg = getenv("VSM_DEBUG_TIMING") != nullptr;
+  static const bool dbg = vsm_host_debug_timing();
   const auto c0 = std::chrono::steady_clock::now();
   w.del.run(w.x.data(), w.y.data(), n, w.pool, w.async);
   const auto c1 = std::chrono::steady_clock::now();
@@ -1154,7 +1161,6 @@ class LibcRandStream {
 
  private:
   static bool self_test() {
-    if (getenv("VSM_PLAIN_RAND")) return false;
     char *probe = park_;
     char *old = initstate(20240229u, probe, sizeof(park_));
     if (!old) return false;

@@ -1344,7 +1344,7 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
       brank = better ? ork : brank;
     }
   }
-  if (!RELOAD) return bestq;  // (the staged form: the next stage's kernel fetches the winner)
+  if (!RELOAD) return bestq;
   if (bestq == VSM_NONE) {  // group-uniform
     q = load_query(B, 0);
     return VSM_NONE;
@@ -1530,137 +1530,6 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
     }
   }
 #endif
-}
-
-// The same chains, one kernel per stage (VSM_MATCH_STAGED=1, an experiment): a stage keeps only its own query in registers
-// (68-84 VGPRs, 5-7 waves per SIMD instead of 106 / 4) and the double-precision distance term is compiled only into the
-// stages that can have a prediction.  Measured on MI355X, 50 pairs per launch: 155 us for the four stage kernels against
-// 122 us for the single launch - occupancy is not what bounds the chain (texture addresser 33 % busy, VALU 39 %); the
-// extra state round trip per stage and four ramp-ups / tails cost more than the resident waves win.  State between stages: one word per query and stage in the query's own result
-// slot pair.raw[qi] (nobody else reads it before the last stage writes the record): winner position | class << 30, position
-// VSM_CHAIN_NONE = empty window, i.e. feature 0 of the searched set (viso/matcher.cpp:898), whose class the word carries.
-// KIND: 0..3 = the four stages of a quad chain (:1088-1153), 4,5 = flow (:1006-1041), 6,7 = stereo (:1045-1084).
-#define VSM_CHAIN_NONE 0x3fffffffu
-__device__ __forceinline__ uint32_t chain_uv(const VsmSet &B, uint32_t st) {  // packed coordinates of a stage's winner
-  const uint32_t pos = st & VSM_CHAIN_NONE;
-  if (pos == VSM_CHAIN_NONE) {
-    const int4 hd = ldg_i4(B.feat);
-    return (uint32_t)hd.x | ((uint32_t)hd.y << 16);
-  }
-  return ldg_u32(B.s_uv + pos);
-}
-__device__ __forceinline__ int chain_index(const VsmSet &B, uint32_t st) {
-  const uint32_t pos = st & VSM_CHAIN_NONE;
-  return pos == VSM_CHAIN_NONE ? 0 : ldg_i32(B.s_idx + pos);
-}
-
-template <int G, int KIND>
-__global__ void __launch_bounds__(VSM_MATCH_BLOCK)
-    k_chain(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs, VsmJob job0,
-            VsmDims d, VsmMatchCfg cfg, int nbx, int npairs) {
-  constexpr bool QUAD = KIND < 4, FLOWM = KIND == 4 || KIND == 5;
-  constexpr int STAGE = QUAD ? KIND : (KIND & 1);  // 0-based stage within the chain
-  constexpr bool FIRST = STAGE == 0, LAST = QUAD ? STAGE == 3 : STAGE == 1;
-  constexpr bool FLOW = QUAD ? (STAGE == 1 || STAGE == 3) : FLOWM;  // window in both axes (else +-disp_tol rows)
-  constexpr bool MAYPRED = QUAD && FLOW;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int pj = lb / nbx, bx = lb - pj * nbx;
-  if (pj >= npairs) return;
-  const VsmJob &jb = jobs ? jobs[pj] : job0;
-  const VsmPair &pair = pairs[pj];
-  const int lane = threadIdx.x & (G - 1);
-  const int qi = (bx * blockDim.x + threadIdx.x) / G;
-  const int si = cfg.sparse ? 0 : 1;
-  if (qi >= jb.nq[si]) return;
-  const VsmSet &s1p = imgs[jb.img_prev].set[si], &s2p = imgs[jb.img_prev + 1].set[si];
-  const VsmSet &s1c = imgs[jb.img_curr].set[si], &s2c = imgs[jb.img_curr + 1].set[si];
-  // A: the set the chain starts in; P: the set the previous stage searched; B: the set this stage searches
-  const VsmSet &A = QUAD ? s1p : s1c;
-  const VsmSet &P = QUAD ? (STAGE == 1 ? s2p : (STAGE == 2 ? s2c : s1c)) : (FLOWM ? s1p : s2c);
-  const VsmSet &B = QUAD ? (STAGE == 0 ? s2p : (STAGE == 1 ? s2c : (STAGE == 2 ? s1c : s1p))) : (STAGE == 1 ? s1c : (FLOWM ? s1p : s2c));
-  uint32_t *st = (uint32_t *)(pair.raw + qi);
-  const bool prior = cfg.use_prior != 0;
-  VsmQuery q;
-  int u0, v0;
-  if (FIRST) {
-    q = load_query(A, qi);
-    u0 = q.u();
-    v0 = q.v();
-  } else {
-    const uint32_t prev = ldg_u32(st + STAGE - 1);
-    const int4 hd = ldg_i4(A.feat + (size_t)qi * 12);
-    u0 = hd.x;
-    v0 = hd.y;
-    const uint32_t pos = prev & VSM_CHAIN_NONE;
-    if (pos == VSM_CHAIN_NONE) {
-      q = load_query(P, 0);
-    } else {
-      q.uv = ldg_u32(P.s_uv + pos);
-      q.da = ldg_u4(P.s_desc + 2 * pos);
-      q.db = ldg_u4(P.s_desc + 2 * pos + 1);
-    }
-    q.c = (int)(prev >> 30);
-  }
-  float4 r = make_float4(0, 0, 0, 0);
-  if (prior) {
-    const uint4 rr = ldg_u4(pair.ranges + 16 * stat_bin_of(u0, v0, cfg, d.ub, d.vb) + 4 * STAGE);
-    r = make_float4(__uint_as_float(rr.x), __uint_as_float(rr.y), __uint_as_float(rr.z), __uint_as_float(rr.w));
-  }
-  double u_ = -1, v_ = -1;
-  if (MAYPRED && jb.use_tr) {
-    if (STAGE == 1) {  // :1114-1126, contraction-free double arithmetic
-      double dd = (double)u0 - (double)q.u();
-      if (!(dd > 1.0)) dd = 1.0;
-      double x1p = ((double)u0 - cfg.cu) * cfg.base / dd;
-      double y1p = ((double)v0 - cfg.cv) * cfg.base / dd;
-      double z1p = cfg.f * cfg.base / dd;
-      double x2c = jb.t[0] * x1p + jb.t[1] * y1p + jb.t[2] * z1p + jb.t[3] - cfg.base;
-      double y2c = jb.t[4] * x1p + jb.t[5] * y1p + jb.t[6] * z1p + jb.t[7];
-      double z2c = jb.t[8] * x1p + jb.t[9] * y1p + jb.t[10] * z1p + jb.t[11];
-      u_ = cfg.f * x2c / z2c + cfg.cu;
-      v_ = cfg.f * y2c / z2c + cfg.cv;
-    } else {  // stage 4 predicts the chain's own start (:1134)
-      u_ = (double)u0;
-      v_ = (double)v0;
-    }
-  }
-  const int cq = q.c;
-  const uint32_t p = find_match<G, false, MAYPRED>(q, B, d, cfg, prior, r.x, r.y, r.z, r.w, FLOW, MAYPRED ? u_ : -1.0, MAYPRED ? v_ : -1.0, lane);
-  if (!LAST) {
-    if (lane == 0) {
-      uint32_t w = p | ((uint32_t)cq << 30);
-      if (p == VSM_NONE) w = VSM_CHAIN_NONE | ((uint32_t)ldg_i32(B.feat + 3) << 30);  // feature 0 of B, class included
-      st[STAGE] = w;
-    }
-    return;
-  }
-  if (lane != 0) return;
-  const uint32_t last = p == VSM_NONE ? VSM_CHAIN_NONE : p;
-  bool ok = chain_index(B, last) == qi;
-  vsm_p_match m;
-  if (QUAD) {
-    if (ok) {
-      const uint32_t t0 = st[0], t1 = st[1], t2 = st[2];
-      const uint32_t w2p = chain_uv(s2p, t0), w2c = chain_uv(s2c, t1), w1c = chain_uv(s1c, t2);
-      const int u2p = (int)(w2p & 0xffffu), u2c = (int)(w2c & 0xffffu), u1c = (int)(w1c & 0xffffu);
-      ok = (u0 >= u2p) && (u1c >= u2c);
-      if (ok)
-        m = {(float)u0, (float)v0, qi, (float)u2p, (float)(int)(w2p >> 16), chain_index(s2p, t0), (float)u1c,
-             (float)(int)(w1c >> 16), chain_index(s1c, t2), (float)u2c, (float)(int)(w2c >> 16), chain_index(s2c, t1)};
-    }
-  } else if (ok) {
-    const uint32_t t0 = st[0];
-    const uint32_t w = chain_uv(P, t0);
-    const int uw = (int)(w & 0xffffu), vw = (int)(w >> 16), iw = chain_index(P, t0);
-    if (FLOWM) {
-      m = {(float)uw, (float)vw, iw, -1.f, -1.f, -1, (float)u0, (float)v0, qi, -1.f, -1.f, -1};
-    } else {
-      ok = u0 >= uw;
-      m = {-1.f, -1.f, -1, -1.f, -1.f, -1, (float)u0, (float)v0, qi, (float)uw, (float)vw, iw};
-    }
-  }
-  pair.flag[qi] = ok ? 1 : 0;
-  if (ok) pair.raw[qi] = m;
 }
 
 // ordered compaction of the accepted queries (push_back order = ascending query index) with the
@@ -2351,14 +2220,8 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
                       const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq) {
   // lanes per query: the chain is latency-bound per wavefront, so big batches want many
   // queries per wave (G = 2..4) and a lone frame pair wants more lanes per query (G = 8).
-  // VSM_MATCH_G overrides (2, 4, 8, 16) for experiments.
-  int Genv = 0;  // (read on every call: the tests switch it inside one process)
-  if (const char *e = getenv("VSM_MATCH_G")) {
-    Genv = atoi(e);
-    if (Genv != 1 && Genv != 2 && Genv != 4 && Genv != 8 && Genv != 16) Genv = 0;
-  }
   const long total_q = (long)npairs * max_nq;
-  const int G = Genv ? Genv : (total_q >= 200000 ? 2 : (total_q >= 30000 ? 4 : 8));
+  const int G = total_q >= 200000 ? 2 : (total_q >= 30000 ? 4 : 8);
   const int pass = cfg.sparse ? 0 : 1;
   if (max_nq > 0) {
     pf.begin(cfg.sparse ? VSM_K_MATCH1 : VSM_K_MATCH2, s);
@@ -2372,33 +2235,7 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
     else                                                                                                                           \
       hipLaunchKernelGGL((k_match<GG, true>), grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);  \
   } while (0)
-    // VSM_MATCH_STAGED=1: one kernel per stage (k_chain) - measured slower than the single launch, kept for experiments
-    const char *se = getenv("VSM_MATCH_STAGED");
-    const bool staged = se && atoi(se) != 0;
-    if (staged && (G == 2 || G == 4 || G == 8)) {
-#define VSM_CHAIN_LAUNCH(GG, KIND) \
-  hipLaunchKernelGGL((k_chain<GG, KIND>), grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs)
-#define VSM_CHAIN_ALL(GG)                                                           \
-  if (cfg.method == 2) {                                                            \
-    VSM_CHAIN_LAUNCH(GG, 0);                                                        \
-    VSM_CHAIN_LAUNCH(GG, 1);                                                        \
-    VSM_CHAIN_LAUNCH(GG, 2);                                                        \
-    VSM_CHAIN_LAUNCH(GG, 3);                                                        \
-  } else if (cfg.method == 0) {                                                     \
-    VSM_CHAIN_LAUNCH(GG, 4);                                                        \
-    VSM_CHAIN_LAUNCH(GG, 5);                                                        \
-  } else {                                                                          \
-    VSM_CHAIN_LAUNCH(GG, 6);                                                        \
-    VSM_CHAIN_LAUNCH(GG, 7);                                                        \
-  }
-      if (G == 2) {
-        VSM_CHAIN_ALL(2)
-      } else if (G == 4) {
-        VSM_CHAIN_ALL(4)
-      } else {
-        VSM_CHAIN_ALL(8)
-      }
-    } else if (G == 1)
+    if (G == 1)
       VSM_MATCH_LAUNCH(1);
     else if (G == 2)
       VSM_MATCH_LAUNCH(2);

@@ -199,7 +199,7 @@ struct MonoGpu {  // device side of one estimator
   bool init() {
     ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
          hipMalloc((void **)&d_chir, sizeof(int32_t) * 4) == hipSuccess;
-    if (ok) svd_on_device = getenv("VSM_MONO_HOST_SVD") ? false : self_test();
+    if (ok) svd_on_device = self_test();
     return ok;
   }
   // 64 random hypotheses through k_mono_fit against the host's vsm_linalg.h

@@ -373,7 +373,9 @@ class Matcher:
 
     _inputs = None
 
-    def __init__(self, stage_capture=False, **params):
+    def __init__(self, stage_capture=False, options=None, **params):
+        """params: fields of the reference's Matcher::parameters; options: measurement / test switches of the handle
+        (vsm_set_option: "seq_chunk", "dc_gpu", ...), applied right after creation"""
         L = lib()
         p = default_params()
         for k, v in params.items():
@@ -387,6 +389,8 @@ class Matcher:
         self.h = C.c_void_p(self.h)
         if stage_capture:
             L.vsm_set_stage_capture(self.h, 1)
+        for k, v in (options or {}).items():
+            self.set_option(k, int(v))
 
     # --- reference API -------------------------------------------------------------------
     def set_intrinsics(self, f, cu, cv, base):

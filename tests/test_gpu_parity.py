@@ -80,9 +80,8 @@ def test_golden_cfg5_highres_lookahead_gpu_final_stage(vm, synth, monkeypatch, f
     g = G.load("cfg5_2048x1024_quad")
     w, h, nf, method = int(g["w"]), int(g["h"]), int(g["n_frames"]), int(g["method"])
     seq = synth.stereo_sequence(int(g["seed"]), w, h, nf, blur=int(g["blur"]))
-    monkeypatch.setenv("VSM_DC_GPU", "1")
-    monkeypatch.setenv("VSM_DC_FULL", full)
-    m = vm.Matcher()
+    opt = {"dc_gpu": 1, "dc_full": int(full)}
+    m = vm.Matcher(options=opt)
     got = m.run_sequence(np.stack([l for l, _ in seq]), np.stack([r for _, r in seq]), method)
     for f in range(nf):
         assert len(got[f]) == int(g["counts"][f][-1]) and G.sha(got[f]) == str(g["hashes"][f][-1]), f
@@ -105,9 +104,8 @@ def test_golden_cfg5_as_specified_20k_lookahead(vm, synth, monkeypatch, form):
     seq = synth.stereo_sequence(int(g["seed"]), w, h, nf, blur=int(g["blur"]))
     monkeypatch.setenv("VSM_SEQ_CHUNK", "3")
     monkeypatch.setenv("VSM_SEQ_V2", "1" if form == "GPU-resident" else "0")
-    monkeypatch.setenv("VSM_DC_GPU", "1")
-    monkeypatch.setenv("VSM_DC_FULL", "1" if "all on the GPU" in form else "0")
-    m = vm.Matcher()
+    opt = {"dc_gpu": 1, "dc_full": 1 if "all on the GPU" in form else 0}
+    m = vm.Matcher(options=opt)
     left = torch.from_numpy(np.stack([l for l, _ in seq])).cuda()
     right = torch.from_numpy(np.stack([r for _, r in seq])).cuda()
     got = m.run_sequence(left, right, method)
@@ -242,13 +240,13 @@ def test_sequence_api_equals_frame_by_frame(vm, B, synth, monkeypatch, method, c
     whole path (lists stay in HBM, removeOutliers + prior statistics as device kernels)"""
     monkeypatch.setenv("VSM_SEQ_CHUNK", chunk)
     monkeypatch.setenv("VSM_SEQ_V2", "1" if final_stage == "GPU-resident form" else "0")
+    opt = {}
     if final_stage not in ("as it comes", "GPU-resident form"):
-        monkeypatch.setenv("VSM_DC_GPU", "1")
-        monkeypatch.setenv("VSM_DC_FULL", "1" if final_stage == "all on the GPU" else "0")
+        opt = {"dc_gpu": 1, "dc_full": 1 if final_stage == "all on the GPU" else 0}
     seq = synth.stereo_sequence(31, 417, 163, 7, disparity=10, ramp=(1, 12))
     left = np.stack([l for l, _ in seq])
     right = np.stack([r for _, r in seq])
-    g = vm.Matcher()
+    g = vm.Matcher(options=opt)
     got = g.run_sequence(left, right, method)
     assert g.sequence_path() == (2 if final_stage == "GPU-resident form" else 1)
     c = B.CpuMatcher("oracle")
@@ -268,14 +266,14 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
     import torch
     monkeypatch.setenv("VSM_SEQ_CHUNK", chunk)
     monkeypatch.setenv("VSM_SEQ_V2", "1" if form == "GPU-resident" else "0")
-    monkeypatch.setenv("VSM_DC_GPU", "1")   # (chunks with fewer pairs than host threads would stay on the host)
+    opt = {"dc_gpu": 1}   # (chunks with fewer pairs than host threads would stay on the host)
     g = G.load("cfg2_seq200_tr")
     w, h, nf = int(g["w"]), int(g["h"]), 60
     cv = synth.canvas(int(g["seed"]), w, h)
     fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
     left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
     right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
-    m = vm.Matcher()
+    m = vm.Matcher(options=opt)
     m.set_intrinsics(*[float(x) for x in g["intr"]])
     got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
     for f in range(nf):
@@ -287,11 +285,11 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
                                  {"VSM_SEQ_EARLY_EXPORT": "1", "VSM_HOST_THREADS": "2"}, {"VSM_SEQ_DC_STREAMS": "1"},
                                  {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNK": "5"}, {"VSM_SEQ_CHUNK": "2", "VSM_SEQ_EARLY_EXPORT": "0"},
                                  {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
-                                 {"VSM_MATCH_STAGED": "1"}, {"VSM_FRONT": "0"}, {"VSM_MATCH_G": "8"}])
+                                 {"VSM_FRONT": "0"}])
 def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), both ways of
     result delivery at both ends of the pool size, one / four chain streams (eight chunks of five, twenty of two: every bank
-    comes round), the vertex sorts on the device, one matching kernel per chain stage, the unfused front end, eight lanes per query: always
+    comes round), the vertex sorts on the device, the unfused front end: always
     the reference's lists, and always this form (it must not quietly hand the run to the other one)."""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1")
@@ -345,11 +343,11 @@ def test_sequence_api_single_stage(vm, B, synth, monkeypatch, method, form):
     forms, flow / stereo / quad: the GPU-resident form then has no first-pass chain (and no first-pass slab) at all"""
     monkeypatch.setenv("VSM_SEQ_CHUNK", "3")
     monkeypatch.setenv("VSM_SEQ_V2", "1" if form == "GPU-resident" else "0")
-    monkeypatch.setenv("VSM_DC_GPU", "1")
+    opt = {"dc_gpu": 1}
     seq = synth.stereo_sequence(33, 417, 163, 7, disparity=10, ramp=(1, 12))
     left = np.stack([l for l, _ in seq])
     right = np.stack([r for _, r in seq])
-    g = vm.Matcher(multi_stage=0)
+    g = vm.Matcher(multi_stage=0, options=opt)
     got = g.run_sequence(left, right, method)   # (stereo input also for flow matching: mono input goes frame by frame)
     assert g.sequence_path() == (2 if form == "GPU-resident" else 1)
     c = B.CpuMatcher("oracle", multi_stage=0)
@@ -420,19 +418,15 @@ def test_sequence_forms_alternate_on_one_handle(vm, B, synth):
     g.close()
 
 
-@pytest.mark.parametrize("env", [{"VSM_DC_GPU": "0"}, {"VSM_DC_FULL": "1"}, {"VSM_DC_FULL": "0"}, {"VSM_DC_FULL": "0", "VSM_DC_TIES": "1"}, {"VSM_DC_FULL": "1", "VSM_DC_KD": "0"},
-                                 {"VSM_DC_BLOCK": "0"}, {"VSM_DC_BLOCK": "0", "VSM_DC_KD": "0"},
-                                 {"VSM_DC_KD": "0"}, {"VSM_DC_BLOCK": "0", "VSM_DC_LEAF": "64", "VSM_DC_TOP": "0"},
-                                 {"VSM_DC_BLOCK": "0", "VSM_DC_LEAF": "5", "VSM_DC_TOP": "100000"}])
-def test_sequence_api_final_stage_variants(vm, synth, monkeypatch, env):
-    """the ways the exact Delaunay of the look-ahead final stage can be shared between host and GPU (host only;
-    everything after the sort on the GPU; sub-trees per thread + merge levels; kd order on either side; the last
-    one overflows the level table and falls back to the host pair by pair) all give the reference's lists"""
+@pytest.mark.parametrize("opt", [{"dc_gpu": 0}, {"dc_gpu": 1, "dc_full": 1}, {"dc_gpu": 1, "dc_full": 0}, {"dc_gpu": 1}, {}])
+def test_sequence_api_final_stage_variants(vm, synth, monkeypatch, opt):
+    """the ways the exact Delaunay of the host-shared look-ahead form can be shared between host and GPU (host only;
+    everything after the sort on the GPU; block sub-trees on the GPU and the merges above them on the host; forced or
+    left to the chunk size) all give the reference's lists.  (Round 1's further sub-variants of this form are compile-time
+    choices of csrc/vsm_api.cpp now.)"""
     import torch
-    monkeypatch.setenv("VSM_DC_GPU", "1")   # (chunks with fewer pairs than host threads would stay on the host)
     monkeypatch.setenv("VSM_SEQ_V2", "0")
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    env = opt
     g = G.load("cfg2_seq200_tr")
     w, h, nf = int(g["w"]), int(g["h"]), 24
     cv = synth.canvas(int(g["seed"]), w, h)
@@ -440,7 +434,7 @@ def test_sequence_api_final_stage_variants(vm, synth, monkeypatch, env):
     left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
     right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
     monkeypatch.setenv("VSM_SEQ_CHUNK", "10")
-    m = vm.Matcher()
+    m = vm.Matcher(options=opt)
     m.set_intrinsics(*[float(x) for x in g["intr"]])
     got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
     for f in range(nf):
@@ -453,7 +447,7 @@ def test_two_matchers_in_two_threads(vm, synth, monkeypatch):
     with its own handle, host pool and streams, both with the final stage on the GPU share"""
     import threading
     import torch
-    monkeypatch.setenv("VSM_DC_GPU", "1")
+    opt = {"dc_gpu": 1}
     monkeypatch.setenv("VSM_SEQ_CHUNK", "12")
     g = G.load("cfg2_seq200_tr")
     w, h, nf = int(g["w"]), int(g["h"]), 36
@@ -464,7 +458,7 @@ def test_two_matchers_in_two_threads(vm, synth, monkeypatch):
     out = [None, None]
 
     def work(k):
-        m = vm.Matcher()
+        m = vm.Matcher(options=opt)
         m.set_intrinsics(*[float(x) for x in g["intr"]])
         for _ in range(3):
             out[k] = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
@@ -1049,11 +1043,11 @@ def test_all_eight_sequences_of_config_4_on_one_gpu(vm, synth, monkeypatch, form
     reference's hashes (tests/golden/cfg4_seq200_tr_8seeds.npz)"""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1" if form == "GPU-resident" else "0")
-    monkeypatch.setenv("VSM_DC_GPU", "1")
+    opt = {"dc_gpu": 1}
     monkeypatch.setenv("VSM_SEQ_CHUNK", "20")
     g = G.load("cfg4_seq200_tr_8seeds")
     w, h, nf = 1242, 375, 40
-    m = vm.Matcher()
+    m = vm.Matcher(options=opt)
     m.set_intrinsics(*[float(x) for x in g["intr"]])
     for seed in range(1234, 1242):
         key = f"s{seed}"
@@ -1109,13 +1103,11 @@ def test_inputs_produced_asynchronously_on_another_stream(vm, B, synth):
 
 def test_lost_completion_callback_of_the_delaunay_share(vm, synth, monkeypatch):
     """host-shared look-ahead form, fault injection: the host function that reports the end of the GPU's share of a
-    chunk's Delaunay stage never runs (VSM_DC_FAULT_INJECT=1).  dc_wait()'s watchdog (shortened to 0.3 s) synchronises the
+    chunk's Delaunay stage never runs (option dc_fault_inject = 1).  dc_wait()'s watchdog (shortened to 0.3 s) synchronises the
     stream, finds it healthy and carries on with the device's results: same lists, no error"""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "0")
-    monkeypatch.setenv("VSM_DC_GPU", "1")
-    monkeypatch.setenv("VSM_DC_FAULT_INJECT", "1")
-    monkeypatch.setenv("VSM_DC_WATCHDOG_MS", "300")
+    opt = {"dc_gpu": 1, "dc_fault_inject": 1, "dc_watchdog_ms": 300}
     monkeypatch.setenv("VSM_SEQ_CHUNK", "10")
     g = G.load("cfg2_seq200_tr")
     w, h, nf = int(g["w"]), int(g["h"]), 20
@@ -1123,7 +1115,7 @@ def test_lost_completion_callback_of_the_delaunay_share(vm, synth, monkeypatch):
     fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
     left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
     right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
-    m = vm.Matcher()
+    m = vm.Matcher(options=opt)
     m.set_intrinsics(*[float(x) for x in g["intr"]])
     got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
     for f in range(nf):

@@ -7,7 +7,7 @@ synth = importlib.import_module("opencl-structure-from-motion_amd.synth")
 cv = synth.canvas(1234, 1242, 375)
 fr = [synth.stereo_frame(cv, f, 1242, 375) for f in range(60)]
 L = torch.from_numpy(np.stack([l for l, _ in fr])).cuda(); R = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
-os.environ["VSM_DC_GPU"] = "1"
+
 def rss(): return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024
 for it in range(12):
     m = vm.Matcher()
