@@ -1102,7 +1102,7 @@ __device__ __forceinline__ VsmQuery load_query(const VsmSet &A, int i) {
 // winner's feature index is only looked up once, at the end of the chain.  An empty window
 // yields feature 0 of B like the reference (min_ind = 0, :898), class included.
 #ifndef VSM_UVL
-#define VSM_UVL 2  // 16-byte coordinate loads in flight per lane
+#define VSM_UVL 1  // 16-byte coordinate loads in flight per lane (two cost the registers of the fifth wave per SIMD: 71 -> 56 us for the first pass, 180 -> 175 for the second)
 #endif
 #ifndef VSM_MATCH_BLOCK
 #define VSM_MATCH_BLOCK 256  // threads per block of k_match
@@ -1365,7 +1365,7 @@ __device__ __forceinline__ int stat_bin_of(int u, int v, const VsmMatchCfg &cfg,
 __device__ __forceinline__ int index_of(const VsmSet &B, uint32_t pos) { return pos == VSM_NONE ? 0 : ldg_i32(B.s_idx + pos); }
 
 #ifndef VSM_MATCH_WAVES
-#define VSM_MATCH_WAVES 4  // waves per SIMD the register allocator must leave room for
+#define VSM_MATCH_WAVES 5  // waves per SIMD the register allocator must leave room for (96 registers, no scratch; six would spill)
 #endif
 #ifdef VSM_MATCH_TIMING  // experiments (tools/build_variant.sh NAME -DVSM_MATCH_TIMING): life of every wave of the dense pass
 __device__ unsigned long long vsm_mt_acc[16];  // wave-level trip counts: [0] ubin iterations, [1] scan iterations, [2] judge rounds, [3] findMatch calls, [4..7] cycles of stage 1..4

@@ -389,7 +389,9 @@ class Matcher:
         self.h = C.c_void_p(self.h)
         if stage_capture:
             L.vsm_set_stage_capture(self.h, 1)
-        for k, v in (options or {}).items():
+        # (tools: VSM_PY_OPTIONS="seq_fstreams=2,seq_chunk=50" reaches handles created by scripts that pass no options)
+        env_opts = dict(kv.split("=") for kv in os.environ.get("VSM_PY_OPTIONS", "").split(",") if "=" in kv)
+        for k, v in {**env_opts, **(options or {})}.items():
             self.set_option(k, int(v))
 
     # --- reference API -------------------------------------------------------------------
