@@ -30,7 +30,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")   # before anything initialises HIP: see visomatch.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")   # before anything initialises HIP: see visomatch.py
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -306,6 +306,18 @@ def main():
     dom_all = max((k for k in stats if stats[k][1] and k != "k_export_list"), key=lambda k: stats[k][0])
     gpu_total_ms = sum(v[0] for k, v in stats.items() if k != "k_export_list")
     dom_ms, dom_n = stats[dom]
+    # The dominant kernel once more, in the pipeline, with spans around ITS launches only: a span is two event records on the
+    # kernel's stream, and with every kernel of every stream bracketed the side streams are never empty of such packets -
+    # which slows whatever runs beside them (tools/l2_invalidate_probe.py: bare event records on another stream, back to
+    # back, take k_match from 177 to 219 us, k_refine from 100 to 155).  The roofline figure below is this measurement; the
+    # all-kernels pass keeps its (perturbed) figure beside it.
+    m.set_profiling(True, only=dom)
+    for _ in range(3):
+        run_sequence()
+    torch.cuda.synchronize()
+    dom_only = m.kernel_stats()[dom]
+    m.set_profiling(False)
+    dom_only = (dom_only[0] / 3.0, dom_only[1] // 3)
     # per-launch work counters of the dominant kernel from one representative frame pair
     # (features/candidates are stationary over this sequence)
     P, Ph, Hh = W + 15 - (W - 1) % 16, (W // 2) + 15 - ((W // 2) - 1) % 16, H // 2
@@ -375,8 +387,18 @@ def main():
                           "what": "same kernel, same data, nothing else on the GPU (VSM_SEQ_SERIAL=1 pass)"}
         return r
 
-    roof = roofline_of(dom)
     roof_all = {k: r for k in stats if stats[k][1] for r in [roofline_of(k)] if r}
+    roof = roofline_of(dom)
+    if roof is not None and dom_only[1]:
+        every = {"avg_launch_us": roof["avg_launch_us"], "achieved": roof["achieved"], "frac": roof["frac"],
+                 "what": "the same kernel in the pass that brackets EVERY kernel of every stream with event records (the by-kernel table): "
+                         "those records are packets on six streams and slow what they measure"}
+        stats_dom_all = stats[dom]
+        stats[dom] = dom_only
+        roof = roofline_of(dom)
+        stats[dom] = stats_dom_all
+        roof["measured"] = "HIP events around this kernel's launches only, on its stream, in the pipeline of the timed call (3 calls)"
+        roof["with_every_kernel_profiled"] = every
     if roof is not None:
         roof["traffic_source"] = pmc_src
         da = roof_all.get(dom_all)

@@ -369,7 +369,7 @@ struct DcBank {
 struct VsmSwitches {
   int seq_v2 = 1;          // VSM_SEQ_V2: 0 = the host-shared look-ahead form
   int seq_chunk = 0;       // VSM_SEQ_CHUNK: frames per look-ahead chunk (0 = by host threads)
-  int seq_dc_streams = 3;  // VSM_SEQ_DC_STREAMS: streams the final chains rotate over (1..4)
+  int seq_dc_streams = 3;  // VSM_SEQ_DC_STREAMS: side streams of the GPU-resident form (1..3; with the main and the null stream: five hardware queues)
   int seq_serial = 0;      // VSM_SEQ_SERIAL: nothing overlaps (every kernel's time alone)
   int seq_gpu_sorts = -1;  // VSM_SEQ_GPU_SORTS: percent of a chunk's vertex sorts done on the device (-1 = by host threads)
   int front = 1;           // VSM_FRONT: the fused front end
@@ -387,7 +387,7 @@ struct VsmSwitches {
   void from_environment() {
     seq_v2 = env_int("VSM_SEQ_V2", 1) != 0;
     seq_chunk = std::max(0, env_int("VSM_SEQ_CHUNK", 0));
-    seq_dc_streams = std::min(4, std::max(1, env_int("VSM_SEQ_DC_STREAMS", 3)));
+    seq_dc_streams = std::min(3, std::max(1, env_int("VSM_SEQ_DC_STREAMS", 3)));
     seq_serial = env_int("VSM_SEQ_SERIAL", 0) != 0;
     seq_gpu_sorts = env_int("VSM_SEQ_GPU_SORTS", -1);
     front = env_int("VSM_FRONT", 1) != 0;
@@ -396,7 +396,7 @@ struct VsmSwitches {
   bool set(const char *name, int v) {
     if (!strcmp(name, "seq_v2")) seq_v2 = v != 0;
     else if (!strcmp(name, "seq_chunk")) seq_chunk = std::max(0, v);
-    else if (!strcmp(name, "seq_dc_streams")) seq_dc_streams = std::min(4, std::max(1, v));
+    else if (!strcmp(name, "seq_dc_streams")) seq_dc_streams = std::min(3, std::max(1, v));
     else if (!strcmp(name, "seq_serial")) seq_serial = v != 0;
     else if (!strcmp(name, "seq_gpu_sorts")) seq_gpu_sorts = v;
     else if (!strcmp(name, "front")) front = v != 0;
@@ -1946,6 +1946,7 @@ static const char *kKernelNames[VSM_K_COUNT] = {
 
 void vsm_set_profiling(vsm_handle *h, int on) {
   h->prof.on = on != 0;
+  h->prof.only = on >= 100 ? on - 100 : -1;
   if (on) {
     memset(h->prof.total_ms, 0, sizeof(h->prof.total_ms));
     memset(h->prof.launches, 0, sizeof(h->prof.launches));

@@ -114,15 +114,24 @@ struct VsmProf {
     }
     return pool[used++];
   }
+  int only = -1;  // >= 0: spans of this kernel id only (two event records per launch of ONE kernel instead of two per launch of
+                  // every kernel on every stream: event records are packets too, and a queue that is never empty slows
+                  // whatever runs beside it - tools/l2_invalidate_probe.py)
+  static bool &skipping() {
+    static thread_local bool v = false;
+    return v;
+  }
   void begin(int id, hipStream_t s) {
     if (!on) return;
+    skipping() = only >= 0 && id != only;
+    if (skipping()) return;
     mu.lock();
     Span sp{id, get(), get()};
     (void)hipEventRecord(sp.a, s);
     open.push_back(sp);
   }
   void end(hipStream_t s) {
-    if (!on) return;
+    if (!on || skipping()) return;
     (void)hipEventRecord(open.back().b, s);
     mu.unlock();
   }
@@ -131,6 +140,7 @@ struct VsmProf {
     for (const Span &sp : open) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+        if (only >= 0) fprintf(stderr, "  span kernel %d: %.1f us\n", sp.id, ms * 1e3);  // TEMPORARY
         total_ms[sp.id] += ms;
         launches[sp.id]++;
       }

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # The look-ahead path keeps four streams busy at once (main, pass-1 chain, two final-stage chains); the HIP runtime maps
 # streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the null stream's) and streams that share a queue
 # serialise.  Read when the runtime initialises, so it only helps if nothing in this process has touched the GPU yet.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
 LIB_PATH = os.environ.get("VSM_LIB_PATH") or os.path.join(HERE, "libvisomatch.so")  # override: kernel experiments
 
 P_MATCH = np.dtype(
@@ -566,8 +566,17 @@ class Matcher:
         lib().vsm_sequence_get_timings(self.h, t.ctypes.data_as(C.c_void_p))
         return dict(zip(("gpu_us", "host_us", "total_us", "chunk"), t.tolist()))
 
-    def set_profiling(self, on):
-        lib().vsm_set_profiling(self.h, int(on))
+    def set_profiling(self, on, only=None):
+        """HIP-event spans around the library's kernels: all of them, or (only="k_match<16>:pass2") one kernel's launches
+        alone - the spans' own event records are packets on every stream and slow the pipeline they measure"""
+        L = lib()
+        if on and only is not None:
+            ids = [i for i in range(L.vsm_num_kernels()) if L.vsm_kernel_name(i).decode() == only]
+            if not ids:
+                raise VisoMatchError(f"unknown kernel {only}")
+            L.vsm_set_profiling(self.h, 100 + ids[0])
+        else:
+            L.vsm_set_profiling(self.h, int(bool(on)))
 
     def kernel_stats(self):
         """{kernel name: (total device ms, launches)} since set_profiling(True)"""

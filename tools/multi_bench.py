@@ -1,6 +1,6 @@
 import importlib, os, sys, json, time
 sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo") else os.getcwd())
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12"); os.environ.setdefault("VSM_HOST_THREADS", "14")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5"); os.environ.setdefault("VSM_HOST_THREADS", "14")
 import numpy as np, torch
 import bench
 vm = importlib.import_module("opencl-structure-from-motion_amd.visomatch")

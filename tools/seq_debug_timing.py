@@ -1,7 +1,7 @@
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12"); os.environ.setdefault("VSM_HOST_THREADS", "14"); os.environ["VSM_DEBUG_TIMING"] = "1"
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5"); os.environ.setdefault("VSM_HOST_THREADS", "14"); os.environ["VSM_DEBUG_TIMING"] = "1"
 import numpy as np, torch
 vm = importlib.import_module("opencl-structure-from-motion_amd.visomatch")
 synth = importlib.import_module("opencl-structure-from-motion_amd.synth")
