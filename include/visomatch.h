@@ -174,7 +174,7 @@ void vsm_get_timings(vsm_handle *h, double *out5);
 /* per-kernel device time measured with HIP events on the handle's own stream (bench.py's
  * roofline leg).  vsm_set_profiling(h,1) zeroes the accumulators and starts recording; vsm_set_profiling(h, 100 + id)
  * records kernel `id` only (vsm_kernel_name): every span costs two event records on the kernel's stream, and those of
- * all kernels on all streams together disturb the pipeline they measure. */
+ * all kernels on all streams together disturb the pipeline they measure (1100 + id: also prints every span on stderr). */
 void vsm_set_profiling(vsm_handle *h, int on);
 int32_t vsm_num_kernels(void);
 const char *vsm_kernel_name(int32_t id);

@@ -1946,7 +1946,8 @@ static const char *kKernelNames[VSM_K_COUNT] = {
 
 void vsm_set_profiling(vsm_handle *h, int on) {
   h->prof.on = on != 0;
-  h->prof.only = on >= 100 ? on - 100 : -1;
+  h->prof.print_spans = on >= 1100;
+  h->prof.only = on >= 1100 ? on - 1100 : (on >= 100 ? on - 100 : -1);
   if (on) {
     memset(h->prof.total_ms, 0, sizeof(h->prof.total_ms));
     memset(h->prof.launches, 0, sizeof(h->prof.launches));

@@ -114,6 +114,7 @@ struct VsmProf {
     }
     return pool[used++];
   }
+  bool print_spans = false;  // (tools/span_probe.py: every launch's span on stderr; vsm_set_profiling(h, 1100 + id))
   int only = -1;  // >= 0: spans of this kernel id only (two event records per launch of ONE kernel instead of two per launch of
                   // every kernel on every stream: event records are packets too, and a queue that is never empty slows
                   // whatever runs beside it - tools/l2_invalidate_probe.py)
@@ -140,7 +141,7 @@ struct VsmProf {
     for (const Span &sp : open) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-        if (only >= 0) fprintf(stderr, "  span kernel %d: %.1f us\n", sp.id, ms * 1e3);  // TEMPORARY
+        if (only >= 0 && print_spans) fprintf(stderr, "  span kernel %d: %.1f us\n", sp.id, ms * 1e3);
         total_ms[sp.id] += ms;
         launches[sp.id]++;
       }

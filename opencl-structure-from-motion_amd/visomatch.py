@@ -566,7 +566,7 @@ class Matcher:
         lib().vsm_sequence_get_timings(self.h, t.ctypes.data_as(C.c_void_p))
         return dict(zip(("gpu_us", "host_us", "total_us", "chunk"), t.tolist()))
 
-    def set_profiling(self, on, only=None):
+    def set_profiling(self, on, only=None, print_spans=False):
         """HIP-event spans around the library's kernels: all of them, or (only="k_match<16>:pass2") one kernel's launches
         alone - the spans' own event records are packets on every stream and slow the pipeline they measure"""
         L = lib()
@@ -574,7 +574,7 @@ class Matcher:
             ids = [i for i in range(L.vsm_num_kernels()) if L.vsm_kernel_name(i).decode() == only]
             if not ids:
                 raise VisoMatchError(f"unknown kernel {only}")
-            L.vsm_set_profiling(self.h, 100 + ids[0])
+            L.vsm_set_profiling(self.h, (1100 if print_spans else 100) + ids[0])
         else:
             L.vsm_set_profiling(self.h, int(bool(on)))
 

@@ -1,3 +1,5 @@
+"""Every launch's HIP-event span of a few main-stream kernels inside the otherwise unprofiled look-ahead pipeline (spans around
+ONE kernel at a time: the spans' own event records are packets too).  python tools/span_probe.py [kernel names]"""
 import importlib, os, sys
 ROOT="/root/repo" if os.path.isdir("/root/repo/tests") else os.environ["GRAFT_REPO_ROOT"]
 sys.path.insert(0, ROOT)
@@ -14,6 +16,6 @@ m = vm.Matcher(); m.set_intrinsics(*[float(x) for x in g["intr"]])
 for i in range(3): m.run_sequence(fr[:, 0], fr[:, 1], 2, tr, trv, fetch=False)
 for only in (sys.argv[1:] or ["k_match<16>:pass2", "k_refine", "k_compact_matches:pass2"]):
     print(only, flush=True)
-    m.set_profiling(True, only=only)
+    m.set_profiling(True, only=only, print_spans=True)
     for i in range(3): m.run_sequence(fr[:, 0], fr[:, 1], 2, tr, trv, fetch=False)
     torch.cuda.synchronize(); m.set_profiling(False)
