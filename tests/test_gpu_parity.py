@@ -313,7 +313,7 @@ def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
 
 def test_lookahead_as_shipped_200_frames(vm, synth, monkeypatch):
     """What bench.py times, as it ships: config 2 (200 frames 1242x375 resident in HBM, replayed Tr_delta) through
-    vsm_sequence_run with NO VSM_* variable set - the GPU-resident form, chunks of 67, three chain streams, the default
+    vsm_sequence_run with NO VSM_* variable set - the GPU-resident form, chunks of 80, three side streams, the default
     host pool - every frame's final list against the reference's hash, twice on one handle (banks and slabs are reused)."""
     import os
     import torch
@@ -330,7 +330,7 @@ def test_lookahead_as_shipped_200_frames(vm, synth, monkeypatch):
     for rep in range(2):
         got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
         assert m.sequence_path() == 2
-        assert int(m.sequence_timings()["chunk"]) == 67
+        assert int(m.sequence_timings()["chunk"]) == 80
         for f in range(nf):
             assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), (rep, f)
     m.close()
@@ -440,6 +440,29 @@ def test_sequence_api_final_stage_variants(vm, synth, monkeypatch, opt):
     for f in range(nf):
         assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), (env, f)
     m.close()
+
+
+def test_lookahead_calls_complete_under_pool_races(vm, synth):
+    """120 look-ahead calls back to back with chunk sizes that shift what the pool's tasks overlap with (the chain's completion
+    is seen by a pool task that asks an event; a chunk's state once went 1 -> 3 -> 2 when that task overtook the thread that
+    had submitted it, and the call then waited for ever): every call returns, the last call's lists are the reference's"""
+    import torch
+    g = G.load("cfg2_seq200_tr")
+    w, h, nf = int(g["w"]), int(g["h"]), 60
+    cv = synth.canvas(int(g["seed"]), w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
+    left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
+    right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
+    for chunk in (27, 15, 9):
+        m = vm.Matcher(options={"seq_chunk": chunk})
+        m.set_intrinsics(*[float(x) for x in g["intr"]])
+        for _ in range(40):
+            m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf], fetch=False)
+        assert m.sequence_path() == 2
+        for f in range(nf):
+            got = m.sequence_matches(f)
+            assert len(got) == int(g["counts"][f]) and G.sha(got) == str(g["hashes"][f]), (chunk, f)
+        m.close()
 
 
 def test_two_matchers_in_two_threads(vm, synth, monkeypatch):
