@@ -336,7 +336,7 @@ def main():
     pmc, pmc_src = {}, None
     try:
         import csv
-        pmc_path = os.path.join(ROOT, "profiles", "r03_lookahead_pmc_hbm.csv")
+        pmc_path = os.path.join(ROOT, "profiles", "r04_lookahead_pmc_hbm.csv")
         lib_path = os.path.join(ROOT, PKG, "libvisomatch.so")
         meta = {}
         for line in open(pmc_path):
@@ -353,7 +353,7 @@ def main():
         for pat in ("*.hip", "*.h", "*.inc", "*.cpp"):
             for fn in sorted(glob.glob(os.path.join(csrc, pat))):
                 hsh.update(open(fn, "rb").read())
-        pmc_src = {"file": "profiles/r03_lookahead_pmc_hbm.csv", "commit": meta.get("commit"), "taken": meta.get("taken"),
+        pmc_src = {"file": "profiles/r04_lookahead_pmc_hbm.csv", "commit": meta.get("commit"), "taken": meta.get("taken"),
                    "same_kernel_sources": (meta.get("sources", "").split(" ")[0] == hsh.hexdigest()[:16]) if meta.get("sources") else None}
     except FileNotFoundError:
         pmc_src = {"file": None, "note": "no committed PMC summary"}
