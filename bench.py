@@ -30,7 +30,37 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")   # before anything initialises HIP: see visomatch.py
+
+
+def _cpu_share():
+    """this rank's share of the CPUs the job may use (cgroup quota if there is one - more spinning threads than that only get
+    throttled) and the host-pool size that follows from it"""
+    ncpu = os.cpu_count() or 16
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            ncpu = min(ncpu, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    share = ncpu // max(world, 1)
+    # (two CPUs of the share are left to the HIP runtime's own threads: with as many pool threads as CPUs the rank runs into
+    # its quota now and then, and a throttled call takes 10-14 ms instead of 5)
+    return ncpu, max(2, min(32, share - 2 if share >= 8 else share))
+
+
+NCPU, _threads = _cpu_share()
+os.environ.setdefault("VSM_HOST_THREADS", str(_threads))
+# Before anything initialises HIP (the runtime reads it once).  FIVE hardware queues - the null stream's, the handle's main
+# stream's and three side streams' - carry the look-ahead path, and a sixth queue in the process throttles every kernel's
+# workgroup dispatch (DESIGN.md section 6c), so five is also the cap: whatever else creates streams here (RCCL for the
+# start / end reductions) shares a queue instead of adding one.  A rank with three host threads or fewer lets the device take
+# a share of the final chains' vertex sorts - single waves of 3.2 ms that need streams, hence queues, of their own: twelve
+# queues, and slower kernels, are the better trade there (2 threads: 14.4 ms per call with five queues, ~9 with twelve).
+if int(os.environ["VSM_HOST_THREADS"]) <= 3:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+    os.environ.setdefault("VSM_PY_OPTIONS", "seq_gpu_sorts=%d" % {1: 75, 2: 50, 3: 34}[max(1, int(os.environ["VSM_HOST_THREADS"]))])
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -102,19 +132,7 @@ def main():
             dist.init_process_group("gloo")
             comm_dev = torch.device("cpu")
 
-    # host threads for the exact Delaunay stage: this rank's share of the CPUs the job may use
-    # (cgroup quota if there is one -- more spinning threads than that only get throttled)
-    ncpu = os.cpu_count() or 16
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            ncpu = min(ncpu, max(1, int(q) // int(per)))
-    except Exception:
-        pass
-    # (two CPUs of the share are left to the HIP runtime's own threads - completion callbacks, interrupt waits -: with as many
-    # pool threads as CPUs the rank runs into its quota now and then, and a throttled call takes 10-14 ms instead of 6.5)
-    share = ncpu // max(world, 1)
-    os.environ.setdefault("VSM_HOST_THREADS", str(max(2, min(32, share - 2 if share >= 8 else share))))
+    ncpu = NCPU   # (host threads for the exact Delaunay stage: sized at import time, before HIP initialises - see the top of the file)
     vm = importlib.import_module(PKG + ".visomatch")
     synth = importlib.import_module(PKG + ".synth")
     vm.lib()  # raises if the HIP library is missing
