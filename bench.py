@@ -76,6 +76,7 @@ def sha(a):
 def algorithmic_bytes(kernel, counts):
     """SURVEY.md section 8(d) per-unit figures, split per kernel.  counts: per-launch work."""
     P, Ph, Hh = counts["P"], counts["Ph"], counts["Hh"]
+    W, H = counts.get("W", globals()["W"]), counts.get("H", globals()["H"])
     if kernel == "k_filters<true>":      # read image, write du_full + dv_full
         return counts["imgs"] * (W * H + 2 * P * H)
     if kernel == "k_front":              # read the caller's image once; write half image + the tiled du/dv plane (2 B / pixel)
@@ -598,17 +599,59 @@ def secondary_configs(vm, synth, torch, dev):
         dt = (time.perf_counter() - t) / 2
         form = m.sequence_path()
         chunk5 = int(m.sequence_timings()["chunk"])
-        t2 = time.perf_counter()
-        for f in range(8):
+        # per-kernel HIP-event durations of one more call, priced like the headline's table (work counters of this
+        # configuration: tests/golden/cfg5_work_counters.json, from the oracle - make_cfg5_work_counters.py)
+        m.set_profiling(True)
+        m.run_sequence(L, R, 2, fetch=False)
+        torch.cuda.synchronize()
+        kst = m.kernel_stats()
+        m.set_profiling(False)
+        by_kernel = cfg_kernel_table(kst, nfx, w, h, json.load(open(os.path.join(gdir, "cfg5_work_counters.json"))).get(name))
+        for f in range(8):            # (per-frame API: warm-up first - the first frames size the arena and the host pool's buffers)
             m.push_back(L[f], R[f])
             m.match_features(2)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for f in range(8, 56):
+            m.push_back(L[f], R[f])
+            m.match_features(2)
+        torch.cuda.synchronize()
         dt2 = time.perf_counter() - t2
         m.close()
         out[label] = {"lookahead": {"value": round(nfx / dt, 1), "unit": "frame-pairs/s", "form": form, "frames": nfx, "chunk": chunk5},
-                      "per_frame_api": {"value": round(8 / dt2, 1), "unit": "frame-pairs/s"},
+                      "per_frame_api": {"value": round(48 / dt2, 1), "unit": "frame-pairs/s", "frames": 48, "after_warmup_frames": 8},
+                      "roofline_by_kernel": by_kernel,
                       "dense_features_per_image": int(g["counts"][0][1]), "matches_per_pair": int(g["counts"][1][-1]),
                       "blur": int(g["blur"]), "bit_exact_vs_reference_hashes": bool(ok)}
     return out
+
+
+def cfg_kernel_table(kst, nf, w, h, work):
+    """per-kernel table of a secondary configuration: average launch, launches per call, algorithmic bytes per launch and
+    the fraction of the HBM peak they amount to (same formulas as the headline: algorithmic_bytes())"""
+    P, Ph, Hh = w + 15 - (w - 1) % 16, (w // 2) + 15 - ((w // 2) - 1) % 16, h // 2
+    total = sum(ms for k, (ms, n) in kst.items() if n and k != "k_export_list")
+    tab = {}
+    for k, (ms, nl) in kst.items():
+        if not nl:
+            continue
+        row = {"avg_launch_us": round(ms / nl * 1e3, 2), "launches": int(nl), "share_of_gpu_kernel_time": round(ms / max(total, 1e-9), 3)}
+        c2 = dict(P=P, Ph=Ph, Hh=Hh, W=w, H=h, imgs=2.0 * nf / nl)
+        ab = None
+        if work is not None:
+            pairs = (nf - 1) / nl
+            w1 = k.endswith("pass1")
+            c2.update(Q=work["Q1" if w1 else "Q2"] * pairs, C=work["C1" if w1 else "C2"] * pairs, S=work["S1" if w1 else "S2"] * pairs,
+                      Mraw=work["M1" if w1 else "M"] * pairs, M=work["M"] * pairs, N=work["N"])
+            ab = algorithmic_bytes(k, c2)
+        elif not k.startswith(("k_match", "k_refine", "k_emit")):
+            ab = algorithmic_bytes(k, c2)
+        if ab:
+            row["algorithmic_bytes_per_launch"] = int(ab)
+            row["achieved_GBps"] = round(ab / (ms / nl / 1e3) / 1e9, 1)
+            row["frac"] = round(ab / (ms / nl / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
+        tab[k] = row
+    return tab
 
 
 def mono_leg(vm, with_cpu):
