@@ -220,6 +220,10 @@ int32_t vsm_host_outliers_and_prior(const vsm_params *p, const vsm_p_match *list
                                     int32_t cap, float *ranges, int32_t w, int32_t h);
 int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, int32_t gpu_ties, int32_t copies,
                       vsm_p_match *out, int32_t cap, float *ranges, int32_t w, int32_t h, double *kernel_us);
+/* Test hook of the device chain's merge levels: a node's band (the records near its cut) is cached in 256 + f * sqrt(points)
+ * LDS lines; a node that needs more is redone by one lane in global memory.  f < 0 restores the default (12); a small f
+ * forces that second path, which no list of the benchmark takes.  Process-wide. */
+void vsm_debug_dc2_band_factor(int32_t f);
 
 /* ---- stereo visual odometry on top of the matcher ----
  * class VisualOdometryStereo, viso/viso_stereo.h:28-88 + viso/viso.h:28-131: process() =

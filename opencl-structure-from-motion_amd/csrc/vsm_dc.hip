@@ -9,6 +9,7 @@
 // one thread per merge node): their seams are still short, and there are still thousands of them per
 // chunk of frame pairs.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -1932,15 +1933,23 @@ void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, in
   if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_block, dim3(1 << depth, njobs), dim3(DC2_BLOCK_THREADS), 0, s, d_jobs, depth);
 }
+#ifndef DC2_BAND_F
+#define DC2_BAND_F 12  // LDS lines of a merge node's band: 256 + DC2_BAND_F * sqrt(points of the node); measured need: 256 + 3.2 sqrt (535 lines at the top of a 7.4 k list); 24 cost the top level 66 KB of LDS per workgroup, which waited for room beside the block kernel's
+#endif
+static std::atomic<int> g_dc2_band_factor{DC2_BAND_F};
+// test hook: bands of 256 + f * sqrt(points) LDS lines (f < 0: the default) - with a small f the large merge nodes overflow
+// their band and are redone by one lane in global memory, the path that no list of the benchmark takes
+extern "C" void vsm_debug_dc2_band_factor(int32_t f) { g_dc2_band_factor.store(f < 0 ? DC2_BAND_F : f); }
 void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth, int max_list) {
   if (njobs <= 0) return;
+  const double band_f = (double)g_dc2_band_factor.load(std::memory_order_relaxed);
   static const bool big_lds = hipFuncSetAttribute((const void *)k_dc2_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
   for (int level = depth - 1; level >= 0; level--) {
     // the largest node of the level: ceil(max_list / 2^level) points.  A band is a few records per pixel of cut plus the
     // two hulls, i.e. it grows like the square root of the node: 256 + 24 sqrt(n) lines cover it several times over
     // (measured: 535 lines for the top merge of 7.4 k points), the points its records use are fewer than the lines.
     const int nmax = ((max_list + (1 << level) - 1) >> level) + 1;
-    int lines_cap = (256 + (int)(24.0 * std::sqrt((double)nmax)) + 63) & ~63;
+    int lines_cap = (256 + (int)(band_f * std::sqrt((double)nmax)) + 63) & ~63;
     lines_cap = std::min(lines_cap, 16384);  // (16-bit line handles: line * 4 + edge, the trap record included, below 0xffff)
     int pts_cap = lines_cap;
     int words_cap = ((2 * nmax + 31) >> 5) + 1;

@@ -1037,6 +1037,30 @@ def test_gpu_resident_remove_outliers_chain(vm, B):
     assert _same(vm.remove_outliers(lst, 2, 1242, 375, gpu=True)[0], _oracle_survivors(B, lst, 2))
 
 
+def test_device_chain_merge_nodes_that_overflow_their_band(vm, B):
+    """a merge node of the device chain caches the records near its cut (the band) in LDS; one that needs more lines than
+    the launch gave it is redone by a single lane on the records in global memory.  No list of the benchmark gets there
+    with the default sizing, so the sizing is turned down until the large nodes do (vsm_debug_dc2_band_factor(0): 256 lines
+    whatever the node): survivors against the oracle's removeOutliers, lattice lists (every circumcircle through four
+    points) included"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("dc2_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dc2_check.py"))
+    dc2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dc2)
+    try:
+        for f in (0, 1, 3):
+            vm.lib().vsm_debug_dc2_band_factor(f)
+            for n in (2000, 7400, 9000):
+                for grid in (False, True):
+                    lst = dc2.make_list(n, grid=grid)
+                    want = _oracle_survivors(B, lst, 2)
+                    gs, _, _ = vm.remove_outliers(lst, 2, 1242, 375, gpu=True, copies=2)
+                    assert _same(want, gs), (f, n, grid, len(want), len(gs))
+    finally:
+        vm.lib().vsm_debug_dc2_band_factor(-1)
+
+
 def test_device_chain_at_the_capacity_steps_of_its_lds_kernels(vm, B):
     """the LDS preparation kernel (sort, duplicates, kd order) is launched with a power-of-two capacity and capacity / 4 or / 8
     threads, the chain's last kernel keeps its tables in LDS up to 12288 matches: list lengths on both sides of every step,
