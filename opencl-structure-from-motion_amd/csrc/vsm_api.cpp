@@ -382,6 +382,7 @@ struct VsmSwitches {
   int dc_watchdog_ms = 20000;  // ... how long dc_wait() listens for that callback before it asks the stream itself
   int seq_keys_dma = 1;      // GPU-resident form: the keys reach the host's vertex sort by a DMA copy (1) or by the key kernel's own stores into host-mapped memory (0)
   int seq_ties1_null = 1;    // ... the pass-1 chain's vertex sort (one wave per list) on the null stream (1) or on side stream cs[k + 2] (0)
+  int seq_last_first = 1;    // ... a chain's sort + kd order kernel goes in with its head, and the block kernel of the last chunk but one waits for the last chunk's
   int seq_export_budget = 2; // ... pieces of the early export submitted behind a chunk's keys where the next chunk's keys follow at once (sequence_run_v2: export_some)
   static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
@@ -410,6 +411,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "dc_watchdog_ms")) dc_watchdog_ms = std::max(1, v);
     else if (!strcmp(name, "seq_keys_dma")) seq_keys_dma = v != 0;
     else if (!strcmp(name, "seq_export_budget")) seq_export_budget = v;
+    else if (!strcmp(name, "seq_last_first")) seq_last_first = v != 0;
     else if (!strcmp(name, "seq_ties1_null")) seq_ties1_null = v != 0;
     else return false;
     return true;

@@ -313,7 +313,8 @@ def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
 
 def test_lookahead_as_shipped_200_frames(vm, synth, monkeypatch):
     """What bench.py times, as it ships: config 2 (200 frames 1242x375 resident in HBM, replayed Tr_delta) through
-    vsm_sequence_run with NO VSM_* variable set - the GPU-resident form, chunks of 80, three side streams, the default
+    vsm_sequence_run with NO VSM_* variable set - the GPU-resident form, chunks of 110 (80 / 50 with fewer than ten / six host
+    threads), three side streams, the default
     host pool - every frame's final list against the reference's hash, twice on one handle (banks and slabs are reused)."""
     import os
     import torch
@@ -330,7 +331,7 @@ def test_lookahead_as_shipped_200_frames(vm, synth, monkeypatch):
     for rep in range(2):
         got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
         assert m.sequence_path() == 2
-        assert int(m.sequence_timings()["chunk"]) == 80
+        assert int(m.sequence_timings()["chunk"]) in (110, 80, 50)   # (by the box's CPU share)
         for f in range(nf):
             assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), (rep, f)
     m.close()
