@@ -49,6 +49,37 @@ def _cpu_share():
     return ncpu, max(2, min(32, share - 2 if share >= 8 else share))
 
 
+def _near_gpu():
+    """This rank's threads - Python's, the HIP runtime's, the library's host pool - onto the CPUs of its GPU's NUMA node, BEFORE
+    anything initialises HIP: the runtime allocates its kernel-argument and signal pools in host memory when it starts, on the
+    node of the thread that starts it, and an MI355X node has two sockets with four GPUs each.  A process on the far socket runs
+    the look-ahead call in 4.45-4.57 ms, on the near one in 4.17-4.23, left to the scheduler in anything between - process by
+    process (tools/numa_probe.sh).  What `numactl --cpunodebind` per rank does in a launch script, done here so that the
+    driver's plain `python bench.py` / torchrun lines get it too.  The GPU of local rank r = the r-th render node this
+    container sees; its CPUs from sysfs, no HIP call."""
+    try:
+        import glob
+        import re
+        nodes = sorted((int(re.sub(r"\D", "", os.path.basename(n))), os.path.basename(n)) for n in glob.glob("/dev/dri/renderD*"))
+        nodes = [n for _, n in nodes if open(f"/sys/class/drm/{n}/device/vendor").read().strip() == "0x1002"]
+        if not nodes:
+            return None
+        name = nodes[int(os.environ.get("LOCAL_RANK", "0")) % len(nodes)]
+        cpus = set()
+        for tok in open(f"/sys/class/drm/{name}/device/local_cpulist").read().strip().split(","):
+            a, _, b = tok.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        allowed = os.sched_getaffinity(0)
+        both = cpus & allowed
+        if len(both) >= 2 and len(both) < len(allowed):
+            os.sched_setaffinity(0, both)
+            return {"render_node": name, "numa_node": int(open(f"/sys/class/drm/{name}/device/numa_node").read()), "cpus": len(both)}
+    except Exception:
+        pass
+    return None
+
+
+NEAR_GPU = _near_gpu()
 NCPU, _threads = _cpu_share()
 os.environ.setdefault("VSM_HOST_THREADS", str(_threads))
 # Before anything initialises HIP (the runtime reads it once).  FIVE hardware queues - the null stream's, the handle's main
@@ -473,6 +504,7 @@ def main():
         # what the main stream's kernels alone would sustain: frames / their summed HIP-event durations in the profiled pass
         "gpu_phases_only_frame_pairs_per_s": round(nf / (sum(v[0] for v in stats.values()) * 1e-3), 1),
         "host_threads": int(os.environ["VSM_HOST_THREADS"]),
+        "host_threads_on": NEAR_GPU or "wherever the scheduler puts them",
         "host_cpus": {"os_cpu_count": os.cpu_count(), "cgroup_quota": ncpu, "model": cpu_model()},
         "lookahead_form": {2: "GPU-resident (lists stay in HBM; host only runs Triangle's vertex sort)",
                            1: "host-shared (prior statistics and the top of the exact Delaunay on the host pool)"}.get(lookahead_form),

@@ -131,12 +131,21 @@ void vsm_sequence_get_timings(vsm_handle *h, double *out4);
  * the device chain declines) */
 int32_t vsm_sequence_path(vsm_handle *h);
 /* Measurement / test switches of a handle.  They are read from the environment once, by vsm_create (VSM_SEQ_V2,
- * VSM_SEQ_CHUNK, VSM_SEQ_DC_STREAMS, VSM_SEQ_SERIAL, VSM_SEQ_GPU_SORTS, VSM_SEQ_EARLY_EXPORT, VSM_FRONT); this call changes one
+ * VSM_SEQ_CHUNK, VSM_SEQ_DC_STREAMS, VSM_SEQ_SERIAL, VSM_SEQ_GPU_SORTS, VSM_SEQ_EARLY_EXPORT); this call changes one
  * afterwards: name = the variable's name without the VSM_ prefix, in lower case ("seq_serial", "seq_chunk", ...).
- * Option-only names (never read from the environment): "dc_gpu", "dc_full", "dc_watchdog_ms", "dc_fault_inject" - the GPU's
- * share of the final stage in the host-shared form.
+ * Option-only names (never read from the environment): "front" (0: separate ingest / halving / Sobel passes instead of the
+ * fused front end), "dc_gpu", "dc_full", "dc_watchdog_ms", "dc_fault_inject" (the GPU's share of the final stage in the
+ * host-shared form), and the scheduling experiments of the GPU-resident form recorded in DESIGN.md 6c:
+ * "seq_keys_dma", "seq_ties1_null", "seq_last_first", "seq_export_budget".
  * None of them changes a result.  Returns VSM_OK, or VSM_EARG for an unknown name.  (No counterpart in the reference.) */
 int vsm_set_option(vsm_handle *h, const char *name, int32_t value);
+/* Host threads near the GPU: the library confines the threads IT creates (host pool, look-ahead poller) to the CPUs of the
+ * device's NUMA node (/sys/bus/pci/devices/<bus id>/local_cpulist, within what the process may use; looked up once per
+ * process by the first vsm_create; VSM_HOST_AFFINITY=0 switches it off) - on a two-socket MI355X node a rank whose host
+ * threads run on the other socket loses 6 % of the look-ahead rate.  The caller's threads are left alone; this returns the
+ * CPUs chosen (up to cap of them in out; the return value is how many there are, 0 = none) so that the caller can put the
+ * thread that calls vsm_sequence_run there too, as bench.py does. */
+int32_t vsm_local_cpus(int32_t *out, int32_t cap);
 
 /* ---- stage-level views for parity tests (the reference's private members) ---- */
 

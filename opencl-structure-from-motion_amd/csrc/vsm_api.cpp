@@ -372,7 +372,7 @@ struct VsmSwitches {
   int seq_dc_streams = 3;  // VSM_SEQ_DC_STREAMS: side streams of the GPU-resident form (1..3; with the main and the null stream: five hardware queues)
   int seq_serial = 0;      // VSM_SEQ_SERIAL: nothing overlaps (every kernel's time alone)
   int seq_gpu_sorts = -1;  // VSM_SEQ_GPU_SORTS: percent of a chunk's vertex sorts done on the device (-1 = by host threads)
-  int front = 1;           // VSM_FRONT: the fused front end
+  int front = 1;           // option "front" (not read from the environment): the fused front end
   int seq_early_export = -1;  // VSM_SEQ_EARLY_EXPORT: the refined lists cross PCIe beside the triangulation, survivor bits follow, the pool
                               // closes the gaps (1); survivors compacted on the device, one DMA copy at the chain's end (0); -1: by pool size
   // settable through vsm_set_option only (tests, tools); none of them is read from the environment:
@@ -394,7 +394,6 @@ struct VsmSwitches {
     seq_dc_streams = std::min(3, std::max(1, env_int("VSM_SEQ_DC_STREAMS", 3)));
     seq_serial = env_int("VSM_SEQ_SERIAL", 0) != 0;
     seq_gpu_sorts = env_int("VSM_SEQ_GPU_SORTS", -1);
-    front = env_int("VSM_FRONT", 1) != 0;
     seq_early_export = env_int("VSM_SEQ_EARLY_EXPORT", -1);
   }
   bool set(const char *name, int v) {
@@ -530,6 +529,12 @@ vsm_handle *vsm_create(const vsm_params *p) {
   h->param = *p;
   if (p->half_resolution) h->param.match_radius /= 2;
   h->sw.from_environment();
+  {
+    int dev = 0;
+    char bdf[64] = {0};
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), dev) == hipSuccess)
+      vsm_affinity_from_device(bdf);  // (before the pools start their threads)
+  }
   {
     // host threads (the caller's thread included): VSM_HOST_THREADS frame-parallel workers for
     // the look-ahead API, at most 8 of them for the sub-problems of one triangulation (streaming)
@@ -1862,6 +1867,7 @@ int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out,
 
 void vsm_sequence_get_timings(vsm_handle *h, double *out4) { memcpy(out4, h->seq_timings, sizeof(h->seq_timings)); }
 int32_t vsm_sequence_path(vsm_handle *h) { return h->seq_v2_frames > 0 ? 2 : 1; }
+int32_t vsm_local_cpus(int32_t *out, int32_t cap) { return vsm_affinity_cpus(out, out ? cap : 0); }
 int vsm_set_option(vsm_handle *h, const char *name, int32_t value) { return (h && name && h->sw.set(name, value)) ? VSM_OK : VSM_EARG; }
 
 // ---- stage-level views ----

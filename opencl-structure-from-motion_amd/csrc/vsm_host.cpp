@@ -1,6 +1,11 @@
 // Host-side stages of the matcher path (see vsm_host.h).  Plain C++17, no HIP.
 #include "vsm_host.h"
 
+#include <ctype.h>
+#include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,6 +29,64 @@ static inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
   __builtin_ia32_pause();
 #endif
+}
+
+// ---- host threads near the GPU (vsm_host.h) ----
+static cpu_set_t g_near_cpus;
+static std::atomic<int> g_near_state{0};  // 0: not looked up yet, 1: g_near_cpus is valid, -1: none (off, unknown, or no restriction to gain)
+static std::mutex g_near_mu;
+void vsm_affinity_from_device(const char *pci_bus_id) {
+  std::lock_guard<std::mutex> lk(g_near_mu);
+  if (g_near_state.load() != 0) return;
+  int state = -1;
+  const char *e = getenv("VSM_HOST_AFFINITY");
+  char bdf[64] = {0};
+  if (!(e && atoi(e) == 0) && pci_bus_id && strlen(pci_bus_id) < sizeof(bdf)) {
+    strcpy(bdf, pci_bus_id);
+    for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+    if (FILE *f = fopen(path, "r")) {
+      char line[1024] = {0};
+      if (fgets(line, sizeof(line), f)) {
+        cpu_set_t near, allowed;
+        CPU_ZERO(&near);
+        for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+          int a = -1, b = -1;
+          if (sscanf(tok, "%d-%d", &a, &b) == 2) {
+          } else if (sscanf(tok, "%d", &a) == 1) {
+            b = a;
+          }
+          for (int c = a; a >= 0 && c <= b && c < CPU_SETSIZE; c++) CPU_SET(c, &near);
+        }
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+          cpu_set_t both;
+          CPU_AND(&both, &near, &allowed);
+          // (only where it narrows the choice and leaves room: a process already confined, or one whose allowed CPUs
+          // miss the node, stays as it is)
+          if (CPU_COUNT(&both) >= 2 && CPU_COUNT(&both) < CPU_COUNT(&allowed)) {
+            g_near_cpus = both;
+            state = 1;
+          }
+        }
+      }
+      fclose(f);
+    }
+  }
+  g_near_state.store(state);
+}
+void vsm_pin_this_thread() {
+  if (g_near_state.load(std::memory_order_acquire) == 1) (void)pthread_setaffinity_np(pthread_self(), sizeof(g_near_cpus), &g_near_cpus);
+}
+int vsm_affinity_cpus(int *out, int cap) {
+  if (g_near_state.load(std::memory_order_acquire) != 1) return 0;
+  int n = 0;
+  for (int c = 0; c < CPU_SETSIZE; c++)
+    if (CPU_ISSET(c, &g_near_cpus)) {
+      if (n < cap) out[n] = c;
+      n++;
+    }
+  return n;
 }
 
 VsmPool::VsmPool(int threads) : nthreads_(threads < 1 ? 1 : threads) {
@@ -58,6 +121,7 @@ bool VsmPool::work_one() {
 }
 
 void VsmPool::worker() {
+  vsm_pin_this_thread();
   for (;;) {
     if (stop_) return;
     // (the post counter is read BEFORE the queue is looked at: a batch posted in between changes it, so the wait below
@@ -164,6 +228,7 @@ bool VsmForkJoin::claim(uint64_t g, int n, int &idx) {
 }
 
 void VsmForkJoin::worker() {
+  vsm_pin_this_thread();
   uint64_t seen = 0;
   for (;;) {
     // wait for a new generation: spin first, then block

@@ -19,6 +19,17 @@
 #include "visomatch.h"
 #include "vsm_dc_mesh.h"
 
+// Host threads near the GPU.  An MI355X node has two CPU sockets with four GPUs each; a rank's host threads that run on the
+// other socket read the pinned buffers the GPU's DMA wrote (keys, refined lists) across the socket link, and the look-ahead
+// call takes 4.45-4.57 ms instead of 4.17-4.23 (tools/numa_probe.sh; left to the scheduler: anything between, process by
+// process).  vsm_affinity_from_device() reads the CPUs of the device's NUMA node (/sys/bus/pci/devices/<bdf>/local_cpulist)
+// once per process; every thread the library creates (pool workers, fork-join workers, the look-ahead poller) then
+// confines itself to those CPUs, within what the process is allowed.  The caller's own threads are left alone.
+// VSM_HOST_AFFINITY=0 switches it off.
+void vsm_affinity_from_device(const char *pci_bus_id);  // "0000:0d:00.0" (hipDeviceGetPCIBusId)
+void vsm_pin_this_thread();
+int vsm_affinity_cpus(int *out, int cap);  // the CPUs chosen (for the caller who wants its own threads there too); returns how many
+
 // Small task pool for the host stages (Delaunay sub-problems / frame pairs are independent).
 // Work arrives as batches of n index tasks; batches are served FIFO.  run() is fork-join (the
 // caller takes part); submit()/wait() let the caller keep the GPU busy while a batch is being

@@ -285,7 +285,7 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
                                  {"VSM_SEQ_EARLY_EXPORT": "1", "VSM_HOST_THREADS": "2"}, {"VSM_SEQ_DC_STREAMS": "1"},
                                  {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNK": "5"}, {"VSM_SEQ_CHUNK": "2", "VSM_SEQ_EARLY_EXPORT": "0"},
                                  {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
-                                 {"VSM_FRONT": "0"}])
+                                 {"opt:front": "0"}])
 def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), both ways of
     result delivery at both ends of the pool size, one / four chain streams (eight chunks of five, twenty of two: every bank
@@ -295,14 +295,16 @@ def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     monkeypatch.setenv("VSM_SEQ_V2", "1")
     monkeypatch.setenv("VSM_SEQ_CHUNK", "10")
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        if not k.startswith("opt:"):
+            monkeypatch.setenv(k, v)
+    opt = {k[4:]: int(v) for k, v in env.items() if k.startswith("opt:")}   # (switches vsm_set_option takes but the environment does not)
     g = G.load("cfg2_seq200_tr")
     w, h, nf = int(g["w"]), int(g["h"]), 38
     cv = synth.canvas(int(g["seed"]), w, h)
     fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
     left = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
     right = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
-    m = vm.Matcher()
+    m = vm.Matcher(options=opt)
     m.set_intrinsics(*[float(x) for x in g["intr"]])
     got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
     assert m.sequence_path() == 2, env
