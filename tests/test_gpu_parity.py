@@ -313,6 +313,18 @@ def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     m.close()
 
 
+def test_host_threads_near_the_gpu(vm):
+    """vsm_local_cpus(): the CPUs of the device's NUMA node the library keeps its own threads on - a subset of what the
+    process may use, or nothing (one node, or a process already confined); the caller's thread is left alone"""
+    import os
+    before = os.sched_getaffinity(0)
+    m = vm.Matcher()
+    cpus = vm.local_cpus()
+    assert os.sched_getaffinity(0) == before
+    assert set(cpus) <= before and (not cpus or 2 <= len(cpus) < len(before))
+    m.close()
+
+
 def test_lookahead_as_shipped_200_frames(vm, synth, monkeypatch):
     """What bench.py times, as it ships: config 2 (200 frames 1242x375 resident in HBM, replayed Tr_delta) through
     vsm_sequence_run with NO VSM_* variable set - the GPU-resident form, chunks of 110 (80 / 50 with fewer than ten / six host
