@@ -1178,6 +1178,10 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
   // that is the minimum of (cost, rank), whatever order the candidates are judged in.
   // A stage that cannot have a prediction (MAYPRED = false) compares one integer key, SAD << 32 | rank; the others keep
   // the cost in double as the reference does.  The updates are selects, not branches.
+  // (Round 4 tried the judging spread over the wave instead - the lanes' parked candidates compacted onto one list per wave
+  // in LDS by ballots, 64 entries judged per round whoever found them, the owner's descriptor by cross-lane reads, the
+  // minimum of (cost, rank) per query by ds_min_u64: results identical, but a wave-stage has 56 candidates on average
+  // (1.74 per query), so four rounds become two, and the list's bookkeeping costs more than that: 345-370 us against 322.)
   double best = 10000000.0;
   uint64_t bkey = ~0ull;
   uint32_t bestq = VSM_NONE, brank = VSM_NONE;
@@ -2221,7 +2225,10 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
   // lanes per query: the chain is latency-bound per wavefront, so big batches want many
   // queries per wave (G = 2..4) and a lone frame pair wants more lanes per query (G = 8).
   const long total_q = (long)npairs * max_nq;
-  const int G = total_q >= 200000 ? 2 : (total_q >= 30000 ? 4 : 8);
+#ifndef VSM_MATCH_GBIG
+#define VSM_MATCH_GBIG 2
+#endif
+  const int G = total_q >= 200000 ? VSM_MATCH_GBIG : (total_q >= 30000 ? 4 : 8);
   const int pass = cfg.sparse ? 0 : 1;
   if (max_nq > 0) {
     pf.begin(cfg.sparse ? VSM_K_MATCH1 : VSM_K_MATCH2, s);
