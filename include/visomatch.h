@@ -110,8 +110,9 @@ float vsm_gain(vsm_handle *h, const int32_t *inliers, int32_t n);
 /* ---- look-ahead API: a whole sequence at once ----
  * Semantically identical to
  *     for f in 0..n_frames-1:  pushBack(left[f], right[f], dims, false);  matchFeatures(method, Tr[f])
- * on a fresh Matcher (viso/matcher.cpp:95, :183), but the frames of a chunk (VSM_SEQ_CHUNK; default 67
- * with six or more host-pool threads, else 50, and 50 in the host-shared form) go through every kernel in one launch and the host stages of the chunk's frame pairs run in
+ * on a fresh Matcher (viso/matcher.cpp:95, :183), but the frames of a chunk (VSM_SEQ_CHUNK; default 110
+ * with ten or more host-pool threads and device-resident frames, 80 with six to nine or host-resident frames, else 50, and 50 in
+ * the host-shared form) go through every kernel in one launch and the host stages of the chunk's frame pairs run in
  * parallel.  left/right: n_frames images frame_stride bytes apart (host or, with on_device != 0,
  * HBM); right == NULL (mono) with stereo / quad matching goes frame by frame (the reference's matchFeatures returns early).
  * Tr_delta: NULL or n_frames x 12 doubles, Tr_valid: NULL (all valid) or n_frames flags.
