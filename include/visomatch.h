@@ -137,7 +137,7 @@ int32_t vsm_sequence_path(vsm_handle *h);
  * Option-only names (never read from the environment): "front" (0: separate ingest / halving / Sobel passes instead of the
  * fused front end), "dc_gpu", "dc_full", "dc_watchdog_ms", "dc_fault_inject" (the GPU's share of the final stage in the
  * host-shared form), and the scheduling experiments of the GPU-resident form recorded in DESIGN.md 6c:
- * "seq_keys_dma", "seq_ties1_null", "seq_last_first", "seq_export_budget".
+ * "seq_keys_dma", "seq_ties1_null", "seq_last_first", "seq_export_budget", "seq_first_chunk", "seq_p2_first".
  * None of them changes a result.  Returns VSM_OK, or VSM_EARG for an unknown name.  (No counterpart in the reference.) */
 int vsm_set_option(vsm_handle *h, const char *name, int32_t value);
 /* Host threads near the GPU: the library confines the threads IT creates (host pool, look-ahead poller) to the CPUs of the

@@ -383,6 +383,8 @@ struct VsmSwitches {
   int seq_keys_dma = 1;      // GPU-resident form: the keys reach the host's vertex sort by a DMA copy (1) or by the key kernel's own stores into host-mapped memory (0)
   int seq_ties1_null = 1;    // ... the pass-1 chain's vertex sort (one wave per list) on the null stream (1) or on side stream cs[k + 2] (0)
   int seq_last_first = 1;    // ... a chain's sort + kd order kernel goes in with its head, and the block kernel of the last chunk but one waits for the last chunk's
+  int seq_first_chunk = 0;   // ... frames of the call's first chunk (0: like the others)
+  int seq_p2_first = -1;     // ... a chunk's second pass in front of the features of chunk k + 2 (the order host-resident inputs get): -1 = by pool size
   int seq_export_budget = 2; // ... pieces of the early export submitted behind a chunk's keys where the next chunk's keys follow at once (sequence_run_v2: export_some)
   static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
@@ -410,6 +412,8 @@ struct VsmSwitches {
     else if (!strcmp(name, "dc_watchdog_ms")) dc_watchdog_ms = std::max(1, v);
     else if (!strcmp(name, "seq_keys_dma")) seq_keys_dma = v != 0;
     else if (!strcmp(name, "seq_export_budget")) seq_export_budget = v;
+    else if (!strcmp(name, "seq_first_chunk")) seq_first_chunk = std::max(0, v);
+    else if (!strcmp(name, "seq_p2_first")) seq_p2_first = v;
     else if (!strcmp(name, "seq_last_first")) seq_last_first = v != 0;
     else if (!strcmp(name, "seq_ties1_null")) seq_ties1_null = v != 0;
     else return false;

@@ -285,11 +285,13 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
                                  {"VSM_SEQ_EARLY_EXPORT": "1", "VSM_HOST_THREADS": "2"}, {"VSM_SEQ_DC_STREAMS": "1"},
                                  {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNK": "5"}, {"VSM_SEQ_CHUNK": "2", "VSM_SEQ_EARLY_EXPORT": "0"},
                                  {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
-                                 {"opt:front": "0"}])
+                                 {"opt:front": "0"}, {"opt:seq_p2_first": "1"}, {"opt:seq_p2_first": "0", "VSM_HOST_THREADS": "6"},
+                                 {"opt:seq_p2_first": "1", "opt:seq_first_chunk": "4"}, {"opt:seq_keys_dma": "0", "opt:seq_export_budget": "0"},
+                                 {"opt:seq_ties1_null": "0", "opt:seq_last_first": "0", "opt:seq_export_budget": "5"}])
 def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), both ways of
     result delivery at both ends of the pool size, one / four chain streams (eight chunks of five, twenty of two: every bank
-    comes round), the vertex sorts on the device, the unfused front end: always
+    comes round), the vertex sorts on the device, the unfused front end, the scheduling choices of DESIGN.md 6c either way: always
     the reference's lists, and always this form (it must not quietly hand the run to the other one)."""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1")
