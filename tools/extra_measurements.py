@@ -18,6 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import bench  # noqa: E402,F401  (the rank's CPU share, queue cap and CPUs near its GPU, set the way the benchmark sets them - before HIP starts)
 PKG = "opencl-structure-from-motion_amd"
 import torch  # noqa: E402
 
