@@ -85,12 +85,7 @@ os.environ.setdefault("VSM_HOST_THREADS", str(_threads))
 # Before anything initialises HIP (the runtime reads it once).  FIVE hardware queues - the null stream's, the handle's main
 # stream's and three side streams' - carry the look-ahead path, and a sixth queue in the process throttles every kernel's
 # workgroup dispatch, so five is also the cap: whatever else creates streams here (RCCL for the
-# start / end reductions) shares a queue instead of adding one.  A rank with three host threads or fewer lets the device take
-# a share of the final chains' vertex sorts - single waves of 3.2 ms that need streams, hence queues, of their own: twelve
-# queues, and slower kernels, are the better trade there (2 threads: 14.4 ms per call with five queues, ~9 with twelve).
-if int(os.environ["VSM_HOST_THREADS"]) <= 3:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
-    os.environ.setdefault("VSM_PY_OPTIONS", "seq_gpu_sorts=%d" % {1: 75, 2: 50, 3: 34}[max(1, int(os.environ["VSM_HOST_THREADS"]))])
+# start / end reductions) shares a queue instead of adding one.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -1725,7 +1725,8 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
 template <int CAP>
 __global__ void __launch_bounds__(64) k_dc2_ties(const VsmDc2Job *__restrict__ jobs, int32_t *__restrict__ tie_out, int out_stride) {
   const VsmDc2Job jb = jobs[blockIdx.x];
-  int32_t *out = tie_out + (size_t)blockIdx.x * out_stride;
+  // (tie_out == nullptr: a job table gathered from several chunks' slabs - every job says itself where its verdict goes)
+  int32_t *out = tie_out ? tie_out + (size_t)blockIdx.x * out_stride : const_cast<int32_t *>(jb.tie_out);
   const int n = *jb.count;
   if (n <= 3 || n > jb.cap) {
     if (threadIdx.x == 0) out[0] = n <= 3 ? 0 : -1;

@@ -285,13 +285,15 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
                                  {"VSM_SEQ_EARLY_EXPORT": "1", "VSM_HOST_THREADS": "2"}, {"VSM_SEQ_DC_STREAMS": "1"},
                                  {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNK": "5"}, {"VSM_SEQ_CHUNK": "2", "VSM_SEQ_EARLY_EXPORT": "0"},
                                  {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
+                                 {"VSM_SEQ_GPU_SORTS": "50", "VSM_SEQ_CHUNK": "5"}, {"VSM_SEQ_GPU_SORTS": "50", "VSM_SEQ_CHUNK": "4", "opt:seq_p2_first": "1"},
                                  {"opt:front": "0"}, {"opt:seq_p2_first": "1"}, {"opt:seq_p2_first": "0", "VSM_HOST_THREADS": "6"},
                                  {"opt:seq_p2_first": "1", "opt:seq_first_chunk": "4"}, {"opt:seq_keys_dma": "0", "opt:seq_export_budget": "0"},
                                  {"opt:seq_ties1_null": "0", "opt:seq_last_first": "0", "opt:seq_export_budget": "5"}])
 def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), both ways of
     result delivery at both ends of the pool size, one / four chain streams (eight chunks of five, twenty of two: every bank
-    comes round), the vertex sorts on the device, the unfused front end, the scheduling choices of DESIGN.md 6c either way: always
+    comes round), the vertex sorts on the device (one launch for the chunks that wait for it, also where a slab comes round
+    before the call's last head), the unfused front end, the scheduling choices of DESIGN.md 6c either way: always
     the reference's lists, and always this form (it must not quietly hand the run to the other one)."""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1")
@@ -347,7 +349,7 @@ def test_lookahead_as_shipped_200_frames(vm, synth, monkeypatch):
     for rep in range(2):
         got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
         assert m.sequence_path() == 2
-        assert int(m.sequence_timings()["chunk"]) in (110, 80, 50)   # (by the box's CPU share)
+        assert int(m.sequence_timings()["chunk"]) in (110, 100, 80, 50)   # (by the box's CPU share)
         for f in range(nf):
             assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), (rep, f)
     m.close()
