@@ -159,6 +159,21 @@ def main():
             dist.init_process_group("gloo")
             comm_dev = torch.device("cpu")
 
+    # (the import-time guess of this rank's GPU - the r-th render node - checked against the device HIP really gave it: if the
+    # guess was the other socket, at least the threads created from here on - the library's host pool - go to the right one)
+    global NEAR_GPU
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        cpus = set()
+        for tok in open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read().strip().split(","):
+            a, _, b = tok.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        if cpus and not (cpus & os.sched_getaffinity(0)):
+            os.sched_setaffinity(0, cpus)
+            NEAR_GPU = {"pci": bdf, "cpus": len(cpus), "note": "re-pinned after HIP start: the import-time guess was another socket"}
+    except Exception:
+        pass
     ncpu = NCPU   # (host threads for the exact Delaunay stage: sized at import time, before HIP initialises - see the top of the file)
     vm = importlib.import_module(PKG + ".visomatch")
     synth = importlib.import_module(PKG + ".synth")
