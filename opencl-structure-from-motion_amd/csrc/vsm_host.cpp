@@ -301,6 +301,27 @@ void VsmForkJoin::run(int ntasks, const std::function<void(int)> &fn) {
 #define KXY(k) VSM_KXY(k)
 static inline uint64_t key_yx(uint64_t k) { return (((k >> 20) & 0x3fffu) << 14) | (k >> 34); }
 
+// Triangle's generator (randomnation, :4046) is a linear congruence that starts from 1 for every triangulation
+// (triangleinit, :4031): the SEEDS are one fixed sequence, whatever is sorted - only what a seed is divided by depends on the
+// data.  The emulated sort is one long chain of dependent steps (a partition's pivot comes out of the array the partition
+// before it left behind), and the multiply + modulo of the congruence is a tenth of every link: the first 128 k seeds are
+// tabulated once per process, a draw is a load.
+namespace {
+constexpr uint32_t kSeedTable = 1u << 17;
+const uint32_t *seed_table() {
+  static const std::vector<uint32_t> t = [] {
+    std::vector<uint32_t> v(kSeedTable);
+    uint64_t sd = 1;
+    for (uint32_t i = 0; i < kSeedTable; i++) {
+      sd = (sd * 1366u + 150889u) % 714025u;
+      v[i] = (uint32_t)sd;
+    }
+    return v;
+  }();
+  return t.data();
+}
+}  // namespace
+
 uint32_t ExactDelaunay::rnd(uint32_t choices) {  // randomnation, :4046
   seed_ = (seed_ * 1366u + 150889u) % 714025u;
   // seed / (714025 / choices + 1): most calls come from small sub-arrays, whose divisor and its
@@ -360,10 +381,27 @@ __attribute__((target("avx512f"))) void stop_masks_avx512(const uint64_t *a, int
     LE[w] = l;
   }
 }
+#ifndef VSM_SORT_WORD
+#define VSM_SORT_WORD 1
+#endif
+__attribute__((target("avx512f"))) inline void stop_masks_word_avx512(const uint64_t *a, int32_t n, uint64_t ge_key, uint64_t lt_key, uint64_t &GE,
+                                                                    uint64_t &LE) {  // n <= 64
+  const __m512i vg = _mm512_set1_epi64((long long)ge_key), vl = _mm512_set1_epi64((long long)lt_key);
+  uint64_t g = 0, l = 0;
+  for (int32_t i = 0; i < n; i += 8) {
+    const __mmask8 valid = n - i >= 8 ? (__mmask8)0xff : (__mmask8)((1u << (n - i)) - 1);
+    const __m512i v = _mm512_maskz_loadu_epi64(valid, (const void *)(a + i));
+    g |= (uint64_t)_mm512_mask_cmpge_epu64_mask(valid, v, vg) << i;
+    l |= (uint64_t)_mm512_mask_cmplt_epu64_mask(valid, v, vl) << i;
+  }
+  GE = g;
+  LE = l;
+}
 const bool kHaveAvx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") &&
                          __builtin_cpu_supports("bmi2") && !(getenv("VSM_NO_AVX512") && atoi(getenv("VSM_NO_AVX512")) != 0);
 #else
 void stop_masks_avx512(const uint64_t *, int32_t, uint64_t, uint64_t, uint64_t *, uint64_t *) {}
+inline void stop_masks_word_avx512(const uint64_t *, int32_t, uint64_t, uint64_t, uint64_t &, uint64_t &) {}
 const bool kHaveAvx512 = false;
 #endif
 
@@ -422,8 +460,70 @@ __attribute__((target("avx512f,avx512bw,avx512vl,bmi2"))) inline void tiny_parti
   left = (int32_t)((w >> 24) & 15);
   right = (int32_t)(w >> 28) - 1;
 }
+// A part of 3 to kTinyMax keys with EVERYTHING below it in the recursion, in one register: the keys are loaded once, every
+// partition of the sub-tree is a table lookup and a permute of the register's lanes (the table's source positions, moved to
+// the part's offset inside the register), the pending parts wait on a stack of eight bytes, two-key parts are settled
+// after the one store at the end (they draw no random number, so when does not matter).  The depth-first order - left
+// part first - and with it the order of the random draws is the reference's.  What it saves is memory: the plain form
+// stores a part and loads its halves again, a masked 64-byte store feeding a load at another offset each time.
+#ifndef VSM_SORT_SUBTREE
+#define VSM_SORT_SUBTREE 1
+#endif
+__attribute__((target("avx512f,avx512bw,avx512vl,bmi2"))) void tiny_subtree_avx512(uint64_t *a, int32_t n, const TinyTable &tab, uint64_t &seed, const uint32_t *seeds, uint32_t &draw) {
+  static const struct Magic {
+    uint64_t m[8];
+    Magic() {
+      m[0] = 0;
+      for (uint32_t c = 1; c < 8; c++) m[c] = UINT64_MAX / (714025u / c + 1) + 1;  // (ExactDelaunay::rnd)
+    }
+  } magic;
+  const __mmask8 valid = (__mmask8)((1u << n) - 1);
+  __m512i v = _mm512_maskz_loadu_epi64(valid, (const void *)a);
+  uint32_t stk[8];
+  int sp = 0, np = 0;
+  uint32_t pair_at = 0;
+  stk[sp++] = (uint32_t)n << 8;
+  while (sp > 0) {
+    const uint32_t t = stk[--sp];
+    const int o = (int)(t & 0xffu), m = (int)(t >> 8);  // m >= 3
+    seed = draw < kSeedTable ? seeds[draw] : (seed * 1366u + 150889u) % 714025u;
+    draw++;
+    const uint32_t r = (uint32_t)(((__uint128_t)seed * magic.m[m]) >> 64);
+    // the pivot's key in every lane, its index bits cleared: keys >= that are the GE stops, keys below that + 2^20 the LE stops
+    const __m512i pk = _mm512_permutexvar_epi64(_mm512_set1_epi64((long long)(o + (int)r)), v);
+    const __m512i vg = _mm512_slli_epi64(_mm512_srli_epi64(pk, 20), 20), vl = _mm512_add_epi64(vg, _mm512_set1_epi64(1ll << 20));
+    const unsigned in = (1u << m) - 1;
+    const unsigned ge = ((unsigned)_mm512_cmpge_epu64_mask(v, vg) >> o) & in;
+    const unsigned le = ((unsigned)_mm512_cmplt_epu64_mask(v, vl) >> o) & in;
+    const uint32_t w = tab.e[m][ge | (le << m)];
+    // byte i of `rel`: the source lane (inside the part) of the part's lane i, identity from m on; moved up by o lanes, the
+    // o lanes below keep themselves
+    const uint64_t rel = _pdep_u64(w & 0xffffffu, 0x0707070707070707ull);
+    const uint64_t full = o ? (((rel + 0x0101010101010101ull * (uint64_t)o) << (8 * o)) | (0x0706050403020100ull & ((1ull << (8 * o)) - 1))) : rel;
+    v = _mm512_permutexvar_epi64(_mm512_cvtepu8_epi64(_mm_cvtsi64_si128((long long)full)), v);
+    const int left = (int)((w >> 24) & 15), right = (int)(w >> 28) - 1, rn = m - right - 1;
+    pair_at = (pair_at & ((1u << (3 * np)) - 1)) | ((uint32_t)o << (3 * np));  // (written either way, kept if it is a pair)
+    np += left == 2;
+    pair_at = (pair_at & ((1u << (3 * np)) - 1)) | ((uint32_t)(o + right + 1) << (3 * np));
+    np += rn == 2;
+    stk[sp] = (uint32_t)(o + right + 1) | ((uint32_t)rn << 8);
+    sp += rn > 2;
+    stk[sp] = (uint32_t)o | ((uint32_t)left << 8);
+    sp += left > 2;
+  }
+  _mm512_mask_storeu_epi64((void *)a, valid, v);
+  for (int k = 0; k < np; k++) {
+    uint64_t *p = a + ((pair_at >> (3 * k)) & 7u);
+    const uint64_t x = p[0], y = p[1];
+    const bool sw = KXY(x) > KXY(y);
+    p[0] = sw ? y : x;
+    p[1] = sw ? x : y;
+  }
+}
 #else
 inline void tiny_partition_avx512(uint64_t *, int32_t, uint64_t, uint64_t, const TinyTable &, int32_t &, int32_t &) {}
+#define VSM_SORT_SUBTREE 0
+inline void tiny_subtree_avx512(uint64_t *, int32_t, const TinyTable &, uint64_t &, const uint32_t *, uint32_t &) {}
 #endif
 
 // first set bit at a position >= from, or n
@@ -466,6 +566,22 @@ void ExactDelaunay::vertex_sort(uint64_t *a0, int32_t n0) {
   uint64_t *stack = sort_stack_.data();
   int32_t sp = 0;
   stack[sp++] = (uint64_t)(uint32_t)n0 << 32;  // (offset, length)
+  // (draws from the tabulated seeds while the generator stands where triangleinit left it - always, as the code is used)
+  const uint32_t *seeds = seed_table();
+  uint32_t draw = seed_ == 1 ? 0u : kSeedTable;
+  static const struct Recip {
+    uint64_t magic[256];
+    Recip() {
+      magic[0] = 0;
+      for (uint32_t c = 1; c < 256; c++) magic[c] = UINT64_MAX / (714025u / c + 1) + 1;
+    }
+  } recip;
+  auto draw_rnd = [&](uint32_t choices) -> uint32_t {  // ExactDelaunay::rnd with the seed from the table
+    seed_ = draw < kSeedTable ? seeds[draw] : (seed_ * 1366u + 150889u) % 714025u;
+    draw++;
+    if (choices < 256) return (uint32_t)(((__uint128_t)seed_ * recip.magic[choices]) >> 64);
+    return (uint32_t)(seed_ / (714025u / choices + 1));
+  };
   auto settle_pair = [](uint64_t *p, bool is_pair) {  // vertexsort on two elements if is_pair, nothing otherwise
     const uint64_t x = p[0], y = p[1];
     const bool sw = is_pair & (KXY(x) > KXY(y));
@@ -476,12 +592,37 @@ void ExactDelaunay::vertex_sort(uint64_t *a0, int32_t n0) {
     const uint64_t top = stack[--sp];
     const int32_t off = (int32_t)(uint32_t)top, n = (int32_t)(top >> 32);  // n >= 3
     uint64_t *a = a0 + off;
-    const uint64_t pv = KXY(a[rnd((uint32_t)n)]);
+    if (VSM_SORT_SUBTREE && n <= kTinyMax && kHaveAvx512) {  // the part and everything below it at once
+      static const TinyTable *tiny = new TinyTable();
+      tiny_subtree_avx512(a, n, *tiny, seed_, seeds, draw);
+      continue;
+    }
+    const uint64_t pv = KXY(a[draw_rnd((uint32_t)n)]);
     // KXY(k) >= pv  <=>  k >= pv << 20;  KXY(k) <= pv  <=>  k < (pv + 1) << 20
     int32_t left = -1, right = n;
     if (n <= kTinyMax && kHaveAvx512) {
       static const TinyTable *tiny = new TinyTable();
       tiny_partition_avx512(a, n, pv << 20, (pv + 1) << 20, *tiny, left, right);
+    } else if (VSM_SORT_WORD && n <= 64 && kHaveAvx512) {
+      // one mask word per side: the scans are a count of trailing / leading zeros each, the masks never leave their registers
+      uint64_t ge, le;
+      stop_masks_word_avx512(a, n, pv << 20, (pv + 1) << 20, ge, le);
+      for (;;) {
+        const uint64_t g = left + 1 < 64 ? ge & (~0ull << (left + 1)) : 0ull;
+        const int32_t l = std::min(g ? (int32_t)__builtin_ctzll(g) : n, right);
+        if (l == right) {
+          left = l;
+          right = l - 1;
+          break;
+        }
+        const uint64_t x = right - 1 >= 0 ? le & (~0ull >> (64 - right)) : 0ull;  // positions <= right - 1 (right >= 1 here: l < right)
+        int32_t r = x ? 63 - (int32_t)__builtin_clzll(x) : -1;
+        if (r <= l) r = ((le >> l) & 1) ? l : l - 1;
+        left = l;
+        right = r;
+        if (l >= r) break;
+        std::swap(a[l], a[r]);
+      }
     } else {
     const int32_t nw = (n + 63) >> 6;
     uint64_t *GE = stop_.data(), *LE = stop_.data() + nw;
