@@ -286,6 +286,8 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
                                  {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNK": "5"}, {"VSM_SEQ_CHUNK": "2", "VSM_SEQ_EARLY_EXPORT": "0"},
                                  {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
                                  {"VSM_SEQ_GPU_SORTS": "50", "VSM_SEQ_CHUNK": "5"}, {"VSM_SEQ_GPU_SORTS": "50", "VSM_SEQ_CHUNK": "4", "opt:seq_p2_first": "1"},
+                                 {"VSM_HOST_THREADS": "2", "VSM_SEQ_CHUNK": "19"}, {"VSM_HOST_THREADS": "1", "VSM_SEQ_CHUNK": "20"},
+                                 {"VSM_HOST_THREADS": "3", "VSM_SEQ_CHUNK": "13"},
                                  {"opt:front": "0"}, {"opt:seq_p2_first": "1"}, {"opt:seq_p2_first": "0", "VSM_HOST_THREADS": "6"},
                                  {"opt:seq_p2_first": "1", "opt:seq_first_chunk": "4"}, {"opt:seq_keys_dma": "0", "opt:seq_export_budget": "0"},
                                  {"opt:seq_ties1_null": "0", "opt:seq_last_first": "0", "opt:seq_export_budget": "5"}])
@@ -293,7 +295,7 @@ def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), both ways of
     result delivery at both ends of the pool size, one / four chain streams (eight chunks of five, twenty of two: every bank
     comes round), the vertex sorts on the device (one launch for the chunks that wait for it, also where a slab comes round
-    before the call's last head), the unfused front end, the scheduling choices of DESIGN.md 6c either way: always
+    before the call's last head; two-chunk calls of ranks with few host threads: a launch per chunk, the pool sizes' own shares), the unfused front end, the scheduling choices of DESIGN.md 6c either way: always
     the reference's lists, and always this form (it must not quietly hand the run to the other one)."""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1")
