@@ -142,7 +142,8 @@ int32_t vsm_sequence_path(vsm_handle *h);
 int vsm_set_option(vsm_handle *h, const char *name, int32_t value);
 /* Host threads near the GPU: the library confines the threads IT creates (host pool, look-ahead poller) to the CPUs of the
  * device's NUMA node (/sys/bus/pci/devices/<bus id>/local_cpulist, within what the process may use; looked up once per
- * process by the first vsm_create; VSM_HOST_AFFINITY=0 switches it off) - on a two-socket MI355X node a rank whose host
+ * process by the first vsm_create; spread over that node's L3 domains, thread i on domain i mod n; VSM_HOST_AFFINITY=1: the
+ * node only, =0: off) - on a two-socket MI355X node a rank whose host
  * threads run on the other socket loses 6 % of the look-ahead rate.  The caller's threads are left alone; this returns the
  * CPUs chosen (up to cap of them in out; the return value is how many there are, 0 = none) so that the caller can put the
  * thread that calls vsm_sequence_run there too, as bench.py does. */

@@ -35,6 +35,14 @@ static inline void cpu_relax() {
 static cpu_set_t g_near_cpus;
 static std::atomic<int> g_near_state{0};  // 0: not looked up yet, 1: g_near_cpus is valid, -1: none (off, unknown, or no restriction to gain)
 static std::mutex g_near_mu;
+// ... and spread over the socket's L3 domains (VSM_HOST_AFFINITY=1: the node only, no spreading).  What the pool does with the
+// lists the GPU's DMA wrote - 25 ms of vertex sorts over keys it has to fetch, 64 MB of gap closing - is bound by memory, and a
+// core complex has its own link to memory: fourteen threads on two of the socket's eight complexes run the call in 4.5 ms, on
+// one 4.9-5.3, spread over all eight 4.15 (tools/step_spread.sh, the rank confined to 16 / 8 cores / the whole socket) - and
+// left to the scheduler a process now and then stays packed (the "slower process").  Thread i of the library
+// goes to complex i mod n (all of its CPUs: the scheduler still chooses the core, and ranks that share a socket share it evenly).
+static std::vector<cpu_set_t> g_l3_domains;
+static std::atomic<unsigned> g_pin_next{0};
 void vsm_affinity_from_device(const char *pci_bus_id) {
   std::lock_guard<std::mutex> lk(g_near_mu);
   if (g_near_state.load() != 0) return;
@@ -68,6 +76,31 @@ void vsm_affinity_from_device(const char *pci_bus_id) {
             g_near_cpus = both;
             state = 1;
           }
+          if (!(e && atoi(e) == 1) && CPU_COUNT(&both) >= 2) {  // the L3 domains of the CPUs the threads may use near the GPU
+            cpu_set_t left = both;
+            for (int c = 0; c < CPU_SETSIZE; c++) {
+              if (!CPU_ISSET(c, &left)) continue;
+              cpu_set_t dom;
+              CPU_ZERO(&dom);
+              char p3[160], l3[1024] = {0};
+              snprintf(p3, sizeof(p3), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
+              FILE *f3 = fopen(p3, "r");
+              if (f3 && fgets(l3, sizeof(l3), f3)) {
+                for (char *tok = strtok(l3, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+                  int a = -1, b = -1;
+                  if (sscanf(tok, "%d-%d", &a, &b) != 2 && sscanf(tok, "%d", &a) == 1) b = a;
+                  for (int k = a; a >= 0 && k <= b && k < CPU_SETSIZE; k++)
+                    if (CPU_ISSET(k, &both)) CPU_SET(k, &dom);
+                }
+              }
+              if (f3) fclose(f3);
+              if (CPU_COUNT(&dom) == 0) CPU_SET(c, &dom);
+              for (int k = 0; k < CPU_SETSIZE; k++)
+                if (CPU_ISSET(k, &dom)) CPU_CLR(k, &left);
+              g_l3_domains.push_back(dom);
+            }
+            if (g_l3_domains.size() < 2) g_l3_domains.clear();
+          }
         }
       }
       fclose(f);
@@ -76,7 +109,13 @@ void vsm_affinity_from_device(const char *pci_bus_id) {
   g_near_state.store(state);
 }
 void vsm_pin_this_thread() {
-  if (g_near_state.load(std::memory_order_acquire) == 1) (void)pthread_setaffinity_np(pthread_self(), sizeof(g_near_cpus), &g_near_cpus);
+  if (g_near_state.load(std::memory_order_acquire) == 0) return;
+  if (!g_l3_domains.empty()) {
+    const cpu_set_t &dom = g_l3_domains[g_pin_next.fetch_add(1, std::memory_order_relaxed) % g_l3_domains.size()];
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(dom), &dom);
+  } else if (g_near_state.load(std::memory_order_acquire) == 1) {
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(g_near_cpus), &g_near_cpus);
+  }
 }
 int vsm_affinity_cpus(int *out, int cap) {
   if (g_near_state.load(std::memory_order_acquire) != 1) return 0;
