@@ -1,0 +1,475 @@
+// Fused matching-resolution image side (filters + non-maximum suppression out of one LDS tile), shared by the gfx950
+// kernels (vsm_kernels.hip: k_feat_dense, k_feat_sparse) and by the CPU emulation the "not gpu" tests run
+// (tests/emu/feat_emu.cpp walks the same per-thread functions tile by tile, thread by thread).
+//
+// What is fused (file:line = the reference):
+//   F1 filter::sobel5x5          viso/filter.cpp:316-324   du, dv of the matching-resolution image -> HBM (the descriptors read them)
+//   F2 filter::blob5x5           viso/filter.cpp:343-365   f1 -> LDS only
+//   F3 filter::checkerboard5x5   viso/filter.cpp:331-336   f2 -> LDS only
+//   N1 nonMaximumSuppression     viso/matcher.cpp:330-431  both scales, from the LDS planes
+// so that f1 / f2 (8 of the 19 bytes per matching-resolution pixel of the unfused kernels) never reach HBM.
+//
+// The filters run over the image as ONE byte stream (row stride bpl, pad bytes 0, positions outside the stream 0), exactly
+// like the reference's SSE loops: an LDS tile is filled by stream position, so a tap that leaves a row at its end reads
+// the neighbouring row's bytes as the reference does, whatever the tile.
+//
+// Arithmetic: 16-bit lanes, two pixels per instruction (v_pk_*).  Ranges (8-bit input): column sums of the binomial
+// <= 4080, of the derivative +-765, row passes +-12240; box sums <= 6375; f1 in [-4080, 4080], f2 in [-2040, 2040]:
+// everything fits int16, and (x >> 7) + 128 of a Sobel response lies in [32, 223] - the reference's unsigned saturation
+// never acts on it.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define VF_HD __host__ __device__ __forceinline__
+#define VF_HDM __host__ __device__ __forceinline__
+#else
+#define VF_HD static inline __attribute__((always_inline))
+#define VF_HDM inline __attribute__((always_inline))
+#endif
+
+typedef short vf_s2 __attribute__((ext_vector_type(2)));
+
+VF_HD uint32_t vf_perm(uint32_t hi, uint32_t lo, uint32_t sel) {  // v_perm_b32: selector bytes 0-3 = lo, 4-7 = hi, 0x0c = 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+  const uint64_t src = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int k = 0; k < 4; k++) {
+    const uint32_t s = (sel >> (8 * k)) & 0xffu;
+    const uint32_t b = s <= 7u ? (uint32_t)((src >> (8 * s)) & 0xffu) : 0u;
+    r |= b << (8 * k);
+  }
+  return r;
+#endif
+}
+VF_HD uint32_t vf_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbyte(hi, lo, sh);
+#else
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * sh));
+#endif
+}
+VF_HD uint32_t vf_bits(vf_s2 v) { return __builtin_bit_cast(uint32_t, v); }
+VF_HD vf_s2 vf_pair(uint32_t v) { return __builtin_bit_cast(vf_s2, v); }
+// (a.y, b.x): the pair one column further to the right of a, b = the next aligned pair
+VF_HD vf_s2 vf_shift(vf_s2 a, vf_s2 b) { return vf_pair(vf_alignbyte(vf_bits(b), vf_bits(a), 2u)); }
+
+// 16 bytes of the image stream at 16-byte aligned position p (n = bpl * h, a multiple of 16): zeros outside the stream
+struct vf_u4 {
+  uint32_t x, y, z, w;
+};
+VF_HD vf_u4 vf_stream16(const uint8_t *in, int p, int n) {
+  vf_u4 r = {0u, 0u, 0u, 0u};
+  if (p >= 0 && p < n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    const u4v v = *(const __attribute__((address_space(1))) u4v *)(in + p);
+    r.x = v.x, r.y = v.y, r.z = v.z, r.w = v.w;
+#else
+    const uint32_t *q = (const uint32_t *)(in + p);
+    r.x = q[0], r.y = q[1], r.z = q[2], r.w = q[3];
+#endif
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// One thread's patch: 8 columns x ROWS rows of the four filters from a window of ROWS + 4 rows x 16 stream bytes
+// (W[r][q], dwords; pixel i of the patch is byte 4 + i of a window row, the patch's first row is window row 2).
+// Byte pairs (2+2j, 3+2j), j = 0..5, become 16-bit lane pairs P[r][j]; the patch's four output pairs are j = 1..4.
+// ---------------------------------------------------------------------------------------
+template <int ROWS>
+struct VfWindow {
+  uint32_t w[ROWS + 4][4];
+  VF_HDM vf_s2 pair(int r, int j) const {  // compile-time r, j after unrolling
+    const uint32_t v = w[r][(j + 1) >> 1];
+    return vf_pair(vf_perm(0u, v, (j & 1) ? 0x0c010c00u : 0x0c030c02u));
+  }
+  VF_HDM int byte(int r, int i) const { return (int)((w[r][i >> 2] >> (8 * (i & 3))) & 0xffu); }
+};
+
+// Sobel row pass of one output row from the binomial (S) and derivative (D) column sums of the six pairs:
+// du = S (x) [1 2 0 -2 -1], dv = D (x) [1 4 6 4 1], then (x >> 7) + 128 as bytes: du[0] = pixels 0-3, du[1] = 4-7
+VF_HD void vf_sobel_row(const vf_s2 (&S)[6], const vf_s2 (&D)[6], uint32_t (&du)[2], uint32_t (&dv)[2]) {
+  vf_s2 qs[5], qd[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    qs[i] = vf_shift(S[i], S[i + 1]);
+    qd[i] = vf_shift(D[i], D[i + 1]);
+  }
+  const vf_s2 c128 = {128, 128};
+  vf_s2 u[4], v[4];
+#pragma unroll
+  for (int m = 1; m <= 4; m++) {
+    const vf_s2 hu = (S[m - 1] - S[m + 1]) + (qs[m - 1] - qs[m]) * (short)2;
+    const vf_s2 hv = (D[m - 1] + D[m + 1]) + (qd[m - 1] + qd[m]) * (short)4 + D[m] * (short)6;
+    u[m - 1] = (hu >> 7) + c128;
+    v[m - 1] = (hv >> 7) + c128;
+  }
+  du[0] = vf_perm(vf_bits(u[1]), vf_bits(u[0]), 0x06040200u);
+  du[1] = vf_perm(vf_bits(u[3]), vf_bits(u[2]), 0x06040200u);
+  dv[0] = vf_perm(vf_bits(v[1]), vf_bits(v[0]), 0x06040200u);
+  dv[1] = vf_perm(vf_bits(v[3]), vf_bits(v[2]), 0x06040200u);
+}
+
+// blob + corner row pass of one output row from the column sums of the six pairs: C3 = rows 1..3, C5 = rows 0..4,
+// Cc = rows 0,1 minus rows 3,4; ctr[m-1] = the centre row's pixels of output pair m.
+//   f1 = -box5 + 2 box3 + 7 centre,  f2 = Cc (x) [1 1 0 -1 -1]
+VF_HD void vf_blob_row(const vf_s2 (&C3)[6], const vf_s2 (&C5)[6], const vf_s2 (&Cc)[6], const vf_s2 (&ctr)[4], vf_s2 (&f1)[4],
+                       vf_s2 (&f2)[4]) {
+  vf_s2 q3[5], q5[5], qc[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    q3[i] = vf_shift(C3[i], C3[i + 1]);
+    q5[i] = vf_shift(C5[i], C5[i + 1]);
+    qc[i] = vf_shift(Cc[i], Cc[i + 1]);
+  }
+#pragma unroll
+  for (int m = 1; m <= 4; m++) {
+    const vf_s2 b3 = q3[m - 1] + C3[m] + q3[m];
+    const vf_s2 b5 = (C5[m - 1] + C5[m + 1]) + (q5[m - 1] + q5[m]) + C5[m];
+    f1[m - 1] = b3 * (short)2 + ctr[m - 1] * (short)7 - b5;
+    f2[m - 1] = (Cc[m - 1] - Cc[m + 1]) + (qc[m - 1] - qc[m]);
+  }
+}
+
+// the general Sobel row (top / bottom rows of the image, where the reference's column pass is zero at stream positions
+// outside rows [2, h-3]): k_filters' scalar arithmetic.  f0 = stream position of the row's first pixel, rr = output row
+// inside the patch, [lo, hi) = stream positions of rows 2 .. h-3.
+template <int ROWS>
+VF_HD void vf_sobel_row_general(const VfWindow<ROWS> &W, int rr, int f0, int lo, int hi, uint32_t (&du)[2], uint32_t (&dv)[2]) {
+  int S[12], D[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    const int g = f0 + i - 2;
+    const bool ok = g >= lo && g < hi;
+    const int a = W.byte(rr, i + 2), b = W.byte(rr + 1, i + 2), c = W.byte(rr + 2, i + 2), dd = W.byte(rr + 3, i + 2),
+              e = W.byte(rr + 4, i + 2);
+    S[i] = ok ? a + 4 * b + 6 * c + 4 * dd + e : 0;
+    D[i] = ok ? a + 2 * b - 2 * dd - e : 0;
+  }
+  du[0] = du[1] = dv[0] = dv[1] = 0u;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int hu = S[k] + 2 * S[k + 1] - 2 * S[k + 3] - S[k + 4];
+    const int hv = D[k] + 4 * D[k + 1] + 6 * D[k + 2] + 4 * D[k + 3] + D[k + 4];
+    const int bu = (hu >> 7) + 128, bv = (hv >> 7) + 128;
+    du[k >> 2] |= (uint32_t)(bu < 0 ? 0 : (bu > 255 ? 255 : bu)) << (8 * (k & 3));
+    dv[k >> 2] |= (uint32_t)(bv < 0 ? 0 : (bv > 255 ? 255 : bv)) << (8 * (k & 3));
+  }
+}
+
+// column sums of one window column pair j for output row rr (window rows rr .. rr+4)
+template <int ROWS>
+VF_HD void vf_columns_sobel(const VfWindow<ROWS> &W, int rr, int j, vf_s2 &S, vf_s2 &D) {
+  const vf_s2 a = W.pair(rr, j), b = W.pair(rr + 1, j), c = W.pair(rr + 2, j), dd = W.pair(rr + 3, j), e = W.pair(rr + 4, j);
+  S = (a + e) + (b + dd) * (short)4 + c * (short)6;
+  D = (a - e) + (b - dd) * (short)2;
+}
+template <int ROWS>
+VF_HD void vf_columns_blob(const VfWindow<ROWS> &W, int rr, int j, vf_s2 &C3, vf_s2 &C5, vf_s2 &Cc) {
+  const vf_s2 a = W.pair(rr, j), b = W.pair(rr + 1, j), c = W.pair(rr + 2, j), dd = W.pair(rr + 3, j), e = W.pair(rr + 4, j);
+  C3 = (b + dd) + c;
+  C5 = C3 + (a + e);
+  Cc = (a + b) - (dd + e);
+}
+
+// the masks of the reference's loops for a dumped response (blob: columns / rows 3 .. ; corner: 2 ..; both to bpl-3, h-3)
+VF_HD int vf_f1_mask(int x, int y, int bpl, int h) { return x >= 3 && x <= bpl - 3 && y >= 3 && y <= h - 3; }
+VF_HD int vf_f2_mask(int x, int y, int bpl, int h) { return x >= 2 && x <= bpl - 3 && y >= 2 && y <= h - 3; }
+
+// ---------------------------------------------------------------------------------------
+// Tile geometries.  A tile's LDS image covers stream columns [X0 + IX, X0 + IX + 4 * IWD) and rows [Y0 + IY, .. + IH) with
+// (X0, Y0) = (tx * TW, ty * TH); its patch grid (= the f planes in LDS) starts at (X0 + FX, Y0 + FY), PC x PR patches of
+// 8 x ROWS pixels.  Cells of the suppression grid: origin = N + margin + cell * (N + 1) in the image.
+//   dense (N = 3):  a tile owns du / dv of the first 16 x 12 patches and the 32 x 12 cells whose origin has f-plane
+//                   coordinates (5 + 4 c, 5 + 4 r): image cell (32 tx - 3 + c, 12 ty - 2 + r)
+//   sparse (N = 9): a tile owns the 16 x 4 cells with f-plane origin (11 + 10 c, 9 + 10 r): image cell (16 tx + c, 4 ty + r)
+// ---------------------------------------------------------------------------------------
+struct VfDense {
+  static constexpr int N = 3, ROWS = 4;
+  static constexpr int TW = 128, TH = 48;
+  static constexpr int PC = 17, PR = 14, PC_OWN = 16, PR_OWN = 12;
+  static constexpr int IX = -16, IY = -6, IWD = 40, IH = 60;  // LDS image: 160 bytes x 60 rows
+  static constexpr int FX = -8, FY = -4;
+  static constexpr int FW = PC * 8, FH = PR * ROWS, FS = 138;  // f planes: 136 x 56 values, 138 int16 per row
+  static constexpr int CU = 32, CV = 12, CELL_X0 = 5, CELL_Y0 = 5, CELL_U0 = -3, CELL_V0 = -2;
+  static constexpr int WIN_DW = 1;  // first window dword of patch column 0 in an LDS image row
+};
+struct VfSparse {
+  static constexpr int N = 9, ROWS = 6;
+  static constexpr int TW = 160, TH = 40;
+  static constexpr int PC = 23, PR = 10;
+  static constexpr int IX = 0, IY = 4, IWD = 48, IH = 64;  // 192 bytes x 64 rows
+  static constexpr int FX = 4, FY = 6;
+  static constexpr int FW = PC * 8, FH = PR * ROWS, FS = 186;  // 184 x 60 values
+  static constexpr int CU = 16, CV = 4, CELL_X0 = 11, CELL_Y0 = 9, CELL_U0 = 0, CELL_V0 = 0;
+  static constexpr int WIN_DW = 0;
+};
+
+// LDS image fill: 16-byte pieces of the stream, thread t of nt
+template <class G>
+VF_HD void vf_fill(uint32_t *s_img, const uint8_t *in, int n, int bpl, int tx, int ty, int t, int nt) {
+  constexpr int per_row = G::IWD / 4;
+  for (int e = t; e < G::IH * per_row; e += nt) {
+    const int r = e / per_row, g = e - r * per_row;
+    const int p = (ty * G::TH + G::IY + r) * bpl + tx * G::TW + G::IX + 16 * g;
+    const vf_u4 v = vf_stream16(in, p, n);
+    uint32_t *dst = s_img + r * G::IWD + 4 * g;
+    dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+  }
+}
+
+template <class G>
+VF_HD void vf_load_window(const uint32_t *s_img, int pc, int pr, VfWindow<G::ROWS> &W) {
+#pragma unroll
+  for (int r = 0; r < G::ROWS + 4; r++) {
+    const uint32_t *row = s_img + (G::ROWS * pr + r) * G::IWD + 2 * pc + G::WIN_DW;
+#pragma unroll
+    for (int q = 0; q < 4; q++) W.w[r][q] = row[q];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// N1: one (cell, filter) of the suppression grid from an LDS plane f (STR int16 per row).  The first-wins extrema of
+// the cell in the reference's scan order (u outer, v inner, strict compare, viso/matcher.cpp:356-380) are the minima of the
+// key (value, scan position); a candidate is the extremum of its own cell, so "no strictly better value in its
+// (2N+1)^2 window outside the cell" (:383-428) is "the window extremum equals the candidate's value".  LANES lanes share
+// an item (lane l8 owns cell columns / window rows l8, l8 + LANES, ...) and combine by width-LANES shuffles; fast = no
+// window of this tile is cut by the clip limits (lim_i, lim_j) = (w-1-margin, h-1-margin) in plane coordinates.
+// Returns the packed survivors (plane coordinates + (u0, v0); 0 = none).
+// ---------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VF_SHFL_XOR(v, o, w) __shfl_xor((v), (o), (w))
+#else
+#define VF_SHFL_XOR(v, o, w) (v)  // LANES = 1 on the host: never reached
+#endif
+
+template <int N, int LANES, int STR>
+VF_HD void vf_nms_item(const int16_t *f, int li, int lj, int l8, bool fast, int lim_i, int lim_j, int tau, int u0, int v0,
+                       int32_t &cmin, int32_t &cmax) {
+  constexpr int N1 = N + 1, W = 2 * N + 1;
+  static_assert((STR & 1) == 0, "plane rows must stay dword aligned");
+  uint32_t kmin = 0xffffffffu, kmax = 0xffffffffu;
+  {
+    const int16_t *c0 = f + lj * STR + li;
+#pragma unroll
+    for (int t = 0; t < (N1 + LANES - 1) / LANES; t++) {
+      const int di = l8 + t * LANES;  // this lane's column(s) of the cell
+      if (di < N1) {
+#pragma unroll
+        for (int dj = 0; dj < N1; dj++) {
+          const int val = c0[dj * STR + di];
+          const uint32_t o = (uint32_t)(di * N1 + dj);
+          const uint32_t a = ((uint32_t)(val + 32768) << 10) | o, b = ((uint32_t)(32767 - val) << 10) | o;
+          kmin = a < kmin ? a : kmin;
+          kmax = b < kmax ? b : kmax;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = LANES / 2; o >= 1; o >>= 1) {
+    const uint32_t a = (uint32_t)VF_SHFL_XOR((int)kmin, o, LANES), b = (uint32_t)VF_SHFL_XOR((int)kmax, o, LANES);
+    kmin = a < kmin ? a : kmin;
+    kmax = b < kmax ? b : kmax;
+  }
+  const int mnv = (int)(kmin >> 10) - 32768, mno = (int)(kmin & 1023u);
+  const int mxv = 32767 - (int)(kmax >> 10), mxo = (int)(kmax & 1023u);
+  const int mni = li + mno / N1, mnj = lj + mno % N1, mxi = li + mxo / N1, mxj = lj + mxo % N1;
+  int wmn = 32767, wmx = -32768;  // extrema over this lane's share of the two windows
+  if (fast) {
+    // A window row is W = 2N+1 values from column mi-N on: (W+1)/2 aligned dwords cover it whatever the parity of that
+    // column, with one value too many - the last one (even start) or the first (odd start) - which is replaced by the
+    // neutral element; then two values per v_pk_min_i16 / v_pk_max_i16.
+    constexpr int ND = (W + 1) / 2;
+    const int cn = mni - N, cx = mxi - N;
+    const bool pn1 = (cn & 1) != 0, px1 = (cx & 1) != 0;
+    const uint32_t *pn = (const uint32_t *)(f + (mnj - N) * STR + (cn & ~1)), *px = (const uint32_t *)(f + (mxj - N) * STR + (cx & ~1));
+    vf_s2 amn = {32767, 32767}, amx = {-32768, -32768};
+#pragma unroll
+    for (int t = 0; t < (W + LANES - 1) / LANES; t++) {
+      const int r = l8 + t * LANES;
+      if (r < W) {
+        const uint32_t *rn = pn + r * (STR / 2), *rx = px + r * (STR / 2);
+#pragma unroll
+        for (int c = 0; c < ND; c++) {
+          uint32_t vn = rn[c], vx = rx[c];
+          if (c == 0) {
+            vn = pn1 ? ((vn & 0xffff0000u) | 0x00007fffu) : vn;
+            vx = px1 ? ((vx & 0xffff0000u) | 0x00008000u) : vx;
+          }
+          if (c == ND - 1) {
+            vn = pn1 ? vn : ((vn & 0x0000ffffu) | 0x7fff0000u);
+            vx = px1 ? vx : ((vx & 0x0000ffffu) | 0x80000000u);
+          }
+          amn = __builtin_elementwise_min(amn, vf_pair(vn));
+          amx = __builtin_elementwise_max(amx, vf_pair(vx));
+        }
+      }
+    }
+    wmn = (int)amn.x < (int)amn.y ? (int)amn.x : (int)amn.y;
+    wmx = (int)amx.x > (int)amx.y ? (int)amx.x : (int)amx.y;
+  } else {
+    for (int r = l8; r < W; r += LANES) {
+      if (mnj - N + r <= lim_j)
+        for (int c = 0; c < W && mni - N + c <= lim_i; c++) {
+          const int v = f[(mnj - N + r) * STR + mni - N + c];
+          wmn = v < wmn ? v : wmn;
+        }
+      if (mxj - N + r <= lim_j)
+        for (int c = 0; c < W && mxi - N + c <= lim_i; c++) {
+          const int v = f[(mxj - N + r) * STR + mxi - N + c];
+          wmx = v > wmx ? v : wmx;
+        }
+    }
+  }
+#pragma unroll
+  for (int o = LANES / 2; o >= 1; o >>= 1) {
+    const int a = VF_SHFL_XOR(wmn, o, LANES), b = VF_SHFL_XOR(wmx, o, LANES);
+    wmn = a < wmn ? a : wmn;
+    wmx = b > wmx ? b : wmx;
+  }
+  const bool vmin = (mnv <= -tau) && wmn >= mnv, vmax = (mxv >= tau) && wmx <= mxv;
+  cmin = vmin ? (int32_t)(0x80000000u | (uint32_t)(mni + u0) | ((uint32_t)(mnj + v0) << 14)) : 0;
+  cmax = vmax ? (int32_t)(0x80000000u | (uint32_t)(mxi + u0) | ((uint32_t)(mxj + v0) << 14)) : 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// dense tile, thread t < PC * PR: its patch -> du / dv (HBM, owned patches), f1 / f2 (LDS planes; HBM too when
+// dump_f1 != null: the debug getter of the filter responses)
+// ---------------------------------------------------------------------------------------
+VF_HD void vf_dense_patch(const uint32_t *s_img, int16_t *s_f, int t, int tx, int ty, int bpl, int h, uint8_t *du_plane,
+                          uint8_t *dv_plane, int16_t *dump_f1, int16_t *dump_f2) {
+  typedef VfDense G;
+  const int pr = t / G::PC, pc = t - pr * G::PC;
+  VfWindow<G::ROWS> W;
+  vf_load_window<G>(s_img, pc, pr, W);
+  const int x0 = tx * G::TW + G::FX + 8 * pc, y0 = ty * G::TH + G::FY + G::ROWS * pr;
+  const bool own = pc < G::PC_OWN && pr < G::PR_OWN && x0 >= 0 && x0 < bpl;
+  const bool interior = y0 >= 3 && y0 + 3 <= h - 4;
+  int16_t *f1 = s_f + (G::ROWS * pr) * G::FS + 8 * pc, *f2 = f1 + G::FH * G::FS;
+#pragma unroll
+  for (int rr = 0; rr < G::ROWS; rr++) {
+    const int y = y0 + rr;
+    vf_s2 C3[6], C5[6], Cc[6], ctr[4], o1[4], o2[4];
+#pragma unroll
+    for (int j = 0; j < 6; j++) vf_columns_blob<G::ROWS>(W, rr, j, C3[j], C5[j], Cc[j]);
+#pragma unroll
+    for (int m = 0; m < 4; m++) ctr[m] = W.pair(rr + 2, m + 1);
+    vf_blob_row(C3, C5, Cc, ctr, o1, o2);
+    uint32_t *d1 = (uint32_t *)(f1 + rr * G::FS), *d2 = (uint32_t *)(f2 + rr * G::FS);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      d1[m] = vf_bits(o1[m]);
+      d2[m] = vf_bits(o2[m]);
+    }
+    if (own && y >= 0 && y < h) {
+      uint32_t du[2], dv[2];
+      if (interior) {
+        vf_s2 S[6], D[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) vf_columns_sobel<G::ROWS>(W, rr, j, S[j], D[j]);
+        vf_sobel_row(S, D, du, dv);
+      } else {
+        vf_sobel_row_general<G::ROWS>(W, rr, y * bpl + x0, 2 * bpl, (h - 2) * bpl, du, dv);
+      }
+      uint32_t *pu = (uint32_t *)(du_plane + (size_t)y * bpl + x0), *pv = (uint32_t *)(dv_plane + (size_t)y * bpl + x0);
+      pu[0] = du[0], pu[1] = du[1];
+      pv[0] = dv[0], pv[1] = dv[1];
+      if (dump_f1) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int x = x0 + 2 * m;
+          dump_f1[(size_t)y * bpl + x] = vf_f1_mask(x, y, bpl, h) ? o1[m].x : (short)0;
+          dump_f1[(size_t)y * bpl + x + 1] = vf_f1_mask(x + 1, y, bpl, h) ? o1[m].y : (short)0;
+          dump_f2[(size_t)y * bpl + x] = vf_f2_mask(x, y, bpl, h) ? o2[m].x : (short)0;
+          dump_f2[(size_t)y * bpl + x + 1] = vf_f2_mask(x + 1, y, bpl, h) ? o2[m].y : (short)0;
+        }
+      }
+    }
+  }
+}
+
+// dense tile, suppression item it < CU * CV * 2 (filter fastest): survivors of image cell (ci, cj) -> cand
+VF_HD void vf_dense_nms(const int16_t *s_f, int it, int tx, int ty, int mw, int mh, int margin, int tau, int ncu, int ncv,
+                        int32_t *cand) {
+  typedef VfDense G;
+  const int k = it & 1, cl = it >> 1;
+  const int lcv = cl / G::CU, lcu = cl - lcv * G::CU;
+  const int ci = G::CU * tx + G::CELL_U0 + lcu, cj = G::CV * ty + G::CELL_V0 + lcv;
+  const int u0 = tx * G::TW + G::FX, v0 = ty * G::TH + G::FY;
+  const int lim_i = mw - 1 - margin - u0, lim_j = mh - 1 - margin - v0;
+  const bool fast = lim_i >= G::FW - 1 && lim_j >= G::FH - 1;
+  int32_t cmin, cmax;
+  vf_nms_item<G::N, 1, G::FS>(s_f + k * G::FH * G::FS, G::CELL_X0 + (G::N + 1) * lcu, G::CELL_Y0 + (G::N + 1) * lcv, 0, fast, lim_i,
+                              lim_j, tau, u0, v0, cmin, cmax);
+  if (ci >= 0 && ci < ncu && cj >= 0 && cj < ncv) {
+    int32_t *c = cand + (size_t)(ci * ncv + cj) * 4 + 2 * k;
+    c[0] = cmin;
+    c[1] = cmax;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// sparse tile: one f plane in LDS at a time.  A thread's patch gives f1 (to LDS at once) and f2 (kept in registers
+// until the first plane's suppression is through).
+// ---------------------------------------------------------------------------------------
+struct VfSparseKeep {
+  uint32_t f2[VfSparse::ROWS][4];
+};
+VF_HD void vf_sparse_patch(const uint32_t *s_img, int16_t *s_f, int t, VfSparseKeep &keep) {
+  typedef VfSparse G;
+  const int pr = t / G::PC, pc = t - pr * G::PC;
+  VfWindow<G::ROWS> W;
+  vf_load_window<G>(s_img, pc, pr, W);
+  int16_t *f1 = s_f + (G::ROWS * pr) * G::FS + 8 * pc;
+#pragma unroll
+  for (int rr = 0; rr < G::ROWS; rr++) {
+    vf_s2 C3[6], C5[6], Cc[6], ctr[4], o1[4], o2[4];
+#pragma unroll
+    for (int j = 0; j < 6; j++) vf_columns_blob<G::ROWS>(W, rr, j, C3[j], C5[j], Cc[j]);
+#pragma unroll
+    for (int m = 0; m < 4; m++) ctr[m] = W.pair(rr + 2, m + 1);
+    vf_blob_row(C3, C5, Cc, ctr, o1, o2);
+    uint32_t *d1 = (uint32_t *)(f1 + rr * G::FS);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      d1[m] = vf_bits(o1[m]);
+      keep.f2[rr][m] = vf_bits(o2[m]);
+    }
+  }
+}
+VF_HD void vf_sparse_store_f2(int16_t *s_f, int t, const VfSparseKeep &keep) {
+  typedef VfSparse G;
+  const int pr = t / G::PC, pc = t - pr * G::PC;
+  int16_t *f = s_f + (G::ROWS * pr) * G::FS + 8 * pc;
+#pragma unroll
+  for (int rr = 0; rr < G::ROWS; rr++) {
+    uint32_t *d = (uint32_t *)(f + rr * G::FS);
+#pragma unroll
+    for (int m = 0; m < 4; m++) d[m] = keep.f2[rr][m];
+  }
+}
+// item it < CU * CV (x LANES lanes: l8), filter k: survivors of image cell (ci, cj)
+template <int LANES>
+VF_HD void vf_sparse_nms(const int16_t *s_f, int it, int l8, int k, int tx, int ty, int mw, int mh, int margin, int tau, int ncu,
+                         int ncv, int32_t *cand) {
+  typedef VfSparse G;
+  const int lcv = it / G::CU, lcu = it - lcv * G::CU;
+  const int ci = G::CU * tx + G::CELL_U0 + lcu, cj = G::CV * ty + G::CELL_V0 + lcv;
+  const int u0 = tx * G::TW + G::FX, v0 = ty * G::TH + G::FY;
+  const int lim_i = mw - 1 - margin - u0, lim_j = mh - 1 - margin - v0;
+  const bool fast = lim_i >= G::FW - 1 && lim_j >= G::FH - 1;
+  int32_t cmin, cmax;
+  vf_nms_item<G::N, LANES, G::FS>(s_f, G::CELL_X0 + (G::N + 1) * lcu, G::CELL_Y0 + (G::N + 1) * lcv, l8, fast, lim_i, lim_j, tau, u0,
+                                  v0, cmin, cmax);
+  if (l8 == 0 && ci < ncu && cj < ncv) {
+    int32_t *c = cand + (size_t)(ci * ncv + cj) * 4 + 2 * k;
+    c[0] = cmin;
+    c[1] = cmax;
+  }
+}

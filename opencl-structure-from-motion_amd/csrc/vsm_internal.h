@@ -95,6 +95,8 @@ enum VsmKernelId {
   VSM_K_FRONT,  // fused ingest + half-resolution image + full-resolution Sobel (half_resolution = 1)
   // the exact Delaunay stage of the look-ahead forms (their own streams; launched from the caller's and from pool threads)
   VSM_K_DC_KEYS, VSM_K_DC_TIES, VSM_K_DC_KD, VSM_K_DC_BLOCK, VSM_K_DC_MERGE, VSM_K_DC_SUPPORT, VSM_K_DC_COMPACT, VSM_K_DC_PRIOR,
+  // the fused matching-resolution image side (filters + suppression out of one LDS tile; vsm_feat.h)
+  VSM_K_FEAT_DENSE, VSM_K_FEAT_SPARSE,
   VSM_K_COUNT
 };
 struct VsmProf {
@@ -154,13 +156,15 @@ struct VsmProf {
 // ---- launchers (vsm_kernels.hip) ----
 void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0,
                        const uint8_t *src1, size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d);
+// fused: bit 0 = the fused filter + suppression tiles where the radii allow, bit 1 = they also write f1 / f2 (debug getter)
 // half_resolution = 1 only: caller image(s) -> [padded copy if write_img], half-resolution image, full-resolution Sobel planes
 // in one pass; vsm_launch_features(front_done = 1) then skips its own halving and full-resolution Sobel
 void vsm_launch_front(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0, const uint8_t *src1,
                       size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d, int write_img);
-void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d,
-                         int16_t *f1, int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res,
-                         int binsize, const VsmImage *h_imgs, int front_done = 0);
+// returns 1 if f1 / f2 hold the launch's filter responses afterwards (unfused kernels, or fused bit 1)
+int vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d,
+                        int16_t *f1, int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res,
+                        int binsize, const VsmImage *h_imgs, int front_done = 0, int fused = 1);
 void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
                       const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq);
 void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair *d_pairs, int npairs, int pass, int n_upper);

@@ -10,7 +10,10 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "vsm_internal.h"
+#include "vsm_feat.h"
 
 #define WAVE 64
 
@@ -757,6 +760,72 @@ __global__ void __launch_bounds__(256)
     c[0] = vmin ? (int32_t)(0x80000000u | (uint32_t)(mni + u0) | ((uint32_t)(mnj + v0) << 14)) : 0;
     c[1] = vmax ? (int32_t)(0x80000000u | (uint32_t)(mxi + u0) | ((uint32_t)(mxj + v0) << 14)) : 0;
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// The fused matching-resolution image side for the default suppression radii (dense n = 3, sparse n = 9): F1-F3 + N1 out of
+// one LDS tile per workgroup, f1 / f2 never in HBM.  All per-thread work is in vsm_feat.h (shared with the CPU emulation
+// of the "not gpu" tests); here: the phases.
+//   k_feat_dense   tile = 128 x 48 owned pixels: image tile (+ 8 / 6 pixels of halo) -> LDS, 17 x 14 patches of 8 x 4 pixels,
+//                  one per thread: du / dv (HBM), f1 / f2 (LDS), then 32 x 12 cells x 2 filters, a thread each
+//   k_feat_sparse  tile = 16 x 4 cells of 10 x 10 pixels: the 19 x 19 windows want 11 pixels of halo, so this scale gets its
+//                  own coarser tile and recomputes f1 / f2 (12 of 26 operations per pixel) rather than doubling the dense
+//                  tile's filter work: 23 x 10 patches of 8 x 6 pixels; one response plane in LDS at a time (34 KB: four
+//                  workgroups per compute unit), f2 waits in registers; 8 lanes per (cell, filter)
+// XCD-aware placement: neighbouring tiles (which share halo lines) follow each other on one XCD's L2.
+// ---------------------------------------------------------------------------------------
+template <bool DUMP>
+__global__ void __launch_bounds__(256)
+    k_feat_dense(const VsmImage *__restrict__ imgs, int first, VsmDims d, int tau, int tiles_x, int nbx, int n_img,
+                 int16_t *__restrict__ f1base, int16_t *__restrict__ f2base, size_t f_stride) {
+  typedef VfDense G;
+  __shared__ uint32_t s_img[G::IH * G::IWD];
+  __shared__ int16_t s_f[2 * G::FH * G::FS];
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int zi = lb / nbx, bx = lb - zi * nbx;
+  if (zi >= n_img) return;
+  const VsmImage &im = imgs[first + zi];
+  const VsmSet &st = im.set[1];
+  const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+  const int t = threadIdx.x;
+  vf_fill<G>(s_img, im.imgm, d.mbpl * d.mh, d.mbpl, tx, ty, t, 256);
+  __syncthreads();
+  if (t < G::PC * G::PR)
+    vf_dense_patch(s_img, s_f, t, tx, ty, d.mbpl, d.mh, im.du, im.dv, DUMP ? f1base + (size_t)zi * f_stride : nullptr,
+                   DUMP ? f2base + (size_t)zi * f_stride : nullptr);
+  __syncthreads();
+  for (int it = t; it < G::CU * G::CV * 2; it += 256) vf_dense_nms(s_f, it, tx, ty, d.mw, d.mh, VSM_MARGIN, tau, st.ncu, st.ncv, st.cand);
+}
+
+__global__ void __launch_bounds__(256)
+    k_feat_sparse(const VsmImage *__restrict__ imgs, int first, VsmDims d, int tau, int tiles_x, int nbx, int n_img) {
+  typedef VfSparse G;
+  __shared__ uint32_t s_img[G::IH * G::IWD];
+  __shared__ int16_t s_f[G::FH * G::FS];
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int zi = lb / nbx, bx = lb - zi * nbx;
+  if (zi >= n_img) return;
+  const VsmImage &im = imgs[first + zi];
+  const VsmSet &st = im.set[0];
+  const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+  const int t = threadIdx.x;
+  vf_fill<G>(s_img, im.imgm, d.mbpl * d.mh, d.mbpl, tx, ty, t, 256);
+  __syncthreads();
+  VfSparseKeep keep;
+  if (t < G::PC * G::PR) vf_sparse_patch(s_img, s_f, t, keep);
+  __syncthreads();
+  static_assert((G::CU * G::CV) % 32 == 0, "whole rounds of 32 items x 8 lanes");
+  for (int it = t >> 3; it < G::CU * G::CV; it += 32) vf_sparse_nms<8>(s_f, it, t & 7, 0, tx, ty, d.mw, d.mh, VSM_MARGIN, tau, st.ncu, st.ncv, st.cand);
+  __syncthreads();
+  if (t < G::PC * G::PR) vf_sparse_store_f2(s_f, t, keep);
+  __syncthreads();
+  for (int it = t >> 3; it < G::CU * G::CV; it += 32) vf_sparse_nms<8>(s_f, it, t & 7, 1, tx, ty, d.mw, d.mh, VSM_MARGIN, tau, st.ncu, st.ncv, st.cand);
+}
+
+// tiles per image of the two kernels (the CPU emulation mirrors this: tests/emu/feat_emu.cpp)
+static void vsm_feat_tiles(const VsmDims &d, const VsmSet &dense, int &dx, int &dy) {
+  dx = std::max((d.mbpl + 8 + 127) / 128, (dense.ncu + 3 + 31) / 32);
+  dy = std::max((d.mh + 4 + 47) / 48, (dense.ncv + 2 + 11) / 12);
 }
 
 // block-wide exclusive scan of one int per thread (blockDim.x == 1024); returns the exclusive
@@ -2140,9 +2209,9 @@ void vsm_launch_front(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int fi
   pf.end(s);
 }
 
-void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d,
-                         int16_t *f1, int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res,
-                         int binsize, const VsmImage *h_imgs, int front_done) {
+int vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d,
+                        int16_t *f1, int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res,
+                        int binsize, const VsmImage *h_imgs, int front_done, int fused) {
   if (half_res && !front_done) {
     pf.begin(VSM_K_HALVE, s);
     hipLaunchKernelGGL(k_halve, dim3(cdiv(d.mbpl / 4, 256), d.mh, n_img), dim3(256), 0, s, d_imgs, first, d);
@@ -2152,10 +2221,6 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
                        d.bpl, d.h, (int16_t *)nullptr, (int16_t *)nullptr, (size_t)0);
     pf.end(s);
   }
-  pf.begin(VSM_K_FILTERS, s);
-  hipLaunchKernelGGL(k_filters<false>, dim3(cdiv(d.mbpl / 4, 64), cdiv(d.mh, 16), n_img), dim3(256), 0, s, d_imgs, first,
-                     d.mbpl, d.mh, f1, f2, f_stride);
-  pf.end(s);
   const int set_lo = multi_stage ? 0 : 1;
   const int nb = 4 * d.ub * d.vb * VSM_VSUB;  // fine bins
   int max_cells = 0, max_cap = 0;
@@ -2163,7 +2228,36 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
     max_cells = max(max_cells, h_imgs[first].set[k].ncu * h_imgs[first].set[k].ncv);
     max_cap = max(max_cap, h_imgs[first].set[k].cap);
   }
-  if (max_cells > 0) {
+  // the fused tiles serve the default radii (dense 3, sparse 9: viso/matcher.cpp:685-687); other radii take the separate
+  // filter + suppression kernels with f1 / f2 in HBM
+  const VsmSet &sd = h_imgs[first].set[1], &ss = h_imgs[first].set[0];
+  const bool fuse = (fused & 1) && sd.nms_n == 3 && sd.ncu * sd.ncv > 0 && (!multi_stage || (ss.nms_n == 9 && ss.ncu * ss.ncv > 0));
+  if (fuse) {
+    int dx, dy;
+    vsm_feat_tiles(d, sd, dx, dy);
+    const int nbx = dx * dy;
+    pf.begin(VSM_K_FEAT_DENSE, s);
+    if (fused & 2)
+      hipLaunchKernelGGL(k_feat_dense<true>, dim3(((nbx * n_img + 7) / 8) * 8), dim3(256), 0, s, d_imgs, first, d, nms_tau, dx, nbx,
+                         n_img, f1, f2, f_stride);
+    else
+      hipLaunchKernelGGL(k_feat_dense<false>, dim3(((nbx * n_img + 7) / 8) * 8), dim3(256), 0, s, d_imgs, first, d, nms_tau, dx, nbx,
+                         n_img, f1, f2, f_stride);
+    pf.end(s);
+    if (multi_stage) {
+      const int sx = cdiv(ss.ncu, VfSparse::CU), sy = cdiv(ss.ncv, VfSparse::CV);
+      pf.begin(VSM_K_FEAT_SPARSE, s);
+      hipLaunchKernelGGL(k_feat_sparse, dim3(((sx * sy * n_img + 7) / 8) * 8), dim3(256), 0, s, d_imgs, first, d, nms_tau, sx, sx * sy,
+                         n_img);
+      pf.end(s);
+    }
+  } else {
+    pf.begin(VSM_K_FILTERS, s);
+    hipLaunchKernelGGL(k_filters<false>, dim3(cdiv(d.mbpl / 4, 64), cdiv(d.mh, 16), n_img), dim3(256), 0, s, d_imgs, first,
+                       d.mbpl, d.mh, f1, f2, f_stride);
+    pf.end(s);
+  }
+  if (max_cells > 0 && !fuse) {
     // per set: small n -> LDS tile kernel, mid n -> 8-lane LDS tile kernel, else wave per cell
     for (int k = set_lo; k < 2; k++) {
       const VsmSet &st = h_imgs[first].set[k];
@@ -2216,6 +2310,7 @@ void vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int
   pf.begin(VSM_K_BINRANK, s);
   hipLaunchKernelGGL(k_bin_rank, dim3(cdiv(max_cap, 256), 2, n_img), dim3(256), 0, s, d_imgs, first, set_lo);
   pf.end(s);
+  return (!fuse || (fused & 2)) ? 1 : 0;
 }
 
 // One launch serves `npairs` frame pairs (blockIdx.y); jobs == nullptr: the single pair job0.

@@ -25,10 +25,12 @@ def _same(a, b):
     return a.shape == b.shape and a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("w,h,half", [(320, 96, 1), (333, 101, 1), (640, 480, 1), (1242, 375, 1), (304, 128, 0), (64, 48, 0)])
-def test_filters_vs_oracle(vm, B, synth, w, h, half):
+def test_filters_vs_oracle(vm, B, synth, w, h, half, fused):
+    """whole planes; fused = 1: the responses are a side output of the fused filter + suppression tiles (k_feat_dense)"""
     l, r = synth.stereo_sequence(21, w, h, 1)[0]
-    m = vm.Matcher(half_resolution=half)
+    m = vm.Matcher(half_resolution=half, options={"fused_features": fused, "filter_planes": 1})
     assert m.push_back(l, r) == 0
     img = B.pad_image(l)
     mimg = B.half_image("oracle", img, w) if half else img
@@ -48,6 +50,10 @@ def test_filters_vs_oracle(vm, B, synth, w, h, half):
     du2, _ = B.sobel5x5("oracle", rm)
     assert np.array_equal(m.gradients(3, False)[0], du2.ravel())
     m.close()
+    if fused:  # without the option the fused tiles keep f1 / f2 in LDS: nothing to read back
+        m = vm.Matcher(half_resolution=half)
+        assert m.push_back(l, r) == 0 and m.filter_responses() == (None, None)
+        m.close()
 
 
 @pytest.mark.parametrize("method", [2, 0, 1])
