@@ -248,9 +248,9 @@ VF_HD void vf_load_window(const uint32_t *s_img, int pc, int pr, VfWindow<G::ROW
 #define VF_SHFL_XOR(v, o, w) (v)  // LANES = 1 on the host: never reached
 #endif
 
-template <int N, int LANES, int STR>
-VF_HD void vf_nms_item(const int16_t *f, int li, int lj, int l8, bool fast, int lim_i, int lim_j, int tau, int u0, int v0,
-                       int32_t &cmin, int32_t &cmax) {
+template <int N, int LANES, int STR, bool fast>
+VF_HD void vf_nms_item(const int16_t *f, int li, int lj, int l8, int lim_i, int lim_j, int tau, int u0, int v0, int32_t &cmin,
+                       int32_t &cmax) {
   constexpr int N1 = N + 1, W = 2 * N + 1;
   static_assert((STR & 1) == 0, "plane rows must stay dword aligned");
   uint32_t kmin = 0xffffffffu, kmax = 0xffffffffu;
@@ -280,52 +280,53 @@ VF_HD void vf_nms_item(const int16_t *f, int li, int lj, int l8, bool fast, int 
   const int mnv = (int)(kmin >> 10) - 32768, mno = (int)(kmin & 1023u);
   const int mxv = 32767 - (int)(kmax >> 10), mxo = (int)(kmax & 1023u);
   const int mni = li + mno / N1, mnj = lj + mno % N1, mxi = li + mxo / N1, mxj = lj + mxo % N1;
-  int wmn = 32767, wmx = -32768;  // extrema over this lane's share of the two windows
-  if (fast) {
+  int wmn, wmx;  // extrema over this lane's share of the two windows
+  {
     // A window row is W = 2N+1 values from column mi-N on: (W+1)/2 aligned dwords cover it whatever the parity of that
     // column, with one value too many - the last one (even start) or the first (odd start) - which is replaced by the
-    // neutral element; then two values per v_pk_min_i16 / v_pk_max_i16.
+    // neutral element; then two values per v_pk_min_i16 / v_pk_max_i16.  In tiles the clip limits cut (fast = false),
+    // columns beyond lim_i become neutral through one v_bfi per dword (the masks do not depend on the row) and rows
+    // beyond lim_j are left out.
     constexpr int ND = (W + 1) / 2;
     const int cn = mni - N, cx = mxi - N;
     const bool pn1 = (cn & 1) != 0, px1 = (cx & 1) != 0;
     const uint32_t *pn = (const uint32_t *)(f + (mnj - N) * STR + (cn & ~1)), *px = (const uint32_t *)(f + (mxj - N) * STR + (cx & ~1));
+    const int nvn = lim_i - (cn & ~1) + 1, nvx = lim_i - (cx & ~1) + 1;  // columns within the limit, counted from the first dword
     vf_s2 amn = {32767, 32767}, amx = {-32768, -32768};
 #pragma unroll
     for (int t = 0; t < (W + LANES - 1) / LANES; t++) {
       const int r = l8 + t * LANES;
-      if (r < W) {
-        const uint32_t *rn = pn + r * (STR / 2), *rx = px + r * (STR / 2);
+      if (r < W && (fast || (mnj - N + r <= lim_j))) {
+        const uint32_t *rn = pn + r * (STR / 2);
 #pragma unroll
         for (int c = 0; c < ND; c++) {
-          uint32_t vn = rn[c], vx = rx[c];
-          if (c == 0) {
-            vn = pn1 ? ((vn & 0xffff0000u) | 0x00007fffu) : vn;
-            vx = px1 ? ((vx & 0xffff0000u) | 0x00008000u) : vx;
-          }
-          if (c == ND - 1) {
-            vn = pn1 ? vn : ((vn & 0x0000ffffu) | 0x7fff0000u);
-            vx = px1 ? vx : ((vx & 0x0000ffffu) | 0x80000000u);
+          uint32_t vn = rn[c];
+          if (c == 0) vn = pn1 ? ((vn & 0xffff0000u) | 0x00007fffu) : vn;
+          if (c == ND - 1) vn = pn1 ? vn : ((vn & 0x0000ffffu) | 0x7fff0000u);
+          if (!fast) {
+            const uint32_t keep = nvn >= 2 * c + 2 ? 0xffffffffu : (nvn == 2 * c + 1 ? 0x0000ffffu : 0u);
+            vn = (vn & keep) | (0x7fff7fffu & ~keep);
           }
           amn = __builtin_elementwise_min(amn, vf_pair(vn));
+        }
+      }
+      if (r < W && (fast || (mxj - N + r <= lim_j))) {
+        const uint32_t *rx = px + r * (STR / 2);
+#pragma unroll
+        for (int c = 0; c < ND; c++) {
+          uint32_t vx = rx[c];
+          if (c == 0) vx = px1 ? ((vx & 0xffff0000u) | 0x00008000u) : vx;
+          if (c == ND - 1) vx = px1 ? vx : ((vx & 0x0000ffffu) | 0x80000000u);
+          if (!fast) {
+            const uint32_t keep = nvx >= 2 * c + 2 ? 0xffffffffu : (nvx == 2 * c + 1 ? 0x0000ffffu : 0u);
+            vx = (vx & keep) | (0x80008000u & ~keep);
+          }
           amx = __builtin_elementwise_max(amx, vf_pair(vx));
         }
       }
     }
     wmn = (int)amn.x < (int)amn.y ? (int)amn.x : (int)amn.y;
     wmx = (int)amx.x > (int)amx.y ? (int)amx.x : (int)amx.y;
-  } else {
-    for (int r = l8; r < W; r += LANES) {
-      if (mnj - N + r <= lim_j)
-        for (int c = 0; c < W && mni - N + c <= lim_i; c++) {
-          const int v = f[(mnj - N + r) * STR + mni - N + c];
-          wmn = v < wmn ? v : wmn;
-        }
-      if (mxj - N + r <= lim_j)
-        for (int c = 0; c < W && mxi - N + c <= lim_i; c++) {
-          const int v = f[(mxj - N + r) * STR + mxi - N + c];
-          wmx = v > wmx ? v : wmx;
-        }
-    }
   }
 #pragma unroll
   for (int o = LANES / 2; o >= 1; o >>= 1) {
@@ -405,8 +406,12 @@ VF_HD void vf_dense_nms(const int16_t *s_f, int it, int tx, int ty, int mw, int 
   const int lim_i = mw - 1 - margin - u0, lim_j = mh - 1 - margin - v0;
   const bool fast = lim_i >= G::FW - 1 && lim_j >= G::FH - 1;
   int32_t cmin, cmax;
-  vf_nms_item<G::N, 1, G::FS>(s_f + k * G::FH * G::FS, G::CELL_X0 + (G::N + 1) * lcu, G::CELL_Y0 + (G::N + 1) * lcv, 0, fast, lim_i,
-                              lim_j, tau, u0, v0, cmin, cmax);
+  const int16_t *f = s_f + k * G::FH * G::FS;
+  const int li = G::CELL_X0 + (G::N + 1) * lcu, lj = G::CELL_Y0 + (G::N + 1) * lcv;
+  if (fast)  // (the same for all items of a tile)
+    vf_nms_item<G::N, 1, G::FS, true>(f, li, lj, 0, lim_i, lim_j, tau, u0, v0, cmin, cmax);
+  else
+    vf_nms_item<G::N, 1, G::FS, false>(f, li, lj, 0, lim_i, lim_j, tau, u0, v0, cmin, cmax);
   if (ci >= 0 && ci < ncu && cj >= 0 && cj < ncv) {
     int32_t *c = cand + (size_t)(ci * ncv + cj) * 4 + 2 * k;
     c[0] = cmin;
@@ -465,8 +470,11 @@ VF_HD void vf_sparse_nms(const int16_t *s_f, int it, int l8, int k, int tx, int 
   const int lim_i = mw - 1 - margin - u0, lim_j = mh - 1 - margin - v0;
   const bool fast = lim_i >= G::FW - 1 && lim_j >= G::FH - 1;
   int32_t cmin, cmax;
-  vf_nms_item<G::N, LANES, G::FS>(s_f, G::CELL_X0 + (G::N + 1) * lcu, G::CELL_Y0 + (G::N + 1) * lcv, l8, fast, lim_i, lim_j, tau, u0,
-                                  v0, cmin, cmax);
+  const int li = G::CELL_X0 + (G::N + 1) * lcu, lj = G::CELL_Y0 + (G::N + 1) * lcv;
+  if (fast)  // (the same for all items of a tile)
+    vf_nms_item<G::N, LANES, G::FS, true>(s_f, li, lj, l8, lim_i, lim_j, tau, u0, v0, cmin, cmax);
+  else
+    vf_nms_item<G::N, LANES, G::FS, false>(s_f, li, lj, l8, lim_i, lim_j, tau, u0, v0, cmin, cmax);
   if (l8 == 0 && ci < ncu && cj < ncv) {
     int32_t *c = cand + (size_t)(ci * ncv + cj) * 4 + 2 * k;
     c[0] = cmin;

@@ -774,6 +774,29 @@ __global__ void __launch_bounds__(256)
 //                  workgroups per compute unit), f2 waits in registers; 8 lanes per (cell, filter)
 // XCD-aware placement: neighbouring tiles (which share halo lines) follow each other on one XCD's L2.
 // ---------------------------------------------------------------------------------------
+#ifdef VSM_FEAT_TIMING  // experiments (tools/build_variant.sh NAME -DVSM_FEAT_TIMING, tools/feat_timing.py): cycles per phase of every wave
+__device__ unsigned int vsm_ft_rec[2][1 << 16][10];  // [kernel][wave] start (low bits), phase lengths ...
+extern "C" int vsm_debug_feat_rec(unsigned int *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vsm_ft_rec), sizeof(vsm_ft_rec)) != hipSuccess) return -1;
+  (void)reset;
+  return 0;
+}
+#define FT_DECL unsigned long long ft_t[10]; int ft_n = 0
+#define FT_STAMP ft_t[ft_n++] = __builtin_amdgcn_s_memtime()
+#define FT_FLUSH(kern)                                                              \
+  do {                                                                              \
+    const unsigned wv = blockIdx.x * 4 + (threadIdx.x >> 6);                        \
+    if ((threadIdx.x & 63) == 0 && wv < (1u << 16)) {                               \
+      vsm_ft_rec[kern][wv][0] = (unsigned)ft_t[0] | 1u;                             \
+      for (int q = 1; q < ft_n; q++) vsm_ft_rec[kern][wv][q] = (unsigned)(ft_t[q] - ft_t[q - 1]); \
+    }                                                                               \
+  } while (0)
+#else
+#define FT_DECL
+#define FT_STAMP
+#define FT_FLUSH(base)
+#endif
+
 template <bool DUMP>
 __global__ void __launch_bounds__(256)
     k_feat_dense(const VsmImage *__restrict__ imgs, int first, VsmDims d, int tau, int tiles_x, int nbx, int n_img,
@@ -788,13 +811,21 @@ __global__ void __launch_bounds__(256)
   const VsmSet &st = im.set[1];
   const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
   const int t = threadIdx.x;
+  FT_DECL;
+  FT_STAMP;
   vf_fill<G>(s_img, im.imgm, d.mbpl * d.mh, d.mbpl, tx, ty, t, 256);
+  FT_STAMP;
   __syncthreads();
+  FT_STAMP;
   if (t < G::PC * G::PR)
     vf_dense_patch(s_img, s_f, t, tx, ty, d.mbpl, d.mh, im.du, im.dv, DUMP ? f1base + (size_t)zi * f_stride : nullptr,
                    DUMP ? f2base + (size_t)zi * f_stride : nullptr);
+  FT_STAMP;
   __syncthreads();
+  FT_STAMP;
   for (int it = t; it < G::CU * G::CV * 2; it += 256) vf_dense_nms(s_f, it, tx, ty, d.mw, d.mh, VSM_MARGIN, tau, st.ncu, st.ncv, st.cand);
+  FT_STAMP;
+  FT_FLUSH(0);
 }
 
 __global__ void __launch_bounds__(256)
@@ -809,17 +840,27 @@ __global__ void __launch_bounds__(256)
   const VsmSet &st = im.set[0];
   const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
   const int t = threadIdx.x;
+  FT_DECL;
+  FT_STAMP;
   vf_fill<G>(s_img, im.imgm, d.mbpl * d.mh, d.mbpl, tx, ty, t, 256);
+  FT_STAMP;
   __syncthreads();
+  FT_STAMP;
   VfSparseKeep keep;
   if (t < G::PC * G::PR) vf_sparse_patch(s_img, s_f, t, keep);
+  FT_STAMP;
   __syncthreads();
+  FT_STAMP;
   static_assert((G::CU * G::CV) % 32 == 0, "whole rounds of 32 items x 8 lanes");
   for (int it = t >> 3; it < G::CU * G::CV; it += 32) vf_sparse_nms<8>(s_f, it, t & 7, 0, tx, ty, d.mw, d.mh, VSM_MARGIN, tau, st.ncu, st.ncv, st.cand);
+  FT_STAMP;
   __syncthreads();
   if (t < G::PC * G::PR) vf_sparse_store_f2(s_f, t, keep);
   __syncthreads();
+  FT_STAMP;
   for (int it = t >> 3; it < G::CU * G::CV; it += 32) vf_sparse_nms<8>(s_f, it, t & 7, 1, tx, ty, d.mw, d.mh, VSM_MARGIN, tau, st.ncu, st.ncv, st.cand);
+  FT_STAMP;
+  FT_FLUSH(1);
 }
 
 // tiles per image of the two kernels (the CPU emulation mirrors this: tests/emu/feat_emu.cpp)
