@@ -76,6 +76,13 @@ VF_HD vf_u4 vf_stream16(const uint8_t *in, int p, int n) {
   return r;
 }
 
+// 16 bytes to a 16-byte aligned address (ds_write_b128 on LDS)
+VF_HD void vf_store16(void *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+  u4v v = {a, b, c, d};
+  *(u4v *)p = v;
+}
+
 // ---------------------------------------------------------------------------------------
 // One thread's patch: 8 columns x ROWS rows of the four filters from a window of ROWS + 4 rows x 16 stream bytes
 // (W[r][q], dwords; pixel i of the patch is byte 4 + i of a window row, the patch's first row is window row 2).
@@ -136,29 +143,16 @@ VF_HD void vf_blob_row(const vf_s2 (&C3)[6], const vf_s2 (&C5)[6], const vf_s2 (
   }
 }
 
-// the general Sobel row (top / bottom rows of the image, where the reference's column pass is zero at stream positions
-// outside rows [2, h-3]): k_filters' scalar arithmetic.  f0 = stream position of the row's first pixel, rr = output row
-// inside the patch, [lo, hi) = stream positions of rows 2 .. h-3.
-template <int ROWS>
-VF_HD void vf_sobel_row_general(const VfWindow<ROWS> &W, int rr, int f0, int lo, int hi, uint32_t (&du)[2], uint32_t (&dv)[2]) {
-  int S[12], D[12];
+// Rows at the top / bottom of the image: the reference's column pass is zero at stream positions outside rows [2, h-3]
+// ([lo, hi) = those rows' positions; both even, like the position g of a pair's first pixel, so a pair is in or out as
+// a whole).  f0 = stream position of the patch row's first pixel; pair j starts at f0 - 2 + 2j.
+VF_HD void vf_sobel_zero_outside(vf_s2 (&S)[6], vf_s2 (&D)[6], int f0, int lo, int hi) {
 #pragma unroll
-  for (int i = 0; i < 12; i++) {
-    const int g = f0 + i - 2;
-    const bool ok = g >= lo && g < hi;
-    const int a = W.byte(rr, i + 2), b = W.byte(rr + 1, i + 2), c = W.byte(rr + 2, i + 2), dd = W.byte(rr + 3, i + 2),
-              e = W.byte(rr + 4, i + 2);
-    S[i] = ok ? a + 4 * b + 6 * c + 4 * dd + e : 0;
-    D[i] = ok ? a + 2 * b - 2 * dd - e : 0;
-  }
-  du[0] = du[1] = dv[0] = dv[1] = 0u;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int hu = S[k] + 2 * S[k + 1] - 2 * S[k + 3] - S[k + 4];
-    const int hv = D[k] + 4 * D[k + 1] + 6 * D[k + 2] + 4 * D[k + 3] + D[k + 4];
-    const int bu = (hu >> 7) + 128, bv = (hv >> 7) + 128;
-    du[k >> 2] |= (uint32_t)(bu < 0 ? 0 : (bu > 255 ? 255 : bu)) << (8 * (k & 3));
-    dv[k >> 2] |= (uint32_t)(bv < 0 ? 0 : (bv > 255 ? 255 : bv)) << (8 * (k & 3));
+  for (int j = 0; j < 6; j++) {
+    const int g = f0 - 2 + 2 * j;
+    const uint32_t keep = (uint32_t)0 - (uint32_t)(g >= lo && g < hi);
+    S[j] = vf_pair(vf_bits(S[j]) & keep);
+    D[j] = vf_pair(vf_bits(D[j]) & keep);
   }
 }
 
@@ -195,7 +189,7 @@ struct VfDense {
   static constexpr int PC = 17, PR = 14, PC_OWN = 16, PR_OWN = 12;
   static constexpr int IX = -16, IY = -6, IWD = 40, IH = 60;  // LDS image: 160 bytes x 60 rows
   static constexpr int FX = -8, FY = -4;
-  static constexpr int FW = PC * 8, FH = PR * ROWS, FS = 138;  // f planes: 136 x 56 values, 138 int16 per row
+  static constexpr int FW = PC * 8, FH = PR * ROWS, FS = 136;  // f planes: 136 x 56 values; rows of 272 bytes: a patch row is one 16-byte store
   static constexpr int CU = 32, CV = 12, CELL_X0 = 5, CELL_Y0 = 5, CELL_U0 = -3, CELL_V0 = -2;
   static constexpr int WIN_DW = 1;  // first window dword of patch column 0 in an LDS image row
 };
@@ -205,7 +199,7 @@ struct VfSparse {
   static constexpr int PC = 23, PR = 10;
   static constexpr int IX = 0, IY = 4, IWD = 48, IH = 64;  // 192 bytes x 64 rows
   static constexpr int FX = 4, FY = 6;
-  static constexpr int FW = PC * 8, FH = PR * ROWS, FS = 186;  // 184 x 60 values
+  static constexpr int FW = PC * 8, FH = PR * ROWS, FS = 184;  // 184 x 60 values; rows of 368 bytes
   static constexpr int CU = 16, CV = 4, CELL_X0 = 11, CELL_Y0 = 9, CELL_U0 = 0, CELL_V0 = 0;
   static constexpr int WIN_DW = 0;
 };
@@ -218,8 +212,7 @@ VF_HD void vf_fill(uint32_t *s_img, const uint8_t *in, int n, int bpl, int tx, i
     const int r = e / per_row, g = e - r * per_row;
     const int p = (ty * G::TH + G::IY + r) * bpl + tx * G::TW + G::IX + 16 * g;
     const vf_u4 v = vf_stream16(in, p, n);
-    uint32_t *dst = s_img + r * G::IWD + 4 * g;
-    dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+    vf_store16(s_img + r * G::IWD + 4 * g, v.x, v.y, v.z, v.w);
   }
 }
 
@@ -340,6 +333,88 @@ VF_HD void vf_nms_item(const int16_t *f, int li, int lj, int l8, int lim_i, int 
 }
 
 // ---------------------------------------------------------------------------------------
+// N1 for the dense scale (N = 3), one lane per (cell, filter), WITHOUT data-dependent LDS addresses: the lane reads the
+// 10 x 10 values around its cell - rows lj-3 .. lj+6, columns li-3 .. li+6, five aligned dwords per row (li is odd) - which
+// hold both candidates' windows wherever the candidates lie in the cell.  Neighbouring lanes read neighbouring 8-byte
+// pieces, so the reads are wide and free of bank conflicts (windows addressed by the candidate's position cost three to
+// four LDS cycles per read: the suppression was bound by them).  The cell scan works on those registers; a window is
+// selected from them: region rows [dy, dy+6] = rows 3..6 always, a suffix of rows 0..2 and a prefix of rows 7..9 chosen by
+// dy, columns [dx, dx+6] by four dword masks.  The clip limits only shorten the prefixes to the right / below:
+// dxr = min(dx, lim_i - (li+3)), dyb = min(dy, lim_j - (lj+3)) (a cell itself never crosses the limits).
+// ---------------------------------------------------------------------------------------
+template <bool MAX>
+VF_HD vf_s2 vf_mm(vf_s2 a, vf_s2 b) { return MAX ? __builtin_elementwise_max(a, b) : __builtin_elementwise_min(a, b); }
+VF_HD uint32_t vf_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }  // v_bfi_b32
+
+VF_HD uint32_t vf_all(bool c) { return (uint32_t)0 - (uint32_t)c; }  // all ones if c (selects are written as v_bfi on such masks:
+                                                                       // left as ?: the compiler turns them into divergent branches)
+template <bool MAX>
+VF_HD int vf_dense_window(const uint32_t (&R)[10][5], int dx, int dy, int dxr, int dyb) {
+  const uint32_t neutral = MAX ? 0x80008000u : 0x7fff7fffu;
+  const uint32_t t0 = vf_all(dy == 0), t1 = vf_all(dy == 1), t2 = vf_all(dy == 2);
+  const uint32_t b3 = vf_all(dyb >= 3), b2 = vf_all(dyb == 2), b1 = vf_all(dyb == 1);
+  uint32_t col[5];
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    const vf_s2 s2 = vf_pair(R[2][c]), s1 = vf_mm<MAX>(vf_pair(R[1][c]), s2), s0 = vf_mm<MAX>(vf_pair(R[0][c]), s1);
+    const vf_s2 p7 = vf_pair(R[7][c]), p8 = vf_mm<MAX>(p7, vf_pair(R[8][c])), p9 = vf_mm<MAX>(p8, vf_pair(R[9][c]));
+    const vf_s2 mid = vf_mm<MAX>(vf_mm<MAX>(vf_pair(R[3][c]), vf_pair(R[4][c])), vf_mm<MAX>(vf_pair(R[5][c]), vf_pair(R[6][c])));
+    const uint32_t top = vf_bfi(t0, vf_bits(s0), vf_bfi(t1, vf_bits(s1), vf_bfi(t2, vf_bits(s2), neutral)));
+    const uint32_t bot = vf_bfi(b3, vf_bits(p9), vf_bfi(b2, vf_bits(p8), vf_bfi(b1, vf_bits(p7), neutral)));
+    col[c] = vf_bits(vf_mm<MAX>(vf_mm<MAX>(vf_pair(top), vf_pair(bot)), mid));
+  }
+  // columns [dx, dxr + 6] of the region's ten: column 2c is the low half of dword c
+  const uint32_t m0 = (vf_all(dx == 0) & 0x0000ffffu) | (vf_all(dx <= 1) & 0xffff0000u), m1 = vf_all(dx <= 2) | 0xffff0000u;
+  const uint32_t m3 = vf_all(dxr >= 1) | 0x0000ffffu, m4 = (vf_all(dxr >= 2) & 0x0000ffffu) | (vf_all(dxr >= 3) & 0xffff0000u);
+  vf_s2 w = vf_pair(col[2]);
+  w = vf_mm<MAX>(w, vf_pair(vf_bfi(m0, col[0], neutral)));
+  w = vf_mm<MAX>(w, vf_pair(vf_bfi(m1, col[1], neutral)));
+  w = vf_mm<MAX>(w, vf_pair(vf_bfi(m3, col[3], neutral)));
+  w = vf_mm<MAX>(w, vf_pair(vf_bfi(m4, col[4], neutral)));
+  return MAX ? ((int)w.x > (int)w.y ? (int)w.x : (int)w.y) : ((int)w.x < (int)w.y ? (int)w.x : (int)w.y);
+}
+
+template <int STR>
+VF_HD void vf_nms_dense_region(const int16_t *f, int li, int lj, int lim_i, int lim_j, int tau, int u0, int v0, int32_t &cmin,
+                               int32_t &cmax) {
+  static_assert((STR & 1) == 0, "plane rows must stay dword aligned");
+  uint32_t R[10][5];
+  {
+    const uint32_t *base = (const uint32_t *)(f + (lj - 3) * STR + (li - 3));  // li - 3 is even
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+#pragma unroll
+      for (int c = 0; c < 5; c++) R[r][c] = base[r * (STR / 2) + c];
+    }
+  }
+  // first-wins extrema of the cell (region rows / columns 3..6) in the reference's scan order (u outer, v inner, strict
+  // compare, viso/matcher.cpp:356-380): minimum of the key (value, scan position)
+  uint32_t kmin = 0xffffffffu, kmax = 0xffffffffu;
+#pragma unroll
+  for (int di = 0; di < 4; di++) {
+#pragma unroll
+    for (int dj = 0; dj < 4; dj++) {
+      const int q = 3 + di;
+      const uint32_t dw = R[3 + dj][q >> 1];
+      const int val = (q & 1) ? ((int)dw >> 16) : (int)(short)(dw & 0xffffu);
+      const uint32_t o = (uint32_t)(di * 4 + dj);
+      const uint32_t a = ((uint32_t)(val + 32768) << 10) | o, b = ((uint32_t)(32767 - val) << 10) | o;
+      kmin = a < kmin ? a : kmin;
+      kmax = b < kmax ? b : kmax;
+    }
+  }
+  const int mnv = (int)(kmin >> 10) - 32768, mno = (int)(kmin & 1023u);
+  const int mxv = 32767 - (int)(kmax >> 10), mxo = (int)(kmax & 1023u);
+  const int dxn = mno >> 2, dyn = mno & 3, dxx = mxo >> 2, dyx = mxo & 3;
+  const int cx = lim_i - (li + 3), cy = lim_j - (lj + 3);  // columns / rows within the limits beyond the cell (>= 3: no cut)
+  const int wmn = vf_dense_window<false>(R, dxn, dyn, dxn < cx ? dxn : cx, dyn < cy ? dyn : cy);
+  const int wmx = vf_dense_window<true>(R, dxx, dyx, dxx < cx ? dxx : cx, dyx < cy ? dyx : cy);
+  const bool vmin = (mnv <= -tau) && wmn >= mnv, vmax = (mxv >= tau) && wmx <= mxv;
+  cmin = vmin ? (int32_t)(0x80000000u | (uint32_t)(li + dxn + u0) | ((uint32_t)(lj + dyn + v0) << 14)) : 0;
+  cmax = vmax ? (int32_t)(0x80000000u | (uint32_t)(li + dxx + u0) | ((uint32_t)(lj + dyx + v0) << 14)) : 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // dense tile, thread t < PC * PR: its patch -> du / dv (HBM, owned patches), f1 / f2 (LDS planes; HBM too when
 // dump_f1 != null: the debug getter of the filter responses)
 // ---------------------------------------------------------------------------------------
@@ -351,7 +426,6 @@ VF_HD void vf_dense_patch(const uint32_t *s_img, int16_t *s_f, int t, int tx, in
   vf_load_window<G>(s_img, pc, pr, W);
   const int x0 = tx * G::TW + G::FX + 8 * pc, y0 = ty * G::TH + G::FY + G::ROWS * pr;
   const bool own = pc < G::PC_OWN && pr < G::PR_OWN && x0 >= 0 && x0 < bpl;
-  const bool interior = y0 >= 3 && y0 + 3 <= h - 4;
   int16_t *f1 = s_f + (G::ROWS * pr) * G::FS + 8 * pc, *f2 = f1 + G::FH * G::FS;
 #pragma unroll
   for (int rr = 0; rr < G::ROWS; rr++) {
@@ -362,22 +436,15 @@ VF_HD void vf_dense_patch(const uint32_t *s_img, int16_t *s_f, int t, int tx, in
 #pragma unroll
     for (int m = 0; m < 4; m++) ctr[m] = W.pair(rr + 2, m + 1);
     vf_blob_row(C3, C5, Cc, ctr, o1, o2);
-    uint32_t *d1 = (uint32_t *)(f1 + rr * G::FS), *d2 = (uint32_t *)(f2 + rr * G::FS);
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-      d1[m] = vf_bits(o1[m]);
-      d2[m] = vf_bits(o2[m]);
-    }
+    vf_store16(f1 + rr * G::FS, vf_bits(o1[0]), vf_bits(o1[1]), vf_bits(o1[2]), vf_bits(o1[3]));
+    vf_store16(f2 + rr * G::FS, vf_bits(o2[0]), vf_bits(o2[1]), vf_bits(o2[2]), vf_bits(o2[3]));
     if (own && y >= 0 && y < h) {
       uint32_t du[2], dv[2];
-      if (interior) {
-        vf_s2 S[6], D[6];
+      vf_s2 S[6], D[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) vf_columns_sobel<G::ROWS>(W, rr, j, S[j], D[j]);
-        vf_sobel_row(S, D, du, dv);
-      } else {
-        vf_sobel_row_general<G::ROWS>(W, rr, y * bpl + x0, 2 * bpl, (h - 2) * bpl, du, dv);
-      }
+      for (int j = 0; j < 6; j++) vf_columns_sobel<G::ROWS>(W, rr, j, S[j], D[j]);
+      if (y < 3 || y > h - 4) vf_sobel_zero_outside(S, D, y * bpl + x0, 2 * bpl, (h - 2) * bpl);
+      vf_sobel_row(S, D, du, dv);
       uint32_t *pu = (uint32_t *)(du_plane + (size_t)y * bpl + x0), *pv = (uint32_t *)(dv_plane + (size_t)y * bpl + x0);
       pu[0] = du[0], pu[1] = du[1];
       pv[0] = dv[0], pv[1] = dv[1];
@@ -395,23 +462,19 @@ VF_HD void vf_dense_patch(const uint32_t *s_img, int16_t *s_f, int t, int tx, in
   }
 }
 
-// dense tile, suppression item it < CU * CV * 2 (filter fastest): survivors of image cell (ci, cj) -> cand
+// dense tile, suppression item it < CU * CV * 2: lanes 0-31 of a wave = the 32 cells of a cell row in f1, lanes 32-63 the
+// same in f2 (a group of 32 lanes reads 256 contiguous bytes per LDS instruction); survivors of image cell (ci, cj) -> cand
 VF_HD void vf_dense_nms(const int16_t *s_f, int it, int tx, int ty, int mw, int mh, int margin, int tau, int ncu, int ncv,
                         int32_t *cand) {
   typedef VfDense G;
-  const int k = it & 1, cl = it >> 1;
-  const int lcv = cl / G::CU, lcu = cl - lcv * G::CU;
+  static_assert(G::CU == 32, "a cell row per half wave");
+  const int lcu = it & 31, k = (it >> 5) & 1, lcv = it >> 6;
   const int ci = G::CU * tx + G::CELL_U0 + lcu, cj = G::CV * ty + G::CELL_V0 + lcv;
   const int u0 = tx * G::TW + G::FX, v0 = ty * G::TH + G::FY;
   const int lim_i = mw - 1 - margin - u0, lim_j = mh - 1 - margin - v0;
-  const bool fast = lim_i >= G::FW - 1 && lim_j >= G::FH - 1;
   int32_t cmin, cmax;
-  const int16_t *f = s_f + k * G::FH * G::FS;
-  const int li = G::CELL_X0 + (G::N + 1) * lcu, lj = G::CELL_Y0 + (G::N + 1) * lcv;
-  if (fast)  // (the same for all items of a tile)
-    vf_nms_item<G::N, 1, G::FS, true>(f, li, lj, 0, lim_i, lim_j, tau, u0, v0, cmin, cmax);
-  else
-    vf_nms_item<G::N, 1, G::FS, false>(f, li, lj, 0, lim_i, lim_j, tau, u0, v0, cmin, cmax);
+  vf_nms_dense_region<G::FS>(s_f + k * G::FH * G::FS, G::CELL_X0 + (G::N + 1) * lcu, G::CELL_Y0 + (G::N + 1) * lcv, lim_i, lim_j, tau, u0,
+                             v0, cmin, cmax);
   if (ci >= 0 && ci < ncu && cj >= 0 && cj < ncv) {
     int32_t *c = cand + (size_t)(ci * ncv + cj) * 4 + 2 * k;
     c[0] = cmin;
@@ -440,12 +503,9 @@ VF_HD void vf_sparse_patch(const uint32_t *s_img, int16_t *s_f, int t, VfSparseK
 #pragma unroll
     for (int m = 0; m < 4; m++) ctr[m] = W.pair(rr + 2, m + 1);
     vf_blob_row(C3, C5, Cc, ctr, o1, o2);
-    uint32_t *d1 = (uint32_t *)(f1 + rr * G::FS);
+    vf_store16(f1 + rr * G::FS, vf_bits(o1[0]), vf_bits(o1[1]), vf_bits(o1[2]), vf_bits(o1[3]));
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-      d1[m] = vf_bits(o1[m]);
-      keep.f2[rr][m] = vf_bits(o2[m]);
-    }
+    for (int m = 0; m < 4; m++) keep.f2[rr][m] = vf_bits(o2[m]);
   }
 }
 VF_HD void vf_sparse_store_f2(int16_t *s_f, int t, const VfSparseKeep &keep) {
@@ -454,9 +514,7 @@ VF_HD void vf_sparse_store_f2(int16_t *s_f, int t, const VfSparseKeep &keep) {
   int16_t *f = s_f + (G::ROWS * pr) * G::FS + 8 * pc;
 #pragma unroll
   for (int rr = 0; rr < G::ROWS; rr++) {
-    uint32_t *d = (uint32_t *)(f + rr * G::FS);
-#pragma unroll
-    for (int m = 0; m < 4; m++) d[m] = keep.f2[rr][m];
+    vf_store16(f + rr * G::FS, keep.f2[rr][0], keep.f2[rr][1], keep.f2[rr][2], keep.f2[rr][3]);
   }
 }
 // item it < CU * CV (x LANES lanes: l8), filter k: survivors of image cell (ci, cj)

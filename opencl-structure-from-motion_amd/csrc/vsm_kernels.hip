@@ -802,8 +802,8 @@ __global__ void __launch_bounds__(256)
     k_feat_dense(const VsmImage *__restrict__ imgs, int first, VsmDims d, int tau, int tiles_x, int nbx, int n_img,
                  int16_t *__restrict__ f1base, int16_t *__restrict__ f2base, size_t f_stride) {
   typedef VfDense G;
-  __shared__ uint32_t s_img[G::IH * G::IWD];
-  __shared__ int16_t s_f[2 * G::FH * G::FS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_img[G::IH * G::IWD];
+  __shared__ __attribute__((aligned(16))) int16_t s_f[2 * G::FH * G::FS];
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int zi = lb / nbx, bx = lb - zi * nbx;
   if (zi >= n_img) return;
@@ -831,8 +831,8 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     k_feat_sparse(const VsmImage *__restrict__ imgs, int first, VsmDims d, int tau, int tiles_x, int nbx, int n_img) {
   typedef VfSparse G;
-  __shared__ uint32_t s_img[G::IH * G::IWD];
-  __shared__ int16_t s_f[G::FH * G::FS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_img[G::IH * G::IWD];
+  __shared__ __attribute__((aligned(16))) int16_t s_f[G::FH * G::FS];
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int zi = lb / nbx, bx = lb - zi * nbx;
   if (zi >= n_img) return;

@@ -26,16 +26,16 @@ void emu_feat_dense(const uint8_t *img, int mw, int mh, int mbpl, int tau, int n
   typedef VfDense G;
   int32_t tl[4];
   emu_feat_tiles(mbpl, mh, ncu, ncv, 0, 0, tl);
-  std::vector<uint32_t> s_img(G::IH * G::IWD);
-  std::vector<int16_t> s_f(2 * G::FH * G::FS);
+  alignas(16) static uint32_t s_img[G::IH * G::IWD];   // (16-byte stores, like the kernels' LDS arrays)
+  alignas(16) static int16_t s_f[2 * G::FH * G::FS];
   for (int ty = 0; ty < tl[1]; ty++)
     for (int tx = 0; tx < tl[0]; tx++) {
       // poison: nothing may depend on what a previous tile left behind
-      memset(s_img.data(), 0xa5, s_img.size() * 4);
-      memset(s_f.data(), 0x5a, s_f.size() * 2);
-      for (int t = 0; t < 256; t++) vf_fill<G>(s_img.data(), img, mbpl * mh, mbpl, tx, ty, t, 256);
-      for (int t = 0; t < G::PC * G::PR; t++) vf_dense_patch(s_img.data(), s_f.data(), t, tx, ty, mbpl, mh, du, dv, f1, f2);
-      for (int it = 0; it < G::CU * G::CV * 2; it++) vf_dense_nms(s_f.data(), it, tx, ty, mw, mh, 6, tau, ncu, ncv, cand);
+      memset(s_img, 0xa5, sizeof(s_img));
+      memset(s_f, 0x5a, sizeof(s_f));
+      for (int t = 0; t < 256; t++) vf_fill<G>(s_img, img, mbpl * mh, mbpl, tx, ty, t, 256);
+      for (int t = 0; t < G::PC * G::PR; t++) vf_dense_patch(s_img, s_f, t, tx, ty, mbpl, mh, du, dv, f1, f2);
+      for (int it = 0; it < G::CU * G::CV * 2; it++) vf_dense_nms(s_f, it, tx, ty, mw, mh, 6, tau, ncu, ncv, cand);
     }
 }
 
@@ -43,18 +43,18 @@ void emu_feat_sparse(const uint8_t *img, int mw, int mh, int mbpl, int tau, int 
   typedef VfSparse G;
   int32_t tl[4];
   emu_feat_tiles(mbpl, mh, 0, 0, ncu, ncv, tl);
-  std::vector<uint32_t> s_img(G::IH * G::IWD);
-  std::vector<int16_t> s_f(G::FH * G::FS);
+  alignas(16) static uint32_t s_img[G::IH * G::IWD];
+  alignas(16) static int16_t s_f[G::FH * G::FS];
   std::vector<VfSparseKeep> keep(G::PC * G::PR);
   for (int ty = 0; ty < tl[3]; ty++)
     for (int tx = 0; tx < tl[2]; tx++) {
-      memset(s_img.data(), 0xa5, s_img.size() * 4);
-      memset(s_f.data(), 0x5a, s_f.size() * 2);
-      for (int t = 0; t < 256; t++) vf_fill<G>(s_img.data(), img, mbpl * mh, mbpl, tx, ty, t, 256);
-      for (int t = 0; t < G::PC * G::PR; t++) vf_sparse_patch(s_img.data(), s_f.data(), t, keep[t]);
-      for (int it = 0; it < G::CU * G::CV; it++) vf_sparse_nms<1>(s_f.data(), it, 0, 0, tx, ty, mw, mh, 6, tau, ncu, ncv, cand);
-      for (int t = 0; t < G::PC * G::PR; t++) vf_sparse_store_f2(s_f.data(), t, keep[t]);
-      for (int it = 0; it < G::CU * G::CV; it++) vf_sparse_nms<1>(s_f.data(), it, 0, 1, tx, ty, mw, mh, 6, tau, ncu, ncv, cand);
+      memset(s_img, 0xa5, sizeof(s_img));
+      memset(s_f, 0x5a, sizeof(s_f));
+      for (int t = 0; t < 256; t++) vf_fill<G>(s_img, img, mbpl * mh, mbpl, tx, ty, t, 256);
+      for (int t = 0; t < G::PC * G::PR; t++) vf_sparse_patch(s_img, s_f, t, keep[t]);
+      for (int it = 0; it < G::CU * G::CV; it++) vf_sparse_nms<1>(s_f, it, 0, 0, tx, ty, mw, mh, 6, tau, ncu, ncv, cand);
+      for (int t = 0; t < G::PC * G::PR; t++) vf_sparse_store_f2(s_f, t, keep[t]);
+      for (int it = 0; it < G::CU * G::CV; it++) vf_sparse_nms<1>(s_f, it, 0, 1, tx, ty, mw, mh, 6, tau, ncu, ncv, cand);
     }
 }
 }
