@@ -387,6 +387,7 @@ struct VsmSwitches {
   int seq_p2_first = -1;     // ... a chunk's second pass in front of the features of chunk k + 2 (the order host-resident inputs get): -1 = by pool size
   int seq_export_budget = 2; // ... pieces of the early export submitted behind a chunk's keys where the next chunk's keys follow at once (sequence_run_v2: export_some)
   int fused_features = 1;    // filters + suppression of the matching resolution out of one LDS tile (k_feat_dense / k_feat_sparse; default radii) or the separate kernels (0)
+  int feat_order = 1;        // feature records + bin-sorted copy by k_feat_scan / k_feat_order (tiles of whole search bins) or by k_scan_cells / k_emit / k_bin_* (0)
   int filter_planes = 0;     // vsm_push_back keeps f1 / f2 in HBM for vsm_get_filter_responses (the fused tiles write them on the side)
   static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
@@ -420,6 +421,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "seq_ties1_null")) seq_ties1_null = v != 0;
     else if (!strcmp(name, "fused_features")) fused_features = v != 0;
     else if (!strcmp(name, "filter_planes")) filter_planes = v != 0;
+    else if (!strcmp(name, "feat_order")) feat_order = v != 0;
     else return false;
     return true;
   }
@@ -703,7 +705,7 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
   }
   const int f_planes = vsm_launch_features(h->stream, h->prof, c.d_imgs, slot * 2, n_img, c.dims, c.f1, c.f2, c.f_stride, h->param.nms_tau,
                                            h->param.multi_stage, h->param.half_resolution, h->param.match_binsize, c.h_imgs.data(),
-                                           fused_front ? 1 : 0, (h->sw.fused_features ? 1 : 0) | (h->sw.filter_planes ? 2 : 0));
+                                           fused_front ? 1 : 0, (h->sw.fused_features ? 1 : 0) | (h->sw.filter_planes ? 2 : 0) | (h->sw.feat_order ? 0 : 4));
   HIPCHK(hipGetLastError());
   h->have[slot] = true;
   h->right[slot] = (I2 != nullptr);
@@ -1547,7 +1549,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       if (seq_ingest_host_frames(h, c, first_img, left, right, frame_stride, bpl, w, hh, f0, n) != VSM_OK) return hipErrorUnknown;
     }
     vsm_launch_features(h->stream, h->prof, c.d_imgs, first_img, 2 * n, c.dims, c.f1, c.f2, c.f_stride, p.nms_tau,
-                        p.multi_stage, p.half_resolution, p.match_binsize, c.h_imgs.data(), fused_front ? 1 : 0, h->sw.fused_features ? 1 : 0);
+                        p.multi_stage, p.half_resolution, p.match_binsize, c.h_imgs.data(), fused_front ? 1 : 0, (h->sw.fused_features ? 1 : 0) | (h->sw.feat_order ? 0 : 4));
     return hipEventRecord(h->seq_ev[0], h->stream);
   };
   // what a chunk needs from one step to the next
@@ -1966,7 +1968,7 @@ static const char *kKernelNames[VSM_K_COUNT] = {
     "k_bin_scatter", "k_bin_rank", "k_match<16>:pass1", "k_compact_matches:pass1", "k_match<16>:pass2",
     "k_compact_matches:pass2", "k_refine", "k_export_list", "k_front",
     "k_dc_keys", "k_dc_vertex_sort", "k_dc_prepare_kd_order", "k_dc_block", "k_dc_merge", "k_dc_support", "k_dc_compact", "k_dc_prior",
-    "k_feat_dense", "k_feat_sparse"};
+    "k_feat_dense", "k_feat_sparse", "k_feat_scan", "k_feat_order"};
 
 void vsm_set_profiling(vsm_handle *h, int on) {
   h->prof.on = on != 0;

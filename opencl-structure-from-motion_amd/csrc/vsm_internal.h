@@ -97,6 +97,8 @@ enum VsmKernelId {
   VSM_K_DC_KEYS, VSM_K_DC_TIES, VSM_K_DC_KD, VSM_K_DC_BLOCK, VSM_K_DC_MERGE, VSM_K_DC_SUPPORT, VSM_K_DC_COMPACT, VSM_K_DC_PRIOR,
   // the fused matching-resolution image side (filters + suppression out of one LDS tile; vsm_feat.h)
   VSM_K_FEAT_DENSE, VSM_K_FEAT_SPARSE,
+  // feature records + bin-sorted copy in two kernels (k_feat_scan, k_feat_order)
+  VSM_K_FEAT_SCAN, VSM_K_FEAT_ORDER,
   VSM_K_COUNT
 };
 struct VsmProf {
@@ -156,7 +158,8 @@ struct VsmProf {
 // ---- launchers (vsm_kernels.hip) ----
 void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0,
                        const uint8_t *src1, size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d);
-// fused: bit 0 = the fused filter + suppression tiles where the radii allow, bit 1 = they also write f1 / f2 (debug getter)
+// fused: bit 0 = the fused filter + suppression tiles where the radii allow, bit 1 = they also write f1 / f2 (debug getter),
+// bit 2 = NOT the two-kernel records + bin order (k_feat_scan / k_feat_order) but k_scan_cells / k_emit / k_bin_*
 // half_resolution = 1 only: caller image(s) -> [padded copy if write_img], half-resolution image, full-resolution Sobel planes
 // in one pass; vsm_launch_features(front_done = 1) then skips its own halving and full-resolution Sobel
 void vsm_launch_front(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0, const uint8_t *src1,

@@ -1095,6 +1095,221 @@ __global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs,
 }
 
 // ---------------------------------------------------------------------------------------
+// T1 + D1 + M1 in two kernels (the default path; k_scan_cells / k_emit / k_bin_* above and below remain for geometries it
+// declines):
+//   k_feat_scan   one workgroup per (image, set): ONE pass over the survivors gives the exclusive prefix of the cells'
+//                 survivor counts (feature index = rank in the reference's emission order, viso/matcher.cpp:344-430) and,
+//                 through a histogram in LDS, the start of every fine search bin (createIndexVector, :870-890)
+//   k_feat_order  a workgroup owns a TILE OF WHOLE SEARCH BINS (bu coarse u-bins x one v-bin) of one image, both sets: it
+//                 stages the Sobel responses of the tile's rectangle + the 5-pixel descriptor halo in LDS once, collects the
+//                 survivors that fall into its bins from the cells overlapping the rectangle, and - because every feature
+//                 of a bin is then in the workgroup - ranks them inside their fine bin and inside the reference's bin by
+//                 counting smaller feature indices in a short LDS list per (bin, class).  Each survivor's 48-byte record
+//                 goes to feat[index] and, in the same breath, its coordinates / descriptor / index / reference rank to
+//                 their place in the bin-sorted arrays: no bin ids, scatter cursors or unordered slots in HBM, no second
+//                 read of the records (k_bin_rank gathered them back: 2.5 x its algorithmic bytes).
+// ---------------------------------------------------------------------------------------
+struct VsmOrderPlan {
+  int32_t bu;                  // coarse u-bins per tile
+  int32_t tiles_u, tiles_v;    // tiles per image (tiles_v = v-bins)
+  int32_t stage_w, stage_h;    // staged Sobel responses: uint16 (du | dv << 8) per pixel
+  int32_t cells_cap[2];        // cells of a set that can overlap a tile's rectangle
+  int32_t lcap[2];             // entries a (bin, class) list can take
+  int32_t o_cand, o_cnt, o_list, o_sv, o_svi, lds_bytes;  // LDS layout (bytes)
+};
+
+__device__ __forceinline__ int ceil_div_pos(int a, int b) { return (a + b - 1) / b; }
+
+__global__ void __launch_bounds__(1024) k_feat_scan(const VsmImage *__restrict__ imgs, int first, int set_lo, VsmDims d, int binsize, int nb) {
+  extern __shared__ int s_dyn[];
+  __shared__ int s_w[17];
+  int *s_hist = s_dyn;
+  const VsmSet &st = imgs[first + blockIdx.z].set[blockIdx.y];
+  if ((int)blockIdx.y < set_lo) {
+    if (threadIdx.x == 0) {
+      *st.count = 0;
+      *st.count_host = 0;
+    }
+    return;
+  }
+  for (int b = threadIdx.x; b < nb; b += 1024) s_hist[b] = 0;
+  __syncthreads();
+  const int ncells = st.ncu * st.ncv;
+  const int chunk = (ncells + 1023) / 1024;
+  const int c0 = min((int)threadIdx.x * chunk, ncells), c1 = min(c0 + chunk, ncells);
+  int sum = 0;
+  for (int c = c0; c < c1; c++) {
+    const int4 v = ldg_i4(st.cand + (size_t)c * 4);
+    const int cc[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+      if (cc[g] < 0) {
+        sum++;
+        atomicAdd(&s_hist[bin_of((cc[g] & 0x3fff) * d.scale, ((cc[g] >> 14) & 0x3fff) * d.scale, g, binsize, d.ub, d.vb)], 1);
+      }
+  }
+  int total;
+  int run = block_excl_scan_1024(sum, total, s_w);
+  for (int c = c0; c < c1; c++) {
+    const int4 v = ldg_i4(st.cand + (size_t)c * 4);  // (L2)
+    st.cell_off[c] = run;
+    run += (v.x < 0) + (v.y < 0) + (v.z < 0) + (v.w < 0);
+  }
+  if (threadIdx.x == 0) {
+    st.cell_off[ncells] = total;
+    *st.count = total;
+    *st.count_host = total;
+  }
+  // (block_excl_scan_1024's barriers also order the histogram's atomics before the reads below)
+  const int bchunk = (nb + 1023) / 1024;
+  const int b0 = min((int)threadIdx.x * bchunk, nb), b1 = min(b0 + bchunk, nb);
+  int bsum = 0;
+  for (int b = b0; b < b1; b++) bsum += s_hist[b];
+  int btotal;
+  int brun = block_excl_scan_1024(bsum, btotal, s_w);
+  for (int b = b0; b < b1; b++) {
+    st.bin_start[b] = brun;
+    brun += s_hist[b];
+  }
+  if (threadIdx.x == 0) st.bin_start[nb] = btotal;
+}
+
+__global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__ imgs, int first, VsmDims d, int set_lo, int binsize,
+                                                    VsmOrderPlan pl, int nbx, int n_img) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  uint16_t *s_g = (uint16_t *)s_raw;                      // [stage_h][stage_w]
+  int4 *s_cand = (int4 *)(s_raw + pl.o_cand);            // the cells overlapping the rectangle
+  int *s_cnt = (int *)(s_raw + pl.o_cnt);                // [bu * 4] list lengths, [bu * 4] = number of survivors
+  uint32_t *s_list = (uint32_t *)(s_raw + pl.o_list);    // [bu * 4][lcap]: index * 8 + v sub-row
+  uint16_t *s_sv = (uint16_t *)(s_raw + pl.o_sv);        // survivors of the tile: cell slot * 4 + class
+  uint32_t *s_svi = (uint32_t *)(s_raw + pl.o_svi);      // ... and their feature indices
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int zi = lb / nbx, bx = lb - zi * nbx;
+  if (zi >= n_img) return;
+  const VsmImage &im = imgs[first + zi];
+  const int tv = bx / pl.tiles_u, tu = bx - tv * pl.tiles_u;
+  const int t = threadIdx.x;
+  // the tile's bins and their pixel rectangle at the matching resolution (bin = min(coordinate * scale / binsize, bins - 1))
+  const int ub0 = tu * pl.bu, ub1 = min(ub0 + pl.bu, d.ub);
+  const int x_lo = ub0 == 0 ? 0 : min(ceil_div_pos(ub0 * binsize, d.scale), d.mw);
+  const int x_hi = ub1 == d.ub ? d.mw : min(ceil_div_pos(ub1 * binsize, d.scale), d.mw);
+  const int y_lo = tv == 0 ? 0 : min(ceil_div_pos(tv * binsize, d.scale), d.mh);
+  const int y_hi = tv + 1 == d.vb ? d.mh : min(ceil_div_pos((tv + 1) * binsize, d.scale), d.mh);
+  // ---- Sobel responses of the rectangle + 5 pixels of halo, du | dv << 8 per pixel ----
+  const int xa = (x_lo - EMIT_HALO) & ~3, ya = y_lo - EMIT_HALO;  // (may be negative: nothing there is ever read)
+  const int sw4 = pl.stage_w >> 2;
+  for (int e = t; e < sw4 * pl.stage_h; e += 256) {
+    const int y = e / sw4, x = 4 * (e - y * sw4);
+    const int u = xa + x, v = ya + y;
+    uint32_t a = 0, b = 0;
+    if (u >= 0 && u + 3 < d.mbpl && v >= 0 && v < d.mh && u < x_hi + EMIT_HALO && v < y_hi + EMIT_HALO) {
+      a = ldg_u32(im.du + (size_t)v * d.mbpl + u);
+      b = ldg_u32(im.dv + (size_t)v * d.mbpl + u);
+    }
+    const uint32_t lo = (a & 0xffu) | ((b & 0xffu) << 8) | ((a & 0xff00u) << 8) | ((b & 0xff00u) << 16);
+    const uint32_t hi = ((a >> 16) & 0xffu) | (((b >> 16) & 0xffu) << 8) | ((a >> 24) << 16) | ((b >> 24) << 24);
+    *(uint2 *)&s_g[y * pl.stage_w + x] = make_uint2(lo, hi);
+  }
+  for (int si = set_lo; si < 2; si++) {
+    const VsmSet &st = im.set[si];
+    const int n = st.nms_n, n1 = n + 1, o0 = n + VSM_MARGIN;  // cell c covers pixels o0 + c * n1 .. + n
+    // cells that can hold a pixel of the rectangle
+    const int cu_lo = max(0, ceil_div_pos(max(x_lo - n - o0, 0), n1)), cu_hi = min(st.ncu - 1, x_hi - 1 >= o0 ? (x_hi - 1 - o0) / n1 : -1);
+    const int cv_lo = max(0, ceil_div_pos(max(y_lo - n - o0, 0), n1)), cv_hi = min(st.ncv - 1, y_hi - 1 >= o0 ? (y_hi - 1 - o0) / n1 : -1);
+    const int cw = cu_hi - cu_lo + 1, ch = cv_hi - cv_lo + 1;
+    const int ncell = (cw > 0 && ch > 0) ? cw * ch : 0;  // <= cells_cap[si] by the plan
+    const int nl = pl.bu * 4, lcap = pl.lcap[si];
+    __syncthreads();  // (stage complete; the previous set's lists are no longer read)
+    if (t <= nl) s_cnt[t] = 0;
+    __syncthreads();
+    for (int e = t; e < ncell; e += 256) {
+      const int lcu = e / ch, lcv = e - lcu * ch;  // v fastest: neighbouring threads read neighbouring cand[] entries
+      const int cell = (cu_lo + lcu) * st.ncv + cv_lo + lcv;
+      const int4 c4 = ldg_i4(st.cand + (size_t)cell * 4);
+      s_cand[e] = c4;
+      if ((c4.x | c4.y | c4.z | c4.w) >= 0) continue;
+      const int off = ldg_i32(st.cell_off + cell);
+      const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
+      int idx = off;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        if (cc[g] >= 0) continue;
+        const int u = (cc[g] & 0x3fff) * d.scale, v = ((cc[g] >> 14) & 0x3fff) * d.scale;
+        const int ubin = min(u / binsize, d.ub - 1), vbin = min(v / binsize, d.vb - 1);
+        if (ubin >= ub0 && ubin < ub1 && vbin == tv) {
+          const int vsub = vfine_of(v, binsize, d.vb) - vbin * VSM_VSUB;
+          const int l = (ubin - ub0) * 4 + g;
+          const int p = atomicAdd(&s_cnt[l], 1);
+          if (p < lcap) s_list[l * lcap + p] = (uint32_t)idx * 8u + (uint32_t)vsub;
+          const int q = atomicAdd(&s_cnt[nl], 1);
+          s_sv[q] = (uint16_t)(e * 4 + g);
+          s_svi[q] = (uint32_t)idx;
+        }
+        idx++;
+      }
+    }
+    __syncthreads();
+    const int nsv = s_cnt[nl];
+    for (int q = t; q < nsv; q += 256) {
+      const int e = s_sv[q] >> 2, g = s_sv[q] & 3;
+      const uint32_t idx = s_svi[q];
+      const int4 c4 = s_cand[e];
+      const int cc = g == 0 ? c4.x : (g == 1 ? c4.y : (g == 2 ? c4.z : c4.w));
+      const int u = cc & 0x3fff, v = (cc >> 14) & 0x3fff;
+      const int us = u * d.scale, vs = v * d.scale;
+      const int ubin = min(us / binsize, d.ub - 1), vbin = min(vs / binsize, d.vb - 1);
+      const int vsub = vfine_of(vs, binsize, d.vb) - vbin * VSM_VSUB;
+      const int l = (ubin - ub0) * 4 + g;
+      // ranks: smaller indices in the reference's bin (all of the list) and in the fine bin (same sub-row)
+      const int cnt = min(s_cnt[l], lcap);
+      const uint32_t *L = s_list + l * lcap;
+      int rank = 0, crank = 0;
+      for (int k = 0; k < cnt; k++) {
+        const uint32_t en = L[k];
+        const int before = (en >> 3) < idx;
+        crank += before;
+        rank += (before && (int)(en & 7u) == vsub) ? 1 : 0;
+      }
+      const int b = (g * d.ub + ubin) * (d.vb * VSM_VSUB) + vbin * VSM_VSUB + vsub;  // = bin_of()
+      const int lo = ldg_i32(st.bin_start + b), clo = ldg_i32(st.bin_start + b - vsub);
+      const int dst = lo + rank;
+      // descriptor (computeDescriptor, viso/matcher.cpp:433-477): 16 taps of (du, dv) from the staged rectangle
+      const uint16_t *c0 = s_g + (v - ya) * pl.stage_w + (u - xa);
+      uint32_t t16[16];
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        constexpr int8_t kdv[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
+        constexpr int8_t kdu[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
+        t16[m] = c0[kdv[m] * pl.stage_w + kdu[m]];
+      }
+      vsm_u4 r0, r1, r2;
+      r0.x = (uint32_t)us;
+      r0.y = (uint32_t)vs;
+      r0.z = 0u;
+      r0.w = (uint32_t)g;
+      r1.x = t16[0] | (t16[1] << 16);
+      r1.y = t16[2] | (t16[3] << 16);
+      r1.z = t16[4] | (t16[5] << 16);
+      r1.w = t16[6] | (t16[7] << 16);
+      r2.x = t16[8] | (t16[9] << 16);
+      r2.y = t16[10] | (t16[11] << 16);
+      r2.z = t16[12] | (t16[13] << 16);
+      r2.w = t16[14] | (t16[15] << 16);
+      VSM_AS1 vsm_u4 *rec = (VSM_AS1 vsm_u4 *)(st.feat + (size_t)idx * 12);
+      rec[0] = r0;
+      rec[1] = r1;
+      rec[2] = r2;
+      VSM_AS1 vsm_u4 *sd = (VSM_AS1 vsm_u4 *)(st.s_desc + 2 * (size_t)dst);
+      sd[0] = r1;
+      sd[1] = r2;
+      *(VSM_AS1 uint32_t *)(st.s_uv + dst) = (uint32_t)us | ((uint32_t)vs << 16);  // coordinates are < 16384
+      *(VSM_AS1 int32_t *)(st.s_idx + dst) = (int32_t)idx;
+      *(VSM_AS1 int32_t *)(st.s_rank + dst) = clo + crank;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // M1 createIndexVector, viso/matcher.cpp:870-890, as a stable counting sort into the
 // bin-contiguous SoA arrays (see VsmSet).  fine bin = (class*ub + u_bin)*(vb*VSM_VSUB) + v sub-row,
 // so that the rows a query visits for one u_bin are one contiguous run.  Histogram: k_emit.  Then
@@ -2231,6 +2446,51 @@ __global__ void __launch_bounds__(1024) k_parabolic_apply(const VsmPair *__restr
 // =======================================================================================
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// plan of k_feat_order for a geometry; false = it does not fit (huge search bins or suppression cells: the separate kernels)
+static bool vsm_order_plan(const VsmDims &d, const VsmImage &im, int set_lo, int binsize, int nb, VsmOrderPlan &pl) {
+  static bool attr_set = false;  // (the scan kernel's histogram may want more than the default 64 KB of dynamic LDS)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_feat_scan), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  if ((size_t)nb * 4 > 150 * 1024) return false;
+  const int bw = (binsize + d.scale - 1) / d.scale + 1;  // pixels of one search bin at the matching resolution (at most)
+  if (bw > 72) return false;
+  pl.bu = std::max(1, std::min(8, 128 / bw));
+  pl.tiles_u = cdiv(d.ub, pl.bu);
+  pl.tiles_v = d.vb;
+  pl.stage_w = (pl.bu * bw + 13 + 3) & ~3;
+  pl.stage_h = bw + 10;
+  int maxcells = 0, maxl = 0;
+  for (int k = 0; k < 2; k++) {
+    const VsmSet &st = im.set[k];
+    pl.cells_cap[k] = pl.lcap[k] = 0;
+    if (k < set_lo || st.ncu * st.ncv <= 0) continue;
+    const int n1 = st.nms_n + 1;
+    const int cwt = std::min(st.ncu, (pl.bu * bw - 1) / n1 + 2), cht = std::min(st.ncv, (bw - 1) / n1 + 2);  // cells meeting a tile / ...
+    const int cwb = std::min(st.ncu, (bw - 1) / n1 + 2);                                                  // ... one bin
+    pl.cells_cap[k] = cwt * cht;
+    pl.lcap[k] = cwb * cht;
+    maxcells = std::max(maxcells, pl.cells_cap[k]);
+    maxl = std::max(maxl, pl.lcap[k]);
+  }
+  if (maxcells <= 0 || maxcells * 4 > 65535) return false;
+  int o = pl.stage_w * pl.stage_h * 2;
+  auto take = [&](int bytes) {
+    o = (o + 15) & ~15;
+    const int at = o;
+    o += bytes;
+    return at;
+  };
+  pl.o_cand = take(maxcells * 16);
+  pl.o_cnt = take((pl.bu * 4 + 1) * 4);
+  pl.o_list = take(pl.bu * 4 * maxl * 4);
+  pl.o_sv = take(maxcells * 4 * 2);
+  pl.o_svi = take(maxcells * 4 * 4);
+  pl.lds_bytes = (o + 15) & ~15;
+  return pl.lds_bytes <= 64 * 1024;
+}
+
 void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0,
                        const uint8_t *src1, size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d) {
   const int sides = src1 ? 2 : 1;
@@ -2326,6 +2586,19 @@ int vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int 
                            f_stride, nms_tau, k, k);
       pf.end(s);
     }
+  }
+  // records + bin-sorted copy: the two-kernel form where a tile of whole search bins fits a workgroup's LDS
+  VsmOrderPlan pl;
+  if ((fused & 4) == 0 && max_cells > 0 && vsm_order_plan(d, h_imgs[first], set_lo, binsize, nb, pl)) {
+    pf.begin(VSM_K_FEAT_SCAN, s);
+    hipLaunchKernelGGL(k_feat_scan, dim3(1, 2, n_img), dim3(1024), (size_t)nb * 4, s, d_imgs, first, set_lo, d, binsize, nb);
+    pf.end(s);
+    pf.begin(VSM_K_FEAT_ORDER, s);
+    const int nbx = pl.tiles_u * pl.tiles_v;
+    hipLaunchKernelGGL(k_feat_order, dim3(((nbx * n_img + 7) / 8) * 8), dim3(256), (size_t)pl.lds_bytes, s, d_imgs, first, d, set_lo, binsize,
+                       pl, nbx, n_img);
+    pf.end(s);
+    return (!fuse || (fused & 2)) ? 1 : 0;
   }
   pf.begin(VSM_K_SCAN, s);
   hipLaunchKernelGGL(k_scan_cells, dim3(1, 2, n_img), dim3(1024), 0, s, d_imgs, first, set_lo, nb);
