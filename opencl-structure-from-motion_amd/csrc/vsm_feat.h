@@ -204,15 +204,21 @@ struct VfSparse {
   static constexpr int WIN_DW = 0;
 };
 
-// LDS image fill: 16-byte pieces of the stream, thread t of nt
-template <class G>
-VF_HD void vf_fill(uint32_t *s_img, const uint8_t *in, int n, int bpl, int tx, int ty, int t, int nt) {
-  constexpr int per_row = G::IWD / 4;
-  for (int e = t; e < G::IH * per_row; e += nt) {
-    const int r = e / per_row, g = e - r * per_row;
-    const int p = (ty * G::TH + G::IY + r) * bpl + tx * G::TW + G::IX + 16 * g;
-    const vf_u4 v = vf_stream16(in, p, n);
-    vf_store16(s_img + r * G::IWD + 4 * g, v.x, v.y, v.z, v.w);
+// LDS image fill: 16-byte pieces of the stream, thread t of NT; all of a thread's loads are requested before the first
+// LDS store waits for one
+template <class G, int NT>
+VF_HD void vf_fill(uint32_t *s_img, const uint8_t *in, int n, int bpl, int tx, int ty, int t) {
+  constexpr int per_row = G::IWD / 4, total = G::IH * per_row, iters = (total + NT - 1) / NT;
+  vf_u4 v[iters];
+#pragma unroll
+  for (int i = 0; i < iters; i++) {
+    const int e = t + i * NT, r = e / per_row, g = e - r * per_row;
+    v[i] = vf_stream16(in, e < total ? (ty * G::TH + G::IY + r) * bpl + tx * G::TW + G::IX + 16 * g : -16, n);
+  }
+#pragma unroll
+  for (int i = 0; i < iters; i++) {
+    const int e = t + i * NT, r = e / per_row, g = e - r * per_row;
+    if (e < total) vf_store16(s_img + r * G::IWD + 4 * g, v[i].x, v[i].y, v[i].z, v[i].w);
   }
 }
 

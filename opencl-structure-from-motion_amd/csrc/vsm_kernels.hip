@@ -241,13 +241,19 @@ __global__ void __launch_bounds__(256)
 #define FRONT_LH (FRONT_TH + 4)
 __global__ void __launch_bounds__(256)
     k_front(const VsmImage *__restrict__ imgs, int first, const uint8_t *__restrict__ src0, const uint8_t *__restrict__ src1,
-            size_t frame_stride, int src_bpl, int sides, VsmDims d, int write_img) {
+            size_t frame_stride, int src_bpl, int sides, VsmDims d, int write_img, int nbx, int nby, int n_img) {
   __shared__ uint32_t s_in[FRONT_LH][FRONT_LW / 4];
-  const int fr = blockIdx.z / sides, side = blockIdx.z - fr * sides;
+  // (XCD-aware placement: neighbouring tiles share the 128-byte lines their unaligned rows straddle and two halo rows; dealt
+  // round-robin over the eight L2s every such line was fetched from HBM twice: 1.41 x the kernel's bytes)
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int zi = lb / (nbx * nby), rem = lb - zi * (nbx * nby);
+  if (zi >= n_img) return;
+  const int by = rem / nbx, bx = rem - by * nbx;
+  const int fr = zi / sides, side = zi - fr * sides;
   const uint8_t *__restrict__ src = (side ? src1 : src0) + (size_t)fr * frame_stride;
   const VsmImage &im = imgs[first + 2 * fr + side];
   const int bpl = d.bpl, h = d.h, w = d.w;
-  const int x0 = blockIdx.x * FRONT_TW, y0 = blockIdx.y * FRONT_TH;
+  const int x0 = bx * FRONT_TW, y0 = by * FRONT_TH;
   const int t = threadIdx.x;
   // ---- tile of the padded stream into LDS ----
   // Items of four LDS dwords (16 stream bytes; the last item of a row has two).  An item that lies inside one image row
@@ -775,7 +781,7 @@ __global__ void __launch_bounds__(256)
 // XCD-aware placement: neighbouring tiles (which share halo lines) follow each other on one XCD's L2.
 // ---------------------------------------------------------------------------------------
 #ifdef VSM_FEAT_TIMING  // experiments (tools/build_variant.sh NAME -DVSM_FEAT_TIMING, tools/feat_timing.py): cycles per phase of every wave
-__device__ unsigned int vsm_ft_rec[2][1 << 16][10];  // [kernel][wave] start (low bits), phase lengths ...
+__device__ unsigned int vsm_ft_rec[3][1 << 16][10];  // [kernel][wave] start (low bits), phase lengths ...
 extern "C" int vsm_debug_feat_rec(unsigned int *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vsm_ft_rec), sizeof(vsm_ft_rec)) != hipSuccess) return -1;
   (void)reset;
@@ -813,7 +819,7 @@ __global__ void __launch_bounds__(256)
   const int t = threadIdx.x;
   FT_DECL;
   FT_STAMP;
-  vf_fill<G>(s_img, im.imgm, d.mbpl * d.mh, d.mbpl, tx, ty, t, 256);
+  vf_fill<G, 256>(s_img, im.imgm, d.mbpl * d.mh, d.mbpl, tx, ty, t);
   FT_STAMP;
   __syncthreads();
   FT_STAMP;
@@ -842,7 +848,7 @@ __global__ void __launch_bounds__(256)
   const int t = threadIdx.x;
   FT_DECL;
   FT_STAMP;
-  vf_fill<G>(s_img, im.imgm, d.mbpl * d.mh, d.mbpl, tx, ty, t, 256);
+  vf_fill<G, 256>(s_img, im.imgm, d.mbpl * d.mh, d.mbpl, tx, ty, t);
   FT_STAMP;
   __syncthreads();
   FT_STAMP;
@@ -1114,8 +1120,9 @@ struct VsmOrderPlan {
   int32_t tiles_u, tiles_v;    // tiles per image (tiles_v = v-bins)
   int32_t stage_w, stage_h;    // staged Sobel responses: uint16 (du | dv << 8) per pixel
   int32_t cells_cap[2];        // cells of a set that can overlap a tile's rectangle
+  int32_t cells_max;           // the larger of the two
   int32_t lcap[2];             // entries a (bin, class) list can take
-  int32_t o_cand, o_cnt, o_list, o_sv, o_svi, lds_bytes;  // LDS layout (bytes)
+  int32_t o_cand, o_bs, o_cnt, o_list, o_sv, lds_bytes;  // LDS layout (bytes)
 };
 
 __device__ __forceinline__ int ceil_div_pos(int a, int b) { return (a + b - 1) / b; }
@@ -1137,23 +1144,43 @@ __global__ void __launch_bounds__(1024) k_feat_scan(const VsmImage *__restrict__
   const int ncells = st.ncu * st.ncv;
   const int chunk = (ncells + 1023) / 1024;
   const int c0 = min((int)threadIdx.x * chunk, ncells), c1 = min(c0 + chunk, ncells);
-  int sum = 0;
-  for (int c = c0; c < c1; c++) {
-    const int4 v = ldg_i4(st.cand + (size_t)c * 4);
+  int sum = 0, total, run;
+  auto tally = [&](const int4 &v) -> int {  // survivors of a cell into the histogram; returns their number
     const int cc[4] = {v.x, v.y, v.z, v.w};
+    int n = 0;
 #pragma unroll
     for (int g = 0; g < 4; g++)
       if (cc[g] < 0) {
-        sum++;
+        n++;
         atomicAdd(&s_hist[bin_of((cc[g] & 0x3fff) * d.scale, ((cc[g] >> 14) & 0x3fff) * d.scale, g, binsize, d.ub, d.vb)], 1);
       }
-  }
-  int total;
-  int run = block_excl_scan_1024(sum, total, s_w);
-  for (int c = c0; c < c1; c++) {
-    const int4 v = ldg_i4(st.cand + (size_t)c * 4);  // (L2)
-    st.cell_off[c] = run;
-    run += (v.x < 0) + (v.y < 0) + (v.z < 0) + (v.w < 0);
+    return n;
+  };
+  if (chunk <= 8) {  // (the usual case: all of a thread's cells requested at once, their counts kept for the second sweep)
+    int4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = (c0 + k < c1) ? ldg_i4(st.cand + (size_t)(c0 + k) * 4) : make_int4(0, 0, 0, 0);
+    int cnt[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      cnt[k] = tally(v[k]);
+      sum += cnt[k];
+    }
+    run = block_excl_scan_1024(sum, total, s_w);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (c0 + k < c1) {
+        st.cell_off[c0 + k] = run;
+        run += cnt[k];
+      }
+  } else {
+    for (int c = c0; c < c1; c++) sum += tally(ldg_i4(st.cand + (size_t)c * 4));
+    run = block_excl_scan_1024(sum, total, s_w);
+    for (int c = c0; c < c1; c++) {
+      const int4 v = ldg_i4(st.cand + (size_t)c * 4);  // (L2)
+      st.cell_off[c] = run;
+      run += (v.x < 0) + (v.y < 0) + (v.z < 0) + (v.w < 0);
+    }
   }
   if (threadIdx.x == 0) {
     st.cell_off[ncells] = total;
@@ -1178,11 +1205,11 @@ __global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__
                                                     VsmOrderPlan pl, int nbx, int n_img) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   uint16_t *s_g = (uint16_t *)s_raw;                      // [stage_h][stage_w]
-  int4 *s_cand = (int4 *)(s_raw + pl.o_cand);            // the cells overlapping the rectangle
+  int4 *s_cand = (int4 *)(s_raw + pl.o_cand);            // [cells_max] the cells overlapping the rectangle (one set at a time)
+  int *s_bs = (int *)(s_raw + pl.o_bs);                  // [2][bu * 4][VSM_VSUB + 1]: bin_start of the tile's fine bins, per set
   int *s_cnt = (int *)(s_raw + pl.o_cnt);                // [bu * 4] list lengths, [bu * 4] = number of survivors
   uint32_t *s_list = (uint32_t *)(s_raw + pl.o_list);    // [bu * 4][lcap]: index * 8 + v sub-row
-  uint16_t *s_sv = (uint16_t *)(s_raw + pl.o_sv);        // survivors of the tile: cell slot * 4 + class
-  uint32_t *s_svi = (uint32_t *)(s_raw + pl.o_svi);      // ... and their feature indices
+  uint32_t *s_sv = (uint32_t *)(s_raw + pl.o_sv);        // survivors of the tile: feature index << 11 | cell slot * 4 + class
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int zi = lb / nbx, bx = lb - zi * nbx;
   if (zi >= n_img) return;
@@ -1195,7 +1222,19 @@ __global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__
   const int x_hi = ub1 == d.ub ? d.mw : min(ceil_div_pos(ub1 * binsize, d.scale), d.mw);
   const int y_lo = tv == 0 ? 0 : min(ceil_div_pos(tv * binsize, d.scale), d.mh);
   const int y_hi = tv + 1 == d.vb ? d.mh : min(ceil_div_pos((tv + 1) * binsize, d.scale), d.mh);
-  // ---- Sobel responses of the rectangle + 5 pixels of halo, du | dv << 8 per pixel ----
+  const int nl = pl.bu * 4;
+  FT_DECL;
+  FT_STAMP;
+  // ---- the starts of the tile's fine bins (both sets) and the Sobel responses of the rectangle + 5 pixels of halo, du | dv << 8
+  // per pixel.  (Requesting every load of the workgroup up front - cells of both sets, offsets, responses, in registers - was
+  // tried: the wait is the same 4-5 us of loaded memory latency either way, and what the extra registers and LDS cost in
+  // resident workgroups made the kernel slower: 108 -> 114-150 us per 220 images.) ----
+  for (int si = set_lo; si < 2; si++)
+    for (int e = t; e < nl * (VSM_VSUB + 1); e += 256) {
+      const int l = e / (VSM_VSUB + 1), k = e - l * (VSM_VSUB + 1);
+      const int ubin = min(ub0 + (l >> 2), d.ub - 1);
+      s_bs[si * nl * (VSM_VSUB + 1) + e] = ldg_i32(im.set[si].bin_start + ((l & 3) * d.ub + ubin) * (d.vb * VSM_VSUB) + tv * VSM_VSUB + k);
+    }
   const int xa = (x_lo - EMIT_HALO) & ~3, ya = y_lo - EMIT_HALO;  // (may be negative: nothing there is ever read)
   const int sw4 = pl.stage_w >> 2;
   for (int e = t; e < sw4 * pl.stage_h; e += 256) {
@@ -1212,25 +1251,27 @@ __global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__
   }
   for (int si = set_lo; si < 2; si++) {
     const VsmSet &st = im.set[si];
+    const int lcap = pl.lcap[si];
     const int n = st.nms_n, n1 = n + 1, o0 = n + VSM_MARGIN;  // cell c covers pixels o0 + c * n1 .. + n
     // cells that can hold a pixel of the rectangle
     const int cu_lo = max(0, ceil_div_pos(max(x_lo - n - o0, 0), n1)), cu_hi = min(st.ncu - 1, x_hi - 1 >= o0 ? (x_hi - 1 - o0) / n1 : -1);
     const int cv_lo = max(0, ceil_div_pos(max(y_lo - n - o0, 0), n1)), cv_hi = min(st.ncv - 1, y_hi - 1 >= o0 ? (y_hi - 1 - o0) / n1 : -1);
     const int cw = cu_hi - cu_lo + 1, ch = cv_hi - cv_lo + 1;
     const int ncell = (cw > 0 && ch > 0) ? cw * ch : 0;  // <= cells_cap[si] by the plan
-    const int nl = pl.bu * 4, lcap = pl.lcap[si];
-    __syncthreads();  // (stage complete; the previous set's lists are no longer read)
+    const int4 *cand = s_cand;
+    FT_STAMP;
+    __syncthreads();  // (stage complete; the previous set's lists and cells are no longer read)
     if (t <= nl) s_cnt[t] = 0;
     __syncthreads();
+    FT_STAMP;
     for (int e = t; e < ncell; e += 256) {
       const int lcu = e / ch, lcv = e - lcu * ch;  // v fastest: neighbouring threads read neighbouring cand[] entries
       const int cell = (cu_lo + lcu) * st.ncv + cv_lo + lcv;
       const int4 c4 = ldg_i4(st.cand + (size_t)cell * 4);
       s_cand[e] = c4;
       if ((c4.x | c4.y | c4.z | c4.w) >= 0) continue;
-      const int off = ldg_i32(st.cell_off + cell);
       const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
-      int idx = off;
+      int idx = ldg_i32(st.cell_off + cell);
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         if (cc[g] >= 0) continue;
@@ -1242,18 +1283,19 @@ __global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__
           const int p = atomicAdd(&s_cnt[l], 1);
           if (p < lcap) s_list[l * lcap + p] = (uint32_t)idx * 8u + (uint32_t)vsub;
           const int q = atomicAdd(&s_cnt[nl], 1);
-          s_sv[q] = (uint16_t)(e * 4 + g);
-          s_svi[q] = (uint32_t)idx;
+          s_sv[q] = ((uint32_t)idx << 11) | (uint32_t)(e * 4 + g);
         }
         idx++;
       }
     }
+    FT_STAMP;
     __syncthreads();
     const int nsv = s_cnt[nl];
     for (int q = t; q < nsv; q += 256) {
-      const int e = s_sv[q] >> 2, g = s_sv[q] & 3;
-      const uint32_t idx = s_svi[q];
-      const int4 c4 = s_cand[e];
+      const uint32_t sv = s_sv[q];
+      const int e = (int)((sv >> 2) & 511u), g = (int)(sv & 3u);
+      const uint32_t idx = sv >> 11;
+      const int4 c4 = cand[e];
       const int cc = g == 0 ? c4.x : (g == 1 ? c4.y : (g == 2 ? c4.z : c4.w));
       const int u = cc & 0x3fff, v = (cc >> 14) & 0x3fff;
       const int us = u * d.scale, vs = v * d.scale;
@@ -1264,15 +1306,18 @@ __global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__
       const int cnt = min(s_cnt[l], lcap);
       const uint32_t *L = s_list + l * lcap;
       int rank = 0, crank = 0;
-      for (int k = 0; k < cnt; k++) {
-        const uint32_t en = L[k];
-        const int before = (en >> 3) < idx;
-        crank += before;
-        rank += (before && (int)(en & 7u) == vsub) ? 1 : 0;
+      for (int k = 0; k < cnt; k += 4) {  // (lists are 16-byte aligned and a multiple of four long; entries beyond cnt do not count)
+        const uint4 en4 = *(const uint4 *)(L + k);
+        const uint32_t en[4] = {en4.x, en4.y, en4.z, en4.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int before = (k + j < cnt) && (en[j] >> 3) < idx;
+          crank += before;
+          rank += (before && (int)(en[j] & 7u) == vsub) ? 1 : 0;
+        }
       }
-      const int b = (g * d.ub + ubin) * (d.vb * VSM_VSUB) + vbin * VSM_VSUB + vsub;  // = bin_of()
-      const int lo = ldg_i32(st.bin_start + b), clo = ldg_i32(st.bin_start + b - vsub);
-      const int dst = lo + rank;
+      const int *bs = s_bs + (si * nl + l) * (VSM_VSUB + 1);  // bin_start of the fine bins (g, ubin, vbin, 0..)
+      const int dst = bs[vsub] + rank, clo = bs[0];
       // descriptor (computeDescriptor, viso/matcher.cpp:433-477): 16 taps of (du, dv) from the staged rectangle
       const uint16_t *c0 = s_g + (v - ya) * pl.stage_w + (u - xa);
       uint32_t t16[16];
@@ -1307,6 +1352,8 @@ __global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__
       *(VSM_AS1 int32_t *)(st.s_rank + dst) = clo + crank;
     }
   }
+  FT_STAMP;
+  FT_FLUSH(2);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2470,11 +2517,12 @@ static bool vsm_order_plan(const VsmDims &d, const VsmImage &im, int set_lo, int
     const int cwt = std::min(st.ncu, (pl.bu * bw - 1) / n1 + 2), cht = std::min(st.ncv, (bw - 1) / n1 + 2);  // cells meeting a tile / ...
     const int cwb = std::min(st.ncu, (bw - 1) / n1 + 2);                                                  // ... one bin
     pl.cells_cap[k] = cwt * cht;
-    pl.lcap[k] = cwb * cht;
+    pl.lcap[k] = (cwb * cht + 3) & ~3;
     maxcells = std::max(maxcells, pl.cells_cap[k]);
     maxl = std::max(maxl, pl.lcap[k]);
+    if (st.cap >= (1 << 21)) return false;  // (survivor words: 21 bits of feature index)
   }
-  if (maxcells <= 0 || maxcells * 4 > 65535) return false;
+  if (maxcells <= 0 || maxcells > 512) return false;
   int o = pl.stage_w * pl.stage_h * 2;
   auto take = [&](int bytes) {
     o = (o + 15) & ~15;
@@ -2482,11 +2530,12 @@ static bool vsm_order_plan(const VsmDims &d, const VsmImage &im, int set_lo, int
     o += bytes;
     return at;
   };
+  pl.cells_max = maxcells;
   pl.o_cand = take(maxcells * 16);
+  pl.o_bs = take(2 * pl.bu * 4 * (VSM_VSUB + 1) * 4);
   pl.o_cnt = take((pl.bu * 4 + 1) * 4);
   pl.o_list = take(pl.bu * 4 * maxl * 4);
-  pl.o_sv = take(maxcells * 4 * 2);
-  pl.o_svi = take(maxcells * 4 * 4);
+  pl.o_sv = take(maxcells * 4 * 4);
   pl.lds_bytes = (o + 15) & ~15;
   return pl.lds_bytes <= 64 * 1024;
 }
@@ -2504,9 +2553,10 @@ void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int f
 void vsm_launch_front(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0, const uint8_t *src1,
                       size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d, int write_img) {
   const int sides = src1 ? 2 : 1;
-  dim3 grid(cdiv(d.bpl, FRONT_TW), cdiv(d.h, FRONT_TH), n_frames * sides);
+  const int nbx = cdiv(d.bpl, FRONT_TW), nby = cdiv(d.h, FRONT_TH), n_img = n_frames * sides;
+  dim3 grid(((nbx * nby * n_img + 7) / 8) * 8);
   pf.begin(VSM_K_FRONT, s);
-  hipLaunchKernelGGL(k_front, grid, dim3(256), 0, s, d_imgs, first, src0, src1, frame_stride, src_bpl, sides, d, write_img);
+  hipLaunchKernelGGL(k_front, grid, dim3(256), 0, s, d_imgs, first, src0, src1, frame_stride, src_bpl, sides, d, write_img, nbx, nby, n_img);
   pf.end(s);
 }
 

@@ -33,7 +33,7 @@ void emu_feat_dense(const uint8_t *img, int mw, int mh, int mbpl, int tau, int n
       // poison: nothing may depend on what a previous tile left behind
       memset(s_img, 0xa5, sizeof(s_img));
       memset(s_f, 0x5a, sizeof(s_f));
-      for (int t = 0; t < 256; t++) vf_fill<G>(s_img, img, mbpl * mh, mbpl, tx, ty, t, 256);
+      for (int t = 0; t < 256; t++) vf_fill<G, 256>(s_img, img, mbpl * mh, mbpl, tx, ty, t);
       for (int t = 0; t < G::PC * G::PR; t++) vf_dense_patch(s_img, s_f, t, tx, ty, mbpl, mh, du, dv, f1, f2);
       for (int it = 0; it < G::CU * G::CV * 2; it++) vf_dense_nms(s_f, it, tx, ty, mw, mh, 6, tau, ncu, ncv, cand);
     }
@@ -50,7 +50,7 @@ void emu_feat_sparse(const uint8_t *img, int mw, int mh, int mbpl, int tau, int 
     for (int tx = 0; tx < tl[2]; tx++) {
       memset(s_img, 0xa5, sizeof(s_img));
       memset(s_f, 0x5a, sizeof(s_f));
-      for (int t = 0; t < 256; t++) vf_fill<G>(s_img, img, mbpl * mh, mbpl, tx, ty, t, 256);
+      for (int t = 0; t < 256; t++) vf_fill<G, 256>(s_img, img, mbpl * mh, mbpl, tx, ty, t);
       for (int t = 0; t < G::PC * G::PR; t++) vf_sparse_patch(s_img, s_f, t, keep[t]);
       for (int it = 0; it < G::CU * G::CV; it++) vf_sparse_nms<1>(s_f, it, 0, 0, tx, ty, mw, mh, 6, tau, ncu, ncv, cand);
       for (int t = 0; t < G::PC * G::PR; t++) vf_sparse_store_f2(s_f, t, keep[t]);
