@@ -780,8 +780,9 @@ __global__ void __launch_bounds__(256)
 //                  workgroups per compute unit), f2 waits in registers; 8 lanes per (cell, filter)
 // XCD-aware placement: neighbouring tiles (which share halo lines) follow each other on one XCD's L2.
 // ---------------------------------------------------------------------------------------
+
 #ifdef VSM_FEAT_TIMING  // experiments (tools/build_variant.sh NAME -DVSM_FEAT_TIMING, tools/feat_timing.py): cycles per phase of every wave
-__device__ unsigned int vsm_ft_rec[3][1 << 16][10];  // [kernel][wave] start (low bits), phase lengths ...
+__device__ unsigned int vsm_ft_rec[4][1 << 16][10];  // [kernel][wave] start (low bits), phase lengths ...
 extern "C" int vsm_debug_feat_rec(unsigned int *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vsm_ft_rec), sizeof(vsm_ft_rec)) != hipSuccess) return -1;
   (void)reset;
@@ -791,7 +792,7 @@ extern "C" int vsm_debug_feat_rec(unsigned int *out, int reset) {
 #define FT_STAMP ft_t[ft_n++] = __builtin_amdgcn_s_memtime()
 #define FT_FLUSH(kern)                                                              \
   do {                                                                              \
-    const unsigned wv = blockIdx.x * 4 + (threadIdx.x >> 6);                        \
+    const unsigned wv = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); \
     if ((threadIdx.x & 63) == 0 && wv < (1u << 16)) {                               \
       vsm_ft_rec[kern][wv][0] = (unsigned)ft_t[0] | 1u;                             \
       for (int q = 1; q < ft_n; q++) vsm_ft_rec[kern][wv][q] = (unsigned)(ft_t[q] - ft_t[q - 1]); \
@@ -1115,6 +1116,13 @@ __global__ void __launch_bounds__(256) k_emit(const VsmImage *__restrict__ imgs,
 //                 their place in the bin-sorted arrays: no bin ids, scatter cursors or unordered slots in HBM, no second
 //                 read of the records (k_bin_rank gathered them back: 2.5 x its algorithmic bytes).
 // ---------------------------------------------------------------------------------------
+// division by the search bin size as a multiply-high (exact for 0 <= x < 2^32 / binsize; the arguments are image coordinates)
+struct VsmBinDiv {
+  int32_t binsize;
+  uint32_t magic;  // ceil(2^32 / binsize), 0 for binsize 1
+  __device__ __forceinline__ int div(int x) const { return binsize == 1 ? x : (int)__umulhi((uint32_t)x, magic); }
+  __device__ __forceinline__ int vsub(int v, int vbin) const { return min(div((v - vbin * binsize) * VSM_VSUB), VSM_VSUB - 1); }  // sub-row inside the bin
+};
 struct VsmOrderPlan {
   int32_t bu;                  // coarse u-bins per tile
   int32_t tiles_u, tiles_v;    // tiles per image (tiles_v = v-bins)
@@ -1127,7 +1135,7 @@ struct VsmOrderPlan {
 
 __device__ __forceinline__ int ceil_div_pos(int a, int b) { return (a + b - 1) / b; }
 
-__global__ void __launch_bounds__(1024) k_feat_scan(const VsmImage *__restrict__ imgs, int first, int set_lo, VsmDims d, int binsize, int nb) {
+__global__ void __launch_bounds__(1024) k_feat_scan(const VsmImage *__restrict__ imgs, int first, int set_lo, VsmDims d, VsmBinDiv bd, int nb) {
   extern __shared__ int s_dyn[];
   __shared__ int s_w[17];
   int *s_hist = s_dyn;
@@ -1139,8 +1147,11 @@ __global__ void __launch_bounds__(1024) k_feat_scan(const VsmImage *__restrict__
     }
     return;
   }
+  FT_DECL;
+  FT_STAMP;
   for (int b = threadIdx.x; b < nb; b += 1024) s_hist[b] = 0;
   __syncthreads();
+  FT_STAMP;
   const int ncells = st.ncu * st.ncv;
   const int chunk = (ncells + 1023) / 1024;
   const int c0 = min((int)threadIdx.x * chunk, ncells), c1 = min(c0 + chunk, ncells);
@@ -1152,7 +1163,9 @@ __global__ void __launch_bounds__(1024) k_feat_scan(const VsmImage *__restrict__
     for (int g = 0; g < 4; g++)
       if (cc[g] < 0) {
         n++;
-        atomicAdd(&s_hist[bin_of((cc[g] & 0x3fff) * d.scale, ((cc[g] >> 14) & 0x3fff) * d.scale, g, binsize, d.ub, d.vb)], 1);
+        const int u = (cc[g] & 0x3fff) * d.scale, v = ((cc[g] >> 14) & 0x3fff) * d.scale;
+        const int ubin = min(bd.div(u), d.ub - 1), vbin = min(bd.div(v), d.vb - 1);
+        atomicAdd(&s_hist[(g * d.ub + ubin) * (d.vb * VSM_VSUB) + vbin * VSM_VSUB + bd.vsub(v, vbin)], 1);  // = bin_of()
       }
     return n;
   };
@@ -1166,7 +1179,9 @@ __global__ void __launch_bounds__(1024) k_feat_scan(const VsmImage *__restrict__
       cnt[k] = tally(v[k]);
       sum += cnt[k];
     }
+    FT_STAMP;
     run = block_excl_scan_1024(sum, total, s_w);
+    FT_STAMP;
 #pragma unroll
     for (int k = 0; k < 8; k++)
       if (c0 + k < c1) {
@@ -1193,16 +1208,21 @@ __global__ void __launch_bounds__(1024) k_feat_scan(const VsmImage *__restrict__
   int bsum = 0;
   for (int b = b0; b < b1; b++) bsum += s_hist[b];
   int btotal;
+  FT_STAMP;
   int brun = block_excl_scan_1024(bsum, btotal, s_w);
+  FT_STAMP;
   for (int b = b0; b < b1; b++) {
     st.bin_start[b] = brun;
     brun += s_hist[b];
   }
   if (threadIdx.x == 0) st.bin_start[nb] = btotal;
+  FT_STAMP;
+  FT_FLUSH(3);
 }
 
-__global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__ imgs, int first, VsmDims d, int set_lo, int binsize,
+__global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__ imgs, int first, VsmDims d, int set_lo, VsmBinDiv bd,
                                                     VsmOrderPlan pl, int nbx, int n_img) {
+  const int binsize = bd.binsize;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   uint16_t *s_g = (uint16_t *)s_raw;                      // [stage_h][stage_w]
   int4 *s_cand = (int4 *)(s_raw + pl.o_cand);            // [cells_max] the cells overlapping the rectangle (one set at a time)
@@ -1276,9 +1296,9 @@ __global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__
       for (int g = 0; g < 4; g++) {
         if (cc[g] >= 0) continue;
         const int u = (cc[g] & 0x3fff) * d.scale, v = ((cc[g] >> 14) & 0x3fff) * d.scale;
-        const int ubin = min(u / binsize, d.ub - 1), vbin = min(v / binsize, d.vb - 1);
+        const int ubin = min(bd.div(u), d.ub - 1), vbin = min(bd.div(v), d.vb - 1);
         if (ubin >= ub0 && ubin < ub1 && vbin == tv) {
-          const int vsub = vfine_of(v, binsize, d.vb) - vbin * VSM_VSUB;
+          const int vsub = bd.vsub(v, vbin);
           const int l = (ubin - ub0) * 4 + g;
           const int p = atomicAdd(&s_cnt[l], 1);
           if (p < lcap) s_list[l * lcap + p] = (uint32_t)idx * 8u + (uint32_t)vsub;
@@ -1299,8 +1319,8 @@ __global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__
       const int cc = g == 0 ? c4.x : (g == 1 ? c4.y : (g == 2 ? c4.z : c4.w));
       const int u = cc & 0x3fff, v = (cc >> 14) & 0x3fff;
       const int us = u * d.scale, vs = v * d.scale;
-      const int ubin = min(us / binsize, d.ub - 1), vbin = min(vs / binsize, d.vb - 1);
-      const int vsub = vfine_of(vs, binsize, d.vb) - vbin * VSM_VSUB;
+      const int ubin = min(bd.div(us), d.ub - 1), vbin = min(bd.div(vs), d.vb - 1);
+      const int vsub = bd.vsub(vs, vbin);
       const int l = (ubin - ub0) * 4 + g;
       // ranks: smaller indices in the reference's bin (all of the list) and in the fine bin (same sub-row)
       const int cnt = min(s_cnt[l], lcap);
@@ -2641,12 +2661,15 @@ int vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int 
   VsmOrderPlan pl;
   if ((fused & 4) == 0 && max_cells > 0 && vsm_order_plan(d, h_imgs[first], set_lo, binsize, nb, pl)) {
     pf.begin(VSM_K_FEAT_SCAN, s);
-    hipLaunchKernelGGL(k_feat_scan, dim3(1, 2, n_img), dim3(1024), (size_t)nb * 4, s, d_imgs, first, set_lo, d, binsize, nb);
+    VsmBinDiv bd;
+    bd.binsize = binsize;
+    bd.magic = binsize >= 2 ? (uint32_t)(((1ull << 32) + (uint64_t)binsize - 1) / (uint64_t)binsize) : 0u;
+    hipLaunchKernelGGL(k_feat_scan, dim3(1, 2, n_img), dim3(1024), (size_t)nb * 4, s, d_imgs, first, set_lo, d, bd, nb);
     pf.end(s);
     pf.begin(VSM_K_FEAT_ORDER, s);
     const int nbx = pl.tiles_u * pl.tiles_v;
-    hipLaunchKernelGGL(k_feat_order, dim3(((nbx * n_img + 7) / 8) * 8), dim3(256), (size_t)pl.lds_bytes, s, d_imgs, first, d, set_lo, binsize,
-                       pl, nbx, n_img);
+    hipLaunchKernelGGL(k_feat_order, dim3(((nbx * n_img + 7) / 8) * 8), dim3(256), (size_t)pl.lds_bytes, s, d_imgs, first, d, set_lo, bd, pl,
+                       nbx, n_img);
     pf.end(s);
     return (!fuse || (fused & 2)) ? 1 : 0;
   }
