@@ -229,14 +229,14 @@ __global__ void __launch_bounds__(256)
 // k_filters<true> produced in three (each streaming the full image): the padded copy (only where something reads it
 // later - the per-frame path's getGain), the half-resolution image (F0, viso/matcher.cpp:636-647) and the full-resolution
 // Sobel planes (F1, viso/filter.cpp:316-324), which only the refinement reads.
-// A block owns a tile of 128 x 32 pixels.  Its 36 x 136 bytes of input (2 rows / 4 bytes of halo) go to LDS as coalesced
-// dword loads in the layout of the PADDED byte stream (row stride bpl, pad bytes 0, positions outside the image 0 - the
-// reference's filters run over that stream and wrap at row ends): caller rows need no alignment (two aligned dwords and a
-// byte funnel shift per LDS dword, as in k_ingest).  Then every thread takes a 4 x 4 patch from an 8 x 12-byte LDS window
-// with exactly k_filters' arithmetic, and 4 half-resolution pixels.
+// A block owns a tile of 128 x 64 pixels.  Its 68 x 136 bytes of input (2 rows / 4 bytes of halo) go to LDS as coalesced
+// loads in the layout of the PADDED byte stream (row stride bpl, pad bytes 0, positions outside the image 0 - the
+// reference's filters run over that stream and wrap at row ends): caller rows need no alignment (aligned loads and a
+// byte funnel shift per LDS dword, as in k_ingest).  Then every thread takes an 8 x 4 patch from an 8-row x 16-byte LDS
+// window (two pixels per instruction, vsm_feat.h) and 8 half-resolution pixels.
 // ---------------------------------------------------------------------------------------
 #define FRONT_TW 128
-#define FRONT_TH 32
+#define FRONT_TH 64
 #define FRONT_LW (FRONT_TW + 8)  // bytes per LDS row
 #define FRONT_LH (FRONT_TH + 4)
 __global__ void __launch_bounds__(256)
@@ -307,9 +307,10 @@ __global__ void __launch_bounds__(256)
       if (y < h && x4 < bpl) *(VSM_AS1 uint32_t *)(im.img + (size_t)y * bpl + x4) = s_in[r + 2][c + 1];
     }
   }
-  // ---- half-resolution image: 64 x 16 pixels of this tile, 4 per thread ----
-  {
-    const int hy = t >> 4, hx4 = (t & 15) * 4;
+  // ---- half-resolution image: 64 x 32 pixels of this tile, 2 x 4 per thread ----
+#pragma unroll
+  for (int k2 = 0; k2 < FRONT_TH / 32; k2++) {
+    const int idx = t + 256 * k2, hy = idx >> 4, hx4 = (idx & 15) * 4;
     const int my = (y0 >> 1) + hy, mx4 = (x0 >> 1) + hx4;
     if (my < d.mh && mx4 < d.mbpl) {
       const uint32_t a0 = s_in[2 + 2 * hy][1 + (hx4 >> 1)], a1 = s_in[2 + 2 * hy][2 + (hx4 >> 1)];
@@ -325,92 +326,36 @@ __global__ void __launch_bounds__(256)
       *(VSM_AS1 uint32_t *)(im.imgm + (size_t)my * d.mbpl + mx4) = out;
     }
   }
-  // ---- full-resolution Sobel: 4 x 4 patch per thread ----
-  const int tx = t & 31, ty = t >> 5;
-  const int x4 = x0 + 4 * tx, yb = y0 + 4 * ty;
-  if (x4 >= bpl || yb >= h) return;
-  uint32_t Wn[8][3];
+  // ---- full-resolution Sobel: an 8 x 4 patch per thread from a window of 8 rows x 16 bytes, two pixels per instruction in
+  // 16-bit lanes (vsm_feat.h: the same column / row passes as the matching-resolution tiles); a patch row = du 0-3, dv 0-3,
+  // du 4-7, dv 4-7 = one 16-byte row of the tiled plane ----
+  static_assert(FRONT_TW == 128 && FRONT_TH == 64, "16 x 16 patches of 8 x 4 pixels");
+  const int tx = t & 15, ty = t >> 4;
+  const int x8 = x0 + 8 * tx, yb = y0 + 4 * ty;
+  if (x8 >= bpl || yb >= h) return;
+  VfWindow<4> W;
 #pragma unroll
   for (int r = 0; r < 8; r++) {
 #pragma unroll
-    for (int q = 0; q < 3; q++) Wn[r][q] = s_in[4 * ty + r][tx + q];
+    for (int q = 0; q < 4; q++) W.w[r][q] = s_in[4 * ty + r][2 * tx + q];
   }
-  if (yb >= 3 && yb + 3 <= h - 4) {
-    // Interior patch (every stream position of the 8 x 4 window lies in rows [2, h-3]: no zeroing): the same sums two
-    // pixels per instruction.  Bytes 2..9 of a window row become four pairs of 16-bit lanes; the 5-tap column sums
-    // (<= 4080 unsigned, +-765 signed) and the row passes (+-24480, +-12240) fit 16 bits, and (x >> 7) + 128 clamped to a
-    // byte is the same arithmetic shift as in 32 bits.
-    typedef short vsm_s2 __attribute__((ext_vector_type(2)));
-    vsm_s2 Pk[8][4];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-      Pk[r][0] = __builtin_bit_cast(vsm_s2, __builtin_amdgcn_perm(0u, Wn[r][0], 0x0c030c02u));
-      Pk[r][1] = __builtin_bit_cast(vsm_s2, __builtin_amdgcn_perm(0u, Wn[r][1], 0x0c010c00u));
-      Pk[r][2] = __builtin_bit_cast(vsm_s2, __builtin_amdgcn_perm(0u, Wn[r][1], 0x0c030c02u));
-      Pk[r][3] = __builtin_bit_cast(vsm_s2, __builtin_amdgcn_perm(0u, Wn[r][2], 0x0c010c00u));
-    }
-    auto shl1 = [](vsm_s2 hi2, vsm_s2 lo2) -> vsm_s2 {  // (lo2.y, hi2.x): the pair one column further
-      return __builtin_bit_cast(vsm_s2, __builtin_amdgcn_alignbyte(__builtin_bit_cast(uint32_t, hi2), __builtin_bit_cast(uint32_t, lo2), 2u));
-    };
-    auto to_byte = [](vsm_s2 v) -> vsm_s2 {
-      const vsm_s2 c128 = {128, 128}, c0 = {0, 0}, c255 = {255, 255};
-      v = (v >> 7) + c128;
-      return __builtin_elementwise_min(__builtin_elementwise_max(v, c0), c255);
-    };
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      const int y = yb + rr;
-      vsm_s2 S[4], D[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const vsm_s2 a = Pk[rr][j], b = Pk[rr + 1][j], c = Pk[rr + 2][j], dd = Pk[rr + 3][j], e = Pk[rr + 4][j];
-        S[j] = (a + e) + (b + dd) * (short)4 + c * (short)6;
-        D[j] = (a - e) + (b - dd) * (short)2;
-      }
-      const vsm_s2 S12 = shl1(S[1], S[0]), S34 = shl1(S[2], S[1]), S56 = shl1(S[3], S[2]);
-      const vsm_s2 D12 = shl1(D[1], D[0]), D34 = shl1(D[2], D[1]), D56 = shl1(D[3], D[2]);
-      const vsm_s2 hu01 = (S[0] - S[2]) + (S12 - S34) * (short)2, hu23 = (S[1] - S[3]) + (S34 - S56) * (short)2;
-      const vsm_s2 hv01 = (D[0] + D[2]) + (D12 + D34) * (short)4 + D[1] * (short)6, hv23 = (D[1] + D[3]) + (D34 + D56) * (short)4 + D[2] * (short)6;
-      const uint32_t du = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, to_byte(hu23)), __builtin_bit_cast(uint32_t, to_byte(hu01)), 0x06040200u);
-      const uint32_t dv = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, to_byte(hv23)), __builtin_bit_cast(uint32_t, to_byte(hv01)), 0x06040200u);
-      typedef uint32_t vsm_u2 __attribute__((ext_vector_type(2)));
-      vsm_u2 o;
-      o.x = du;
-      o.y = dv;
-      *(VSM_AS1 vsm_u2 *)(im.duv_tiled + vsm_tiled_at(bpl, x4, y)) = o;
-    }
-    return;
-  }
-#define FPB(r, i) ((int)((Wn[(r)][(i) >> 2] >> (8 * ((i)&3))) & 0xffu))
-  const int lo = 2 * bpl, hi = (h - 2) * bpl;
 #pragma unroll
   for (int rr = 0; rr < 4; rr++) {
     const int y = yb + rr;
     if (y >= h) break;
-    const int f0 = y * bpl + x4;
-    // column pass at stream positions f0-2 .. f0+5 (window index 2..9); zero outside rows [2,h-3]
-    int S[8], D[8];
+    vf_s2 S[6], D[6];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int g = f0 + i - 2;
-      const bool ok = g >= lo && g < hi;
-      const int a = FPB(rr, i + 2), b = FPB(rr + 1, i + 2), c = FPB(rr + 2, i + 2), dd = FPB(rr + 3, i + 2), e = FPB(rr + 4, i + 2);
-      S[i] = ok ? a + 4 * b + 6 * c + 4 * dd + e : 0;
-      D[i] = ok ? a + 2 * b - 2 * dd - e : 0;
-    }
-    uint32_t du = 0, dv = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int hu = S[k] + 2 * S[k + 1] - 2 * S[k + 3] - S[k + 4];
-      const int hv = D[k] + 4 * D[k + 1] + 6 * D[k + 2] + 4 * D[k + 3] + D[k + 4];
-      du |= (uint32_t)min(max((hu >> 7) + 128, 0), 255) << (8 * k);
-      dv |= (uint32_t)min(max((hv >> 7) + 128, 0), 255) << (8 * k);
-    }
-    const size_t o0 = vsm_tiled_at(bpl, x4, y);
-    *(VSM_AS1 uint32_t *)(im.duv_tiled + o0) = du;
-    *(VSM_AS1 uint32_t *)(im.duv_tiled + o0 + VSM_TILED_DV) = dv;
+    for (int j = 0; j < 6; j++) vf_columns_sobel<4>(W, rr, j, S[j], D[j]);
+    if (y < 3 || y > h - 4) vf_sobel_zero_outside(S, D, y * bpl + x8, 2 * bpl, (h - 2) * bpl);
+    uint32_t du[2], dv[2];
+    vf_sobel_row(S, D, du, dv);
+    vsm_u4 o;
+    o.x = du[0];
+    o.y = dv[0];
+    o.z = du[1];
+    o.w = dv[1];
+    *(VSM_AS1 vsm_u4 *)(im.duv_tiled + vsm_tiled_at(bpl, x8, y)) = o;
   }
-#undef FPB
 }
 
 // ---------------------------------------------------------------------------------------
