@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=N_FRAMES)
-    ap.add_argument("--startup", type=int, default=30, help="untimed calls in front of the warm-up steps (reported as startup_calls)")
+    ap.add_argument("--startup", type=int, default=0, help="untimed calls in front of the warm-up steps (reported as startup_calls; none by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-per-frame", action="store_true", help="skip the per-frame API leg (profiling runs)")
@@ -219,9 +219,9 @@ def main():
 
     dmod = dist if world > 1 else None
 
-    # (process start-up, not part of the W warm-up steps the contract asks for: about 130 ms after the process's first call
-    # every thread of the host pool stalls once for ~6 ms - once per process, at that time whatever runs then
-    # (tools/outliers.py; the calls before and after are normal) - so the start-up is let pass first)
+    # (rounds 3-4 let 30 calls pass here: once per process one call took 10-13 ms.  Its cause - the runtime creating a hardware
+    # queue in the middle of a run for a table upload whose DMA engine was busy - is gone (k_upload), and so are
+    # the hidden calls; --startup N still runs N untimed calls and the line reports them)
     startup_ms = []
     for _ in range(args.startup):
         ts = time.perf_counter()

@@ -820,7 +820,7 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
     vsm_host_remove_outliers(h->work, p, h->stage[1], method);
     vsm_host_prior_statistics(p, h->dims_c, h->stage[1], method, h->ranges);
     ranges_to_device_layout(c.h_ranges, h->ranges.data(), h->ranges.size());
-    HIPCHK(hipMemcpyAsync(c.d_ranges, c.h_ranges, h->ranges.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(vsm_upload(h->stream, c.d_ranges, c.h_ranges, h->ranges.size() * sizeof(float)));
     t2 = now_us();
   }
   cfg.sparse = 0;
@@ -1632,7 +1632,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       nprev[0][s] = c.hm_counts[(first_img + 2 * (n - 1)) * 2 + s];
       nprev[1][s] = c.hm_counts[(first_img + 2 * (n - 1) + 1) * 2 + s];
     }
-    HIPCHK(hipMemcpyAsync(d_jobs, h_jobs, sizeof(VsmJob) * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(vsm_upload(h->stream, d_jobs, h_jobs, sizeof(VsmJob) * n));
     if (p.multi_stage) {
       VsmMatchCfg cfg = make_cfg(p, method);
       VsmJob dummy;
@@ -1719,8 +1719,8 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
       });
       ta = now_us();
       thost += ta - tb;
-      HIPCHK(hipMemcpyAsync(c.d_ranges + (size_t)first_pair * c.ranges_stride, c.h_ranges + (size_t)first_pair * c.ranges_stride,
-                            c.ranges_stride * 4 * n, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(vsm_upload(h->stream, c.d_ranges + (size_t)first_pair * c.ranges_stride, c.h_ranges + (size_t)first_pair * c.ranges_stride,
+                        c.ranges_stride * 4 * n));
     }
     if (k > 0) {  // pass 2 of the previous chunk ran meanwhile
       const int rc = finalize(k - 1);

@@ -2453,6 +2453,25 @@ __global__ void __launch_bounds__(1024) k_parabolic_apply(const VsmPair *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Small tables (job descriptions of a chunk: 10-20 KB) from pinned host memory to HBM by a kernel on the stream that needs
+// them, not by hipMemcpyAsync.  The runtime takes a copy of more than 16 KB to a DMA engine, and when that engine is busy
+// with another upload - two chunks' tables now and then - it falls back to a shader copy on a hardware queue of its own,
+// which it creates then and there: 180 MB of context-save area mapped and touched, 6-7 ms during which every launch of
+// the process waits (the "once per process" stall of round 4; tools/stall_probe.py, tools/shim/mmap_trace.c).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_upload(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, int n_words) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_words) dst[i] = src[i];
+}
+hipError_t vsm_upload(hipStream_t s, void *dst_device, const void *src_pinned, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  if ((bytes & 3) || ((uintptr_t)dst_device & 3) || ((uintptr_t)src_pinned & 3)) return hipMemcpyAsync(dst_device, src_pinned, bytes, hipMemcpyHostToDevice, s);
+  const int n = (int)(bytes >> 2);
+  hipLaunchKernelGGL(k_upload, dim3((n + 255) / 256), dim3(256), 0, s, (uint32_t *)dst_device, (const uint32_t *)src_pinned, n);
+  return hipGetLastError();
+}
+
 // =======================================================================================
 // launchers
 // =======================================================================================
