@@ -116,7 +116,11 @@ float vsm_gain(vsm_handle *h, const int32_t *inliers, int32_t n);
  * parallel.  left/right: n_frames images frame_stride bytes apart (host or, with on_device != 0,
  * HBM); right == NULL (mono) with stereo / quad matching goes frame by frame (the reference's matchFeatures returns early).
  * Tr_delta: NULL or n_frames x 12 doubles, Tr_valid: NULL (all valid) or n_frames flags.
- * The streaming ring buffer (vsm_push_back / vsm_match) is not touched except by the fallback. */
+ * The streaming ring buffer (vsm_push_back / vsm_match) is not touched except by the fallback.
+ * STREAMS: besides the handle's own non-blocking streams the GPU-resident form uses the process's NULL stream (result
+ * export copies, device vertex sorts) and drains it before it returns: an application that keeps work of its own on the
+ * null stream - PyTorch's default stream is it, blocking streams synchronise with it - sets option "seq_null_stream" = 0
+ * (vsm_set_option) and the library uses a non-blocking stream of its own instead. */
 int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, int64_t frame_stride, int on_device,
                      int32_t n_frames, int32_t width, int32_t height, int32_t bpl, int32_t method,
                      const double *Tr_delta, const uint8_t *Tr_valid);
@@ -137,7 +141,10 @@ int32_t vsm_sequence_path(vsm_handle *h);
  * Option-only names (never read from the environment): "front" (0: separate ingest / halving / Sobel passes instead of the
  * fused front end), "dc_gpu", "dc_full", "dc_watchdog_ms", "dc_fault_inject" (the GPU's share of the final stage in the
  * host-shared form), and the scheduling experiments of the GPU-resident form recorded in DESIGN.md 6c:
- * "seq_keys_dma", "seq_ties1_null", "seq_last_first", "seq_export_budget", "seq_first_chunk", "seq_p2_first".
+ * "seq_keys_dma", "seq_ties1_null", "seq_last_first", "seq_export_budget", "seq_first_chunk", "seq_p2_first";
+ * "seq_null_stream" (above); "fused_features" / "feat_order" (0: the separate filter, suppression, record and bin kernels
+ * instead of k_feat_dense / k_feat_sparse / k_feat_scan / k_feat_order) and "filter_planes" (1: vsm_push_back keeps the
+ * blob / corner responses in HBM for vsm_get_filter_responses; the fused kernels leave them in LDS otherwise).
  * None of them changes a result.  Returns VSM_OK, or VSM_EARG for an unknown name.  (No counterpart in the reference.) */
 int vsm_set_option(vsm_handle *h, const char *name, int32_t value);
 /* Host threads near the GPU: the library confines the threads IT creates (host pool, look-ahead poller) to the CPUs of the
@@ -171,7 +178,8 @@ int32_t vsm_get_ranges(vsm_handle *h, float *out, int32_t cap_bins);
 int32_t vsm_get_gradients(vsm_handle *h, int32_t which, int32_t full, uint8_t *du, uint8_t *dv);
 
 /* blob / corner filter responses of the current left image (f1,f2 of viso/matcher.cpp:651-678;
- * transient in the reference).  Returns elements per plane or 0. */
+ * transient in the reference - and here: with the default suppression radii they never leave LDS, so set option
+ * "filter_planes" = 1 before the push whose responses are wanted).  Returns elements per plane or 0 (none kept). */
 int32_t vsm_get_filter_responses(vsm_handle *h, int16_t *f1, int16_t *f2);
 
 /* work counters of the last vsm_match(): {findMatch calls, 0, 0, matches refined, matches out}

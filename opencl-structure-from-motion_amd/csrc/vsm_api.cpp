@@ -386,6 +386,8 @@ struct VsmSwitches {
   int seq_first_chunk = 0;   // ... frames of the call's first chunk (0: like the others)
   int seq_p2_first = -1;     // ... a chunk's second pass in front of the features of chunk k + 2 (the order host-resident inputs get): -1 = by pool size
   int seq_export_budget = 2; // ... pieces of the early export submitted behind a chunk's keys where the next chunk's keys follow at once (sequence_run_v2: export_some)
+  int seq_null_stream = 1;   // ... its fifth stream (early exports, the device's vertex sorts) is the process's null stream (1) or a non-blocking stream of
+                             // the library's own (0: for applications that keep work of their own on the null stream - INTEGRATION.md)
   int fused_features = 1;    // filters + suppression of the matching resolution out of one LDS tile (k_feat_dense / k_feat_sparse; default radii) or the separate kernels (0)
   int feat_order = 1;        // feature records + bin-sorted copy by k_feat_scan / k_feat_order (tiles of whole search bins) or by k_scan_cells / k_emit / k_bin_* (0)
   int filter_planes = 0;     // vsm_push_back keeps f1 / f2 in HBM for vsm_get_filter_responses (the fused tiles write them on the side)
@@ -419,6 +421,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "seq_p2_first")) seq_p2_first = v;
     else if (!strcmp(name, "seq_last_first")) seq_last_first = v != 0;
     else if (!strcmp(name, "seq_ties1_null")) seq_ties1_null = v != 0;
+    else if (!strcmp(name, "seq_null_stream")) seq_null_stream = v != 0;
     else if (!strcmp(name, "fused_features")) fused_features = v != 0;
     else if (!strcmp(name, "filter_planes")) filter_planes = v != 0;
     else if (!strcmp(name, "feat_order")) feat_order = v != 0;
@@ -429,6 +432,7 @@ struct VsmSwitches {
 
 struct vsm_handle {
   vsm_params param;  // match_radius already halved for half_resolution (viso/matcher.cpp:59-60)
+  void *aff = nullptr;  // CPU record of the handle's device (vsm_host.h): where the threads created for this handle confine themselves
   VsmSwitches sw;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -544,6 +548,7 @@ vsm_handle *vsm_create(const vsm_params *p) {
     char bdf[64] = {0};
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), dev) == hipSuccess)
       vsm_affinity_from_device(bdf);  // (before the pools start their threads)
+    h->aff = vsm_affinity_current();
   }
   {
     // host threads (the caller's thread included): VSM_HOST_THREADS frame-parallel workers for

@@ -1277,7 +1277,18 @@ __device__ inline bool dc2_reaches(uint32_t w, bool left_half, int32_t cl, int32
 #define DC2_BLOCK_OCC 5
 #endif
 #ifndef DC2_BLOCK_TAIL
-#define DC2_BLOCK_TAIL 1  // waves that carry the levels below DC2_BLOCK_PACKED nodes (and the write-back); the others end early
+// waves that carry the levels below DC2_BLOCK_PACKED nodes (and the write-back); the others END early (s_endpgm) and the
+// workgroup's later __syncthreads() count the surviving waves only.  That is how gfx9 hardware works (s_barrier waits for the
+// waves of the workgroup that have not terminated), not something HIP's programming model promises: the early exits are
+// compiled for gfx9 targets only - elsewhere every wave stays to the end (DC2_BLOCK_TAIL = DC2_BLOCK_WAVES); this library is
+// built for gfx950 and nothing else, and test_gpu_resident_remove_outliers_chain / test_delaunay_subtrees_on_gpu pin the
+// behaviour (a wave waiting for a terminated one would hang them).
+#if defined(__gfx900__) || defined(__gfx906__) || defined(__gfx908__) || defined(__gfx90a__) || defined(__gfx940__) || defined(__gfx941__) || \
+    defined(__gfx942__) || defined(__gfx950__) || !defined(__HIP_DEVICE_COMPILE__)
+#define DC2_BLOCK_TAIL 1
+#else
+#define DC2_BLOCK_TAIL DC2_BLOCK_WAVES
+#endif
 #endif
 __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(const VsmDc2Job *__restrict__ jobs, int depth) {
   __shared__ __attribute__((aligned(16))) uint32_t s_w[2 * VSM_DC_BLOCK_POINTS * 4];  // edge words (vsm_dc_lds.h)

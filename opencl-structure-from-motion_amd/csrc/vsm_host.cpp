@@ -11,16 +11,18 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <string>
 #include <chrono>
 #if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 
 // VSM_DEBUG_TIMING: phase times on stderr (read once)
 static bool vsm_host_debug_timing() {
   static const bool on = getenv("VSM_DEBUG_TIMING") != nullptr;
   return on;
 }
-#endif
 
 // =======================================================================================
 // VsmPool
@@ -32,103 +34,126 @@ static inline void cpu_relax() {
 }
 
 // ---- host threads near the GPU (vsm_host.h) ----
-static cpu_set_t g_near_cpus;
-static std::atomic<int> g_near_state{0};  // 0: not looked up yet, 1: g_near_cpus is valid, -1: none (off, unknown, or no restriction to gain)
-static std::mutex g_near_mu;
+// One record per device (PCI bus id): a second handle on another GPU gets its own node.
 // ... and spread over the socket's L3 domains (VSM_HOST_AFFINITY=1: the node only, no spreading).  What the pool does with the
 // lists the GPU's DMA wrote - 25 ms of vertex sorts over keys it has to fetch, 64 MB of gap closing - is bound by memory, and a
 // core complex has its own link to memory: fourteen threads on two of the socket's eight complexes run the call in 4.5 ms, on
 // one 4.9-5.3, spread over all eight 4.15 (tools/step_spread.sh, the rank confined to 16 / 8 cores / the whole socket) - and
-// left to the scheduler a process now and then stays packed (the "slower process").  Thread i of the library
-// goes to complex i mod n (all of its CPUs: the scheduler still chooses the core, and ranks that share a socket share it evenly).
-static std::vector<cpu_set_t> g_l3_domains;
-static std::atomic<unsigned> g_pin_next{0};
+// left to the scheduler a process now and then stays packed (the "slower process").  The library's threads are
+// dealt over the complexes IN PROPORTION TO THE CPUS each complex has inside the allowed set (a cpuset that cuts a complex
+// leaves it its share, not half the pool); a thread may use all CPUs of its complex: the scheduler still chooses the core, and
+// ranks that share a socket share it evenly.
+struct VsmAffinity {
+  cpu_set_t near;                 // the device's node within what the process may use
+  bool narrow = false;            // ... and that is fewer CPUs than the process may use
+  std::vector<cpu_set_t> order;   // pin sequence: thread i of this device -> order[i % size]
+  cpu_set_t used;                 // union of what the threads are confined to
+  bool any = false;
+  std::atomic<unsigned> next{0};
+};
+static std::mutex g_near_mu;
+static std::map<std::string, VsmAffinity *> g_aff;
+static std::atomic<VsmAffinity *> g_aff_last{nullptr};
+static thread_local VsmAffinity *t_aff = nullptr;
+
+static void parse_cpulist(char *line, cpu_set_t *out, const cpu_set_t *within) {
+  for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+    int a = -1, b = -1;
+    if (sscanf(tok, "%d-%d", &a, &b) != 2 && sscanf(tok, "%d", &a) == 1) b = a;
+    for (int c = a; a >= 0 && c <= b && c < CPU_SETSIZE; c++)
+      if (!within || CPU_ISSET(c, within)) CPU_SET(c, out);
+  }
+}
+
 void vsm_affinity_from_device(const char *pci_bus_id) {
   std::lock_guard<std::mutex> lk(g_near_mu);
-  if (g_near_state.load() != 0) return;
-  int state = -1;
+  t_aff = nullptr;
   const char *e = getenv("VSM_HOST_AFFINITY");
   char bdf[64] = {0};
-  if (!(e && atoi(e) == 0) && pci_bus_id && strlen(pci_bus_id) < sizeof(bdf)) {
-    strcpy(bdf, pci_bus_id);
-    for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
-    char path[160];
-    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
-    if (FILE *f = fopen(path, "r")) {
-      char line[1024] = {0};
-      if (fgets(line, sizeof(line), f)) {
-        cpu_set_t near, allowed;
-        CPU_ZERO(&near);
-        for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
-          int a = -1, b = -1;
-          if (sscanf(tok, "%d-%d", &a, &b) == 2) {
-          } else if (sscanf(tok, "%d", &a) == 1) {
-            b = a;
-          }
-          for (int c = a; a >= 0 && c <= b && c < CPU_SETSIZE; c++) CPU_SET(c, &near);
-        }
-        if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
-          cpu_set_t both;
-          CPU_AND(&both, &near, &allowed);
-          // (only where it narrows the choice and leaves room: a process already confined, or one whose allowed CPUs
-          // miss the node, stays as it is)
-          if (CPU_COUNT(&both) >= 2 && CPU_COUNT(&both) < CPU_COUNT(&allowed)) {
-            g_near_cpus = both;
-            state = 1;
-          }
-          if (!(e && atoi(e) == 1) && CPU_COUNT(&both) >= 2) {  // the L3 domains of the CPUs the threads may use near the GPU
-            cpu_set_t left = both;
-            for (int c = 0; c < CPU_SETSIZE; c++) {
-              if (!CPU_ISSET(c, &left)) continue;
-              cpu_set_t dom;
-              CPU_ZERO(&dom);
-              char p3[160], l3[1024] = {0};
-              snprintf(p3, sizeof(p3), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
-              FILE *f3 = fopen(p3, "r");
-              if (f3 && fgets(l3, sizeof(l3), f3)) {
-                for (char *tok = strtok(l3, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
-                  int a = -1, b = -1;
-                  if (sscanf(tok, "%d-%d", &a, &b) != 2 && sscanf(tok, "%d", &a) == 1) b = a;
-                  for (int k = a; a >= 0 && k <= b && k < CPU_SETSIZE; k++)
-                    if (CPU_ISSET(k, &both)) CPU_SET(k, &dom);
-                }
-              }
-              if (f3) fclose(f3);
-              if (CPU_COUNT(&dom) == 0) CPU_SET(c, &dom);
-              for (int k = 0; k < CPU_SETSIZE; k++)
-                if (CPU_ISSET(k, &dom)) CPU_CLR(k, &left);
-              g_l3_domains.push_back(dom);
-            }
-            if (g_l3_domains.size() < 2) g_l3_domains.clear();
-          }
-        }
-      }
-      fclose(f);
+  if ((e && atoi(e) == 0) || !pci_bus_id || strlen(pci_bus_id) >= sizeof(bdf)) return;
+  strcpy(bdf, pci_bus_id);
+  for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
+  auto it = g_aff.find(bdf);
+  if (it != g_aff.end()) {
+    t_aff = it->second;
+    g_aff_last.store(t_aff);
+    return;
+  }
+  VsmAffinity *A = new VsmAffinity();
+  CPU_ZERO(&A->near);
+  CPU_ZERO(&A->used);
+  g_aff[bdf] = A;  // (looked up once per device, whatever comes of it)
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  FILE *f = fopen(path, "r");
+  if (!f) return;
+  char line[1024] = {0};
+  cpu_set_t near, allowed, both;
+  CPU_ZERO(&near);
+  if (fgets(line, sizeof(line), f)) parse_cpulist(line, &near, nullptr);
+  fclose(f);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+  CPU_AND(&both, &near, &allowed);
+  if (CPU_COUNT(&both) < 2) return;  // (a process whose allowed CPUs miss the node stays as it is)
+  A->near = both;
+  A->narrow = CPU_COUNT(&both) < CPU_COUNT(&allowed);
+  std::vector<cpu_set_t> doms;
+  if (!(e && atoi(e) == 1)) {  // the L3 domains of the CPUs the threads may use near the GPU
+    cpu_set_t left = both;
+    for (int c = 0; c < CPU_SETSIZE; c++) {
+      if (!CPU_ISSET(c, &left)) continue;
+      cpu_set_t dom;
+      CPU_ZERO(&dom);
+      char p3[160], l3[1024] = {0};
+      snprintf(p3, sizeof(p3), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
+      FILE *f3 = fopen(p3, "r");
+      if (f3 && fgets(l3, sizeof(l3), f3)) parse_cpulist(l3, &dom, &both);
+      if (f3) fclose(f3);
+      if (CPU_COUNT(&dom) == 0) CPU_SET(c, &dom);
+      for (int k = 0; k < CPU_SETSIZE; k++)
+        if (CPU_ISSET(k, &dom)) CPU_CLR(k, &left);
+      doms.push_back(dom);
     }
   }
-  g_near_state.store(state);
-}
-void vsm_pin_this_thread() {
-  if (g_near_state.load(std::memory_order_acquire) == 0) return;
-  if (!g_l3_domains.empty()) {
-    const cpu_set_t &dom = g_l3_domains[g_pin_next.fetch_add(1, std::memory_order_relaxed) % g_l3_domains.size()];
-    (void)pthread_setaffinity_np(pthread_self(), sizeof(dom), &dom);
-  } else if (g_near_state.load(std::memory_order_acquire) == 1) {
-    (void)pthread_setaffinity_np(pthread_self(), sizeof(g_near_cpus), &g_near_cpus);
+  if (doms.size() >= 2) {
+    // round r takes every domain that has more than r CPUs: interleaved, and in proportion to the domains' sizes
+    int most = 0;
+    for (const cpu_set_t &d : doms) most = std::max(most, CPU_COUNT(&d));
+    for (int r = 0; r < most; r++)
+      for (const cpu_set_t &d : doms)
+        if (CPU_COUNT(&d) > r) A->order.push_back(d);
+    A->used = both;
+    A->any = true;
+  } else if (A->narrow) {
+    A->order.push_back(both);
+    A->used = both;
+    A->any = true;
+  }
+  if (A->any) {
+    t_aff = A;
+    g_aff_last.store(A);
   }
 }
-int vsm_affinity_cpus(int *out, int cap) {
-  if (g_near_state.load(std::memory_order_acquire) != 1) return 0;
+void *vsm_affinity_current() { return t_aff; }
+void vsm_pin_this_thread(void *aff) {
+  VsmAffinity *A = aff ? (VsmAffinity *)aff : t_aff;
+  if (!A || !A->any || A->order.empty()) return;
+  const cpu_set_t &dom = A->order[A->next.fetch_add(1, std::memory_order_relaxed) % A->order.size()];
+  (void)pthread_setaffinity_np(pthread_self(), sizeof(dom), &dom);
+}
+int vsm_affinity_cpus(int *out, int cap) {  // the CPUs the threads of the device looked up last are confined to (their union)
+  VsmAffinity *A = g_aff_last.load();
+  if (!A || !A->any) return 0;
   int n = 0;
   for (int c = 0; c < CPU_SETSIZE; c++)
-    if (CPU_ISSET(c, &g_near_cpus)) {
+    if (CPU_ISSET(c, &A->used)) {
       if (n < cap) out[n] = c;
       n++;
     }
   return n;
 }
 
-VsmPool::VsmPool(int threads) : nthreads_(threads < 1 ? 1 : threads) {
+VsmPool::VsmPool(int threads) : nthreads_(threads < 1 ? 1 : threads), aff_(vsm_affinity_current()) {
   spin_us_ = 100;  // millisecond-sized tasks: a wake-up is cheap next to them, spinning burns quota
   for (int i = 1; i < nthreads_; i++) threads_.emplace_back([this] { worker(); });
 }
@@ -160,7 +185,7 @@ bool VsmPool::work_one() {
 }
 
 void VsmPool::worker() {
-  vsm_pin_this_thread();
+  vsm_pin_this_thread(aff_);
   for (;;) {
     if (stop_) return;
     // (the post counter is read BEFORE the queue is looked at: a batch posted in between changes it, so the wait below
@@ -239,7 +264,7 @@ void VsmPool::run(int ntasks, const std::function<void(int)> &fn) {
 // ---------------------------------------------------------------------------------------
 // VsmForkJoin: lock-free fork-join for the fine-grained phases inside one Delaunay
 // ---------------------------------------------------------------------------------------
-VsmForkJoin::VsmForkJoin(int threads) : nthreads_(threads < 1 ? 1 : threads) {
+VsmForkJoin::VsmForkJoin(int threads) : nthreads_(threads < 1 ? 1 : threads), aff_(vsm_affinity_current()) {
   for (int i = 1; i < nthreads_; i++) threads_.emplace_back([this] { worker(); });
 }
 
@@ -267,7 +292,7 @@ bool VsmForkJoin::claim(uint64_t g, int n, int &idx) {
 }
 
 void VsmForkJoin::worker() {
-  vsm_pin_this_thread();
+  vsm_pin_this_thread(aff_);
   uint64_t seen = 0;
   for (;;) {
     // wait for a new generation: spin first, then block

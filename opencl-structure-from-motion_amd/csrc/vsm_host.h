@@ -23,12 +23,13 @@
 // other socket read the pinned buffers the GPU's DMA wrote (keys, refined lists) across the socket link, and the look-ahead
 // call takes 4.45-4.57 ms instead of 4.17-4.23 (tools/numa_probe.sh; left to the scheduler: anything between, process by
 // process).  vsm_affinity_from_device() reads the CPUs of the device's NUMA node (/sys/bus/pci/devices/<bdf>/local_cpulist)
-// once per process; every thread the library creates (pool workers, fork-join workers, the look-ahead poller) then
-// confines itself to those CPUs, within what the process is allowed.  The caller's own threads are left alone.
-// VSM_HOST_AFFINITY=0 switches it off.
-void vsm_affinity_from_device(const char *pci_bus_id);  // "0000:0d:00.0" (hipDeviceGetPCIBusId)
-void vsm_pin_this_thread();
-int vsm_affinity_cpus(int *out, int cap);  // the CPUs chosen (for the caller who wants its own threads there too); returns how many
+// once per DEVICE; every thread the library creates for a handle on that device (pool workers, fork-join workers, the
+// look-ahead poller) then confines itself to those CPUs, within what the process is allowed.  The caller's own threads are
+// left alone.  VSM_HOST_AFFINITY=0 switches it off.
+void vsm_affinity_from_device(const char *pci_bus_id);  // "0000:0d:00.0" (hipDeviceGetPCIBusId); makes that device's record the calling thread's current one
+void *vsm_affinity_current();                           // the calling thread's current record (what pools created now will pin their workers by)
+void vsm_pin_this_thread(void *affinity = nullptr);     // nullptr: the calling thread's current record
+int vsm_affinity_cpus(int *out, int cap);  // the CPUs the threads of the device looked up last may use (for the caller who wants its own threads there too); returns how many
 
 // Small task pool for the host stages (Delaunay sub-problems / frame pairs are independent).
 // Work arrives as batches of n index tasks; batches are served FIFO.  run() is fork-join (the
@@ -57,6 +58,7 @@ class VsmPool {
   void worker();
   bool work_one();  // runs one task of the oldest unfinished batch; false if none
   int nthreads_;
+  void *aff_ = nullptr;  // where the workers confine themselves (vsm_affinity_current() of the creating thread)
   std::vector<std::thread> threads_;
   std::mutex mu_;
   std::condition_variable cv_;
@@ -99,6 +101,7 @@ class VsmForkJoin {
   void worker();
   bool claim(uint64_t g, int n, int &idx);
   int nthreads_;
+  void *aff_ = nullptr;
   std::vector<std::thread> threads_;
   std::mutex mu_;
   std::condition_variable cv_;

@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle.so")
-REF_SO = os.path.join(HERE, "_ref", "libvisoref.so")
+REF_SO = os.environ.get("VISO_REF_SO") or os.path.join(HERE, "_ref", "libvisoref.so")
 
 MATCH_DTYPE = np.dtype(
     [("u1p", "<f4"), ("v1p", "<f4"), ("i1p", "<i4"), ("u2p", "<f4"), ("v2p", "<f4"), ("i2p", "<i4"),

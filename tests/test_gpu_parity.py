@@ -1,6 +1,8 @@
 """GPU parity suite (run with -m gpu on an MI355X): the HIP path, called through the C-ABI
 (libvisomatch.so), must be bit-identical to the CPU oracle on seeded inputs and to the committed
 golden vectors of the real reference, stage by stage."""
+import os
+
 import numpy as np
 import pytest
 
@@ -287,7 +289,9 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
     m.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"VSM_SEQ_SERIAL": "1"}, {"VSM_SEQ_EARLY_EXPORT": "0"}, {"VSM_SEQ_EARLY_EXPORT": "1"},
+@pytest.mark.parametrize("env", [{}, {"VSM_SEQ_SERIAL": "1"}, {"VSM_SEQ_EARLY_EXPORT": "0"},
+                                 {"opt:seq_null_stream": "0"}, {"opt:seq_null_stream": "0", "VSM_SEQ_GPU_SORTS": "50", "VSM_SEQ_CHUNK": "5"},
+                                 {"opt:fused_features": "0"}, {"opt:feat_order": "0"}, {"opt:fused_features": "0", "opt:feat_order": "0", "opt:front": "0"},
                                  {"VSM_SEQ_EARLY_EXPORT": "1", "VSM_HOST_THREADS": "2"}, {"VSM_SEQ_DC_STREAMS": "1"},
                                  {"VSM_SEQ_DC_STREAMS": "4", "VSM_SEQ_CHUNK": "5"}, {"VSM_SEQ_CHUNK": "2", "VSM_SEQ_EARLY_EXPORT": "0"},
                                  {"VSM_SEQ_GPU_SORTS": "100"}, {"VSM_SEQ_GPU_SORTS": "40", "VSM_HOST_THREADS": "2"},
@@ -301,7 +305,8 @@ def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), both ways of
     result delivery at both ends of the pool size, one / four chain streams (eight chunks of five, twenty of two: every bank
     comes round), the vertex sorts on the device (one launch for the chunks that wait for it, also where a slab comes round
-    before the call's last head; two-chunk calls of ranks with few host threads: a launch per chunk, the pool sizes' own shares), the unfused front end, the scheduling choices of DESIGN.md 6c either way: always
+    before the call's last head; two-chunk calls of ranks with few host threads: a launch per chunk, the pool sizes' own shares), the unfused front end, the
+    separate filter / suppression / record / bin kernels instead of the fused tiles, a fifth stream of the library's own instead of the null stream, the scheduling choices of DESIGN.md 6c either way: always
     the reference's lists, and always this form (it must not quietly hand the run to the other one)."""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1")
@@ -676,7 +681,7 @@ def test_multi_sequence_lockstep_live_feedback(vm, synth, K, device_inputs):
     canv = {sd: synth.canvas(sd, w, h) for sd in seeds}
     seq_seed = [seeds[k % len(seeds)] for k in range(K)]
     vo = vm.MultiVisualOdometryStereo(K, *[float(x) for x in g["intr"]])
-    for f in range(nf if K <= 8 else 12):
+    for f in range(nf):
         fr = {sd: synth.stereo_frame(canv[sd], f, w, h) for sd in seeds}
         left = np.stack([fr[sd][0] for sd in seq_seed])
         right = np.stack([fr[sd][1] for sd in seq_seed])
@@ -699,14 +704,27 @@ def test_multi_sequence_lockstep_live_feedback(vm, synth, K, device_inputs):
     vo.close()
 
 
-def test_multi_sequence_with_subpixel_refinement(vm, synth):
-    """refinement = 2 inside vsm_multi_process: per sequence and frame, matchFeatures' final list equals what the per-frame
-    matcher gives for the same images and the Tr_delta the multi-sequence step actually used (that path is checked against
-    the oracle elsewhere); two sequences fed the same images stay identical to each other and to a run with K = 1"""
+def test_multi_sequence_with_subpixel_refinement(vm, B, synth):
+    """refinement = 2 inside vsm_multi_process, against the ORACLE's VisualOdometryStereo(refinement = 2) run on each sequence's
+    images (a fresh object and sampler per sequence, like a process of its own): process()'s flag, Tr_delta, the bucketed
+    list and the inlier set of every frame.  Besides: matchFeatures' un-bucketed final list equals what the per-frame matcher
+    gives for the same images and the Tr_delta the step actually used; two sequences fed the same images stay identical to
+    each other and to a run with K = 1"""
     w, h, nf, K = 640, 192, 6, 3
     canv = [synth.canvas(77, w, h), synth.canvas(78, w, h)]
     which = [0, 1, 0]
     intr = (645.24, 635.96, 194.13, 0.5707)
+    want = []
+    for cv in canv:
+        B.oracle_sampler_seed(71)
+        o = B.OracleStereoVO(*intr, refinement=2)
+        rows = []
+        for f in range(nf):
+            l, r = synth.stereo_frame(cv, f, w, h)
+            ok, _, _, T = o.process(l, r)
+            rows.append((ok, T.copy(), o.bucketed().copy(), o.inliers().copy()))
+        o.close()
+        want.append(rows)
     vo = vm.MultiVisualOdometryStereo(K, *intr, refinement=2)
     solo = vm.MultiVisualOdometryStereo(1, *intr, refinement=2)
     per = [vm.Matcher(refinement=2) for _ in range(K)]
@@ -718,9 +736,12 @@ def test_multi_sequence_with_subpixel_refinement(vm, synth):
         left = np.stack([fr[i][0] for i in which])
         right = np.stack([fr[i][1] for i in which])
         tin = [(vo.motion_valid(k), vo.get_motion(k)) for k in range(K)]
-        vo.process(left, right)
+        ok = vo.process(left, right)
         solo.process(left[:1], right[:1])
         for k in range(K):
+            wk = want[which[k]][f]
+            assert bool(ok[k]) == wk[0] and vo.get_motion(k).tobytes() == wk[1].tobytes(), (f, k)
+            assert _same(vo.get_matches(k), wk[2]) and np.array_equal(vo.get_inlier_indices(k), wk[3]), (f, k)
             per[k].push_back(left[k], right[k])
             per[k].match_features(2, tin[k][1] if tin[k][0] else None)
             fin = vo.get_matches(k, bucketed=False)
@@ -1026,11 +1047,16 @@ def test_delaunay_subtrees_on_gpu(vm, B):
 
 
 def _oracle_survivors(B, lst, method):
-    """Matcher::removeOutliers (viso/matcher.cpp:1207-1377) of the CPU oracle on a match list.  (The oracle's removeOutliers is
-    pinned against the reference's own on these very lists by the CPU suite, tests/test_oracle_vs_ref.py; the reference's
-    library is not loaded into a process that holds the HIP runtime - its Triangle keeps file-scope state behind global
-    C symbols.)"""
-    return B.remove_outliers("oracle", lst, method)
+    """Matcher::removeOutliers (viso/matcher.cpp:1207-1377) on a match list: the CPU oracle's (pinned against the reference's
+    own on these very lists by the CPU suite, tests/test_oracle_vs_ref.py) and, where the compiled reference travelled to
+    this box (oracle/_ref), the reference's as well - both must agree.  (Round 4 saw one segmentation fault inside the
+    reference's call in this process and took it out; neither 156 lists in a HIP process (tools/ref_crash_probe.py) nor the
+    address sanitizer on the reference build reproduce it, its data symbols bind to itself (LD_DEBUG=bindings) - the call is
+    back in, so that a recurrence leaves a record with this test's name on it.)"""
+    want = B.remove_outliers("oracle", lst, method)
+    if os.environ.get("VSM_TEST_CHAIN_REF", "1") == "1" and B.have_ref():
+        assert _same(want, B.remove_outliers("ref", lst, method))
+    return want
 
 
 def test_gpu_resident_remove_outliers_chain(vm, B):
