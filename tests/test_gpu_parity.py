@@ -1049,12 +1049,16 @@ def test_delaunay_subtrees_on_gpu(vm, B):
 def _oracle_survivors(B, lst, method):
     """Matcher::removeOutliers (viso/matcher.cpp:1207-1377) on a match list: the CPU oracle's (pinned against the reference's
     own on these very lists by the CPU suite, tests/test_oracle_vs_ref.py) and, where the compiled reference travelled to
-    this box (oracle/_ref), the reference's as well - both must agree.  (Round 4 saw one segmentation fault inside the
-    reference's call in this process and took it out; neither 156 lists in a HIP process (tools/ref_crash_probe.py) nor the
-    address sanitizer on the reference build reproduce it, its data symbols bind to itself (LD_DEBUG=bindings) - the call is
-    back in, so that a recurrence leaves a record with this test's name on it.)"""
+    this box (oracle/_ref), the reference's as well - both must agree.
+    One kind of list never goes to the reference: more than three matches that all share ONE pixel.  Its vendored Triangle
+    then recurses without end (viso/triangle.cpp:5966-6092: divconqrecurse on a single distinct vertex halves it into 0 + 1
+    and calls itself on the 1) until the stack is gone - the segmentation fault round 4 recorded in this test and put down
+    to symbol clashes with the HIP runtime.  It happens in a process without any GPU library just the same
+    (tests/test_oracle_vs_ref.py::test_reference_crashes_on_a_one_pixel_list); the oracle and this library define the case:
+    no triangulation, no support, nothing survives."""
     want = B.remove_outliers("oracle", lst, method)
-    if os.environ.get("VSM_TEST_CHAIN_REF", "1") == "1" and B.have_ref():
+    distinct = len(set(zip(np.asarray(lst["u1c"]).tolist(), np.asarray(lst["v1c"]).tolist()))) if len(lst) else 0
+    if B.have_ref() and not (len(lst) > 3 and distinct < 2):
         assert _same(want, B.remove_outliers("ref", lst, method))
     return want
 

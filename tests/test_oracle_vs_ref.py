@@ -3,6 +3,8 @@ place (oracle/_ref/libvisoref.so, built by `make -C oracle ref` where /root/refe
 exists; the built .so travels to the GPU box).  Skipped when that build is absent --
 tests/test_golden.py then still pins the oracle through the committed fixtures.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -180,3 +182,31 @@ def test_remove_outliers_on_the_chain_test_lists(B):
                 assert len(a) == len(b) and a.tobytes() == b.tobytes(), (n, method, grid, len(a), len(b))
                 n_checked += len(a)
     assert n_checked > 100000
+
+
+def test_reference_crashes_on_a_one_pixel_list(B, have_ref):
+    """A defect of the reference, pinned so that nobody goes looking for it in the GPU stack again: removeOutliers on more than
+    three matches that all lie on ONE pixel never returns - Triangle's divconqrecurse (viso/triangle.cpp:5966-6092) splits
+    the single distinct vertex into 0 + 1 and calls itself on the 1 until the stack overflows (SIGSEGV).  Run in a process
+    of its own; the oracle's answer for the same list is "nothing survives"."""
+    if not have_ref:
+        pytest.skip("compiled reference not available")
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import importlib.util, sys
+        sys.path.insert(0, %r)
+        from oracle import bindings as B
+        spec = importlib.util.spec_from_file_location("dc2_check", %r)
+        dc2 = importlib.util.module_from_spec(spec); spec.loader.exec_module(dc2)
+        lst = dc2.make_list(60, dup=0)
+        lst["u1c"], lst["v1c"] = 100, 50
+        print("oracle", len(B.remove_outliers("oracle", lst, 2)), flush=True)
+        B.remove_outliers("ref", lst, 2)
+        print("reference returned", flush=True)
+    """) % (root, os.path.join(root, "tools", "dc2_check.py"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "oracle 0" in r.stdout
+    assert r.returncode == -11 and "reference returned" not in r.stdout, (r.returncode, r.stdout, r.stderr[-400:])
