@@ -247,6 +247,12 @@ def main():
     value = total_pairs / elapsed
     seq_t = m.sequence_timings()          # phase split of the last timed step (rank-local)
     lookahead_form = m.sequence_path()
+    # what every rank ran with (a SCALE run explains its own efficiency: DESIGN section 7): its host threads, the CPUs it is
+    # confined to, frames per chunk, its own median and slowest step
+    rank_rows = shard.gather_rows(dmod, torch, [rank, int(os.environ["VSM_HOST_THREADS"]), len(os.sched_getaffinity(0)), seq_t.get("chunk", 0),
+                                                sorted(step_ms)[len(step_ms) // 2], max(step_ms), lookahead_form], comm_dev)
+    ranks_info = [{"rank": int(r[0]), "host_threads": int(r[1]), "cpus_allowed": int(r[2]), "chunk_frames": int(r[3]), "median_step_ms": round(r[4], 3),
+                   "slowest_step_ms": round(r[5], 3), "lookahead_form": int(r[6])} for r in rank_rows]
 
     # ---- the same sequence through the per-frame (drop-in) entry points ---------------------
     per_frame_value = None
@@ -527,6 +533,7 @@ def main():
         # what the main stream's kernels alone would sustain: frames / their summed HIP-event durations in the profiled pass
         "gpu_phases_only_frame_pairs_per_s": round(nf / (sum(v[0] for v in stats.values()) * 1e-3), 1),
         "host_threads": int(os.environ["VSM_HOST_THREADS"]),
+        "ranks": ranks_info,
         "host_threads_on": NEAR_GPU or "wherever the scheduler puts them",
         "host_cpus": {"os_cpu_count": os.cpu_count(), "cgroup_quota": ncpu, "model": cpu_model()},
         "lookahead_form": {2: "GPU-resident (lists stay in HBM; host only runs Triangle's vertex sort)",

@@ -39,3 +39,16 @@ def aggregate(dist_mod, torch_mod, units, seconds, device=None, all_ok=True):
     dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
     dist_mod.all_reduce(o, op=dist_mod.ReduceOp.MIN)
     return float(s.item()), float(t.item()), bool(o.item())
+
+
+def gather_rows(dist_mod, torch_mod, row, device=None):
+    """every rank's row of a few numbers (host threads, chunk plan, its own step time ...) on every rank: a SCALE run then
+    explains its own efficiency in the rank-0 line.  A few bytes per rank, once, outside the timed region."""
+    row = [float(x) for x in row]
+    if dist_mod is None or not dist_mod.is_initialized() or dist_mod.get_world_size() == 1:
+        return [row]
+    dev = device if device is not None else torch_mod.device("cpu")
+    mine = torch_mod.tensor(row, dtype=torch_mod.float64, device=dev)
+    out = [torch_mod.zeros_like(mine) for _ in range(dist_mod.get_world_size())]
+    dist_mod.all_gather(out, mine)
+    return [[float(x) for x in t.tolist()] for t in out]

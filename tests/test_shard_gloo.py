@@ -41,6 +41,8 @@ def _worker(rank, world, port, out):
     tot, tmax, ok = shard.aggregate(dist, torch, units, seconds, all_ok=True)
     # one rank reports a failed verification: every rank must see it (MIN reduction), sums and maxima unchanged
     tot2, tmax2, ok2 = shard.aggregate(dist, torch, units, seconds, all_ok=(rank == 0))
+    rows = shard.gather_rows(dist, torch, [rank, 14 - 6 * rank, 110 - 30 * rank, 4.0 + rank])   # what bench.py reports per rank
+    assert rows == [[0.0, 14.0, 110.0, 4.0], [1.0, 8.0, 80.0, 5.0]], rows
     out.put((rank, seed, n, tot, tmax, ok, tot2, tmax2, ok2))
     dist.destroy_process_group()
 

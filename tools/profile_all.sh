@@ -1,7 +1,7 @@
 # Regenerates the raw material of profiles/ on the GPU box (run through gpurun, from the repo root):
-#   C=$(git rev-parse --short HEAD); gpurun --timeout 1100 -- "VSM_COMMIT=$C bash tools/profile_all.sh r04"
+#   C=$(git rev-parse --short HEAD); gpurun --timeout 1100 -- "VSM_COMMIT=$C bash tools/profile_all.sh r05"
 # Every artefact is stamped with the commit it was taken at.  Outputs: gpurun_out/prof/<tag>_* (copy into profiles/).
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof
 rm -rf $O && mkdir -p $O
