@@ -84,7 +84,7 @@ NCPU, _threads = _cpu_share()
 os.environ.setdefault("VSM_HOST_THREADS", str(_threads))
 # Before anything initialises HIP (the runtime reads it once).  FIVE hardware queues - the null stream's, the handle's main
 # stream's and three side streams' - carry the look-ahead path, and a sixth queue in the process throttles every kernel's
-# workgroup dispatch, so five is also the cap: whatever else creates streams here (RCCL for the
+# workgroup dispatch (DESIGN_HISTORY.md section 6c), so five is also the cap: whatever else creates streams here (RCCL for the
 # start / end reductions) shares a queue instead of adding one.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
 
@@ -220,7 +220,7 @@ def main():
     dmod = dist if world > 1 else None
 
     # (rounds 3-4 let 30 calls pass here: once per process one call took 10-13 ms.  Its cause - the runtime creating a hardware
-    # queue in the middle of a run for a table upload whose DMA engine was busy - is gone (DESIGN 6d: k_upload), and so are
+    # queue in the middle of a run for a table upload whose DMA engine was busy - is gone (DESIGN.md section 6: k_upload), and so are
     # the hidden calls; --startup N still runs N untimed calls and the line reports them)
     startup_ms = []
     for _ in range(args.startup):
@@ -502,7 +502,7 @@ def main():
         "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        # untimed calls in front of the W warm-up steps (process start-up; DESIGN 6d) and the slowest call among start-up + warm-up
+        # untimed calls in front of the W warm-up steps (process start-up; DESIGN.md section 6) and the slowest call among start-up + warm-up
         "startup_calls": args.startup, "startup_worst_ms": max(startup_ms) if startup_ms else None,
         "config": {"workload": f"KITTI-shaped synthetic stereo sequence 1242x375, {nf} frames per GPU, quad matching, "
                                "default parameters, replayed Tr_delta feedback, look-ahead C-ABI entry point "

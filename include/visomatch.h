@@ -140,7 +140,7 @@ int32_t vsm_sequence_path(vsm_handle *h);
  * afterwards: name = the variable's name without the VSM_ prefix, in lower case ("seq_serial", "seq_chunk", ...).
  * Option-only names (never read from the environment): "front" (0: separate ingest / halving / Sobel passes instead of the
  * fused front end), "dc_gpu", "dc_full", "dc_watchdog_ms", "dc_fault_inject" (the GPU's share of the final stage in the
- * host-shared form), and the scheduling experiments of the GPU-resident form recorded in DESIGN.md 6c:
+ * host-shared form), and the scheduling experiments of the GPU-resident form recorded in DESIGN_HISTORY.md 6c:
  * "seq_keys_dma", "seq_ties1_null", "seq_last_first", "seq_export_budget", "seq_first_chunk", "seq_p2_first";
  * "seq_null_stream" (above); "fused_features" / "feat_order" (0: the separate filter, suppression, record and bin kernels
  * instead of k_feat_dense / k_feat_sparse / k_feat_scan / k_feat_order) and "filter_planes" (1: vsm_push_back keeps the

@@ -1359,7 +1359,7 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
         // slot go back to the compute unit at once (the workgroup's LDS stays until the last wave is through) and
         // s_barrier counts the surviving waves only.  What this is for is not this kernel: five resident workgroups of
         // four waves hold 5 x 96 of a SIMD's 512 vector registers, and a k_match wave (104) then has nowhere to go on that
-        // compute unit for as long as the block's single-lane upper levels take.
+        // compute unit for as long as the block's single-lane upper levels take (DESIGN_HISTORY.md section 6c).
         if (DC2_BLOCK_TAIL < DC2_BLOCK_WAVES && wv >= DC2_BLOCK_TAIL && wv * 64 >= nodes) return;
         node = lane < nodes ? lane : -1;
       } else if (nodes >= DC2_BLOCK_TAIL) {
@@ -1441,7 +1441,7 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
 // translate during the walk, and the node itself may be of any size.  One lane then zips the seam (dc2_zip); afterwards
 // all lanes write the band's records back under global numbering.  A neighbour that is not in the band is the handle of
 // the band's TRAP record (vsm_dc_lds.h): a walk that would need what lies behind it - it does not happen on the test
-// sets: the band is closed under the walk's accesses, DESIGN.md section 6b - poisons its own check or leaves a store in
+// sets: the band is closed under the walk's accesses, DESIGN_HISTORY.md section 6b - poisons its own check or leaves a store in
 // the trap, and the node is then redone by one lane on the records in global memory, which are untouched until the
 // write-back.  The same happens to a node whose band does not fit the LDS the level was launched with.
 // ---------------------------------------------------------------------------------------

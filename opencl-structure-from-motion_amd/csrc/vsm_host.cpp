@@ -39,7 +39,7 @@ static inline void cpu_relax() {
 // lists the GPU's DMA wrote - 25 ms of vertex sorts over keys it has to fetch, 64 MB of gap closing - is bound by memory, and a
 // core complex has its own link to memory: fourteen threads on two of the socket's eight complexes run the call in 4.5 ms, on
 // one 4.9-5.3, spread over all eight 4.15 (tools/step_spread.sh, the rank confined to 16 / 8 cores / the whole socket) - and
-// left to the scheduler a process now and then stays packed (the "slower process").  The library's threads are
+// left to the scheduler a process now and then stays packed (the "slower process", DESIGN_HISTORY.md 6c).  The library's threads are
 // dealt over the complexes IN PROPORTION TO THE CPUS each complex has inside the allowed set (a cpuset that cuts a complex
 // leaves it its share, not half the pool); a thread may use all CPUs of its complex: the scheduler still chooses the core, and
 // ranks that share a socket share it evenly.

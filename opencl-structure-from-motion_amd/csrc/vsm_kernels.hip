@@ -1191,15 +1191,41 @@ __global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__
   FT_DECL;
   FT_STAMP;
   // ---- the starts of the tile's fine bins (both sets) and the Sobel responses of the rectangle + 5 pixels of halo, du | dv << 8
-  // per pixel.  (Requesting every load of the workgroup up front - cells of both sets, offsets, responses, in registers - was
-  // tried: the wait is the same 4-5 us of loaded memory latency either way, and what the extra registers and LDS cost in
-  // resident workgroups made the kernel slower: 108 -> 114-150 us per 220 images.) ----
+  // per pixel.  (Requesting EVERY load of the workgroup up front, the responses in registers too, was tried: what the extra
+  // registers and LDS cost in resident workgroups made the kernel slower, 108 -> 114-150 us per 220 images.) ----
   for (int si = set_lo; si < 2; si++)
     for (int e = t; e < nl * (VSM_VSUB + 1); e += 256) {
       const int l = e / (VSM_VSUB + 1), k = e - l * (VSM_VSUB + 1);
       const int ubin = min(ub0 + (l >> 2), d.ub - 1);
       s_bs[si * nl * (VSM_VSUB + 1) + e] = ldg_i32(im.set[si].bin_start + ((l & 3) * d.ub + ubin) * (d.vb * VSM_VSUB) + tv * VSM_VSUB + k);
     }
+  // the cells of both sets that can hold a pixel of the rectangle (<= 2 per thread and set: cells_cap <= 512), requested now,
+  // kept in registers until their set's turn: their wait is over by the time the responses below have arrived
+  int cell_h[2], ncell[2];
+  int4 pc[2][2];
+  int po[2][2];
+#pragma unroll
+  for (int si = 0; si < 2; si++) {
+    const VsmSet &st = im.set[si];
+    const int n = st.nms_n, n1 = n + 1, o0 = n + VSM_MARGIN;  // cell c covers pixels o0 + c * n1 .. + n
+    const int cu_lo = max(0, ceil_div_pos(max(x_lo - n - o0, 0), n1)), cu_hi = min(st.ncu - 1, x_hi - 1 >= o0 ? (x_hi - 1 - o0) / n1 : -1);
+    const int cv_lo = max(0, ceil_div_pos(max(y_lo - n - o0, 0), n1)), cv_hi = min(st.ncv - 1, y_hi - 1 >= o0 ? (y_hi - 1 - o0) / n1 : -1);
+    const int cw = cu_hi - cu_lo + 1, ch = cv_hi - cv_lo + 1;
+    cell_h[si] = ch;
+    ncell[si] = (si >= set_lo && cw > 0 && ch > 0) ? cw * ch : 0;  // <= cells_cap[si] by the plan
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int e = t + 256 * i;
+      pc[si][i] = make_int4(0, 0, 0, 0);
+      po[si][i] = 0;
+      if (e < ncell[si]) {
+        const int lcu = e / ch, lcv = e - lcu * ch;  // v fastest: neighbouring threads read neighbouring cand[] entries
+        const int cell = (cu_lo + lcu) * st.ncv + cv_lo + lcv;
+        pc[si][i] = ldg_i4(st.cand + (size_t)cell * 4);
+        po[si][i] = ldg_i32(st.cell_off + cell);
+      }
+    }
+  }
   const int xa = (x_lo - EMIT_HALO) & ~3, ya = y_lo - EMIT_HALO;  // (may be negative: nothing there is ever read)
   const int sw4 = pl.stage_w >> 2;
   for (int e = t; e < sw4 * pl.stage_h; e += 256) {
@@ -1214,29 +1240,26 @@ __global__ void __launch_bounds__(256) k_feat_order(const VsmImage *__restrict__
     const uint32_t hi = ((a >> 16) & 0xffu) | (((b >> 16) & 0xffu) << 8) | ((a >> 24) << 16) | ((b >> 24) << 24);
     *(uint2 *)&s_g[y * pl.stage_w + x] = make_uint2(lo, hi);
   }
-  for (int si = set_lo; si < 2; si++) {
+#pragma unroll
+  for (int si = 0; si < 2; si++) {
+    if (si < set_lo) continue;
     const VsmSet &st = im.set[si];
     const int lcap = pl.lcap[si];
-    const int n = st.nms_n, n1 = n + 1, o0 = n + VSM_MARGIN;  // cell c covers pixels o0 + c * n1 .. + n
-    // cells that can hold a pixel of the rectangle
-    const int cu_lo = max(0, ceil_div_pos(max(x_lo - n - o0, 0), n1)), cu_hi = min(st.ncu - 1, x_hi - 1 >= o0 ? (x_hi - 1 - o0) / n1 : -1);
-    const int cv_lo = max(0, ceil_div_pos(max(y_lo - n - o0, 0), n1)), cv_hi = min(st.ncv - 1, y_hi - 1 >= o0 ? (y_hi - 1 - o0) / n1 : -1);
-    const int cw = cu_hi - cu_lo + 1, ch = cv_hi - cv_lo + 1;
-    const int ncell = (cw > 0 && ch > 0) ? cw * ch : 0;  // <= cells_cap[si] by the plan
     const int4 *cand = s_cand;
     FT_STAMP;
     __syncthreads();  // (stage complete; the previous set's lists and cells are no longer read)
     if (t <= nl) s_cnt[t] = 0;
     __syncthreads();
     FT_STAMP;
-    for (int e = t; e < ncell; e += 256) {
-      const int lcu = e / ch, lcv = e - lcu * ch;  // v fastest: neighbouring threads read neighbouring cand[] entries
-      const int cell = (cu_lo + lcu) * st.ncv + cv_lo + lcv;
-      const int4 c4 = ldg_i4(st.cand + (size_t)cell * 4);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int e = t + 256 * i;
+      if (e >= ncell[si]) continue;
+      const int4 c4 = pc[si][i];
       s_cand[e] = c4;
       if ((c4.x | c4.y | c4.z | c4.w) >= 0) continue;
       const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
-      int idx = ldg_i32(st.cell_off + cell);
+      int idx = po[si][i];
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         if (cc[g] >= 0) continue;

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # The look-ahead path uses four streams (the handle's and three side streams the Delaunay chains rotate over).  The HIP
 # runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4: two of ours would share one and serialise), and
 # with SIX or more hardware queues in a process every kernel's workgroup dispatch runs at a half or a quarter of its rate
-# (DESIGN.md 6c), so: five - ours and the null stream's.  Read when the runtime initialises, so it only helps if nothing in
+# (DESIGN_HISTORY.md 6c), so: five - ours and the null stream's.  Read when the runtime initialises, so it only helps if nothing in
 # this process has touched the GPU yet.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
 LIB_PATH = os.environ.get("VSM_LIB_PATH") or os.path.join(HERE, "libvisomatch.so")  # override: kernel experiments

@@ -306,7 +306,7 @@ def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     result delivery at both ends of the pool size, one / four chain streams (eight chunks of five, twenty of two: every bank
     comes round), the vertex sorts on the device (one launch for the chunks that wait for it, also where a slab comes round
     before the call's last head; two-chunk calls of ranks with few host threads: a launch per chunk, the pool sizes' own shares), the unfused front end, the
-    separate filter / suppression / record / bin kernels instead of the fused tiles, a fifth stream of the library's own instead of the null stream, the scheduling choices of DESIGN.md 6c either way: always
+    separate filter / suppression / record / bin kernels instead of the fused tiles, a fifth stream of the library's own instead of the null stream, the scheduling choices of DESIGN_HISTORY.md 6c either way: always
     the reference's lists, and always this form (it must not quietly hand the run to the other one)."""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1")

@@ -1,5 +1,5 @@
 // LD_PRELOAD shim: prints a backtrace for every anonymous mmap of 150-260 MB (the size of a hardware compute queue's
-// context-save area on MI355X) - who creates a queue in the middle of a run?  tools/stall_probe.py, DESIGN 6d.
+// context-save area on MI355X) - who creates a queue in the middle of a run?  tools/stall_probe.py, DESIGN.md section 6.
 //   gcc -O1 -g -shared -fPIC tools/shim/mmap_trace.c -o tools/shim/libmmaptrace.so -ldl
 #define _GNU_SOURCE
 #include <dlfcn.h>
