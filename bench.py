@@ -328,6 +328,7 @@ def main():
 
     # ---- the same look-ahead call fed from host memory (PCIe inclusive: the reference's pushBack takes host images) ----
     host_in_value, host_in_verified = None, None
+    host_pin_value, host_pin_verified = None, None
     if not args.no_per_frame:
         hl, hr = np.ascontiguousarray(host[:, 0]), np.ascontiguousarray(host[:, 1])
         m.run_sequence(hl, hr, 2, tr12, trv, fetch=False)
@@ -342,6 +343,24 @@ def main():
         hdt = time.perf_counter() - th
         hp, hdt, _ = shard.aggregate(dmod, torch, 6 * nf, hdt, comm_dev)
         host_in_value = hp / hdt
+        # ... and once more from the SAME two arrays page-locked once by their owner (vsm_host_register + option seq_host_pinned:
+        # what a caller that reuses its frame buffers can do; the copies leave straight from its memory)
+        host_pin_value, host_pin_verified = None, None
+        if vm.host_register(hl) and vm.host_register(hr):
+            try:
+                m.set_option("seq_host_pinned", 1)
+                m.run_sequence(hl, hr, 2, tr12, trv, fetch=False)
+                if not args.no_verify and key == f"s{seed}":
+                    host_pin_verified = bool(all(sha(m.sequence_matches(f)) == str(g[key + "_hashes"][f]) for f in range(nf)))
+                m.run_sequence(hl, hr, 2, tr12, trv, fetch=False)
+                th = time.perf_counter()
+                for _ in range(6):
+                    m.run_sequence(hl, hr, 2, tr12, trv, fetch=False)
+                host_pin_value = 6 * nf / (time.perf_counter() - th)
+            finally:
+                m.set_option("seq_host_pinned", 0)
+                vm.host_unregister(hl)
+                vm.host_unregister(hr)
 
     if rank != 0:
         if world > 1:
@@ -542,7 +561,12 @@ def main():
                                   "of_resident": round(host_in_value / value, 3) if host_in_value else None,
                                   "bit_exact_vs_reference_hashes": host_in_verified if host_in_value else None,
                                   "what": "the same look-ahead call fed from pageable host memory (on_device = 0): PCIe inclusive; the frames cross "
-                                          "in pieces of 20 (pool gathers into pinned memory, DMA on a stream of its own) beside the GPU's work; 6 calls"},
+                                          "in pieces of 20 (pool gathers into pinned memory, DMA on a stream of its own) beside the GPU's work; 6 calls",
+                                  "page_locked_by_the_caller": {"value": round(host_pin_value, 3) if host_pin_value else None,
+                                                                "of_resident": round(host_pin_value / (value / world), 3) if host_pin_value else None,
+                                                                "bit_exact_vs_reference_hashes": host_pin_verified if host_pin_value else None,
+                                                                "what": "the same arrays registered once (vsm_host_register) + option seq_host_pinned: DMA straight "
+                                                                        "out of the caller's memory, no gather pass; rank 0's own rate"}},
         "secondary_configs": secondary,
         "verified_ranks": n_verified,
         "step_ms_rank0": step_ms,

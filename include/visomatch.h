@@ -142,7 +142,7 @@ int32_t vsm_sequence_path(vsm_handle *h);
  * fused front end), "dc_gpu", "dc_full", "dc_watchdog_ms", "dc_fault_inject" (the GPU's share of the final stage in the
  * host-shared form), and the scheduling experiments of the GPU-resident form recorded in DESIGN_HISTORY.md 6c:
  * "seq_keys_dma", "seq_ties1_null", "seq_last_first", "seq_export_budget", "seq_first_chunk", "seq_p2_first";
- * "seq_null_stream" (above); "fused_features" / "feat_order" (0: the separate filter, suppression, record and bin kernels
+ * "seq_null_stream" (above); "seq_host_pinned" (below, vsm_host_register); "fused_features" / "feat_order" (0: the separate filter, suppression, record and bin kernels
  * instead of k_feat_dense / k_feat_sparse / k_feat_scan / k_feat_order) and "filter_planes" (1: vsm_push_back keeps the
  * blob / corner responses in HBM for vsm_get_filter_responses; the fused kernels leave them in LDS otherwise).
  * None of them changes a result.  Returns VSM_OK, or VSM_EARG for an unknown name.  (No counterpart in the reference.) */
@@ -155,6 +155,15 @@ int vsm_set_option(vsm_handle *h, const char *name, int32_t value);
  * CPUs chosen (up to cap of them in out; the return value is how many there are, 0 = none) so that the caller can put the
  * thread that calls vsm_sequence_run there too, as bench.py does. */
 int32_t vsm_local_cpus(int32_t *out, int32_t cap);
+/* Host-resident input at the link's rate.  Matcher::pushBack takes pageable host pointers (viso/matcher.cpp:95-181) and so do
+ * vsm_push_back / vsm_sequence_run(on_device = 0): pageable memory is gathered into a pinned buffer by the host pool before it
+ * can cross PCIe by DMA.  A caller whose images live in a buffer it reuses can page-lock that buffer ONCE
+ * (vsm_host_register = hipHostRegister; or allocate it with hipHostMalloc) and promise so with
+ * vsm_set_option(handle, "seq_host_pinned", 1): vsm_sequence_run then copies straight out of the caller's memory.  The promise is
+ * the caller's: with the option set and pageable images the copies fall back to the runtime's staged path (slow, still correct).
+ * Unregister before the buffer is freed.  (No counterpart in the reference.) */
+int vsm_host_register(const void *p, uint64_t bytes);
+int vsm_host_unregister(const void *p);
 
 /* ---- stage-level views for parity tests (the reference's private members) ---- */
 

@@ -388,6 +388,7 @@ struct VsmSwitches {
   int seq_export_budget = 2; // ... pieces of the early export submitted behind a chunk's keys where the next chunk's keys follow at once (sequence_run_v2: export_some)
   int seq_null_stream = 1;   // ... its fifth stream (early exports, the device's vertex sorts) is the process's null stream (1) or a non-blocking stream of
                              // the library's own (0: for applications that keep work of their own on the null stream - INTEGRATION.md)
+  int seq_host_pinned = 0;   // ... host-resident input images are in page-locked memory (the caller's promise): DMA straight out of them, no gather pass
   int fused_features = 1;    // filters + suppression of the matching resolution out of one LDS tile (k_feat_dense / k_feat_sparse; default radii) or the separate kernels (0)
   int feat_order = 1;        // feature records + bin-sorted copy by k_feat_scan / k_feat_order (tiles of whole search bins) or by k_scan_cells / k_emit / k_bin_* (0)
   int filter_planes = 0;     // vsm_push_back keeps f1 / f2 in HBM for vsm_get_filter_responses (the fused tiles write them on the side)
@@ -422,6 +423,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "seq_last_first")) seq_last_first = v != 0;
     else if (!strcmp(name, "seq_ties1_null")) seq_ties1_null = v != 0;
     else if (!strcmp(name, "seq_null_stream")) seq_null_stream = v != 0;
+    else if (!strcmp(name, "seq_host_pinned")) seq_host_pinned = v != 0;
     else if (!strcmp(name, "fused_features")) fused_features = v != 0;
     else if (!strcmp(name, "filter_planes")) filter_planes = v != 0;
     else if (!strcmp(name, "feat_order")) feat_order = v != 0;
@@ -1884,6 +1886,20 @@ int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out,
 void vsm_sequence_get_timings(vsm_handle *h, double *out4) { memcpy(out4, h->seq_timings, sizeof(h->seq_timings)); }
 int32_t vsm_sequence_path(vsm_handle *h) { return h->seq_v2_frames > 0 ? 2 : 1; }
 int32_t vsm_local_cpus(int32_t *out, int32_t cap) { return vsm_affinity_cpus(out, out ? cap : 0); }
+
+int vsm_host_register(const void *p, uint64_t bytes) {
+  if (!p || bytes == 0) return VSM_EARG;
+  const hipError_t e = hipHostRegister(const_cast<void *>(p), (size_t)bytes, hipHostRegisterDefault);
+  if (e == hipSuccess) return VSM_OK;
+  (void)hipGetLastError();
+  return e == hipErrorHostMemoryAlreadyRegistered ? VSM_OK : VSM_EHIP;
+}
+int vsm_host_unregister(const void *p) {
+  if (!p) return VSM_EARG;
+  const hipError_t e = hipHostUnregister(const_cast<void *>(p));
+  if (e != hipSuccess) (void)hipGetLastError();
+  return e == hipSuccess ? VSM_OK : VSM_EHIP;
+}
 int vsm_set_option(vsm_handle *h, const char *name, int32_t value) { return (h && name && h->sw.set(name, value)) ? VSM_OK : VSM_EARG; }
 
 // ---- stage-level views ----

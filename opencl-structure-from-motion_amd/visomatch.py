@@ -35,7 +35,7 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
            "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
            "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_host_outliers_and_prior", "vsm_debug_dc2", "vsm_debug_dc2_band_factor", "vsm_local_cpus", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
-           "vsm_sequence_get_timings", "vsm_sequence_path", "vsm_set_option", "vsm_version",
+           "vsm_sequence_get_timings", "vsm_sequence_path", "vsm_set_option", "vsm_version", "vsm_host_register", "vsm_host_unregister",
            "vsm_multi_create", "vsm_multi_destroy", "vsm_multi_process", "vsm_multi_num_sequences", "vsm_multi_get_motion",
            "vsm_multi_motion_valid", "vsm_multi_num_matches", "vsm_multi_get_matches", "vsm_multi_num_inliers", "vsm_multi_get_inliers",
            "vsm_multi_get_timings",
@@ -68,6 +68,17 @@ class VsmVoMonoParams(C.Structure):
                 ("bucket_height", C.c_double), ("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double),
                 ("height", C.c_double), ("pitch", C.c_double), ("ransac_iters", C.c_int32),
                 ("inlier_threshold", C.c_double), ("motion_threshold", C.c_double)]
+
+
+def host_register(arr):
+    """page-lock a (contiguous) numpy array for DMA (vsm_host_register = hipHostRegister); True on success.  Pair with
+    Matcher.set_option("seq_host_pinned", 1) and host_unregister(arr) before the array is freed."""
+    assert arr.flags["C_CONTIGUOUS"]
+    return lib().vsm_host_register(arr.ctypes.data_as(C.c_void_p), arr.nbytes) == 0
+
+
+def host_unregister(arr):
+    return lib().vsm_host_unregister(arr.ctypes.data_as(C.c_void_p)) == 0
 
 
 class VisoMatchError(RuntimeError):
@@ -141,6 +152,8 @@ def lib():
         L.vsm_sequence_get_timings.argtypes = [vp, vp]
         L.vsm_sequence_path.argtypes = [vp]
         L.vsm_set_option.argtypes = [vp, C.c_char_p, i32]
+        L.vsm_host_register.argtypes = [vp, C.c_uint64]
+        L.vsm_host_unregister.argtypes = [vp]
         L.vsm_multi_create.restype = vp
         L.vsm_multi_create.argtypes = [C.POINTER(VsmVoStereoParams), i32]
         L.vsm_multi_destroy.argtypes = [vp]

@@ -330,6 +330,37 @@ def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     m.close()
 
 
+@pytest.mark.parametrize("pinned", [0, 1])
+def test_lookahead_host_inputs_short_last_chunk_and_page_locked_memory(vm, synth, monkeypatch, pinned):
+    """vsm_sequence_run fed from host memory (what Matcher::pushBack takes, viso/matcher.cpp:95-181): chunks of 25 + 50 + 25 + a
+    short last one of 20 frames (the call's end waits for what follows the last frames' arrival); pinned = 1: the caller has
+    page-locked its arrays (vsm_host_register) and says so (option seq_host_pinned) - the pieces leave straight from its memory,
+    row strides included.  The reference's lists either way."""
+    monkeypatch.setenv("VSM_SEQ_V2", "1")
+    g = G.load("cfg2_seq200_tr")
+    w, h, nf = int(g["w"]), int(g["h"]), 120
+    cv = synth.canvas(int(g["seed"]), w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
+    left = np.ascontiguousarray(np.stack([l for l, _ in fr]))
+    right = np.ascontiguousarray(np.stack([r for _, r in fr]))
+    m = vm.Matcher(options={"seq_chunk": 50})
+    m.set_intrinsics(*[float(x) for x in g["intr"]])
+    if pinned:
+        assert vm.host_register(left) and vm.host_register(right)
+        m.set_option("seq_host_pinned", 1)
+    try:
+        for _ in range(2):   # (the second call reuses streams, events and the upload buffer)
+            got = m.run_sequence(left, right, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
+            assert m.sequence_path() == 2
+            for f in range(nf):
+                assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), (pinned, f)
+    finally:
+        m.close()
+        if pinned:
+            vm.host_unregister(left)
+            vm.host_unregister(right)
+
+
 def test_host_threads_near_the_gpu(vm):
     """vsm_local_cpus(): the CPUs of the device's NUMA node the library keeps its own threads on - a subset of what the
     process may use, or nothing (one node, or a process already confined); the caller's thread is left alone"""
