@@ -388,6 +388,7 @@ struct VsmSwitches {
   int seq_export_budget = 2; // ... pieces of the early export submitted behind a chunk's keys where the next chunk's keys follow at once (sequence_run_v2: export_some)
   int seq_null_stream = 1;   // ... its fifth stream (early exports, the device's vertex sorts) is the process's null stream (1) or a non-blocking stream of
                              // the library's own (0: for applications that keep work of their own on the null stream - INTEGRATION.md)
+  int seq_defer_refine = 0;  // ... a chunk's refinement behind the NEXT chunk's second-pass matching where that follows at once (the chain's keys do not need it)
   int seq_host_pinned = 0;   // ... host-resident input images are in page-locked memory (the caller's promise): DMA straight out of them, no gather pass
   int fused_features = 1;    // filters + suppression of the matching resolution out of one LDS tile (k_feat_dense / k_feat_sparse; default radii) or the separate kernels (0)
   int feat_order = 1;        // feature records + bin-sorted copy by k_feat_scan / k_feat_order (tiles of whole search bins) or by k_scan_cells / k_emit / k_bin_* (0)
@@ -424,6 +425,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "seq_ties1_null")) seq_ties1_null = v != 0;
     else if (!strcmp(name, "seq_null_stream")) seq_null_stream = v != 0;
     else if (!strcmp(name, "seq_host_pinned")) seq_host_pinned = v != 0;
+    else if (!strcmp(name, "seq_defer_refine")) seq_defer_refine = v != 0;
     else if (!strcmp(name, "fused_features")) fused_features = v != 0;
     else if (!strcmp(name, "filter_planes")) filter_planes = v != 0;
     else if (!strcmp(name, "feat_order")) feat_order = v != 0;

@@ -14,12 +14,16 @@
 #include <stdio.h>
 
 #include <algorithm>
+#include <mutex>
+#include <vector>
 #include <cmath>
 
 #include "vsm_dc_gpu.h"
 #include "vsm_dc_mesh.h"
 #include "vsm_dc_lds.h"
 #include "vsm_internal.h"
+
+static const uint32_t *dc2_tiny_table();  // the tiny-partition table of the device's vertex sort on the current device (below)
 
 // ---------------------------------------------------------------------------------------
 // kd order (ExactDelaunay::kd_order, vsm_host.cpp; Triangle's alternateaxes, viso/triangle.cpp:5583):
@@ -462,16 +466,35 @@ struct TieFromKeys {
   __device__ inline uint32_t idx(int i) const { return (uint32_t)(keys[i] & 0xfffffu); }
 };
 
+// Most partitions of a sort have 3..7 keys (3500 of the 4900 of a 7.4 k list), and what the Hoare loop does to such a part
+// depends only on the two masks: the host looks the outcome up (TinyTable, vsm_host.cpp) - so does the wave now.  The table
+// (vsm_host_tiny_table: sizes 3..7, 21824 words) lies in LDS for the lists of the first pass (CAP 2048: 25 + 87 KB, one list
+// per compute unit) and, sizes 3..5 only (5.4 KB), beside the 139 KB of a second-pass list; one LDS read (uniform address)
+// and two ds_bpermute replace the rounds of mask arithmetic and lane-by-lane swaps.  MEASURED: 3.39 -> 3.21 ms for a 7.4 k
+// list (5 %), 422 -> 421 us for the first-pass lists: the Hoare emulation is not what a partition costs - its ~1400 cycles
+// are the scalar bookkeeping around it (the generator's modulo and division, readlanes with their wait states, the pending
+// parts' stack, a handful of uniform branches), all of it one dependent chain.  Kept (it is exact and tested); what would
+// help is the host's other trick, a whole sub-tree of <= 7 keys in one tight loop.
+#define TIE_TINY_WORDS 21824
+__host__ __device__ constexpr int tie_tiny_off(int n) { return ((1 << (2 * n)) - 64) / 3; }
 template <int CAP, typename Src>
-__device__ inline void tie_sort(const Src src, const int n0, int32_t *__restrict__ tie_out) {
+__device__ inline void tie_sort(const Src src, const int n0, int32_t *__restrict__ tie_out, const uint32_t *__restrict__ g_tiny = nullptr) {
+  constexpr int TMAX = CAP <= 2048 ? 6 : 5;  // part sizes the LDS copy of the table covers (size 7 alone would be another 64 KB)
+  constexpr int TWORDS = tie_tiny_off(TMAX + 1);
   __shared__ uint32_t s_k[CAP], s_i[CAP];
   __shared__ uint16_t s_L[CAP], s_R[CAP];
   __shared__ uint64_t s_ge[CAP / 64], s_le[CAP / 64];
   __shared__ uint32_t s_stack[TIE_STACK * 2];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tiny[TWORDS];
   const int lane = threadIdx.x;
   if (n0 > CAP) {
     if (lane == 0) tie_out[0] = -1;
     return;
+  }
+  const bool tiny = g_tiny != nullptr;
+  if (tiny) {
+    static_assert(TWORDS % 4 == 0, "16-byte pieces");
+    for (int i = lane * 4; i < TWORDS; i += 256) *(uint4 *)&s_tiny[i] = *(const uint4 *)&g_tiny[i];
   }
   for (int i = lane; i < n0; i += 64) {
     s_k[i] = src.kxy(i);
@@ -526,6 +549,15 @@ __device__ inline void tie_sort(const Src src, const int n0, int32_t *__restrict
         const bool in = lane >= lo && lane < lo + m;
         const uint64_t GE = __ballot(in && k >= pv) >> lo, LE = __ballot(in && k <= pv) >> lo;
         int left, right;
+        if (tiny && m <= TMAX) {
+          // the table's verdict: where every key of the part comes from, and the loop's final (left, right)
+          const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tiny[tie_tiny_off(m) + (int)((uint32_t)GE | ((uint32_t)LE << m))]);
+          const int from = in ? lo + (int)((w >> (3 * (lane - lo))) & 7u) : lane;
+          k = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)k);
+          ix = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)ix);
+          left = (int)((w >> 24) & 15u);
+          right = (int)(w >> 28) - 1;
+        } else
         tie_hoare64(GE, LE, m, left, right, [&](int l, int r) {
           const uint32_t ka = tie_readlane(k, lo + l), kb = tie_readlane(k, lo + r);
           const uint32_t ia = tie_readlane(ix, lo + l), ib = tie_readlane(ix, lo + r);
@@ -688,10 +720,10 @@ __device__ inline void tie_sort(const Src src, const int n0, int32_t *__restrict
   if (lane == 0) tie_out[0] = np > VSM_DC_TIE_PATCHES ? -1 : np;
 }
 
-__global__ void __launch_bounds__(64) k_dc_ties(const VsmDcJob *__restrict__ jobs, int njobs) {
+__global__ void __launch_bounds__(64) k_dc_ties(const VsmDcJob *__restrict__ jobs, int njobs, const uint32_t *__restrict__ tiny) {
   const VsmDcJob jb = jobs[blockIdx.x];
   if (!jb.tie_keys || !jb.tie_out) return;
-  tie_sort<VSM_DC_TIE_POINTS>(TieFromKeys{jb.tie_keys}, jb.n_in, jb.tie_out);
+  tie_sort<VSM_DC_TIE_POINTS>(TieFromKeys{jb.tie_keys}, jb.n_in, jb.tie_out, tiny);
 }
 
 // The same for the pairs of a look-ahead chunk, as soon as their compacted pass-2 lists exist (refinement does
@@ -710,14 +742,14 @@ __global__ void __launch_bounds__(256) k_dc_tie_keys(const VsmPair *__restrict__
 }
 
 __global__ void __launch_bounds__(64) k_dc_ties_of_keys(const uint64_t *__restrict__ keys, int stride, const int32_t *__restrict__ counts,
-                                                        int32_t *__restrict__ tie_out, int out_stride) {
+                                                        int32_t *__restrict__ tie_out, int out_stride, const uint32_t *__restrict__ tiny) {
   int32_t *out = tie_out + (size_t)blockIdx.x * out_stride;
   const int n = counts[blockIdx.x];
   if (n < 2 || n > stride) {
     if (threadIdx.x == 0) out[0] = n < 2 ? 0 : -1;
     return;
   }
-  tie_sort<VSM_DC_TIE_POINTS>(TieFromKeys{keys + (size_t)blockIdx.x * stride}, n, out);
+  tie_sort<VSM_DC_TIE_POINTS>(TieFromKeys{keys + (size_t)blockIdx.x * stride}, n, out, tiny);
 }
 
 // The support test of removeOutliers (viso/matcher.cpp:1266-1364; vsm_host_outliers_end is the host form):
@@ -763,7 +795,7 @@ void vsm_dc_launch_support(hipStream_t s, const VsmDcJob *d_jobs, int njobs, int
 
 void vsm_dc_launch_ties(hipStream_t s, const VsmDcJob *d_jobs, int njobs) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(k_dc_ties, dim3(njobs), dim3(64), 0, s, d_jobs, njobs);
+  hipLaunchKernelGGL(k_dc_ties, dim3(njobs), dim3(64), 0, s, d_jobs, njobs, dc2_tiny_table());
 }
 
 void vsm_dc_launch_tie_keys(hipStream_t s, const VsmPair *d_pairs, int npairs, int max_list, uint64_t *keys, int stride, int32_t *counts) {
@@ -773,7 +805,7 @@ void vsm_dc_launch_tie_keys(hipStream_t s, const VsmPair *d_pairs, int npairs, i
 void vsm_dc_launch_ties_of_keys(hipStream_t s, int npairs, const uint64_t *keys, int stride, const int32_t *counts, int32_t *tie_out,
                                 int out_stride) {
   if (npairs <= 0) return;
-  hipLaunchKernelGGL(k_dc_ties_of_keys, dim3(npairs), dim3(64), 0, s, keys, stride, counts, tie_out, out_stride);
+  hipLaunchKernelGGL(k_dc_ties_of_keys, dim3(npairs), dim3(64), 0, s, keys, stride, counts, tie_out, out_stride, dc2_tiny_table());
 }
 
 // =======================================================================================
@@ -1734,7 +1766,7 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
 // Triangle's vertex sort for the jobs of a chunk on the device (one wave each): the verdicts go to
 // tie_out + job * out_stride; lists the wave cannot take get -1 there
 template <int CAP>
-__global__ void __launch_bounds__(64) k_dc2_ties(const VsmDc2Job *__restrict__ jobs, int32_t *__restrict__ tie_out, int out_stride) {
+__global__ void __launch_bounds__(64) k_dc2_ties(const VsmDc2Job *__restrict__ jobs, int32_t *__restrict__ tie_out, int out_stride, const uint32_t *__restrict__ tiny) {
   const VsmDc2Job jb = jobs[blockIdx.x];
   // (tie_out == nullptr: a job table gathered from several chunks' slabs - every job says itself where its verdict goes)
   int32_t *out = tie_out ? tie_out + (size_t)blockIdx.x * out_stride : const_cast<int32_t *>(jb.tie_out);
@@ -1743,7 +1775,7 @@ __global__ void __launch_bounds__(64) k_dc2_ties(const VsmDc2Job *__restrict__ j
     if (threadIdx.x == 0) out[0] = n <= 3 ? 0 : -1;
     return;
   }
-  tie_sort<CAP>(TieFromKeys{jb.keys_in}, n, out);
+  tie_sort<CAP>(TieFromKeys{jb.keys_in}, n, out, tiny);
 }
 
 // which match stands for a pixel that several share: remap[index carried] = index Triangle's sort puts first
@@ -1978,14 +2010,39 @@ void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, in
     hipLaunchKernelGGL(k_dc2_merge, dim3(1 << level, njobs), dim3(DC2_MERGE_THREADS), bytes_of(), s, d_jobs, level, lines_cap, pts_cap, words_cap);
   }
 }
+int vsm_host_tiny_table(uint32_t *out, int cap);  // (vsm_host.cpp)
+// the tiny-partition table on the current device (uploaded once per device and process; nullptr = without it)
+static const uint32_t *dc2_tiny_table() {
+  static std::mutex mu;
+  static const uint32_t *tab[64] = {};
+  static bool tried[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tried[dev]) {
+    tried[dev] = true;
+    std::vector<uint32_t> h(TIE_TINY_WORDS);
+    uint32_t *d = nullptr;
+    if (vsm_host_tiny_table(h.data(), TIE_TINY_WORDS) == TIE_TINY_WORDS && hipMalloc((void **)&d, TIE_TINY_WORDS * 4) == hipSuccess) {
+      if (hipMemcpy(d, h.data(), TIE_TINY_WORDS * 4, hipMemcpyHostToDevice) == hipSuccess) {
+        tab[dev] = d;
+      } else {
+        (void)hipFree(d);
+      }
+    }
+    (void)hipGetLastError();
+  }
+  return tab[dev];
+}
 void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride, int max_list) {
   if (njobs <= 0) return;
+  const uint32_t *tiny = dc2_tiny_table();
   // (the first-pass lists are a tenth of the second-pass ones: 25 KB of LDS per list instead of 141 - a list that turns out
   // longer than the bound it was launched with reports -1 like one beyond VSM_DC_TIE_POINTS)
   if (max_list > 0 && max_list <= 2048)
-    hipLaunchKernelGGL(k_dc2_ties<2048>, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride);
+    hipLaunchKernelGGL(k_dc2_ties<2048>, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride, tiny);
   else
-    hipLaunchKernelGGL(k_dc2_ties<VSM_DC_TIE_POINTS>, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride);
+    hipLaunchKernelGGL(k_dc2_ties<VSM_DC_TIE_POINTS>, dim3(njobs), dim3(64), 0, s, d_jobs, tie_out, out_stride, tiny);
 }
 #define DC2_SUPPORT_LDS 12288
 // The end of a chain in ONE kernel for lists of up to DC2_SUPPORT_LDS matches (k_dc2_apply_ties + k_dc2_support_lds +

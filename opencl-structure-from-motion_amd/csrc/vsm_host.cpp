@@ -511,6 +511,7 @@ struct TinyTable {
   }
 };
 constexpr int kTinyMax = TinyTable::kMax;
+
 #if defined(__x86_64__)
 __attribute__((target("avx512f,avx512bw,avx512vl,bmi2"))) inline void tiny_partition_avx512(uint64_t *a, int32_t n, uint64_t ge_key, uint64_t lt_key,
                                                                                              const TinyTable &tab, int32_t &left, int32_t &right) {
@@ -614,6 +615,18 @@ inline int32_t prev_bit(const uint64_t *m, int32_t from) {
   return w * 64 + 63 - __builtin_clzll(x);
 }
 }  // namespace
+
+// the same table for the device's emulation (vsm_dc.hip: tie_sort): sizes 3..7 one after the other, [GE | LE << n] inside a size
+int vsm_host_tiny_table(uint32_t *out, int cap) {
+  static const TinyTable tab;
+  int at = 0;
+  for (int n = 3; n <= TinyTable::kMax; n++) {
+    if (at + (int)tab.e[n].size() > cap) return -1;
+    memcpy(out + at, tab.e[n].data(), tab.e[n].size() * sizeof(uint32_t));
+    at += (int)tab.e[n].size();
+  }
+  return at;
+}
 
 // The recursion itself is an explicit stack in the reference's depth-first order (left part first: the
 // random numbers are drawn in that order).  Two-element parts draw no number, so they are settled on the

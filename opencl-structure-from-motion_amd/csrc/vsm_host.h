@@ -26,6 +26,9 @@
 // once per DEVICE; every thread the library creates for a handle on that device (pool workers, fork-join workers, the
 // look-ahead poller) then confines itself to those CPUs, within what the process is allowed.  The caller's own threads are
 // left alone.  VSM_HOST_AFFINITY=0 switches it off.
+// Hoare-partition outcomes of parts of 3..7 keys (ExactDelaunay's TinyTable) as one array: size n starts at (4^n - 64) / 3,
+// entry [GE | LE << n] = eight 3-bit source positions, left << 24, (right + 1) << 28; returns the number of entries (21824)
+int vsm_host_tiny_table(uint32_t *out, int cap);
 void vsm_affinity_from_device(const char *pci_bus_id);  // "0000:0d:00.0" (hipDeviceGetPCIBusId); makes that device's record the calling thread's current one
 void *vsm_affinity_current();                           // the calling thread's current record (what pools created now will pin their workers by)
 void vsm_pin_this_thread(void *affinity = nullptr);     // nullptr: the calling thread's current record

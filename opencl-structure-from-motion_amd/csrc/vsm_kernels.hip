@@ -58,6 +58,29 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
   return (b & 7) * per + (b >> 3);
 }
 
+#ifdef VSM_FEAT_TIMING  // experiments (tools/build_variant.sh NAME -DVSM_FEAT_TIMING, tools/feat_timing.py): cycles per phase of every wave
+__device__ unsigned int vsm_ft_rec[5][1 << 16][10];  // [kernel][wave] start (low bits), phase lengths ...
+extern "C" int vsm_debug_feat_rec(unsigned int *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vsm_ft_rec), sizeof(vsm_ft_rec)) != hipSuccess) return -1;
+  (void)reset;
+  return 0;
+}
+#define FT_DECL unsigned long long ft_t[10]; int ft_n = 0
+#define FT_STAMP ft_t[ft_n++] = __builtin_amdgcn_s_memtime()
+#define FT_FLUSH(kern)                                                              \
+  do {                                                                              \
+    const unsigned wv = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+    if ((threadIdx.x & 63) == 0 && wv < (1u << 16)) {                               \
+      vsm_ft_rec[kern][wv][0] = (unsigned)ft_t[0] | 1u;                             \
+      for (int q = 1; q < ft_n; q++) vsm_ft_rec[kern][wv][q] = (unsigned)(ft_t[q] - ft_t[q - 1]); \
+    }                                                                               \
+  } while (0)
+#else
+#define FT_DECL
+#define FT_STAMP
+#define FT_FLUSH(base)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // ingest: caller image (row stride src_bpl) -> padded HBM copy [h][bpl], pad bytes = 0
 // (Matcher::pushBack row copy, viso/matcher.cpp:163-175, with the pad pinned to 0)
@@ -280,25 +303,46 @@ __global__ void __launch_bounds__(256)
     }
     return v;
   };
+  FT_DECL;
+  FT_STAMP;
   constexpr int kItems = (FRONT_LW / 4 + 3) / 4;  // per row
-  for (int e = t; e < FRONT_LH * kItems; e += 256) {
-    const int r = e / kItems, g = e - r * kItems;
+  constexpr int kIters = (FRONT_LH * kItems + 255) / 256;
+  // (all of a thread's wide loads are requested before the first LDS store waits for one: three round trips become one)
+  uint4 q[kIters];
+  uint32_t q4[kIters];
+#pragma unroll
+  for (int i = 0; i < kIters; i++) {
+    const int e = t + 256 * i, r = e / kItems, g = e - r * kItems;
+    const int y = y0 - 2 + r, x = x0 - 4 + 16 * g;
+    const int nd = min(4, FRONT_LW / 4 - 4 * g);
+    q[i] = make_uint4(0u, 0u, 0u, 0u);
+    q4[i] = 0u;
+    if (e < FRONT_LH * kItems && nd == 4 && y >= 0 && y < h && x >= 0 && x + 20 <= w) {
+      const uintptr_t a = (uintptr_t)(src + (size_t)y * src_bpl + x);
+      const uint32_t sh = (uint32_t)(a & 3);
+      q[i] = ldg_u4((const void *)(a - sh));
+      q4[i] = ldg_u32((const void *)(a - sh + 16));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kIters; i++) {
+    const int e = t + 256 * i, r = e / kItems, g = e - r * kItems;
+    if (e >= FRONT_LH * kItems) continue;
     const int y = y0 - 2 + r, x = x0 - 4 + 16 * g;
     const int nd = min(4, FRONT_LW / 4 - 4 * g);
     if (nd == 4 && y >= 0 && y < h && x >= 0 && x + 20 <= w) {
-      const uintptr_t a = (uintptr_t)(src + (size_t)y * src_bpl + x);
-      const uint32_t sh = (uint32_t)(a & 3);
-      const uint4 q = ldg_u4((const void *)(a - sh));
-      const uint32_t q4 = ldg_u32((const void *)(a - sh + 16));
-      s_in[r][4 * g] = __builtin_amdgcn_alignbyte(q.y, q.x, sh);
-      s_in[r][4 * g + 1] = __builtin_amdgcn_alignbyte(q.z, q.y, sh);
-      s_in[r][4 * g + 2] = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
-      s_in[r][4 * g + 3] = __builtin_amdgcn_alignbyte(q4, q.w, sh);
+      const uint32_t sh = (uint32_t)((uintptr_t)(src + (size_t)y * src_bpl + x) & 3);
+      s_in[r][4 * g] = __builtin_amdgcn_alignbyte(q[i].y, q[i].x, sh);
+      s_in[r][4 * g + 1] = __builtin_amdgcn_alignbyte(q[i].z, q[i].y, sh);
+      s_in[r][4 * g + 2] = __builtin_amdgcn_alignbyte(q[i].w, q[i].z, sh);
+      s_in[r][4 * g + 3] = __builtin_amdgcn_alignbyte(q4[i], q[i].w, sh);
     } else {
       for (int k = 0; k < nd; k++) s_in[r][4 * g + k] = load_dword(y, x + 4 * k);
     }
   }
+  FT_STAMP;
   __syncthreads();
+  FT_STAMP;
   // ---- padded copy (pad bytes 0), where asked for ----
   if (write_img) {
     for (int e = t; e < FRONT_TH * (FRONT_TW / 4); e += 256) {
@@ -326,6 +370,7 @@ __global__ void __launch_bounds__(256)
       *(VSM_AS1 uint32_t *)(im.imgm + (size_t)my * d.mbpl + mx4) = out;
     }
   }
+  FT_STAMP;
   // ---- full-resolution Sobel: an 8 x 4 patch per thread from a window of 8 rows x 16 bytes, two pixels per instruction in
   // 16-bit lanes (vsm_feat.h: the same column / row passes as the matching-resolution tiles); a patch row = du 0-3, dv 0-3,
   // du 4-7, dv 4-7 = one 16-byte row of the tiled plane ----
@@ -356,6 +401,8 @@ __global__ void __launch_bounds__(256)
     o.w = dv[1];
     *(VSM_AS1 vsm_u4 *)(im.duv_tiled + vsm_tiled_at(bpl, x8, y)) = o;
   }
+  FT_STAMP;
+  FT_FLUSH(4);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -726,28 +773,6 @@ __global__ void __launch_bounds__(256)
 // XCD-aware placement: neighbouring tiles (which share halo lines) follow each other on one XCD's L2.
 // ---------------------------------------------------------------------------------------
 
-#ifdef VSM_FEAT_TIMING  // experiments (tools/build_variant.sh NAME -DVSM_FEAT_TIMING, tools/feat_timing.py): cycles per phase of every wave
-__device__ unsigned int vsm_ft_rec[4][1 << 16][10];  // [kernel][wave] start (low bits), phase lengths ...
-extern "C" int vsm_debug_feat_rec(unsigned int *out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vsm_ft_rec), sizeof(vsm_ft_rec)) != hipSuccess) return -1;
-  (void)reset;
-  return 0;
-}
-#define FT_DECL unsigned long long ft_t[10]; int ft_n = 0
-#define FT_STAMP ft_t[ft_n++] = __builtin_amdgcn_s_memtime()
-#define FT_FLUSH(kern)                                                              \
-  do {                                                                              \
-    const unsigned wv = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); \
-    if ((threadIdx.x & 63) == 0 && wv < (1u << 16)) {                               \
-      vsm_ft_rec[kern][wv][0] = (unsigned)ft_t[0] | 1u;                             \
-      for (int q = 1; q < ft_n; q++) vsm_ft_rec[kern][wv][q] = (unsigned)(ft_t[q] - ft_t[q - 1]); \
-    }                                                                               \
-  } while (0)
-#else
-#define FT_DECL
-#define FT_STAMP
-#define FT_FLUSH(base)
-#endif
 
 template <bool DUMP>
 __global__ void __launch_bounds__(256)

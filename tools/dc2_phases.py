@@ -16,9 +16,9 @@ copies = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 lst = make_list(n)
 L = ctypes.CDLL(os.environ["VSM_LIB_PATH"])
 buf = (ctypes.c_ulonglong * 256)()
-vm.remove_outliers(lst, 2, 1242, 375, gpu=True, gpu_ties=True, copies=copies)
+vm.remove_outliers(lst, 2, 1242, 375, gpu=True, gpu_ties=(n <= 8192), copies=copies)
 L.vsm_debug_dc2_phases(buf, 1)
-vm.remove_outliers(lst, 2, 1242, 375, gpu=True, gpu_ties=True, copies=copies)
+vm.remove_outliers(lst, 2, 1242, 375, gpu=True, gpu_ties=(n <= 8192), copies=copies)
 L.vsm_debug_dc2_phases(buf, 1)
 a = np.array(buf[:], dtype=np.float64).reshape(16, 16)
 MHZ = 100.0  # clock64() ticks per microsecond (s_memtime: constant 100 MHz on gfx9)

@@ -22,12 +22,13 @@ trv = np.ascontiguousarray(g["s1234_tr_valid"][:nf].astype(np.uint8))
 m = vm.Matcher(options={"seq_serial": 1} if "serial" in sys.argv else None)
 m.set_intrinsics(*[float(x) for x in g["intr"]])
 Lb = ctypes.CDLL(os.environ["VSM_LIB_PATH"])
-rec = np.zeros((4, 1 << 16, 10), dtype=np.uint32)
+rec = np.zeros((5, 1 << 16, 10), dtype=np.uint32)
 m.run_sequence(frames[:, 0], frames[:, 1], 2, tr12, trv, fetch=False)
 m.run_sequence(frames[:, 0], frames[:, 1], 2, tr12, trv, fetch=False)
 torch.cuda.synchronize()
 Lb.vsm_debug_feat_rec(rec.ctypes.data_as(ctypes.c_void_p), 0)
-for k, name, ph in ((0, "k_feat_dense", ["fill", "barrier", "patches", "barrier", "suppression"]),
+for k, name, ph in ((4, "k_front", ["fill", "barrier", "copy + half image", "Sobel + stores"]),
+                    (0, "k_feat_dense", ["fill", "barrier", "patches", "barrier", "suppression"]),
                     (1, "k_feat_sparse", ["fill", "barrier", "patches", "barrier", "suppression f1", "f2 -> LDS", "suppression f2"]),
                     (3, "k_feat_scan", ["zero + barrier", "cells + histogram", "scan", "offsets + bin sums", "scan", "bin starts"]),
                     (2, "k_feat_order", ["requests", "barriers", "lists 0", "barrier + records 0 + barriers", "lists 1", "barrier + records 1"])):

@@ -1,0 +1,29 @@
+"""per-chunk timeline (VSM_DEBUG_TIMING) of the look-ahead call fed from host memory: python tools/hostfed_timeline.py [pinned]"""
+import importlib, os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["VSM_DEBUG_TIMING"] = "1"
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
+vm = importlib.import_module("opencl-structure-from-motion_amd.visomatch")
+synth = importlib.import_module("opencl-structure-from-motion_amd.synth")
+W, H, nf = 1242, 375, 200
+cv = synth.canvas(1234, W, H)
+fr = [synth.stereo_frame(cv, f, W, H) for f in range(nf)]
+hl = np.ascontiguousarray(np.stack([l for l, _ in fr]))
+hr = np.ascontiguousarray(np.stack([r for _, r in fr]))
+g = np.load(os.path.join(ROOT, "tests", "golden", "cfg4_seq200_tr_8seeds.npz"))
+tr12 = np.ascontiguousarray(g["s1234_tr_in"][:nf].reshape(nf, 16)[:, :12])
+trv = np.ascontiguousarray(g["s1234_tr_valid"][:nf].astype(np.uint8))
+torch.zeros(1).cuda()
+m = vm.Matcher()
+m.set_intrinsics(*[float(x) for x in g["intr"]])
+if "pinned" in sys.argv:
+    assert vm.host_register(hl) and vm.host_register(hr)
+    m.set_option("seq_host_pinned", 1)
+for i in range(8):
+    sys.stderr.write("RUN %d\n" % i)
+    t0 = time.perf_counter()
+    m.run_sequence(hl, hr, 2, tr12, trv, fetch=False)
+    sys.stderr.write("TOOK %.2f ms\n" % ((time.perf_counter() - t0) * 1e3))
