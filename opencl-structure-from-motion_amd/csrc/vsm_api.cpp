@@ -329,6 +329,7 @@ struct DcBank {
     *this = DcBank();
   }
   bool reserve(int pairs, int pts, int tasks) {
+    pts = (pts + 1) & ~1;  // (the long-list y order views two adjacent scratch arrays as 64-bit items)
     if (pairs <= npairs && pts <= stride_pts && tasks <= stride_tasks) return true;
     release();
     npairs = pairs;

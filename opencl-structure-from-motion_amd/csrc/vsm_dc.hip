@@ -134,6 +134,160 @@ __device__ inline void kd_levels(T *X0, T *X1, T *Y0, T *Y1, T *PX, T *PY, uint3
   for (int32_t q = t; q < m; q += KD_THREADS) key_out[q] = ks[X[q]];
 }
 
+// ---------------------------------------------------------------------------------------
+// The same levels for lists beyond the LDS forms (config 5: 20-40 k distinct points), lists in global memory.  kd_levels above
+// gives a thread a contiguous run of positions: its loads are a cache line per lane, every position's node is recomputed from
+// the root at every level, the flags go through a global array twice - 93 us per level, 1.4 ms of the 2 ms a 34 k list took.
+// Here thread t owns positions t, t + 1024, ...: coalesced reads of the list, the node (offset, size) of each of its positions
+// lives in a register and is halved once per level, the "goes left" flags of a level are wave ballots kept in LDS (one
+// 64-bit word per wave and batch) with an exclusive prefix over the words, so the number of flags before ANY position - the
+// node's start included - is one LDS word, a popcount and an add.  Per level: one gather (the cut list's position of the
+// element), two scatters.
+// ---------------------------------------------------------------------------------------
+__device__ inline void dc2_wave_sync_early() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+#define KD_WIDE_E 64  // batches of KD_THREADS positions: m <= 65535
+__device__ inline void kd_levels_wide(uint32_t *X0, uint32_t *X1, uint32_t *Y0, uint32_t *Y1, uint32_t *PX, uint32_t *PY, uint32_t *NODE,
+                                      const int32_t m, uint32_t *lds /* 3 * KD_WIDE_E * 16 words */, uint32_t *tot,
+                                      const uint64_t *__restrict__ ks, uint64_t *__restrict__ key_out) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  constexpr int NW = KD_THREADS / 64;
+  uint64_t *s_ball = (uint64_t *)lds;           // [batch][wave]: word index = position >> 6
+  uint32_t *s_base = lds + 2 * KD_WIDE_E * NW;  // flags before the word
+  const int E = (m + KD_THREADS - 1) / KD_THREADS;
+  // NODE[q] = offset | size << 16 of the node position q belongs to at the current depth (coalesced, a register's worth per
+  // position and level; 64 of them in registers spilled)
+  for (int32_t q = t; q < m; q += KD_THREADS) NODE[q] = (uint32_t)m << 16;
+  uint32_t *X = X0, *Xn = X1, *Y = Y0, *Yn = Y1;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  auto flags_before = [&](int32_t q) -> uint32_t {  // "goes left" flags of this level at positions < q
+    const int w = q >> 6, l = q & 63;
+    return s_base[w] + (uint32_t)__popcll(s_ball[w] & (l == 0 ? 0ull : (~0ull >> (64 - l))));
+  };
+  __syncthreads();
+  for (int depth = 0; ((m + (1 << depth) - 1) >> depth) > 3; depth++) {
+    const bool cut_x = (depth & 1) == 0;
+    const uint32_t *S = cut_x ? Y : X;     // the list to partition
+    uint32_t *D = cut_x ? Yn : Xn;
+    const uint32_t *PO = cut_x ? PX : PY;  // position in the list that is cut in place
+    uint32_t *PS = cut_x ? PY : PX;
+    uint64_t fl = 0;
+    for (int i = 0; i < E; i++) {
+      const int32_t q = i * KD_THREADS + t;
+      bool left = false;
+      if (q < m) {
+        const uint32_t nd = NODE[q];
+        const int32_t off = (int32_t)(nd & 0xffffu), n = (int32_t)(nd >> 16);
+        left = n <= 3 || (int32_t)PO[S[q]] < off + (n >> 1);
+      }
+      const uint64_t b = __ballot(left);
+      if (lane == 0) s_ball[i * NW + wv] = b;
+      fl |= (uint64_t)(left ? 1u : 0u) << i;
+    }
+    __syncthreads();
+    {  // exclusive prefix over the E * 16 <= 1024 words
+      const uint32_t c = t < E * NW ? (uint32_t)__popcll(s_ball[t]) : 0u;
+      const uint32_t run = kd_block_scan(c, tot);
+      if (t < E * NW) s_base[t] = run;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < E; i++) {
+      const int32_t q = i * KD_THREADS + t;
+      if (q < m) {
+        const uint32_t nd = NODE[q];
+        const int32_t off = (int32_t)(nd & 0xffffu), n = (int32_t)(nd >> 16);
+        const uint32_t before = s_base[i * NW + wv] + (uint32_t)__popcll(s_ball[i * NW + wv] & lt) - flags_before(off);
+        const uint32_t e = S[q];
+        const uint32_t np = ((fl >> i) & 1ull) ? (uint32_t)off + before : (uint32_t)off + (uint32_t)(n >> 1) + ((uint32_t)(q - off) - before);
+        D[np] = e;
+        PS[e] = np;
+        // the position's node one level down (kd_node_at's step)
+        const int32_t div = n >> 1;
+        NODE[q] = q < off + div ? ((uint32_t)off | ((uint32_t)div << 16)) : ((uint32_t)(off + div) | ((uint32_t)(n - div) << 16));
+      }
+    }
+    __syncthreads();
+    if (cut_x) {
+      uint32_t *w = Y;
+      Y = Yn;
+      Yn = w;
+    } else {
+      uint32_t *w = X;
+      X = Xn;
+      Xn = w;
+    }
+  }
+  for (int32_t q = t; q < m; q += KD_THREADS) key_out[q] = ks[X[q]];
+}
+
+// One stable LSD pass (7 bits) over n items in global memory with every thread at work: wave w takes the contiguous
+// range [w * per_wave, ...), 64 consecutive items per step (coalesced) and four steps' items requested at once, ranks a
+// step's items with seven ballots, counts per (digit, wave) in LDS; one exclusive scan in (digit, wave) order gives every
+// wave its start per digit.  load(i) -> the item, digit_of(item) -> 0..127, store(dst, item).  hist: 128 * 16 words.
+template <typename T, typename Load, typename Digit, typename Store>
+__device__ inline void kd_radix_pass_wide(const int32_t n, uint32_t *hist, uint32_t *tot, Load load, Digit digit_of, Store store) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  constexpr int NW = KD_THREADS / 64, B = 4;
+  const int32_t per_wave = ((n + NW * 64 - 1) / (NW * 64)) * 64;
+  const int32_t w0 = min(n, wv * per_wave), w1 = min(n, w0 + per_wave);
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  hist[2 * t] = 0;
+  hist[2 * t + 1] = 0;
+  __syncthreads();
+  auto same_digit = [&](uint32_t d, bool valid) -> uint64_t {
+    uint64_t same = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 7; bit++) {
+      const bool on = valid && ((d >> bit) & 1u);
+      const uint64_t bal = __ballot(on);
+      same &= ((d >> bit) & 1u) ? bal : ~bal;
+    }
+    return same;
+  };
+  for (int32_t base = w0; base < w1; base += 64 * B) {
+    T v[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) v[k] = base + 64 * k + lane < w1 ? load(base + 64 * k + lane) : T(0);
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      const bool valid = base + 64 * k + lane < w1;
+      const uint32_t d = valid ? digit_of(v[k]) : 0u;
+      const uint64_t same = same_digit(d, valid);
+      if (valid && (same & lt) == 0) hist[d * NW + wv] += (uint32_t)__popcll(same);  // (the digit's first lane; a wave's LDS operations keep their order)
+      dc2_wave_sync_early();
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t v0 = hist[2 * t], v1 = hist[2 * t + 1];
+    const uint32_t run = kd_block_scan(v0 + v1, tot);
+    hist[2 * t] = run;
+    hist[2 * t + 1] = run + v0;
+  }
+  __syncthreads();
+  for (int32_t base = w0; base < w1; base += 64 * B) {
+    T v[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) v[k] = base + 64 * k + lane < w1 ? load(base + 64 * k + lane) : T(0);
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      const bool valid = base + 64 * k + lane < w1;
+      const uint32_t d = valid ? digit_of(v[k]) : 0u;
+      const uint64_t same = same_digit(d, valid);
+      const uint32_t before = (uint32_t)__popcll(same & lt);
+      const uint32_t prior = valid ? hist[d * NW + wv] : 0u;
+      dc2_wave_sync_early();
+      if (valid && before == 0) hist[d * NW + wv] = prior + (uint32_t)__popcll(same);
+      dc2_wave_sync_early();
+      if (valid) store((int32_t)(prior + before), v[k]);
+    }
+  }
+  __syncthreads();
+}
+
 #define KD_LDS_POINTS 8192  // 6 uint16 lists + the uint32 scan fit where the histogram was
 
 // the whole kd order of one triangulation by one workgroup of KD_THREADS threads: ks = distinct keys in (x,y) order,
@@ -149,6 +303,15 @@ __device__ inline void kd_order_body(const uint64_t *__restrict__ ks, const int3
   // KD_CHUNKS owns a contiguous chunk and its own column of the histogram, so no atomics and the order
   // inside a digit is the order of the source ----
   const int32_t chunk = (m + KD_CHUNKS - 1) / KD_CHUNKS;
+  if (m > KD_LDS_POINTS) {  // long lists: every thread at work, coalesced reads (kd_radix_pass_wide)
+    // (an item = y << 32 | rank, so the rank's key is looked up once; the items of the first pass lie over PX + PY,
+    // adjacent and free until the levels start)
+    uint64_t *Bf = (uint64_t *)PX;
+    kd_radix_pass_wide<uint64_t>(m, hist, tot, [&](int32_t i) { return ((ks[i] >> 20) & 0x3fffull) << 32 | (uint64_t)(uint32_t)i; },
+                                 [&](uint64_t v) { return (uint32_t)(v >> 32) & (KD_DIGITS - 1); }, [&](int32_t dst, uint64_t v) { Bf[dst] = v; });
+    kd_radix_pass_wide<uint64_t>(m, hist, tot, [&](int32_t i) { return Bf[i]; }, [&](uint64_t v) { return (uint32_t)(v >> 39) & (KD_DIGITS - 1); },
+                                 [&](int32_t dst, uint64_t v) { Y0[dst] = (uint32_t)v; });
+  } else
   for (int pass = 0; pass < 2; pass++) {
     const uint32_t *src = X1;            // pass 1 reads what pass 0 wrote (X1 is free until the levels start)
     uint32_t *dst = pass == 0 ? X1 : Y0;
@@ -210,7 +373,10 @@ __device__ inline void kd_order_body(const uint64_t *__restrict__ ks, const int3
     PY[Y0[q]] = (uint32_t)q;
   }
   __syncthreads();
-  kd_levels<uint32_t>(X0, X1, Y0, Y1, PX, PY, P, m, tot, ks, key_out);
+  if (m <= 65535)
+    kd_levels_wide(X0, X1, Y0, Y1, PX, PY, P, m, hist, tot, ks, key_out);
+  else
+    kd_levels<uint32_t>(X0, X1, Y0, Y1, PX, PY, P, m, tot, ks, key_out);
 }
 
 __global__ void __launch_bounds__(KD_THREADS) k_dc_kd_order(const VsmDcJob *__restrict__ jobs, int njobs) {
@@ -903,10 +1069,21 @@ __device__ inline void dc2_prepare_global(const VsmDc2Job &jb, uint32_t *hist, u
 #endif
   if (n > 3) {  // the reference leaves lists of up to three matches alone (viso/matcher.cpp:1210)
     uint64_t *T0 = (uint64_t *)jb.kd_scratch, *T1 = T0 + jb.kd_stride;
-    dc2_radix_pass(jb.keys_in, T0, n, 20, hist, tot);
-    dc2_radix_pass(T0, T1, n, 27, hist, tot);
-    dc2_radix_pass(T1, T0, n, 34, hist, tot);
-    dc2_radix_pass(T0, T1, n, 41, hist, tot);
+    if (n > KD_LDS_POINTS) {
+      const uint64_t *src = jb.keys_in;
+      uint64_t *dst = T0;
+      for (int sh = 20; sh <= 41; sh += 7) {
+        kd_radix_pass_wide<uint64_t>(n, hist, tot, [&](int32_t i) { return src[i]; }, [&](uint64_t v) { return (uint32_t)(v >> sh) & (KD_DIGITS - 1); },
+                                     [&](int32_t at, uint64_t v) { dst[at] = v; });
+        src = dst;
+        dst = dst == T0 ? T1 : T0;
+      }  // (four passes: the result is in T1)
+    } else {
+      dc2_radix_pass(jb.keys_in, T0, n, 20, hist, tot);
+      dc2_radix_pass(T0, T1, n, 27, hist, tot);
+      dc2_radix_pass(T1, T0, n, 34, hist, tot);
+      dc2_radix_pass(T0, T1, n, 41, hist, tot);
+    }
 #ifdef DC2_PHASE_TIMING
     p1 = clock64();
 #endif
@@ -937,9 +1114,11 @@ __device__ inline void dc2_prepare_global(const VsmDc2Job &jb, uint32_t *hist, u
 #endif
 }
 
-__global__ void __launch_bounds__(KD_THREADS) k_dc2_prepare(const VsmDc2Job *__restrict__ jobs) {
+// longer_than: only the lists with more matches than that (the others belong to k_dc2_prepare_lds of the same launch pair)
+__global__ void __launch_bounds__(KD_THREADS) k_dc2_prepare(const VsmDc2Job *__restrict__ jobs, int longer_than) {
   __shared__ uint32_t hist[KD_DIGITS * KD_CHUNKS];
   __shared__ uint32_t tot[KD_THREADS / 64 + 1];
+  if (*jobs[blockIdx.x].count <= longer_than) return;
   dc2_prepare_global(jobs[blockIdx.x], hist, tot);
 }
 
@@ -1063,10 +1242,10 @@ __global__ void __launch_bounds__(1024) k_dc2_prepare_lds(const VsmDc2Job *__res
   const VsmDc2Job jb = jobs[blockIdx.x];
   const int t = threadIdx.x, nwaves = (int)blockDim.x >> 6;
   const int32_t nl = *jb.count;
-  if (big_too && nl > cap2) {  // a list of a launch that may hold longer ones (the host only knows the query counts): the form above,
-    dc2_prepare_global(jb, (uint32_t *)dc2_prep_lds, tot);  // on this kernel's LDS (the launch is KD_THREADS wide and 128 KB deep then)
-    return;
-  }
+  // a list of a launch that may hold longer ones (the host only knows the query counts) is left to k_dc2_prepare, launched
+  // right behind this kernel for exactly those lists (inlined here, the long lists' code cost the short ones their registers:
+  // 74 -> 120 VGPRs, one workgroup per compute unit instead of two)
+  if (big_too && nl > cap2) return;
   int32_t n = min(nl, jb.cap), m = 0;
   if (nl > jb.cap || nl > cap2) {  // (not expected: the host sizes slabs and launches from the query counts)
     if (t == 0) *jb.error = 1;
@@ -1963,6 +2142,7 @@ void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, i
     static_assert(DC2_PREP_LDS / 8 == KD_THREADS && 16 * DC2_PREP_LDS >= 4 * KD_DIGITS * KD_CHUNKS, "the long lists of a launch run k_dc2_prepare's body on this kernel's threads and LDS");
     if (cap2 == DC2_PREP_LDS && big8) {  // (max_list counts queries: most lists of such a launch are shorter than 8192 matches, whoever is not takes the first form)
       hipLaunchKernelGGL(k_dc2_prepare_lds<8>, dim3(njobs), dim3(cap2 / 8), (size_t)16 * cap2, s, d_jobs, cap2, max_list > cap2 ? 1 : 0);
+      if (max_list > cap2) hipLaunchKernelGGL(k_dc2_prepare, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs, cap2);
       return;
     }
     if (cap2 < DC2_PREP_LDS && (big4 || 16 * cap2 <= 64 * 1024)) {
@@ -1971,7 +2151,7 @@ void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, i
     }
   }
 #endif
-  hipLaunchKernelGGL(k_dc2_prepare, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_dc2_prepare, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs, -1);
 }
 void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth) {
   if (njobs <= 0) return;
