@@ -20,6 +20,7 @@
 #include <chrono>
 #include <memory>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "vsm_host.h"
@@ -94,8 +95,103 @@ struct VsmCtx {
   VsmJob *h_jobs = nullptr;      // pinned [npairs]
 };
 
+// ---------------------------------------------------------------------------------------
+// Large device blocks are kept, not handed back.  The driver wipes released VRAM in the background - 23 GB/s on this box,
+// 44 ms per GB - on a DMA engine the look-ahead path's own copies (keys, early export, host-fed frames) then queue behind:
+// for that long every call of the process takes 6.8-7.0 ms instead of 4.0 (tools/hipfree_probe.py; a context re-created for
+// another chunk size gave 3 GB back, a closed handle 4 GB - the "slower mode of whole processes" of rounds 3-4, and the
+// reason bench.py's later legs ran 10-30 % below the same legs in a process of their own).  So: a released block of
+// 8 MB or more waits in a process-wide cache and the next request of its size class (up to 1.5 x) takes it; beyond
+// VSM_DEVICE_POOL_MB (default 24 GB, 0 = hand everything back at once) the oldest blocks do go back to the driver.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct DevPool {
+  struct Block {
+    void *p;
+    size_t bytes;
+    int device;
+  };
+  std::mutex mu;
+  std::unordered_map<void *, Block> live;  // blocks handed out (8 MB and more only)
+  std::vector<Block> cached;               // oldest first
+  size_t cached_bytes = 0;
+  static constexpr size_t kMin = (size_t)8 << 20;
+  static size_t cap() {
+    static const size_t v = (size_t)(getenv("VSM_DEVICE_POOL_MB") ? atoll(getenv("VSM_DEVICE_POOL_MB")) : 24 * 1024) << 20;
+    return v;
+  }
+};
+DevPool &dev_pool() {
+  static DevPool *p = new DevPool();  // (never destroyed: handles may be closed from static destructors)
+  return *p;
+}
+}  // namespace
+
+hipError_t vsm_dev_alloc(void **out, size_t bytes) {
+  *out = nullptr;
+  if (bytes < DevPool::kMin || DevPool::cap() == 0) return hipMalloc(out, bytes);
+  DevPool &P = dev_pool();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    size_t best = P.cached.size();
+    for (size_t i = 0; i < P.cached.size(); i++) {
+      const DevPool::Block &b = P.cached[i];
+      if (b.device == dev && b.bytes >= bytes && b.bytes <= bytes + bytes / 2 && (best == P.cached.size() || b.bytes < P.cached[best].bytes)) best = i;
+    }
+    if (best < P.cached.size()) {
+      const DevPool::Block b = P.cached[best];
+      P.cached.erase(P.cached.begin() + (long)best);
+      P.cached_bytes -= b.bytes;
+      P.live[b.p] = b;
+      *out = b.p;
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {  // (the cache may hold what is missing)
+    (void)hipGetLastError();
+    std::vector<DevPool::Block> drop;
+    {
+      std::lock_guard<std::mutex> lk(P.mu);
+      drop.swap(P.cached);
+      P.cached_bytes = 0;
+    }
+    for (const DevPool::Block &b : drop) (void)hipFree(b.p);
+    e = hipMalloc(out, bytes);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lk(P.mu);
+  P.live[*out] = DevPool::Block{*out, bytes, dev};
+  return hipSuccess;
+}
+
+void vsm_dev_free(void *p) {
+  if (!p) return;
+  DevPool &P = dev_pool();
+  std::vector<DevPool::Block> drop;
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.live.find(p);
+    if (it == P.live.end()) {
+      drop.push_back(DevPool::Block{p, 0, 0});  // (a small block: straight back)
+    } else {
+      P.cached.push_back(it->second);
+      P.cached_bytes += it->second.bytes;
+      P.live.erase(it);
+      while (P.cached_bytes > DevPool::cap() && !P.cached.empty()) {
+        drop.push_back(P.cached.front());
+        P.cached_bytes -= P.cached.front().bytes;
+        P.cached.erase(P.cached.begin());
+      }
+    }
+  }
+  for (const DevPool::Block &b : drop) (void)hipFree(b.p);
+}
+
 static void ctx_destroy(VsmCtx &c) {
-  if (c.arena) (void)hipFree(c.arena);
+  if (c.arena) vsm_dev_free(c.arena);
   if (c.hm_block) (void)hipHostFree(c.hm_block);
   if (c.h_ranges) (void)hipHostFree(c.h_ranges);
   if (c.h_jobs) (void)hipHostFree(c.h_jobs);
@@ -202,7 +298,7 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
   const size_t o_pairs = take((size_t)npairs * sizeof(VsmPair));
   const size_t o_jobs = take((size_t)npairs * sizeof(VsmJob));
   c.arena_bytes = off;
-  HIPCHK(hipMalloc((void **)&c.arena, c.arena_bytes));
+  HIPCHK(vsm_dev_alloc((void **)&c.arena, c.arena_bytes));
   HIPCHK(hipMemsetAsync(c.arena, 0, c.arena_bytes, stream));
   // host-mapped result block: [image counts][list counts][list1, list2 per pair]
   const size_t l1 = al256((size_t)c.cap_set[0] * 48), l2 = al256(qcap * 48);
@@ -274,9 +370,21 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
   c.d_imgs = (VsmImage *)(b + o_imgs);
   c.d_pairs = (VsmPair *)(b + o_pairs);
   c.d_jobs = (VsmJob *)(b + o_jobs);
-  HIPCHK(hipMemcpyAsync(c.d_imgs, c.h_imgs.data(), (size_t)nimg * sizeof(VsmImage), hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(c.d_pairs, c.h_pairs.data(), (size_t)npairs * sizeof(VsmPair), hipMemcpyHostToDevice, stream));
-  HIPCHK(hipStreamSynchronize(stream));
+  {
+    // (the tables cross by the copy kernel out of a page-locked twin, like every other host-to-device transfer of the path: a
+    // runtime copy of more than 16 KB out of pageable memory that finds the DMA engine busy goes through a shader copy on a
+    // hardware queue the runtime creates for it and keeps - DESIGN.md section 6)
+    const size_t bi = (size_t)nimg * sizeof(VsmImage), bp = (size_t)npairs * sizeof(VsmPair);
+    uint8_t *twin = nullptr;
+    HIPCHK(hipHostMalloc((void **)&twin, al256(bi) + al256(bp), hipHostMallocDefault));
+    memcpy(twin, c.h_imgs.data(), bi);
+    memcpy(twin + al256(bi), c.h_pairs.data(), bp);
+    hipError_t e = vsm_upload(stream, c.d_imgs, twin, bi);
+    if (e == hipSuccess) e = vsm_upload(stream, c.d_pairs, twin + al256(bi), bp);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipHostFree(twin);
+    HIPCHK(e);
+  }
   c.ready = true;
   return VSM_OK;
 }
@@ -300,24 +408,24 @@ struct DcBank {
   VsmDcJob *d_jobs = nullptr, *h_jobs = nullptr;
   std::vector<int32_t> m, nt, nn;  // per pair: distinct points, tasks (nt < 0: the host solves the sub-trees), tree nodes
   void release() {
-    (void)hipFree(d_key);
-    (void)hipFree(d_key_sorted);
-    (void)hipFree(d_kd);
-    (void)hipFree(d_tie_keys);
-    (void)hipFree(d_tie_n);
-    (void)hipFree(d_flow);
-    (void)hipFree(d_support);
+    vsm_dev_free(d_key);
+    vsm_dev_free(d_key_sorted);
+    vsm_dev_free(d_kd);
+    vsm_dev_free(d_tie_keys);
+    vsm_dev_free(d_tie_n);
+    vsm_dev_free(d_flow);
+    vsm_dev_free(d_support);
     (void)hipHostFree(h_flow);
     (void)hipHostFree(h_support);
-    (void)hipFree(d_pt);
-    (void)hipFree(d_id);
-    (void)hipFree(d_tri);
-    (void)hipFree(d_trip);
+    vsm_dev_free(d_pt);
+    vsm_dev_free(d_id);
+    vsm_dev_free(d_tri);
+    vsm_dev_free(d_trip);
     (void)hipHostFree(h_trip);
-    (void)hipFree(d_tasks);
-    (void)hipFree(d_merges);
-    (void)hipFree(d_hulls);
-    (void)hipFree(d_jobs);
+    vsm_dev_free(d_tasks);
+    vsm_dev_free(d_merges);
+    vsm_dev_free(d_hulls);
+    vsm_dev_free(d_jobs);
     (void)hipHostFree(h_key);
     (void)hipHostFree(h_pt);
     (void)hipHostFree(h_id);
@@ -336,18 +444,18 @@ struct DcBank {
     stride_pts = pts;
     stride_tasks = tasks;
     const size_t P = (size_t)pairs * pts, T = (size_t)pairs * tasks;
-    bool ok = hipMalloc((void **)&d_key, P * 8) == hipSuccess && hipMalloc((void **)&d_key_sorted, P * 8) == hipSuccess &&
-              hipMalloc((void **)&d_kd, P * 4 * VSM_DC_KD_SCRATCH) == hipSuccess && hipMalloc((void **)&d_pt, P * 4) == hipSuccess &&
-              hipMalloc((void **)&d_flow, P * 12) == hipSuccess && hipMalloc((void **)&d_support, P * 4) == hipSuccess &&
-              hipMalloc((void **)&d_tie_keys, P * 8) == hipSuccess && hipMalloc((void **)&d_tie_n, (size_t)pairs * 4) == hipSuccess &&
+    bool ok = vsm_dev_alloc((void **)&d_key, P * 8) == hipSuccess && vsm_dev_alloc((void **)&d_key_sorted, P * 8) == hipSuccess &&
+              vsm_dev_alloc((void **)&d_kd, P * 4 * VSM_DC_KD_SCRATCH) == hipSuccess && vsm_dev_alloc((void **)&d_pt, P * 4) == hipSuccess &&
+              vsm_dev_alloc((void **)&d_flow, P * 12) == hipSuccess && vsm_dev_alloc((void **)&d_support, P * 4) == hipSuccess &&
+              vsm_dev_alloc((void **)&d_tie_keys, P * 8) == hipSuccess && vsm_dev_alloc((void **)&d_tie_n, (size_t)pairs * 4) == hipSuccess &&
               hipHostMalloc((void **)&h_flow, P * 12, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_support, P * 4, hipHostMallocDefault) == hipSuccess &&
-              hipMalloc((void **)&d_id, P * 4) == hipSuccess && hipMalloc((void **)&d_tri, P * 64) == hipSuccess &&
-              hipMalloc((void **)&d_trip, P * 24) == hipSuccess && hipHostMalloc((void **)&h_trip, P * 24, hipHostMallocDefault) == hipSuccess &&
-              hipMalloc((void **)&d_tasks, T * sizeof(VsmDcTask)) == hipSuccess &&
-              hipMalloc((void **)&d_merges, T * sizeof(VsmDcMerge)) == hipSuccess &&
-              hipMalloc((void **)&d_hulls, 2 * T * sizeof(VsmDcHull)) == hipSuccess &&
-              hipMalloc((void **)&d_jobs, pairs * sizeof(VsmDcJob)) == hipSuccess &&
+              vsm_dev_alloc((void **)&d_id, P * 4) == hipSuccess && vsm_dev_alloc((void **)&d_tri, P * 64) == hipSuccess &&
+              vsm_dev_alloc((void **)&d_trip, P * 24) == hipSuccess && hipHostMalloc((void **)&h_trip, P * 24, hipHostMallocDefault) == hipSuccess &&
+              vsm_dev_alloc((void **)&d_tasks, T * sizeof(VsmDcTask)) == hipSuccess &&
+              vsm_dev_alloc((void **)&d_merges, T * sizeof(VsmDcMerge)) == hipSuccess &&
+              vsm_dev_alloc((void **)&d_hulls, 2 * T * sizeof(VsmDcHull)) == hipSuccess &&
+              vsm_dev_alloc((void **)&d_jobs, pairs * sizeof(VsmDcJob)) == hipSuccess &&
               hipHostMalloc((void **)&h_key, P * 8, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_pt, P * 4, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&h_id, P * 4, hipHostMallocDefault) == hipSuccess &&
@@ -389,6 +497,7 @@ struct VsmSwitches {
   int seq_export_budget = 2; // ... pieces of the early export submitted behind a chunk's keys where the next chunk's keys follow at once (sequence_run_v2: export_some)
   int seq_null_stream = 1;   // ... its fifth stream (early exports, the device's vertex sorts) is the process's null stream (1) or a non-blocking stream of
                              // the library's own (0: for applications that keep work of their own on the null stream - INTEGRATION.md)
+  int seq_host_inorder = 1;  // ... host-resident inputs: chunk by chunk in the order of arrival - the caller's thread waits for a chunk's feature counts only when everything of the chunk in front is enqueued (0: the run-ahead order of HBM-resident inputs)
   int seq_defer_refine = 0;  // ... a chunk's refinement behind the NEXT chunk's second-pass matching where that follows at once (the chain's keys do not need it)
   int seq_host_pinned = 0;   // ... host-resident input images are in page-locked memory (the caller's promise): DMA straight out of them, no gather pass
   int fused_features = 1;    // filters + suppression of the matching resolution out of one LDS tile (k_feat_dense / k_feat_sparse; default radii) or the separate kernels (0)
@@ -427,6 +536,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "seq_null_stream")) seq_null_stream = v != 0;
     else if (!strcmp(name, "seq_host_pinned")) seq_host_pinned = v != 0;
     else if (!strcmp(name, "seq_defer_refine")) seq_defer_refine = v != 0;
+    else if (!strcmp(name, "seq_host_inorder")) seq_host_inorder = v != 0;
     else if (!strcmp(name, "fused_features")) fused_features = v != 0;
     else if (!strcmp(name, "filter_planes")) filter_planes = v != 0;
     else if (!strcmp(name, "feat_order")) feat_order = v != 0;
@@ -607,7 +717,7 @@ void vsm_destroy(vsm_handle *h) {
   if (h->stage_host) (void)hipHostFree(h->stage_host);
   for (int k = 0; k < 2; k++) {
     if (h->seq_stage_h[k]) (void)hipHostFree(h->seq_stage_h[k]);
-    if (h->seq_stage_d[k]) (void)hipFree(h->seq_stage_d[k]);
+    if (h->seq_stage_d[k]) vsm_dev_free(h->seq_stage_d[k]);
     if (h->seq_stage_ev[k]) (void)hipEventDestroy(h->seq_stage_ev[k]);
   }
   for (int b = 0; b < vsm_handle::kDcBanks; b++)
@@ -1312,10 +1422,10 @@ static int seq_ingest_host_frames(vsm_handle *h, VsmCtx &c, int first_img, const
     (void)hipStreamSynchronize(h->stream);
     for (int k = 0; k < 2; k++) {
       if (h->seq_stage_h[k]) (void)hipHostFree(h->seq_stage_h[k]);
-      if (h->seq_stage_d[k]) (void)hipFree(h->seq_stage_d[k]);
+      if (h->seq_stage_d[k]) vsm_dev_free(h->seq_stage_d[k]);
       h->seq_stage_h[k] = h->seq_stage_d[k] = nullptr;
       HIPCHK(hipHostMalloc((void **)&h->seq_stage_h[k], need, hipHostMallocDefault));
-      HIPCHK(hipMalloc((void **)&h->seq_stage_d[k], need));
+      HIPCHK(vsm_dev_alloc((void **)&h->seq_stage_d[k], need));
       if (!h->seq_stage_ev[k]) HIPCHK(hipEventCreateWithFlags(&h->seq_stage_ev[k], hipEventDisableTiming));
       HIPCHK(hipEventRecord(h->seq_stage_ev[k], h->stream));
     }

@@ -158,6 +158,10 @@ struct VsmProf {
 // ---- launchers (vsm_kernels.hip) ----
 // small table in pinned (hipHostMalloc) memory -> HBM by a kernel on stream s (see k_upload)
 hipError_t vsm_upload(hipStream_t s, void *dst_device, const void *src_pinned, size_t bytes);
+// Device memory of the library's large blocks (vsm_api.cpp): a released block of 8 MB or more goes to a process-wide cache
+// instead of back to the driver, and the next request of about its size takes it from there.
+hipError_t vsm_dev_alloc(void **p, size_t bytes);
+void vsm_dev_free(void *p);
 void vsm_launch_ingest(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, const uint8_t *src0,
                        const uint8_t *src1, size_t frame_stride, int32_t src_bpl, int n_frames, const VsmDims &d);
 // fused: bit 0 = the fused filter + suppression tiles where the radii allow, bit 1 = they also write f1 / f2 (debug getter),

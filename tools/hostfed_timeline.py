@@ -4,7 +4,10 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["VSM_DEBUG_TIMING"] = "1"
+if "quiet" not in sys.argv:
+    os.environ["VSM_DEBUG_TIMING"] = "1"
+if "asbench" in sys.argv:  # (bench.py's process set-up: CPUs of the GPU's NUMA node, its host thread count, its queue cap)
+    import bench  # noqa: F401
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
 vm = importlib.import_module("opencl-structure-from-motion_amd.visomatch")
 synth = importlib.import_module("opencl-structure-from-motion_amd.synth")
@@ -19,6 +22,22 @@ trv = np.ascontiguousarray(g["s1234_tr_valid"][:nf].astype(np.uint8))
 torch.zeros(1).cuda()
 m = vm.Matcher()
 m.set_intrinsics(*[float(x) for x in g["intr"]])
+if "resident_first" in sys.argv:  # (as in bench.py: the handle has run the call from HBM before)
+    dl, dr = torch.from_numpy(hl).cuda(), torch.from_numpy(hr).cuda()
+    if "resident80" in sys.argv:
+        m.set_option("seq_chunk", 80)
+    for i in range(3):
+        m.run_sequence(dl, dr, 2, tr12, trv, fetch=False)
+    if "resident80" in sys.argv:
+        m.set_option("seq_chunk", 0)
+    if "free_resident" in sys.argv:
+        del dl, dr
+        torch.cuda.empty_cache()
+if "perframe_first" in sys.argv:
+    dl, dr = torch.from_numpy(hl).cuda(), torch.from_numpy(hr).cuda()
+    for f in range(20):
+        m.push_back(dl[f], dr[f])
+        m.match_features(2, None)
 if "pinned" in sys.argv:
     assert vm.host_register(hl) and vm.host_register(hr)
     m.set_option("seq_host_pinned", 1)
