@@ -437,7 +437,8 @@ def main():
     pmc, pmc_src = {}, None
     try:
         import csv
-        pmc_path = os.path.join(ROOT, "profiles", "r04_lookahead_pmc_hbm.csv")
+        import glob
+        pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_lookahead_pmc_hbm.csv")))[-1]  # (the latest round's)
         lib_path = os.path.join(ROOT, PKG, "libvisomatch.so")
         meta = {}
         for line in open(pmc_path):
@@ -448,15 +449,14 @@ def main():
         for r in rows:
             pmc[r["bench_name"]] = int(float(r["traffic_bytes_per_launch"]))
         # (taken from the same kernel sources as the library that runs now?  file times say nothing after a checkout)
-        import glob
         csrc = os.path.join(ROOT, PKG, "csrc")
         hsh = hashlib.sha256()
         for pat in ("*.hip", "*.h", "*.inc", "*.cpp"):
             for fn in sorted(glob.glob(os.path.join(csrc, pat))):
                 hsh.update(open(fn, "rb").read())
-        pmc_src = {"file": "profiles/r04_lookahead_pmc_hbm.csv", "commit": meta.get("commit"), "taken": meta.get("taken"),
+        pmc_src = {"file": "profiles/" + os.path.basename(pmc_path), "commit": meta.get("commit"), "taken": meta.get("taken"),
                    "same_kernel_sources": (meta.get("sources", "").split(" ")[0] == hsh.hexdigest()[:16]) if meta.get("sources") else None}
-    except FileNotFoundError:
+    except (FileNotFoundError, IndexError):
         pmc_src = {"file": None, "note": "no committed PMC summary"}
     except Exception as e:
         pmc_src = {"file": None, "note": repr(e)}

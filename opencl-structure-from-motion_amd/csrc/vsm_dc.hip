@@ -293,6 +293,10 @@ __device__ inline void kd_radix_pass_wide(const int32_t n, uint32_t *hist, uint3
 // the whole kd order of one triangulation by one workgroup of KD_THREADS threads: ks = distinct keys in (x,y) order,
 // scratch = VSM_DC_KD_SCRATCH arrays of `stride` uint32, hist / tot = the workgroup's LDS (KD_DIGITS * KD_CHUNKS and
 // KD_THREADS / 64 + 1 words); key_out gets the keys in kd order
+// WIDE 1: lists beyond KD_LDS_POINTS with every thread at work (kd_radix_pass_wide, kd_levels_wide); 2: every list that way,
+// whatever its length - 12 KB of LDS instead of the 128 KB the other forms keep their histogram columns and 16-bit lists in
+// (k_dc2_prepare_long); 0: the narrow forms only, which cost the kernel they are inlined in no registers
+template <int WIDE>
 __device__ inline void kd_order_body(const uint64_t *__restrict__ ks, const int32_t m, uint32_t *scratch, const int32_t stride,
                                      uint64_t *__restrict__ key_out, uint32_t *hist, uint32_t *tot, long long *stamp = nullptr) {
   uint32_t *X0 = scratch, *X1 = X0 + stride, *Y0 = X1 + stride, *Y1 = Y0 + stride;
@@ -303,7 +307,7 @@ __device__ inline void kd_order_body(const uint64_t *__restrict__ ks, const int3
   // KD_CHUNKS owns a contiguous chunk and its own column of the histogram, so no atomics and the order
   // inside a digit is the order of the source ----
   const int32_t chunk = (m + KD_CHUNKS - 1) / KD_CHUNKS;
-  if (m > KD_LDS_POINTS) {  // long lists: every thread at work, coalesced reads (kd_radix_pass_wide)
+  if (WIDE == 2 || (WIDE && m > KD_LDS_POINTS)) {  // long lists: every thread at work, coalesced reads (kd_radix_pass_wide)
     // (an item = y << 32 | rank, so the rank's key is looked up once; the items of the first pass lie over PX + PY,
     // adjacent and free until the levels start)
     uint64_t *Bf = (uint64_t *)PX;
@@ -349,7 +353,7 @@ __device__ inline void kd_order_body(const uint64_t *__restrict__ ks, const int3
     __syncthreads();
   }
   if (stamp) *stamp = clock64();
-  if (m <= KD_LDS_POINTS) {
+  if (WIDE != 2 && m <= KD_LDS_POINTS) {
     // the lists move into LDS, over the histogram (no longer needed): a dependent access there costs an LDS round
     // trip instead of one through L2
     uint16_t *l16 = (uint16_t *)hist;
@@ -373,7 +377,7 @@ __device__ inline void kd_order_body(const uint64_t *__restrict__ ks, const int3
     PY[Y0[q]] = (uint32_t)q;
   }
   __syncthreads();
-  if (m <= 65535)
+  if (WIDE && m <= 65535)
     kd_levels_wide(X0, X1, Y0, Y1, PX, PY, P, m, hist, tot, ks, key_out);
   else
     kd_levels<uint32_t>(X0, X1, Y0, Y1, PX, PY, P, m, tot, ks, key_out);
@@ -385,7 +389,7 @@ __global__ void __launch_bounds__(KD_THREADS) k_dc_kd_order(const VsmDcJob *__re
   const VsmDcJob jb = jobs[blockIdx.x];
   const int32_t m = jb.m;
   if (!jb.key_sorted || m < 2 || m > VSM_DC_KD_MAX_POINTS) return;  // (uniform for the block)
-  kd_order_body(jb.key_sorted, m, jb.kd_scratch, jb.kd_stride, jb.key, hist, tot);
+  kd_order_body<0>(jb.key_sorted, m, jb.kd_scratch, jb.kd_stride, jb.key, hist, tot);
 }
 
 __global__ void __launch_bounds__(64) k_dc_subtrees(const VsmDcJob *__restrict__ jobs, int njobs) {
@@ -1054,6 +1058,7 @@ extern "C" int vsm_debug_dc2_phases(unsigned long long *out, int reset) {
 #endif
 // ExactDelaunay::prepare(defer_ties) on the device: stable sort of the keys by (x, y), the first key of every pixel
 // stays (it carries the smallest input index; the vertex sort's verdict is patched in later), kd order.
+template <int WIDE>
 __device__ inline void dc2_prepare_global(const VsmDc2Job &jb, uint32_t *hist, uint32_t *tot) {  // KD_THREADS threads, KD_DIGITS * KD_CHUNKS words of hist
   __shared__ int32_t s_m;
   const int t = threadIdx.x;
@@ -1069,7 +1074,7 @@ __device__ inline void dc2_prepare_global(const VsmDc2Job &jb, uint32_t *hist, u
 #endif
   if (n > 3) {  // the reference leaves lists of up to three matches alone (viso/matcher.cpp:1210)
     uint64_t *T0 = (uint64_t *)jb.kd_scratch, *T1 = T0 + jb.kd_stride;
-    if (n > KD_LDS_POINTS) {
+    if (WIDE == 2 || (WIDE && n > KD_LDS_POINTS)) {
       const uint64_t *src = jb.keys_in;
       uint64_t *dst = T0;
       for (int sh = 20; sh <= 41; sh += 7) {
@@ -1104,22 +1109,30 @@ __device__ inline void dc2_prepare_global(const VsmDc2Job &jb, uint32_t *hist, u
   }
 #ifdef DC2_PHASE_TIMING
   p2 = p3 = clock64();
-  if (m >= 2) kd_order_body(jb.key_sorted, m, jb.kd_scratch, jb.kd_stride, jb.key, hist, tot, &p3);
+  if (m >= 2) kd_order_body<WIDE>(jb.key_sorted, m, jb.kd_scratch, jb.kd_stride, jb.key, hist, tot, &p3);
   if (t == 0) {
     const long long p4 = clock64();
     dc2_prepare_stat(p1 - p0, p2 - p1, p3 - p2, p4 - p3);
   }
 #else
-  if (m >= 2) kd_order_body(jb.key_sorted, m, jb.kd_scratch, jb.kd_stride, jb.key, hist, tot);
+  if (m >= 2) kd_order_body<WIDE>(jb.key_sorted, m, jb.kd_scratch, jb.kd_stride, jb.key, hist, tot);
 #endif
 }
 
-// longer_than: only the lists with more matches than that (the others belong to k_dc2_prepare_lds of the same launch pair)
-__global__ void __launch_bounds__(KD_THREADS) k_dc2_prepare(const VsmDc2Job *__restrict__ jobs, int longer_than) {
+__global__ void __launch_bounds__(KD_THREADS) k_dc2_prepare(const VsmDc2Job *__restrict__ jobs) {
   __shared__ uint32_t hist[KD_DIGITS * KD_CHUNKS];
   __shared__ uint32_t tot[KD_THREADS / 64 + 1];
+  dc2_prepare_global<1>(jobs[blockIdx.x], hist, tot);
+}
+// ... the lists with more matches than `longer_than` only (the others belong to k_dc2_prepare_lds of the same launch pair):
+// 12 KB of LDS, so a workgroup that finds nothing to do comes and goes beside whatever else is resident (with the 128 KB of
+// the kernel above the launch waited 70-80 us for compute units to itself in the pipeline, long list or not)
+__global__ void __launch_bounds__(KD_THREADS) k_dc2_prepare_long(const VsmDc2Job *__restrict__ jobs, int longer_than) {
+  __shared__ uint32_t lds[3 * KD_WIDE_E * (KD_THREADS / 64)];
+  __shared__ uint32_t tot[KD_THREADS / 64 + 1];
+  static_assert(3 * KD_WIDE_E * (KD_THREADS / 64) >= KD_DIGITS * (KD_THREADS / 64), "the wide radix pass counts in the same words");
   if (*jobs[blockIdx.x].count <= longer_than) return;
-  dc2_prepare_global(jobs[blockIdx.x], hist, tot);
+  dc2_prepare_global<2>(jobs[blockIdx.x], lds, tot);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1242,9 +1255,9 @@ __global__ void __launch_bounds__(1024) k_dc2_prepare_lds(const VsmDc2Job *__res
   const VsmDc2Job jb = jobs[blockIdx.x];
   const int t = threadIdx.x, nwaves = (int)blockDim.x >> 6;
   const int32_t nl = *jb.count;
-  // a list of a launch that may hold longer ones (the host only knows the query counts) is left to k_dc2_prepare, launched
-  // right behind this kernel for exactly those lists (inlined here, the long lists' code cost the short ones their registers:
-  // 74 -> 120 VGPRs, one workgroup per compute unit instead of two)
+  // a list of a launch that may hold longer ones (the host only knows the query counts) is left to k_dc2_prepare_long,
+  // launched right behind this kernel for exactly those lists (inlined here the long lists' forms cost the short ones
+  // their registers)
   if (big_too && nl > cap2) return;
   int32_t n = min(nl, jb.cap), m = 0;
   if (nl > jb.cap || nl > cap2) {  // (not expected: the host sizes slabs and launches from the query counts)
@@ -2142,7 +2155,7 @@ void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, i
     static_assert(DC2_PREP_LDS / 8 == KD_THREADS && 16 * DC2_PREP_LDS >= 4 * KD_DIGITS * KD_CHUNKS, "the long lists of a launch run k_dc2_prepare's body on this kernel's threads and LDS");
     if (cap2 == DC2_PREP_LDS && big8) {  // (max_list counts queries: most lists of such a launch are shorter than 8192 matches, whoever is not takes the first form)
       hipLaunchKernelGGL(k_dc2_prepare_lds<8>, dim3(njobs), dim3(cap2 / 8), (size_t)16 * cap2, s, d_jobs, cap2, max_list > cap2 ? 1 : 0);
-      if (max_list > cap2) hipLaunchKernelGGL(k_dc2_prepare, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs, cap2);
+      if (max_list > cap2) hipLaunchKernelGGL(k_dc2_prepare_long, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs, cap2);
       return;
     }
     if (cap2 < DC2_PREP_LDS && (big4 || 16 * cap2 <= 64 * 1024)) {
@@ -2151,7 +2164,7 @@ void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, i
     }
   }
 #endif
-  hipLaunchKernelGGL(k_dc2_prepare, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs, -1);
+  hipLaunchKernelGGL(k_dc2_prepare, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs);
 }
 void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth) {
   if (njobs <= 0) return;
