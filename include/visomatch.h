@@ -142,7 +142,8 @@ int32_t vsm_sequence_path(vsm_handle *h);
  * fused front end), "dc_gpu", "dc_full", "dc_watchdog_ms", "dc_fault_inject" (the GPU's share of the final stage in the
  * host-shared form), and the scheduling experiments of the GPU-resident form recorded in DESIGN_HISTORY.md 6c:
  * "seq_keys_dma", "seq_ties1_null", "seq_last_first", "seq_export_budget", "seq_first_chunk", "seq_p2_first";
- * "seq_null_stream" (above); "seq_host_pinned" (below, vsm_host_register); "fused_features" / "feat_order" (0: the separate filter, suppression, record and bin kernels
+ * "seq_null_stream" (above); "seq_host_pinned" (below, vsm_host_register); "seq_host_inorder" (0: host-resident frames in the
+ * run-ahead order of resident input instead of chunk by chunk as they arrive); "fused_features" / "feat_order" (0: the separate filter, suppression, record and bin kernels
  * instead of k_feat_dense / k_feat_sparse / k_feat_scan / k_feat_order) and "filter_planes" (1: vsm_push_back keeps the
  * blob / corner responses in HBM for vsm_get_filter_responses; the fused kernels leave them in LDS otherwise).
  * None of them changes a result.  Returns VSM_OK, or VSM_EARG for an unknown name.  (No counterpart in the reference.) */
@@ -164,6 +165,12 @@ int32_t vsm_local_cpus(int32_t *out, int32_t cap);
  * Unregister before the buffer is freed.  (No counterpart in the reference.) */
 int vsm_host_register(const void *p, uint64_t bytes);
 int vsm_host_unregister(const void *p);
+/* Device memory the process keeps: large blocks of closed handles and re-created contexts wait in a cache
+ * for the next one instead of going back to the driver, whose background clear of released VRAM slows every call for
+ * 44 ms per GB.  out[0] = blocks in the cache, out[1] = their bytes, out[2] = large blocks in use.  vsm_device_pool_trim()
+ * hands the cached ones back now (an application about to need the memory for itself).  (No counterpart in the reference.) */
+void vsm_device_pool_stats(int64_t out[3]);
+void vsm_device_pool_trim(void);
 
 /* ---- stage-level views for parity tests (the reference's private members) ---- */
 

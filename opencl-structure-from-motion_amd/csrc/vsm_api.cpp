@@ -190,6 +190,25 @@ void vsm_dev_free(void *p) {
   for (const DevPool::Block &b : drop) (void)hipFree(b.p);
 }
 
+void vsm_device_pool_stats(int64_t out[3]) {
+  DevPool &P = dev_pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  out[0] = (int64_t)P.cached.size();
+  out[1] = (int64_t)P.cached_bytes;
+  out[2] = (int64_t)P.live.size();
+}
+
+void vsm_device_pool_trim(void) {
+  DevPool &P = dev_pool();
+  std::vector<DevPool::Block> drop;
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    drop.swap(P.cached);
+    P.cached_bytes = 0;
+  }
+  for (const DevPool::Block &b : drop) (void)hipFree(b.p);
+}
+
 static void ctx_destroy(VsmCtx &c) {
   if (c.arena) vsm_dev_free(c.arena);
   if (c.hm_block) (void)hipHostFree(c.hm_block);

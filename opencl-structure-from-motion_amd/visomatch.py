@@ -34,7 +34,7 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_num_features", "vsm_get_features", "vsm_set_stage_capture", "vsm_stage_size", "vsm_stage_get",
            "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
            "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
-           "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_host_outliers_and_prior", "vsm_debug_dc2", "vsm_debug_dc2_band_factor", "vsm_local_cpus", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
+           "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_host_outliers_and_prior", "vsm_debug_dc2", "vsm_debug_dc2_band_factor", "vsm_local_cpus", "vsm_device_pool_stats", "vsm_device_pool_trim", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
            "vsm_sequence_get_timings", "vsm_sequence_path", "vsm_set_option", "vsm_version", "vsm_host_register", "vsm_host_unregister",
            "vsm_multi_create", "vsm_multi_destroy", "vsm_multi_process", "vsm_multi_num_sequences", "vsm_multi_get_motion",
            "vsm_multi_motion_valid", "vsm_multi_num_matches", "vsm_multi_get_matches", "vsm_multi_num_inliers", "vsm_multi_get_inliers",
@@ -79,6 +79,17 @@ def host_register(arr):
 
 def host_unregister(arr):
     return lib().vsm_host_unregister(arr.ctypes.data_as(C.c_void_p)) == 0
+
+
+def device_pool_stats():
+    """(blocks in the cache, their bytes, large blocks in use): the device memory closed handles left for the next one"""
+    out = (C.c_int64 * 3)()
+    lib().vsm_device_pool_stats(out)
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def device_pool_trim():
+    lib().vsm_device_pool_trim()
 
 
 class VisoMatchError(RuntimeError):
@@ -154,6 +165,10 @@ def lib():
         L.vsm_set_option.argtypes = [vp, C.c_char_p, i32]
         L.vsm_host_register.argtypes = [vp, C.c_uint64]
         L.vsm_host_unregister.argtypes = [vp]
+        L.vsm_device_pool_stats.argtypes = [vp]
+        L.vsm_device_pool_stats.restype = None
+        L.vsm_device_pool_trim.argtypes = []
+        L.vsm_device_pool_trim.restype = None
         L.vsm_multi_create.restype = vp
         L.vsm_multi_create.argtypes = [C.POINTER(VsmVoStereoParams), i32]
         L.vsm_multi_destroy.argtypes = [vp]

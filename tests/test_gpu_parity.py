@@ -361,6 +361,76 @@ def test_lookahead_host_inputs_short_last_chunk_and_page_locked_memory(vm, synth
             vm.host_unregister(right)
 
 
+@pytest.mark.parametrize("inorder", [0, 1])
+def test_lookahead_host_inputs_orders(vm, synth, monkeypatch, inorder):
+    """host-fed vsm_sequence_run: chunk by chunk in the order of arrival (default; two chain streams, pass-1 sorts on the main
+    stream) and the run-ahead order of resident input (option seq_host_inorder = 0), the library's own chunk plan
+    (40 + 80 + 60 + 20), after a call from HBM in the same handle (the third chain stream is given back and comes again)"""
+    import torch
+    monkeypatch.setenv("VSM_SEQ_V2", "1")
+    g = G.load("cfg2_seq200_tr")
+    w, h, nf = int(g["w"]), int(g["h"]), 200
+    cv = synth.canvas(int(g["seed"]), w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
+    left = np.ascontiguousarray(np.stack([l for l, _ in fr]))
+    right = np.ascontiguousarray(np.stack([r for _, r in fr]))
+    dl, dr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    m = vm.Matcher(options={"seq_host_inorder": inorder})
+    m.set_intrinsics(*[float(x) for x in g["intr"]])
+    try:
+        for src in ((dl, dr), (left, right), (dl, dr), (left, right)):
+            got = m.run_sequence(src[0], src[1], 2, g["tr_in"][:nf], g["tr_valid"][:nf])
+            assert m.sequence_path() == 2
+            for f in range(nf):
+                assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), (inorder, f)
+    finally:
+        m.close()
+
+
+def test_device_blocks_wait_for_the_next_handle(vm, synth, monkeypatch):
+    """a closed handle's large device blocks go to the process-wide cache, not back to the driver (whose background clear of
+    released VRAM slows every call for 44 ms per GB); the next handle takes them - as they are, so nothing may
+    rely on fresh memory being zero: same lists as the reference's from re-used blocks, for another chunk size and another
+    image size as well; vsm_device_pool_trim() hands them back"""
+    import torch
+    monkeypatch.setenv("VSM_SEQ_V2", "1")
+    g = G.load("cfg2_seq200_tr")
+    w, h, nf = int(g["w"]), int(g["h"]), 60
+    cv = synth.canvas(int(g["seed"]), w, h)
+    fr = [synth.stereo_frame(cv, f, w, h) for f in range(nf)]
+    dl = torch.from_numpy(np.stack([l for l, _ in fr])).cuda()
+    dr = torch.from_numpy(np.stack([r for _, r in fr])).cuda()
+
+    def run(chunk):
+        m = vm.Matcher(options={"seq_chunk": chunk})
+        m.set_intrinsics(*[float(x) for x in g["intr"]])
+        got = m.run_sequence(dl, dr, 2, g["tr_in"][:nf], g["tr_valid"][:nf])
+        assert m.sequence_path() == 2
+        for f in range(nf):
+            assert len(got[f]) == int(g["counts"][f]) and G.sha(got[f]) == str(g["hashes"][f]), (chunk, f)
+        m.close()
+
+    vm.device_pool_trim()
+    assert vm.device_pool_stats()[0] == 0
+    run(30)
+    blocks, nbytes, _ = vm.device_pool_stats()
+    assert blocks >= 2 and nbytes > 256 << 20     # (the context's arena and the chains' slabs at least)
+    run(30)
+    assert vm.device_pool_stats()[:2] == (blocks, nbytes)   # (everything came out of the cache and went back)
+    run(20)                                      # a smaller context in the larger one's arena
+    # another image size: per-frame calls of a small handle between two look-ahead handles
+    m = vm.Matcher()
+    a = torch.from_numpy(np.ascontiguousarray(fr[0][0][:240, :320])).cuda()
+    b = torch.from_numpy(np.ascontiguousarray(fr[1][0][:240, :320])).cuda()
+    m.push_back(a, None)
+    m.push_back(b, None)
+    m.match_features(0, None)
+    m.close()
+    run(30)
+    vm.device_pool_trim()
+    assert vm.device_pool_stats()[:2] == (0, 0)
+
+
 def test_host_threads_near_the_gpu(vm):
     """vsm_local_cpus(): the CPUs of the device's NUMA node the library keeps its own threads on - a subset of what the
     process may use, or nothing (one node, or a process already confined); the caller's thread is left alone"""
