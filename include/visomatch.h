@@ -143,7 +143,8 @@ int32_t vsm_sequence_path(vsm_handle *h);
  * host-shared form), and the scheduling experiments of the GPU-resident form recorded in DESIGN_HISTORY.md 6c:
  * "seq_keys_dma", "seq_ties1_null", "seq_last_first", "seq_export_budget", "seq_first_chunk", "seq_p2_first";
  * "seq_null_stream" (above); "seq_host_pinned" (below, vsm_host_register); "seq_host_inorder" (0: host-resident frames in the
- * run-ahead order of resident input instead of chunk by chunk as they arrive); "fused_features" / "feat_order" (0: the separate filter, suppression, record and bin kernels
+ * run-ahead order of resident input instead of chunk by chunk as they arrive); "match_heads" (1, before the first image: the
+ * second matching pass on 64-byte per-bin head records - measured slower); "fused_features" / "feat_order" (0: the separate filter, suppression, record and bin kernels
  * instead of k_feat_dense / k_feat_sparse / k_feat_scan / k_feat_order) and "filter_planes" (1: vsm_push_back keeps the
  * blob / corner responses in HBM for vsm_get_filter_responses; the fused kernels leave them in LDS otherwise).
  * None of them changes a result.  Returns VSM_OK, or VSM_EARG for an unknown name.  (No counterpart in the reference.) */

@@ -71,6 +71,7 @@ static inline double now_us() {
 // ---------------------------------------------------------------------------------------
 struct VsmCtx {
   bool ready = false;
+  bool has_heads = false;  // the dense sets carry head records (option match_heads at the time the context was made)
   VsmDims dims{};
   int nframes = 0, npairs = 0;
   uint8_t *arena = nullptr;
@@ -223,8 +224,9 @@ static int nms_cells(int32_t len, int32_t n) {  // loop count of "for (i=n+margi
 }
 
 // One arena per context, zero-filled once, so row padding stays 0.
-static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int nframes, int npairs, hipStream_t stream) {
+static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int nframes, int npairs, hipStream_t stream, bool heads) {
   ctx_destroy(c);
+  c.has_heads = heads;
   VsmDims &d = c.dims;
   d.w = w;
   d.h = hh;
@@ -266,7 +268,7 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
     return o;
   };
   struct SetOff {
-    size_t feat, count, cand, cell_off, bin_start, bin_cnt, binid, s_idx, s_uv, s_desc, s_rank, tmp;
+    size_t feat, count, cand, cell_off, bin_start, bin_cnt, binid, s_idx, s_uv, s_desc, s_rank, tmp, heads;
   };
   struct ImgOff {
     size_t img, imgm, du, dv, duvt;
@@ -293,6 +295,7 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
       io[i].set[k].s_uv = take(cap * 8);
       io[i].set[k].s_desc = take(cap * 32);
       io[i].set[k].tmp = take(cap * 4);
+      io[i].set[k].heads = k == 1 && heads ? take((size_t)nb * VSM_VSUB * 64) : 0;
     }
   }
   c.f_stride = mres;  // int16 elements per image plane
@@ -357,6 +360,7 @@ static int ctx_create(VsmCtx &c, const vsm_params &p, int32_t w, int32_t hh, int
       s.s_uv = (uint32_t *)(b + io[i].set[k].s_uv);
       s.s_desc = (uint4 *)(b + io[i].set[k].s_desc);
       s.tmp = (int32_t *)(b + io[i].set[k].tmp);
+      s.heads = k == 1 && heads ? (uint4 *)(b + io[i].set[k].heads) : nullptr;
       s.cap = c.cap_set[k];
       s.nms_n = nn[k];
       s.ncu = ncu[k];
@@ -519,6 +523,7 @@ struct VsmSwitches {
   int seq_host_inorder = 1;  // ... host-resident inputs: chunk by chunk in the order of arrival - the caller's thread waits for a chunk's feature counts only when everything of the chunk in front is enqueued (0: the run-ahead order of HBM-resident inputs)
   int seq_defer_refine = 0;  // ... a chunk's refinement behind the NEXT chunk's second-pass matching where that follows at once (the chain's keys do not need it)
   int seq_host_pinned = 0;   // ... host-resident input images are in page-locked memory (the caller's promise): DMA straight out of them, no gather pass
+  int match_heads = 0;       // the second matching pass takes a bin's start and its first 15 candidates' coordinates from one 64-byte head record (k_feat_heads) instead of bin starts + coordinate runs: measured slower, off; read when a context is made
   int fused_features = 1;    // filters + suppression of the matching resolution out of one LDS tile (k_feat_dense / k_feat_sparse; default radii) or the separate kernels (0)
   int feat_order = 1;        // feature records + bin-sorted copy by k_feat_scan / k_feat_order (tiles of whole search bins) or by k_scan_cells / k_emit / k_bin_* (0)
   int filter_planes = 0;     // vsm_push_back keeps f1 / f2 in HBM for vsm_get_filter_responses (the fused tiles write them on the side)
@@ -556,6 +561,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "seq_host_pinned")) seq_host_pinned = v != 0;
     else if (!strcmp(name, "seq_defer_refine")) seq_defer_refine = v != 0;
     else if (!strcmp(name, "seq_host_inorder")) seq_host_inorder = v != 0;
+    else if (!strcmp(name, "match_heads")) match_heads = v != 0;
     else if (!strcmp(name, "fused_features")) fused_features = v != 0;
     else if (!strcmp(name, "filter_planes")) filter_planes = v != 0;
     else if (!strcmp(name, "feat_order")) feat_order = v != 0;
@@ -796,7 +802,7 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
     // a change of image size restarts the ring buffer (the reference would match across sizes)
     (void)hipStreamSynchronize(h->stream);
     reset_ring_state(h);
-    int rc = ctx_create(c, h->param, w, hh, 2, 1, h->stream);
+    int rc = ctx_create(c, h->param, w, hh, 2, 1, h->stream, h->sw.match_heads != 0);
     if (rc != VSM_OK) return rc;
   }
   if (h->counts_pending) {  // a previous asynchronous push has not been settled yet
@@ -893,10 +899,11 @@ static bool match_ready(const vsm_params &p, int method, const int32_t n[4][2]) 
   return true;
 }
 
-static VsmMatchCfg make_cfg(const vsm_params &p, int method) {
+static VsmMatchCfg make_cfg(const vsm_params &p, int method, int heads) {
   VsmMatchCfg cfg;
   memset(&cfg, 0, sizeof(cfg));
   cfg.method = method;
+  cfg.heads = heads;
   cfg.binsize = p.match_binsize;
   cfg.bin_magic = p.match_binsize >= 2 ? (uint32_t)(((1ull << 32) + (uint64_t)p.match_binsize - 1) / (uint64_t)p.match_binsize) : 0u;
   cfg.radius = p.match_radius;
@@ -931,7 +938,7 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
   h->matched.clear();
   memset(h->counters, 0, sizeof(h->counters));
 
-  VsmMatchCfg cfg = make_cfg(p, method);
+  VsmMatchCfg cfg = make_cfg(p, method, h->sw.match_heads && c.has_heads);
   VsmJob job;
   memset(&job, 0, sizeof(job));
   // stereo matching only needs the current pair: "prev" then aliases the current slot
@@ -1558,7 +1565,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
   VsmCtx &c = h->seq;
   if (!c.ready || c.dims.w != w || c.dims.h != hh || h->seq_chunk != C || c.npairs != 2 * C || c.nframes != 3 * C) {
     (void)hipStreamSynchronize(h->stream);
-    int rc = ctx_create(c, p, w, hh, 3 * C, 2 * C, h->stream);  // three banks of frames, two of pairs
+    int rc = ctx_create(c, p, w, hh, 3 * C, 2 * C, h->stream, h->sw.match_heads != 0);  // three banks of frames, two of pairs
     if (rc != VSM_OK) return rc;
     h->seq_chunk = C;
   }
@@ -1773,7 +1780,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     }
     HIPCHK(vsm_upload(h->stream, d_jobs, h_jobs, sizeof(VsmJob) * n));
     if (p.multi_stage) {
-      VsmMatchCfg cfg = make_cfg(p, method);
+      VsmMatchCfg cfg = make_cfg(p, method, h->sw.match_heads && c.has_heads);
       VsmJob dummy;
       memset(&dummy, 0, sizeof(dummy));
       cfg.sparse = 1;
@@ -1831,7 +1838,7 @@ int vsm_sequence_run(vsm_handle *h, const uint8_t *left, const uint8_t *right, i
     const int *max_nq = q.max_nq;
     const std::shared_ptr<std::vector<char>> validp = q.validp;
     const std::vector<char> &valid = *validp;
-    VsmMatchCfg cfg = make_cfg(p, method);
+    VsmMatchCfg cfg = make_cfg(p, method, h->sw.match_heads && c.has_heads);
     VsmJob dummy;
     memset(&dummy, 0, sizeof(dummy));
     double ta = now_us();

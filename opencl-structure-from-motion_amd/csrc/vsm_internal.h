@@ -32,6 +32,7 @@ struct VsmSet {
   int32_t *s_idx;      // [cap] sorted position -> original index
   uint32_t *s_uv;      // [cap] u | v << 16 (coordinates < 16384), bin-sorted; 16-byte loads may over-read <= 3 entries
   uint4 *s_desc;       // [cap][2]
+  uint4 *heads;        // [4*ub*vb*VSM_VSUB][4] head record of every fine bin: its start, then the coordinates of the 15 candidates from there on (dense set; else null)
   int32_t *tmp;        // [cap] scratch
   int32_t cap, nms_n, ncu, ncv;
 };
@@ -61,6 +62,7 @@ struct VsmDims {
 struct VsmMatchCfg {  // common to all pairs of a launch
   int32_t method, use_prior, sparse;
   int32_t binsize, radius, disp_tol;
+  int32_t heads, pad_;  // the second pass reads the per-bin head records (k_feat_heads) instead of bin starts + coordinate runs
   uint32_t bin_magic;  // ceil(2^32 / binsize): x / binsize == mulhi(x, bin_magic) for 0 <= x < 2^32 / binsize (binsize >= 2)
   double f, cu, cv, base;
 };

@@ -1511,7 +1511,7 @@ extern __device__ unsigned long long vsm_mt_acc[16];
 #endif
 typedef unsigned short vsm_us2 __attribute__((ext_vector_type(2)));
 
-template <int G, bool RELOAD = true, bool MAYPRED = true, bool BYBIN = false>
+template <int G, bool RELOAD = true, bool MAYPRED = true, bool BYBIN = false, bool HEADS = false>
 __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, const VsmDims &d, const VsmMatchCfg &cfg,
                                                bool prior, float r_umin, float r_umax, float r_vmin, float r_vmax,
                                                bool flow, double u_, double v_, int lane, long long *ph = nullptr) {
@@ -1612,7 +1612,69 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
 #if defined(VSM_MATCH_TIMING) && VSM_MATCH_TIMING == 1
   const long long ph0 = clock64();
 #endif
-  if (BYBIN) {
+#if defined(VSM_MATCH_TIMING) && VSM_MATCH_TIMING == 2
+  int mt_maxrun = 0;  // the longest run of candidates this lane's scans went through (the bound of a per-bin head record)
+#define VSM_MT_RUN(len) mt_maxrun = max(mt_maxrun, (int)(len))
+#else
+#define VSM_MT_RUN(len)
+#endif
+  if (HEADS) {
+  // The window's u-bins one after the other; of a bin's head record (k_feat_heads: 64 bytes = the run's start + the first 15
+  // candidates' coordinates) every lane of the group loads its 16 / G dwords, next to the run's end: one round trip for
+  // what the forms below take two or more for (bin starts, then coordinate loads that need them).
+  constexpr int NDW = 16 / G;  // record dwords per lane
+  auto park = [&](uint32_t w, int p, int q1) {
+    const vsm_us2 off = __builtin_bit_cast(vsm_us2, w) - __builtin_bit_cast(vsm_us2, lo_pk);
+    const vsm_us2 cl = __builtin_elementwise_min(off, __builtin_bit_cast(vsm_us2, rng_pk));
+    if (__builtin_bit_cast(uint32_t, cl) == __builtin_bit_cast(uint32_t, off) && p < q1) {
+      if (nq == 4) {  // queue full (rare): make room first
+        const int pf = q3p;
+        nq = 3;
+        judge(pf);
+      }
+      q3p = q2p;
+      q2p = q1p;
+      q1p = q0p;
+      q0p = p;
+      nq++;
+    }
+  };
+  for (int ubin = ubmin; ubin <= ubmax && !empty; ubin++) {
+    VSM_MT_TRIP(0);
+    const int b0 = (q.c * d.ub + ubin) * vrows;
+    const uint32_t hb = (uint32_t)(b0 + vfmin) * 64u + (uint32_t)lane * (uint32_t)(4 * NDW);
+    uint32_t r[NDW];
+    if (NDW >= 4) {
+#pragma unroll
+      for (int j = 0; j < NDW / 4; j++) {
+        const uint4 v = ldg_u4_at(B.heads, hb + 16u * j);
+        r[4 * j + 0] = v.x;
+        r[4 * j + 1] = v.y;
+        r[4 * j + 2] = v.z;
+        r[4 * j + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NDW; j++) r[j] = ldg_u32_at(B.heads, hb + 4u * j);
+    }
+    const int q1 = (int)ldg_u32_at(B.bin_start, (uint32_t)(b0 + vfmax + 1) * 4u);
+    const int q0 = __shfl((int)r[0], 0, G);  // (the group's lane 0 holds the record's first dword: the start)
+    VSM_MT_RUN(q1 - q0);
+#pragma unroll
+    for (int i = 0; i < NDW; i++) {
+      const int k = lane * NDW + i - 1;  // candidate number of this dword (-1: the start itself)
+      if (i > 0 || lane > 0) park(r[i], q0 + k, q1);
+    }
+    for (int p0 = q0 + 15 + 4 * lane; p0 < q1; p0 += 4 * G) {  // a run of more than 15 candidates: the rest in 16-byte loads
+      VSM_MT_TRIP(1);
+      const uint4 wk = ldg_u4_at_dw(B.s_uv, (uint32_t)p0 * 4u);
+      park(wk.x, p0, q1);
+      park(wk.y, p0 + 1, q1);
+      park(wk.z, p0 + 2, q1);
+      park(wk.w, p0 + 3, q1);
+    }
+  }
+  } else if (BYBIN) {
   // The lanes of a group take the window's u-bins in turn, each scanning its bin's run alone: a stereo stage's disparity
   // range spans 2-3 bins and an unconstrained first-pass window nine, with a handful of candidates in each - the wave goes
   // round ceil(bins / G) times instead of once per bin with most of a 16- or 32-slot sweep empty.  (BYBIN: the launches without prior
@@ -1621,6 +1683,7 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
     VSM_MT_TRIP(0);
     const int b0 = (q.c * d.ub + ubin) * vrows;
     const int q0 = (int)ldg_u32_at(B.bin_start, (uint32_t)(b0 + vfmin) * 4u), q1 = (int)ldg_u32_at(B.bin_start, (uint32_t)(b0 + vfmax + 1) * 4u);
+    VSM_MT_RUN(q1 - q0);
     for (int p0 = q0; p0 < q1; p0 += 4 * VSM_UVL) {
       VSM_MT_TRIP(1);
       uint4 wk[VSM_UVL];
@@ -1658,6 +1721,7 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
     VSM_MT_TRIP(0);
     const int b0 = (q.c * d.ub + ubin) * vrows;
     const int q0 = (int)ldg_u32_at(B.bin_start, (uint32_t)(b0 + vfmin) * 4u), q1 = (int)ldg_u32_at(B.bin_start, (uint32_t)(b0 + vfmax + 1) * 4u);
+    VSM_MT_RUN(q1 - q0);
 #if VSM_SCAN_UNALIGNED
     for (int p0 = q0 + 4 * lane; p0 < q1; p0 += 4 * G * VSM_UVL) {  // (the run's first candidate first: only the tail needs a bound)
 #else
@@ -1706,6 +1770,20 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
   }
 #if defined(VSM_MATCH_TIMING) && VSM_MATCH_TIMING == 1
   const long long ph1 = clock64();
+#endif
+#if defined(VSM_MATCH_TIMING) && VSM_MATCH_TIMING == 2
+  if (!cfg.sparse) {  // dense pass: in how many wave-stages would a head record of 3 / 7 / 15 inline candidates have spared EVERY lane its coordinate loads?
+    if (BYBIN) {  // (a lane scans its own bins: the record is one lane's)
+      VSM_MT_TRIP(11);
+      if (!__any(mt_maxrun > 3)) VSM_MT_TRIP(12);
+      if (!__any(mt_maxrun > 7)) VSM_MT_TRIP(13);
+      if (!__any(mt_maxrun > 15)) VSM_MT_TRIP(14);
+    } else {      // (a group shares a bin's run)
+      VSM_MT_TRIP(8);
+      if (!__any(mt_maxrun > 7)) VSM_MT_TRIP(9);
+      if (!__any(mt_maxrun > 15)) VSM_MT_TRIP(10);
+    }
+  }
 #endif
   while (__any(nq > 0)) pop_and_judge();
 #if defined(VSM_MATCH_TIMING) && VSM_MATCH_TIMING == 1
@@ -1781,7 +1859,7 @@ extern "C" int vsm_debug_match_timing(unsigned int *out, unsigned int cap, int r
   return (int)n;
 }
 #endif
-template <int G, bool BYBIN = false>
+template <int G, bool BYBIN = false, bool HEADS = false>
 __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
     k_match(const VsmImage *__restrict__ imgs, const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs,
             VsmJob job0, VsmDims d, VsmMatchCfg cfg, int nbx, int npairs) {
@@ -1826,17 +1904,17 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
   const int u0 = q.u(), v0 = q.v();
   if (cfg.method == 0) {  // flow, :1006-1041
     const float4 r0 = box(0), r1 = box(1);
-    const uint32_t p1 = find_match<G, true, false, BYBIN>(q, s1p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, true, -1, -1, lane);
+    const uint32_t p1 = find_match<G, true, false, BYBIN, HEADS>(q, s1p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, true, -1, -1, lane);
     const int u1p = q.u(), v1p = q.v();
-    const uint32_t p2 = find_match<G, true, false, BYBIN>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, -1, -1, lane);
+    const uint32_t p2 = find_match<G, true, false, BYBIN, HEADS>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, -1, -1, lane);
     const int i1p = index_of(s1p, p1), i1c2 = index_of(s1c, p2);
     ok = (i1c2 == qi);
     m = {(float)u1p, (float)v1p, i1p, -1.f, -1.f, -1, (float)u0, (float)v0, qi, -1.f, -1.f, -1};
   } else if (cfg.method == 1) {  // stereo, :1045-1084
     const float4 r0 = box(0), r1 = box(1);
-    const uint32_t p1 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN>(q, s2c, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane);
+    const uint32_t p1 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN, HEADS>(q, s2c, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane);
     const int u2c = q.u(), v2c = q.v();
-    const uint32_t p2 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, false, -1, -1, lane);
+    const uint32_t p2 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN, HEADS>(q, s1c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, false, -1, -1, lane);
     const int i2c = index_of(s2c, p1), i1c2 = index_of(s1c, p2);
     ok = (i1c2 == qi) && (u0 >= u2c);
     m = {-1.f, -1.f, -1, -1.f, -1.f, -1, (float)u0, (float)v0, qi, (float)u2c, (float)v2c, i2c};
@@ -1844,7 +1922,7 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
     // (stage results stay packed u | v << 16 until the record is written: registers decide how many
     // chains a SIMD keeps in flight)
     const float4 r0 = box(0), r1 = box(1);
-    const uint32_t p1 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN>(q, s2p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane, mtph);
+    const uint32_t p1 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN, HEADS>(q, s2p, d, cfg, prior, r0.x, r0.y, r0.z, r0.w, false, -1, -1, lane, mtph);
     const uint32_t w2p = q.uv;
 #ifdef VSM_MATCH_TIMING
     const long long ms1 = clock64();
@@ -1863,19 +1941,19 @@ __global__ void __launch_bounds__(VSM_MATCH_BLOCK, VSM_MATCH_WAVES)
       v2c_ = cfg.f * y2c / z2c + cfg.cv;
     }
     const float4 r2 = box(2);
-    const uint32_t p2 = find_match<G, true, true, BYBIN>(q, s2c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, u2c_, v2c_, lane, mtph);
+    const uint32_t p2 = find_match<G, true, true, BYBIN, HEADS>(q, s2c, d, cfg, prior, r1.x, r1.y, r1.z, r1.w, true, u2c_, v2c_, lane, mtph);
     const uint32_t w2c = q.uv;
 #ifdef VSM_MATCH_TIMING
     const long long ms2 = clock64();
 #endif
     const float4 r3 = box(3);
-    const uint32_t p3 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN>(q, s1c, d, cfg, prior, r2.x, r2.y, r2.z, r2.w, false, -1, -1, lane, mtph);
+    const uint32_t p3 = find_match<G, true, false, BYBIN || VSM_STEREO_BY_BIN, HEADS>(q, s1c, d, cfg, prior, r2.x, r2.y, r2.z, r2.w, false, -1, -1, lane, mtph);
     const uint32_t w1c = q.uv;
 #ifdef VSM_MATCH_TIMING
     const long long ms3 = clock64();
 #endif
     // stage 4 predicts the chain's own start (:1134)
-    const uint32_t p4 = find_match<G, true, true, BYBIN>(q, s1p, d, cfg, prior, r3.x, r3.y, r3.z, r3.w, true,
+    const uint32_t p4 = find_match<G, true, true, BYBIN, HEADS>(q, s1p, d, cfg, prior, r3.x, r3.y, r3.z, r3.w, true,
                                       jb.use_tr ? (double)(int)(w0 & 0xffffu) : -1.0,
                                       jb.use_tr ? (double)(int)(w0 >> 16) : -1.0, lane, mtph);
     const int i1p2 = index_of(s1p, p4);
@@ -2512,6 +2590,27 @@ __global__ void __launch_bounds__(256) k_upload(uint32_t *__restrict__ dst, cons
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n_words) dst[i] = src[i];
 }
+// Head records of the dense set's fine bins (VsmSet::heads): dword 0 = the bin's start in the sorted arrays, dwords 1..15 = the
+// packed coordinates of the 15 candidates from there on, whatever bins they lie in (a search window's run of candidates is
+// consecutive in that order: fine rows vfmin..vfmax of one (class, u-bin) column).  k_match's second pass reads a window's bin
+// start AND its candidates' coordinates in one round trip: measured on the benchmark sequence (tools/match_timing.py,
+// -DVSM_MATCH_TIMING=2), 15 inline candidates cover every lane's longest run in 99.9-100 % of a wave's stages, 7 in 1.7 %
+// (groups sharing a run) / 41.7 % (a lane per bin), 3 in 0.4 % - a wave saves the trip only if all of its lanes do.
+// One thread per (bin, quarter of the record).
+__global__ void __launch_bounds__(256) k_feat_heads(const VsmImage *__restrict__ imgs, int first, int nb) {
+  const VsmSet &st = imgs[first + blockIdx.y].set[1];
+  const int tid = blockIdx.x * 256 + threadIdx.x, b = tid >> 2, j = tid & 3;
+  if (b >= nb || st.heads == nullptr) return;
+  const int start = ldg_i32(st.bin_start + b);
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int at = min(start + 4 * j + i - 1, st.cap - 1);  // (beyond the set's count: whatever is there - a position >= the run's end is never taken)
+    w[i] = (j == 0 && i == 0) ? (uint32_t)start : ldg_u32_at(st.s_uv, (uint32_t)max(at, 0) * 4u);
+  }
+  st.heads[b * 4 + j] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 hipError_t vsm_upload(hipStream_t s, void *dst_device, const void *src_pinned, size_t bytes) {
   if (bytes == 0) return hipSuccess;
   if ((bytes & 3) || ((uintptr_t)dst_device & 3) || ((uintptr_t)src_pinned & 3)) return hipMemcpyAsync(dst_device, src_pinned, bytes, hipMemcpyHostToDevice, s);
@@ -2683,6 +2782,7 @@ int vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int 
     hipLaunchKernelGGL(k_feat_order, dim3(((nbx * n_img + 7) / 8) * 8), dim3(256), (size_t)pl.lds_bytes, s, d_imgs, first, d, set_lo, bd, pl,
                        nbx, n_img);
     pf.end(s);
+    if (h_imgs[first].set[1].heads) hipLaunchKernelGGL(k_feat_heads, dim3(cdiv(nb * 4, 256), n_img), dim3(256), 0, s, d_imgs, first, nb);
     return (!fuse || (fused & 2)) ? 1 : 0;
   }
   pf.begin(VSM_K_SCAN, s);
@@ -2709,6 +2809,7 @@ int vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int 
   pf.begin(VSM_K_BINRANK, s);
   hipLaunchKernelGGL(k_bin_rank, dim3(cdiv(max_cap, 256), 2, n_img), dim3(256), 0, s, d_imgs, first, set_lo);
   pf.end(s);
+  if (h_imgs[first].set[1].heads) hipLaunchKernelGGL(k_feat_heads, dim3(cdiv(nb * 4, 256), n_img), dim3(256), 0, s, d_imgs, first, nb);
   return (!fuse || (fused & 2)) ? 1 : 0;
 }
 
@@ -2731,7 +2832,9 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
     // without prior boxes (first pass, single-pass matching) the lanes of a group take whole u-bins
 #define VSM_MATCH_LAUNCH(GG)                                                                                                       \
   do {                                                                                                                             \
-    if (cfg.use_prior)                                                                                                             \
+    if (cfg.use_prior && cfg.heads && !cfg.sparse)                                                                                 \
+      hipLaunchKernelGGL((k_match<GG, false, true>), grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs); \
+    else if (cfg.use_prior)                                                                                                        \
       hipLaunchKernelGGL((k_match<GG, false>), grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs); \
     else                                                                                                                           \
       hipLaunchKernelGGL((k_match<GG, true>), grid, dim3(VSM_MATCH_BLOCK), 0, s, d_imgs, d_pairs, d_jobs, job0, d, cfg, nbx, npairs);  \

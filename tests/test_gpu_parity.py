@@ -300,13 +300,15 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
                                  {"VSM_HOST_THREADS": "3", "VSM_SEQ_CHUNK": "13"},
                                  {"opt:front": "0"}, {"opt:seq_p2_first": "1"}, {"opt:seq_p2_first": "0", "VSM_HOST_THREADS": "6"},
                                  {"opt:seq_p2_first": "1", "opt:seq_first_chunk": "4"}, {"opt:seq_keys_dma": "0", "opt:seq_export_budget": "0"},
-                                 {"opt:seq_ties1_null": "0", "opt:seq_last_first": "0", "opt:seq_export_budget": "5"}])
+                                 {"opt:seq_ties1_null": "0", "opt:seq_last_first": "0", "opt:seq_export_budget": "5"},
+                                 {"opt:match_heads": "1"}, {"opt:match_heads": "1", "opt:feat_order": "0", "VSM_SEQ_CHUNK": "7"}])
 def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), both ways of
     result delivery at both ends of the pool size, one / four chain streams (eight chunks of five, twenty of two: every bank
     comes round), the vertex sorts on the device (one launch for the chunks that wait for it, also where a slab comes round
     before the call's last head; two-chunk calls of ranks with few host threads: a launch per chunk, the pool sizes' own shares), the unfused front end, the
-    separate filter / suppression / record / bin kernels instead of the fused tiles, a fifth stream of the library's own instead of the null stream, the scheduling choices of DESIGN_HISTORY.md 6c either way: always
+    separate filter / suppression / record / bin kernels instead of the fused tiles, a fifth stream of the library's own instead of the null stream, the scheduling choices of DESIGN_HISTORY.md 6c either way,
+    the second pass on per-bin head records (k_feat_heads; measured slower, off by default): always
     the reference's lists, and always this form (it must not quietly hand the run to the other one)."""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1")
@@ -1055,11 +1057,11 @@ def test_road_scene_golden(vm, synth):
     G.replay_road(_load_golden("road_1242x375"), synth, vm.VisualOdometryStereo, vm.VisualOdometryMono, vm.vo_sampler_seed)
 
 
-@pytest.mark.parametrize("seed", [20240607, 7, 424242])
-def test_randomised_configurations_vs_oracle(vm, B, synth, seed):
+@pytest.mark.parametrize("seed,heads", [(20240607, 0), (7, 0), (424242, 0), (7, 1)])
+def test_randomised_configurations_vs_oracle(vm, B, synth, seed, heads):
     """seeded sweep over image sizes, parameters, methods and scene generators: every stage of the
     HIP path equals the oracle's (catches tile-border, bin-border and tie-break mistakes that fixed
-    cases can miss)"""
+    cases can miss); heads = 1: the second pass on per-bin head records (option match_heads)"""
     rs = np.random.RandomState(seed)
     pyr = synth.road_pyramid(77, levels=8, size=1024)
     for case in range(40):
@@ -1079,7 +1081,7 @@ def test_randomised_configurations_vs_oracle(vm, B, synth, seed):
         use_tr = method == 2 and rs.randint(2) == 1
         Tr = np.eye(4)
         Tr[2, 3] = -0.3
-        g, c = vm.Matcher(stage_capture=True, **params), B.CpuMatcher("oracle", **params)
+        g, c = vm.Matcher(stage_capture=True, options={"match_heads": heads}, **params), B.CpuMatcher("oracle", **params)
         intr = (400.0, w / 2.0, h / 2.0, 0.3)
         g.set_intrinsics(*intr)
         c.set_intrinsics(*intr)

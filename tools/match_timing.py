@@ -37,6 +37,11 @@ print("waves", n)
 if A[3]:
     print("wave-level trips per wave (both passes' waves over the dense pass's count): findMatch %.1f, u-bin iterations %.1f, scan iterations %.1f, judge rounds %.1f"
           % (A[3] / n, A[0] / n, A[1] / n, A[2] / n))
+if A[8]:
+    print("dense pass: what a per-bin head record with N inline candidates could spare a wave (every lane's longest run of candidates <= N):")
+    print("  stages whose groups share a bin's run (flow + prediction): %.0f wave-stages, N = 7: %.3f, N = 15: %.3f" % (A[8], A[9] / A[8], A[10] / A[8]))
+    if A[11]:
+        print("  stages whose lanes take a bin each (stereo): %.0f wave-stages, N = 3: %.3f, N = 7: %.3f, N = 15: %.3f" % (A[11], A[12] / A[11], A[13] / A[11], A[14] / A[11]))
 names = ["life", "stage 1", "stage 2", "stage 3", "stage 4", "bins + scan", "judging"]
 for k, nm in enumerate(names):
     c = a[:, k]
