@@ -512,7 +512,7 @@ struct VsmSwitches {
   int dc_full = -1;          // ... everything after the vertex sort on the GPU: -1 = with six host threads or fewer, 0 / 1
   int dc_fault_inject = 0;   // ... tests: the completion callback of the GPU share is "lost" (dc_wait()'s watchdog has to notice)
   int dc_watchdog_ms = 20000;  // ... how long dc_wait() listens for that callback before it asks the stream itself
-  int seq_keys_dma = 1;      // GPU-resident form: the keys reach the host's vertex sort by a DMA copy (1) or by the key kernel's own stores into host-mapped memory (0)
+  int seq_keys_dma = 1;      // GPU-resident form: the keys reach the host's vertex sort by a DMA copy (1; 2: on the fifth stream, so that the mesh does not stand behind it - no difference: median step 3.96-3.99 ms either way) or by the key kernel's own stores into host-mapped memory (0)
   int seq_ties1_null = 1;    // ... the pass-1 chain's vertex sort (one wave per list) on the null stream (1) or on side stream cs[k + 2] (0)
   int seq_last_first = 1;    // ... a chain's sort + kd order kernel goes in with its head, and the block kernel of the last chunk but one waits for the last chunk's
   int seq_first_chunk = 0;   // ... frames of the call's first chunk (0: like the others)
@@ -551,7 +551,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "dc_full")) dc_full = v;
     else if (!strcmp(name, "dc_fault_inject")) dc_fault_inject = v;
     else if (!strcmp(name, "dc_watchdog_ms")) dc_watchdog_ms = std::max(1, v);
-    else if (!strcmp(name, "seq_keys_dma")) seq_keys_dma = v != 0;
+    else if (!strcmp(name, "seq_keys_dma")) seq_keys_dma = v;
     else if (!strcmp(name, "seq_export_budget")) seq_export_budget = v;
     else if (!strcmp(name, "seq_first_chunk")) seq_first_chunk = std::max(0, v);
     else if (!strcmp(name, "seq_p2_first")) seq_p2_first = v;
