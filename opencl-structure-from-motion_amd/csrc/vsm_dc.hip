@@ -138,6 +138,8 @@ __device__ inline void kd_levels(T *X0, T *X1, T *Y0, T *Y1, T *PX, T *PY, uint3
 // The same levels for lists beyond the LDS forms (config 5: 20-40 k distinct points), lists in global memory.  kd_levels above
 // gives a thread a contiguous run of positions: its loads are a cache line per lane, every position's node is recomputed from
 // the root at every level, the flags go through a global array twice - 93 us per level, 1.4 ms of the 2 ms a 34 k list took.
+// (What bounds it then, 31 us per level of a 34 k list: one compute unit's rate of uncoalesced lane accesses - a gather and two
+// scatters per point and level, ~1.5 per clock; having eight positions' loads in flight instead of one changes nothing.)
 // Here thread t owns positions t, t + 1024, ...: coalesced reads of the list, the node (offset, size) of each of its positions
 // lives in a register and is halved once per level, the "goes left" flags of a level are wave ballots kept in LDS (one
 // 64-bit word per wave and batch) with an exclusive prefix over the words, so the number of flags before ANY position - the
