@@ -2428,7 +2428,10 @@ int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, i
         o[0] = nn > 3 ? sorter.sort_ties(B.host_keys(i), nn, o + 1, (B.ties_stride - 1) / 2) : 0;
       }
     }
-    dc2_enqueue_mesh(nullptr, B, copies, n);
+    // (VSM_DC2_EXPECT_LONG=0, tests: a list of 8193..16384 matches through the narrow form inside the LDS kernel, as in a handle
+    // that has not met a long list yet)
+    const char *xl = getenv("VSM_DC2_EXPECT_LONG");
+    dc2_enqueue_mesh(nullptr, B, copies, n, g_no_prof, false, nullptr, xl ? atoi(xl) != 0 : true);
     dc2_enqueue_votes(nullptr, B, copies, n, method, (float)p->outlier_flow_tolerance, (float)p->outlier_disp_tolerance);
     if (ranges) vsm_dc2_launch_prior(nullptr, B.d_jobs, copies, method, p->match_binsize, p->match_radius, w, hh, ub, vb);
     (void)hipEventRecord(e1, nullptr);

@@ -1257,10 +1257,17 @@ __global__ void __launch_bounds__(1024) k_dc2_prepare_lds(const VsmDc2Job *__res
   const VsmDc2Job jb = jobs[blockIdx.x];
   const int t = threadIdx.x, nwaves = (int)blockDim.x >> 6;
   const int32_t nl = *jb.count;
-  // a list of a launch that may hold longer ones (the host only knows the query counts) is left to k_dc2_prepare_long,
-  // launched right behind this kernel for exactly those lists (inlined here the long lists' forms cost the short ones
-  // their registers)
-  if (big_too && nl > cap2) return;
+  // A list of a launch that may hold longer ones (the host only knows the query counts).  big_too 2: left to
+  // k_dc2_prepare_long, launched right behind this kernel for exactly those lists with every thread at work (inlined here
+  // those forms cost the short lists their registers) - where long lists are expected (vsm_dc2_launch_prepare); big_too 1:
+  // the odd long list of a launch of short ones takes the narrow global-memory form here, on this kernel's LDS (the launch is
+  // KD_THREADS wide and 128 KB deep then), and tells the host (the launches after it bring the other kernel along).
+  if (big_too == 2 && nl > cap2) return;
+  if (big_too && nl > cap2) {
+    if (threadIdx.x == 0 && jb.long_seen) *jb.long_seen = 1;
+    dc2_prepare_global<0>(jb, (uint32_t *)dc2_prep_lds, tot);
+    return;
+  }
   int32_t n = min(nl, jb.cap), m = 0;
   if (nl > jb.cap || nl > cap2) {  // (not expected: the host sizes slabs and launches from the query counts)
     if (t == 0) *jb.error = 1;
@@ -2146,7 +2153,7 @@ void vsm_dc2_launch_keys(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int 
   if (njobs <= 0) return;
   hipLaunchKernelGGL(k_dc2_keys, dim3((std::max(max_list, 1) + 255) / 256, njobs), dim3(256), 0, s, d_jobs);
 }
-void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list) {
+void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list, bool expect_long) {
   if (njobs <= 0) return;
 #ifndef DC2_PREP_OLD
   if (max_list > 0) {  // (0: the caller does not know how long the lists are)
@@ -2156,8 +2163,11 @@ void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, i
     while (cap2 < max_list && cap2 < DC2_PREP_LDS) cap2 <<= 1;
     static_assert(DC2_PREP_LDS / 8 == KD_THREADS && 16 * DC2_PREP_LDS >= 4 * KD_DIGITS * KD_CHUNKS, "the long lists of a launch run k_dc2_prepare's body on this kernel's threads and LDS");
     if (cap2 == DC2_PREP_LDS && big8) {  // (max_list counts queries: most lists of such a launch are shorter than 8192 matches, whoever is not takes the first form)
-      hipLaunchKernelGGL(k_dc2_prepare_lds<8>, dim3(njobs), dim3(cap2 / 8), (size_t)16 * cap2, s, d_jobs, cap2, max_list > cap2 ? 1 : 0);
-      if (max_list > cap2) hipLaunchKernelGGL(k_dc2_prepare_long, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs, cap2);
+      // (the second launch costs the chain 26 us in the pipeline - 110 workgroups of sixteen waves that come and go - whether a
+      // list is long or not: only where the counts say that long lists are the rule, or one has been seen)
+      const bool with_long = max_list > cap2 && (expect_long || max_list > 2 * cap2);
+      hipLaunchKernelGGL(k_dc2_prepare_lds<8>, dim3(njobs), dim3(cap2 / 8), (size_t)16 * cap2, s, d_jobs, cap2, with_long ? 2 : (max_list > cap2 ? 1 : 0));
+      if (with_long) hipLaunchKernelGGL(k_dc2_prepare_long, dim3(njobs), dim3(KD_THREADS), 0, s, d_jobs, cap2);
       return;
     }
     if (cap2 < DC2_PREP_LDS && (big4 || 16 * cap2 <= 64 * 1024)) {

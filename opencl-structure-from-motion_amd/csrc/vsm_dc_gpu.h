@@ -103,11 +103,12 @@ struct VsmDc2Job {
   int32_t *h_out_count;     // host-mapped, or null
   float *ranges;            // pass 1: the pair's prior boxes [ub*vb][16], device layout (k_dc2_prior)
   int32_t *error;           // host-mapped flag word: set when a pair cannot be handled on the device
+  int32_t *long_seen;       // host-mapped, or null: set when a list beyond the LDS forms went through the narrow form inside k_dc2_prepare_lds
   uint32_t *h_keep;         // host-mapped, or null: [ceil(cap / 32)] survivor bits - the list itself is on the host already (DMA copy behind the
                             // refinement, while the triangulation runs), k_dc2_compact only says which of its matches stay
 };
 void vsm_dc2_launch_keys(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list);
-void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list = 0);  // max_list: upper bound of the list lengths (0 = unknown)
+void vsm_dc2_launch_prepare(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int max_list = 0, bool expect_long = true);  // max_list: upper bound of the list lengths (0 = unknown); expect_long: lists beyond the LDS forms' 8192 points are likely (their own kernel comes along)
 void vsm_dc2_launch_blocks(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth);
 void vsm_dc2_launch_merges(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int depth, int max_list);  // levels depth-1 .. 0
 void vsm_dc2_launch_ties(hipStream_t s, const VsmDc2Job *d_jobs, int njobs, int32_t *tie_out, int out_stride, int max_list = 0);  // max_list: upper bound of the list lengths (0 = unknown)

@@ -1221,10 +1221,12 @@ def test_device_chain_merge_nodes_that_overflow_their_band(vm, B):
         vm.lib().vsm_debug_dc2_band_factor(-1)
 
 
-def test_device_chain_at_the_capacity_steps_of_its_lds_kernels(vm, B):
+def test_device_chain_at_the_capacity_steps_of_its_lds_kernels(vm, B, monkeypatch):
     """the LDS preparation kernel (sort, duplicates, kd order) is launched with a power-of-two capacity and capacity / 4 or / 8
     threads, the chain's last kernel keeps its tables in LDS up to 12288 matches: list lengths on both sides of every step,
-    heavy duplicates included - survivors against the oracle's removeOutliers, prior boxes against the host code"""
+    heavy duplicates included - survivors against the oracle's removeOutliers, prior boxes against the host code.  Lists beyond
+    8192 matches both ways: their own kernel (every thread at work), and the narrow form inside the LDS kernel that a handle
+    uses until it has met such a list (VSM_DC2_EXPECT_LONG=0)"""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("dc2_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dc2_check.py"))
@@ -1241,6 +1243,11 @@ def test_device_chain_at_the_capacity_steps_of_its_lds_kernels(vm, B):
                     continue
                 gs, gr, _ = vm.remove_outliers(lst, 2, 1242, 375, gpu=True, gpu_ties=gt, copies=3)
                 assert _same(want, gs) and np.array_equal(hr, gr), (n, grid, gt, len(want), len(gs))
+            if n > 8192:
+                monkeypatch.setenv("VSM_DC2_EXPECT_LONG", "0")
+                gs, gr, _ = vm.remove_outliers(lst, 2, 1242, 375, gpu=True, gpu_ties=False, copies=3)
+                monkeypatch.delenv("VSM_DC2_EXPECT_LONG")
+                assert _same(want, gs) and np.array_equal(hr, gr), (n, grid, "narrow", len(want), len(gs))
 
 
 @pytest.mark.parametrize("form", ["host-shared", "GPU-resident"])
