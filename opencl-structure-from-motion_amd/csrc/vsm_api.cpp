@@ -699,7 +699,8 @@ vsm_handle *vsm_create(const vsm_params *p) {
     // (the look-ahead caller sleeps in a blocking event wait while the GPU works, so all nt budgeted
     // CPUs go to pool workers: nt workers + the caller's thread)
     h->pool = new VsmPool(nt + 1);
-    const int fjt = nt < 8 ? nt : 8;
+    int fjt = nt < 8 ? nt : 8;
+    if (const char *e = getenv("VSM_FJ_THREADS")) fjt = std::max(1, std::min(atoi(e), nt));  // (measurements: the fork-join pool of the per-frame path's Delaunay)
     h->fj = new VsmForkJoin(fjt);
     h->work.pool = h->fj;
     h->work.async = h->pool;
