@@ -23,6 +23,14 @@ NAMES = {"k_match<2, false>": "k_match<16>:pass2", "k_match<4, false>": "k_match
          "k_dc2_ties": "k_dc_vertex_sort", "k_dc2_support": "k_dc_support", "k_dc2_support_lds": "k_dc_support", "k_dc2_export": "k_export_list", "k_dc2_compact": "k_dc_compact", "k_dc2_prior": "k_dc_prior"}
 
 
+def bench_name(k):
+    import re
+    m = re.match(r"k_match<\d+, (false|true)", k)  # (k_match<G, BYBIN, HEADS>)
+    if m:
+        return "k_match<16>:pass1" if m.group(1) == "true" else "k_match<16>:pass2"
+    return NAMES.get(k, k)
+
+
 def agg(path, counter):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -41,5 +49,5 @@ with open(sys.argv[3], "w", newline="") as o:
         if k.startswith("__amd"):
             continue
         a, b = f.get(k, (0, 0)), w.get(k, (0, 0))
-        wr.writerow([k, NAMES.get(k, k), f"{a[0]:.2f}", f"{b[0]:.2f}", a[1], f"{(2 * a[0] + b[0]) * 1024:.0f}"])
+        wr.writerow([k, bench_name(k), f"{a[0]:.2f}", f"{b[0]:.2f}", a[1], f"{(2 * a[0] + b[0]) * 1024:.0f}"])
 print("wrote", sys.argv[3])
