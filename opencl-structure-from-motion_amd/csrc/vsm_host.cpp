@@ -155,6 +155,7 @@ int vsm_affinity_cpus(int *out, int cap) {  // the CPUs the threads of the devic
 
 VsmPool::VsmPool(int threads) : nthreads_(threads < 1 ? 1 : threads), aff_(vsm_affinity_current()) {
   spin_us_ = 100;  // millisecond-sized tasks: a wake-up is cheap next to them, spinning burns quota
+  if (const char *e = getenv("VSM_POOL_SPIN_US")) spin_us_ = std::max(0, atoi(e));  // (measurements)
   for (int i = 1; i < nthreads_; i++) threads_.emplace_back([this] { worker(); });
 }
 
