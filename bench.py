@@ -498,7 +498,10 @@ def main():
         stats[dom] = dom_only
         roof = roofline_of(dom)
         stats[dom] = stats_dom_all
-        roof["measured"] = "HIP events around this kernel's launches only, on its stream, in the pipeline of the timed call (3 calls)"
+        roof["measured"] = ("HIP events around this kernel's launches only, on its stream, in the pipeline of the timed call (3 calls); since round 5 "
+                            "the first chunk's block kernel (1760 workgroups that fill every compute unit) starts beside the second chunk's "
+                            "launch of this kernel instead of behind another launch: the call is 5 % shorter and this launch ~70 us longer "
+                            "(option seq_block_after_p2 = 1 separates the two again: profiles/r05_lookahead_bench_block_after_p2.json)")
         roof["with_every_kernel_profiled"] = every
     if roof is not None:
         roof["traffic_source"] = pmc_src
