@@ -301,14 +301,18 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
                                  {"opt:front": "0"}, {"opt:seq_p2_first": "1"}, {"opt:seq_p2_first": "0", "VSM_HOST_THREADS": "6"},
                                  {"opt:seq_p2_first": "1", "opt:seq_first_chunk": "4"}, {"opt:seq_keys_dma": "0", "opt:seq_export_budget": "0"},
                                  {"opt:seq_ties1_null": "0", "opt:seq_last_first": "0", "opt:seq_export_budget": "5"},
-                                 {"opt:match_heads": "1"}, {"opt:match_heads": "1", "opt:feat_order": "0", "VSM_SEQ_CHUNK": "7"}])
+                                 {"opt:match_heads": "1"}, {"opt:match_heads": "1", "opt:feat_order": "0", "VSM_SEQ_CHUNK": "7"},
+                                 {"opt:seq_keys_dma": "1", "opt:seq_keys_pieces": "1"}, {"opt:seq_keys_dma": "2", "opt:seq_keys_pieces": "3", "VSM_SEQ_CHUNK": "19"},
+                                 {"opt:seq_keys_dma": "0"}, {"opt:seq_block_after_p2": "1"}, {"opt:seq_block_after_p2": "1", "VSM_SEQ_CHUNK": "19"},
+                                 {"VSM_POLL_SPIN": "1", "VSM_HOST_THREADS": "3"}, {"VSM_POLL_SPIN": "0"}])
 def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), both ways of
     result delivery at both ends of the pool size, one / four chain streams (eight chunks of five, twenty of two: every bank
     comes round), the vertex sorts on the device (one launch for the chunks that wait for it, also where a slab comes round
     before the call's last head; two-chunk calls of ranks with few host threads: a launch per chunk, the pool sizes' own shares), the unfused front end, the
     separate filter / suppression / record / bin kernels instead of the fused tiles, a fifth stream of the library's own instead of the null stream, the scheduling choices of DESIGN_HISTORY.md 6c either way,
-    the second pass on per-bin head records (k_feat_heads; measured slower, off by default): always
+    the second pass on per-bin head records (k_feat_heads; measured slower, off by default), the keys' copy on either stream and
+    in one / three / four pieces, a chunk's block kernel behind the next chunk's second pass, the poller sleeping or yielding: always
     the reference's lists, and always this form (it must not quietly hand the run to the other one)."""
     import torch
     monkeypatch.setenv("VSM_SEQ_V2", "1")
