@@ -1495,6 +1495,9 @@ __device__ __forceinline__ VsmQuery load_query(const VsmSet &A, int i) {
 #ifndef VSM_STEREO_BY_BIN
 #define VSM_STEREO_BY_BIN 1  // the stereo-type stages (window = a few rows x the disparity range: 2-3 bins, a few candidates each) scan by bin also under prior boxes: -3.5 %
 #endif
+#ifndef VSM_MATCH_BALANCE
+#define VSM_MATCH_BALANCE 0  // passes in which the lanes of a group even out their parked candidates before judging.  MEASURED with 2: judge rounds per wave 20.1 -> 16.6, time unchanged (alone 224-228 us either way) - what bounds the kernel is not a wave's row of round trips but the number of lane accesses its compute unit's texture addresser takes (2.9 M vector loads x 64 scattered lanes per launch: ~730 k per CU in 470 k cycles), and evening the queues out moves none of them: off
+#endif
 #ifndef VSM_SCAN_UNALIGNED
 #define VSM_SCAN_UNALIGNED 1  // coordinate loads start at the run's first candidate (dword-aligned 16-byte loads) instead of at the 16-byte line below it
 #endif
@@ -1782,6 +1785,35 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
       VSM_MT_TRIP(8);
       if (!__any(mt_maxrun > 7)) VSM_MT_TRIP(9);
       if (!__any(mt_maxrun > 15)) VSM_MT_TRIP(10);
+    }
+  }
+#endif
+#if VSM_MATCH_BALANCE
+  // The wave judges as many rounds as its busiest lane has parked candidates (a descriptor fetch each: a round trip), and
+  // who judges a candidate does not matter - the group's minimum of (cost, rank) is taken below.  So the lanes of a group
+  // even their queues out first: a lane with two candidates more than its partner hands its newest one over.
+  if (G >= 2) {
+#pragma unroll
+    for (int rep = 0; rep < VSM_MATCH_BALANCE; rep++) {
+#pragma unroll
+      for (int m = 1; m < G; m <<= 1) {
+        const int onq = __shfl_xor(nq, m, G);
+        const int sent = __shfl_xor(q0p, m, G);
+        const bool give = nq > onq + 1, take = onq > nq + 1;
+        if (give) {
+          q0p = q1p;
+          q1p = q2p;
+          q2p = q3p;
+          nq--;
+        }
+        if (take) {
+          q3p = q2p;
+          q2p = q1p;
+          q1p = q0p;
+          q0p = sent;
+          nq++;
+        }
+      }
     }
   }
 #endif
