@@ -1849,7 +1849,9 @@ __device__ __forceinline__ uint32_t find_match(VsmQuery &q, const VsmSet &B, con
     return VSM_NONE;
   }
   // every lane of the group fetches the winner's record (just touched, so it is in cache; handing it over from the lane
-  // that judged it costs 20 registers and was measured 3 % quicker on pass 2, 15 % slower on pass 1)
+  // that judged it costs 20 registers and was measured 3 % quicker on pass 2, 15 % slower on pass 1; fetched by ONE lane and
+  // passed on in nine shuffles - round 5 - 251 against 226 us alone: the shuffles and 32 bytes of spills cost more than the
+  // lane accesses they save)
   q.uv = ldg_u32_at(B.s_uv, bestq * 4u);
   q.da = ldg_u4_at(B.s_desc, bestq * 32u);
   q.db = ldg_u4_at(B.s_desc, bestq * 32u + 16u);
