@@ -1496,7 +1496,7 @@ __device__ __forceinline__ VsmQuery load_query(const VsmSet &A, int i) {
 #define VSM_STEREO_BY_BIN 1  // the stereo-type stages (window = a few rows x the disparity range: 2-3 bins, a few candidates each) scan by bin also under prior boxes: -3.5 %
 #endif
 #ifndef VSM_MATCH_BALANCE
-#define VSM_MATCH_BALANCE 0  // passes in which the lanes of a group even out their parked candidates before judging.  MEASURED with 2: judge rounds per wave 20.1 -> 16.6, time unchanged (alone 224-228 us either way) - what bounds the kernel is not a wave's row of round trips but the number of lane accesses its compute unit's texture addresser takes (2.9 M vector loads x 64 scattered lanes per launch: ~730 k per CU in 470 k cycles), and evening the queues out moves none of them: off
+#define VSM_MATCH_BALANCE 0  // passes in which the lanes of a group even out their parked candidates before judging.  MEASURED with 2: judge rounds per wave 20.1 -> 16.6, time unchanged (alone 224-228 us either way): a wave's row of round trips is not what bounds the kernel - off
 #endif
 #ifndef VSM_SCAN_UNALIGNED
 #define VSM_SCAN_UNALIGNED 1  // coordinate loads start at the run's first candidate (dword-aligned 16-byte loads) instead of at the 16-byte line below it
