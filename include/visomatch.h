@@ -142,7 +142,7 @@ int32_t vsm_sequence_path(vsm_handle *h);
  * fused front end), "dc_gpu", "dc_full", "dc_watchdog_ms", "dc_fault_inject" (the GPU's share of the final stage in the
  * host-shared form), and the scheduling experiments of the GPU-resident form recorded in DESIGN_HISTORY.md 6c:
  * "seq_keys_dma", "seq_keys_pieces", "seq_ties1_null", "seq_ties1_host", "seq_last_first", "seq_export_budget", "seq_first_chunk",
- * "seq_p2_first", "seq_block_after_p2" (DESIGN.md 5, 9);
+ * "seq_p2_first", "seq_block_after_p2", "seq_warm_gaps" (DESIGN.md 5, 9);
  * "seq_null_stream" (above); "seq_host_pinned" (below, vsm_host_register); "seq_host_inorder" (0: host-resident frames in the
  * run-ahead order of resident input instead of chunk by chunk as they arrive); "match_heads" (1, before the first image: the
  * second matching pass on 64-byte per-bin head records - measured slower); "fused_features" / "feat_order" (0: the separate filter, suppression, record and bin kernels

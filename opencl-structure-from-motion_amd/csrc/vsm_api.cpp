@@ -515,6 +515,7 @@ struct VsmSwitches {
   int seq_keys_dma = -1;     // GPU-resident form: the keys reach the host's vertex sort by a DMA copy - 2: on the fifth stream behind an event, so that the chunk's mesh does not stand behind 6-8 MB crossing PCIe (ranks with ten pool threads and more, where the last mesh bounds the call: median step 3.90 -> 3.83 ms); 1: on the chain's own stream (fewer threads: the pool bounds the call and wants its keys first - 4.88 against 5.01 ms with eight threads, 6.71 against 7.14 with four) - or by the key kernel's own stores into host-mapped memory (0); -1: by pool size
   int seq_ties1_null = 1;    // ... the pass-1 chain's vertex sort (one wave per list) on the null stream (1) or on side stream cs[k + 2] (0)
   int seq_keys_pieces = 0;   // ... in this many pieces, an event behind each (the pool starts on the first lists while the others cross); 0: four with ten pool threads and more, else one
+  int seq_warm_gaps = 1;     // ... the pool reads the last chunk's exported lists into its L3 caches while it waits for their survivor bits, and a list's gaps are closed by a thread of the domain that read it
   int seq_ties1_host = -1;   // ... the pass-1 lists' vertex sorts on the pool while the device triangulates (1) or on the device, one wave per list (0); -1: by pool size
   int seq_block_after_p2 = 0;  // ... a chunk's block kernel waits for the next chunk's second matching pass
   int seq_last_first = 1;    // ... a chain's sort + kd order kernel goes in with its head, and the block kernel of the last chunk but one waits for the last chunk's
@@ -562,6 +563,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "seq_keys_pieces")) seq_keys_pieces = v;
     else if (!strcmp(name, "seq_block_after_p2")) seq_block_after_p2 = v != 0;
     else if (!strcmp(name, "seq_ties1_host")) seq_ties1_host = v;
+    else if (!strcmp(name, "seq_warm_gaps")) seq_warm_gaps = v != 0;
     else if (!strcmp(name, "seq_ties1_null")) seq_ties1_null = v != 0;
     else if (!strcmp(name, "seq_null_stream")) seq_null_stream = v != 0;
     else if (!strcmp(name, "seq_host_pinned")) seq_host_pinned = v != 0;

@@ -135,12 +135,16 @@ void vsm_affinity_from_device(const char *pci_bus_id) {
   }
 }
 void *vsm_affinity_current() { return t_aff; }
+static thread_local int t_domain = -1;
 void vsm_pin_this_thread(void *aff) {
   VsmAffinity *A = aff ? (VsmAffinity *)aff : t_aff;
   if (!A || !A->any || A->order.empty()) return;
-  const cpu_set_t &dom = A->order[A->next.fetch_add(1, std::memory_order_relaxed) % A->order.size()];
+  const unsigned at = A->next.fetch_add(1, std::memory_order_relaxed) % A->order.size();
+  const cpu_set_t &dom = A->order[at];
   (void)pthread_setaffinity_np(pthread_self(), sizeof(dom), &dom);
+  t_domain = (int)at;
 }
+int vsm_thread_domain() { return t_domain; }
 int vsm_affinity_cpus(int *out, int cap) {  // the CPUs the threads of the device looked up last are confined to (their union)
   VsmAffinity *A = g_aff_last.load();
   if (!A || !A->any) return 0;

@@ -32,6 +32,7 @@ int vsm_host_tiny_table(uint32_t *out, int cap);
 void vsm_affinity_from_device(const char *pci_bus_id);  // "0000:0d:00.0" (hipDeviceGetPCIBusId); makes that device's record the calling thread's current one
 void *vsm_affinity_current();                           // the calling thread's current record (what pools created now will pin their workers by)
 void vsm_pin_this_thread(void *affinity = nullptr);     // nullptr: the calling thread's current record
+int vsm_thread_domain();                                // the L3 domain (index in the pin sequence) this thread was pinned to, or -1
 int vsm_affinity_cpus(int *out, int cap);  // the CPUs the threads of the device looked up last may use (for the caller who wants its own threads there too); returns how many
 
 // Small task pool for the host stages (Delaunay sub-problems / frame pairs are independent).

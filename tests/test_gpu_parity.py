@@ -305,7 +305,7 @@ def test_sequence_api_golden_feedback_and_device_inputs(vm, synth, monkeypatch, 
                                  {"opt:seq_keys_dma": "1", "opt:seq_keys_pieces": "1"}, {"opt:seq_keys_dma": "2", "opt:seq_keys_pieces": "3", "VSM_SEQ_CHUNK": "19"},
                                  {"opt:seq_keys_dma": "0"}, {"opt:seq_block_after_p2": "1"}, {"opt:seq_block_after_p2": "1", "VSM_SEQ_CHUNK": "19"},
                                  {"VSM_POLL_SPIN": "1", "VSM_HOST_THREADS": "3"}, {"VSM_POLL_SPIN": "0"},
-                                 {"opt:seq_ties1_host": "0"}, {"opt:seq_ties1_host": "1", "VSM_HOST_THREADS": "2", "VSM_SEQ_CHUNK": "7"},
+                                 {"opt:seq_ties1_host": "0"}, {"opt:seq_warm_gaps": "0"}, {"opt:seq_warm_gaps": "1", "VSM_HOST_THREADS": "12", "VSM_SEQ_CHUNK": "9"}, {"opt:seq_ties1_host": "1", "VSM_HOST_THREADS": "2", "VSM_SEQ_CHUNK": "7"},
                                  {"opt:seq_ties1_host": "1", "opt:seq_p2_first": "1", "VSM_SEQ_CHUNK": "5"}])
 def test_gpu_resident_form_switches(vm, synth, monkeypatch, env):
     """The GPU-resident look-ahead form under its switches - nothing overlapping (the bench's `alone` pass), both ways of
