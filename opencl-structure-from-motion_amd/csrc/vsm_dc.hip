@@ -1681,6 +1681,9 @@ __global__ void __launch_bounds__(DC2_BLOCK_THREADS, DC2_BLOCK_OCC) k_dc2_block(
 #ifndef DC2_MERGE_THREADS
 #define DC2_MERGE_THREADS 256
 #endif
+#ifndef DC2_BAND_BATCH
+#define DC2_BAND_BATCH 8  // independent loads per thread in the band's two streaming passes (extent, reach words)
+#endif
 #ifdef DC2_PHASE_TIMING
 #define DC2_BAND_STAT(level, col, v) atomicAdd(&dc2_dbg[1 + (level)][col], (unsigned long long)(v))
 #else
@@ -1765,14 +1768,25 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
     for (int i = t; i < pwords; i += DC2_MERGE_THREADS) s_pmask[i] = 0;
     __syncthreads();
     {  // extent of the two halves along the cut axis: largest coordinate on the left, smallest on the right
+      // (DC2_BAND_BATCH independent loads in flight per thread: a thread's loads used to wait for each other, 29 round
+      // trips for the 7.4 k points of a top node)
       int32_t cl = -1, cr = 1 << 30;
-      for (int i = t; i < n; i += DC2_MERGE_THREADS) {
-        const uint32_t p = gpt[i];
-        const int32_t c = axis == 0 ? (int32_t)(p & 0xffffu) : (int32_t)(p >> 16);
-        if (i < div)
-          cl = max(cl, c);
-        else
-          cr = min(cr, c);
+      for (int i0 = t; i0 < n; i0 += DC2_BAND_BATCH * DC2_MERGE_THREADS) {
+        uint32_t p[DC2_BAND_BATCH];
+#pragma unroll
+        for (int k = 0; k < DC2_BAND_BATCH; k++) {
+          const int i = i0 + k * DC2_MERGE_THREADS;
+          p[k] = i < n ? gpt[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < DC2_BAND_BATCH; k++) {
+          const int i = i0 + k * DC2_MERGE_THREADS;
+          const int32_t c = axis == 0 ? (int32_t)(p[k] & 0xffffu) : (int32_t)(p[k] >> 16);
+          if (i < div)
+            cl = max(cl, c);
+          else if (i < n)
+            cr = min(cr, c);
+        }
       }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) {
@@ -1787,18 +1801,18 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
     __syncthreads();
     const int32_t cl = s_cl, cr = s_cr;
     // the band's core: own slots, hull triangles, triangles whose circumcircle crosses the cut - one reach word per slot
-    // (above; whoever wrote the record left it there), four independent loads in flight per thread
+    // (above; whoever wrote the record left it there), DC2_BAND_BATCH independent loads in flight per thread
     {
       const int32_t *gw = gnode + (axis == 0 ? 7 : 3);
-      for (int s0 = t; s0 < nslots; s0 += 4 * DC2_MERGE_THREADS) {
-        uint32_t w[4];
+      for (int s0 = t; s0 < nslots; s0 += DC2_BAND_BATCH * DC2_MERGE_THREADS) {
+        uint32_t w[DC2_BAND_BATCH];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < DC2_BAND_BATCH; k++) {
           const int s = s0 + k * DC2_MERGE_THREADS;
           w[k] = s < nslots ? (uint32_t)gw[(size_t)s * 8] : DC2_REACH_NONE;
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < DC2_BAND_BATCH; k++) {
           const int s = s0 + k * DC2_MERGE_THREADS;
           const bool hot = s < nslots && (s == 2 * div - 2 || s == 2 * div - 1 || dc2_reaches(w[k], s < 2 * div, cl, cr));
           if (hot) atomicOr(&s_band[s >> 5], 1u << (s & 31));
@@ -1806,16 +1820,31 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
       }
     }
     __syncthreads();
-    // ... and the neighbours of the core
-    for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
-      if (!dc2_bit(s_band, s)) continue;
-      const dc2_v4i e = grec[2 * s];
-      const int32_t nb[3] = {e.x, e.y, e.z};
+    // ... and the neighbours of the core.  (The loops below used to test one slot per thread and round and load its record
+    // where the bit was set: some lane of a wave always had one, so every one of the 58 rounds of a top node waited for a
+    // round trip of its own.  Now: DC2_BAND_BATCH slots per round with their loads requested together - a cold lane reads
+    // the node's own first new slot, one line for all of them -, and once the band is numbered the passes run over its
+    // lines, two or three rounds.)
+    const int s_own = 2 * div - 2;
+    for (int s0 = t; s0 < nslots; s0 += DC2_BAND_BATCH * DC2_MERGE_THREADS) {
+      dc2_v4i e[DC2_BAND_BATCH];
+      bool hot[DC2_BAND_BATCH];
 #pragma unroll
-      for (int o = 0; o < 3; o++) {
-        if (nb[o] < 0) continue;
-        const int s2 = (nb[o] - tbase4) >> 2;
-        if (s2 >= 0 && s2 < nslots) atomicOr(&s_ring[s2 >> 5], 1u << (s2 & 31));
+      for (int k = 0; k < DC2_BAND_BATCH; k++) {
+        const int s = s0 + k * DC2_MERGE_THREADS;
+        hot[k] = s < nslots && dc2_bit(s_band, s);
+        e[k] = grec[2 * (hot[k] ? s : s_own)];
+      }
+#pragma unroll
+      for (int k = 0; k < DC2_BAND_BATCH; k++) {
+        if (!hot[k]) continue;
+        const int32_t nb[3] = {e[k].x, e[k].y, e[k].z};
+#pragma unroll
+        for (int o = 0; o < 3; o++) {
+          if (nb[o] < 0) continue;
+          const int s2 = (nb[o] - tbase4) >> 2;
+          if (s2 >= 0 && s2 < nslots) atomicOr(&s_ring[s2 >> 5], 1u << (s2 & 31));
+        }
       }
     }
     __syncthreads();
@@ -1825,43 +1854,76 @@ __global__ void __launch_bounds__(DC2_MERGE_THREADS) k_dc2_merge(const VsmDc2Job
     uint32_t npts = 0;
     band_ok = nlines + 1 <= (uint32_t)lines_cap;  // (+ the trap record)
     if (band_ok) {
+      // line -> slot (LDS only)
+      for (int s = t; s < nslots; s += DC2_MERGE_THREADS)
+        if (dc2_bit(s_band, s)) s_l2s[dc2_rank(s_band, s_bpre, s)] = (uint32_t)s;
+      __syncthreads();
       // the points the band's records use
-      for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
-        if (!dc2_bit(s_band, s)) continue;
-        const dc2_v4i v = grec[2 * s + 1];
-        const int32_t vv[3] = {v.x, v.y, v.z};
+      for (uint32_t k0 = t; k0 < nlines; k0 += 3 * DC2_MERGE_THREADS) {
+        dc2_v4i v[3];
 #pragma unroll
-        for (int o = 0; o < 3; o++)
-          if (vv[o] >= 0) atomicOr(&s_pmask[(vv[o] - off) >> 5], 1u << ((vv[o] - off) & 31));
+        for (int k = 0; k < 3; k++) {
+          const uint32_t ln = k0 + k * DC2_MERGE_THREADS;
+          v[k] = grec[2 * (ln < nlines ? (int)s_l2s[ln] : s_own) + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          if (k0 + k * DC2_MERGE_THREADS >= nlines) continue;
+          const int32_t vv[3] = {v[k].x, v[k].y, v[k].z};
+#pragma unroll
+          for (int o = 0; o < 3; o++)
+            if (vv[o] >= 0) atomicOr(&s_pmask[(vv[o] - off) >> 5], 1u << ((vv[o] - off) & 31));
+        }
       }
       __syncthreads();
       npts = dc2_mask_prefix(s_pmask, s_ppre, pwords, s_tot);
       band_ok = npts <= (uint32_t)pts_cap;
       if (band_ok) {
-        for (int i = t; i < n; i += DC2_MERGE_THREADS)
-          if (dc2_bit(s_pmask, i)) {
-            const int c = dc2_rank(s_pmask, s_ppre, i);
-            s_pt[c] = gpt[i];
-            s_c2p[c] = (uint32_t)i;
+        for (int i0 = t; i0 < n; i0 += DC2_BAND_BATCH * DC2_MERGE_THREADS) {
+          uint32_t p[DC2_BAND_BATCH];
+#pragma unroll
+          for (int k = 0; k < DC2_BAND_BATCH; k++) {
+            const int i = i0 + k * DC2_MERGE_THREADS;
+            p[k] = gpt[i < n ? i : 0];
           }
-        for (int s = t; s < nslots; s += DC2_MERGE_THREADS) {
-          if (!dc2_bit(s_band, s)) continue;
-          const int line = dc2_rank(s_band, s_bpre, s);
-          const dc2_v4i e = grec[2 * s], v = grec[2 * s + 1];
-          auto nbw = [&](int32_t g) -> uint32_t {  // neighbour handle under the band's numbering; none / not in the band: the trap
-            if (g < 0) return 4 * nlines;
-            const int s2 = (g - tbase4) >> 2;
-            if (s2 < 0 || s2 >= nslots || !dc2_bit(s_band, s2)) return 4 * nlines;
-            return (uint32_t)(dc2_rank(s_band, s_bpre, s2) * 4 + (g & 3));
-          };
-          auto vxw = [&](int32_t g) -> uint32_t { return g < 0 ? 0xffffu : (uint32_t)dc2_rank(s_pmask, s_ppre, g - off); };
-          dc2_v4u o;  // edge words: neighbour | apex << 16 per edge
-          o.x = nbw(e.x) | (vxw(v.x) << 16);
-          o.y = nbw(e.y) | (vxw(v.y) << 16);
-          o.z = nbw(e.z) | (vxw(v.z) << 16);
-          o.w = 0xffffffffu;
-          ((dc2_v4u *)s_rec)[line] = o;
-          s_l2s[line] = (uint32_t)s;
+#pragma unroll
+          for (int k = 0; k < DC2_BAND_BATCH; k++) {
+            const int i = i0 + k * DC2_MERGE_THREADS;
+            if (i < n && dc2_bit(s_pmask, i)) {
+              const int c = dc2_rank(s_pmask, s_ppre, i);
+              s_pt[c] = p[k];
+              s_c2p[c] = (uint32_t)i;
+            }
+          }
+        }
+        for (uint32_t k0 = t; k0 < nlines; k0 += 3 * DC2_MERGE_THREADS) {
+          dc2_v4i e3[3], v3[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const uint32_t ln = k0 + k * DC2_MERGE_THREADS;
+            const int s = ln < nlines ? (int)s_l2s[ln] : s_own;
+            e3[k] = grec[2 * s];
+            v3[k] = grec[2 * s + 1];
+          }
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const uint32_t line = k0 + k * DC2_MERGE_THREADS;
+            if (line >= nlines) continue;
+            const dc2_v4i e = e3[k], v = v3[k];
+            auto nbw = [&](int32_t g) -> uint32_t {  // neighbour handle under the band's numbering; none / not in the band: the trap
+              if (g < 0) return 4 * nlines;
+              const int s2 = (g - tbase4) >> 2;
+              if (s2 < 0 || s2 >= nslots || !dc2_bit(s_band, s2)) return 4 * nlines;
+              return (uint32_t)(dc2_rank(s_band, s_bpre, s2) * 4 + (g & 3));
+            };
+            auto vxw = [&](int32_t g) -> uint32_t { return g < 0 ? 0xffffu : (uint32_t)dc2_rank(s_pmask, s_ppre, g - off); };
+            dc2_v4u o;  // edge words: neighbour | apex << 16 per edge
+            o.x = nbw(e.x) | (vxw(v.x) << 16);
+            o.y = nbw(e.y) | (vxw(v.y) << 16);
+            o.z = nbw(e.z) | (vxw(v.z) << 16);
+            o.w = 0xffffffffu;
+            ((dc2_v4u *)s_rec)[line] = o;
+          }
         }
       }
     }
