@@ -217,6 +217,22 @@ def main():
         if collect is not None:
             collect.extend(m.sequence_matches(f) for f in range(nf))
 
+    import contextlib
+
+    @contextlib.contextmanager
+    def beside_forkjoin():
+        """The per-frame legs' calling thread inside the L3 domain of the library's fork-join threads (vsm_forkjoin_cpus,
+        include/visomatch.h): it takes part in the one triangulation of every matchFeatures, and from another core complex every
+        record it touches crosses between complexes.  Restored afterwards: the look-ahead legs want the whole node."""
+        before = os.sched_getaffinity(0)
+        dom = set(vm.forkjoin_cpus()) & before
+        if dom and os.environ.get("VSM_BENCH_PIN_CALLER", "1") != "0":
+            os.sched_setaffinity(0, dom)
+        try:
+            yield sorted(dom)
+        finally:
+            os.sched_setaffinity(0, before)
+
     dmod = dist if world > 1 else None
 
     # (rounds 3-4 let 30 calls pass here: once per process one call took 10-13 ms.  Its cause - the runtime creating a hardware
@@ -256,14 +272,16 @@ def main():
 
     # ---- the same sequence through the per-frame (drop-in) entry points ---------------------
     per_frame_value = None
+    caller_cpus = None
     if not args.no_per_frame:
-        run_frames()
-        shard.barrier(dmod, comm_dev)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_frames()
-        torch.cuda.synchronize()
-        pf_elapsed = time.perf_counter() - t1
+        with beside_forkjoin() as caller_cpus:
+            run_frames()
+            shard.barrier(dmod, comm_dev)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_frames()
+            torch.cuda.synchronize()
+            pf_elapsed = time.perf_counter() - t1
         pf_pairs, pf_elapsed, _ = shard.aggregate(dmod, torch, nf, pf_elapsed, comm_dev)
         per_frame_value = pf_pairs / pf_elapsed
 
@@ -279,9 +297,10 @@ def main():
             dt = time.perf_counter() - t
             vo.close()
             return dt, np.array(trail)
-        run_vo()
-        shard.barrier(dmod, comm_dev)
-        vo_dt, trail = run_vo()
+        with beside_forkjoin():
+            run_vo()
+            shard.barrier(dmod, comm_dev)
+            vo_dt, trail = run_vo()
         vo_pairs, vo_dt, _ = shard.aggregate(dmod, torch, nf, vo_dt, comm_dev)
         vo_value = vo_pairs / vo_dt
         if seed == 1234 and not args.no_verify:
@@ -534,7 +553,7 @@ def main():
                               "(viso/matcher.h:86-100), as Matcher::matchFeatures leaves p_matched_2: the refined lists cross PCIe by DMA as they "
                               "are, the device sends one survivor bit per match behind them, the host pool closes the gaps in "
                               "place - all inside the timed call; vsm_sequence_get_matches copies from there"},
-        "per_frame_api": {"value": round(per_frame_value, 3) if per_frame_value else None, "unit": "frame-pairs/s",
+        "per_frame_api": {"value": round(per_frame_value, 3) if per_frame_value else None, "unit": "frame-pairs/s", "caller_thread_on_cpus": caller_cpus,
                           "what": "same sequence through vsm_push_back_device + vsm_match per frame (drop-in "
                                   "Matcher::pushBack/matchFeatures path)"},
         "vo_process_api": {"value": round(vo_value, 3) if vo_value else None, "unit": "frames/s",

@@ -158,6 +158,13 @@ int vsm_set_option(vsm_handle *h, const char *name, int32_t value);
  * CPUs chosen (up to cap of them in out; the return value is how many there are, 0 = none) so that the caller can put the
  * thread that calls vsm_sequence_run there too, as bench.py does. */
 int32_t vsm_local_cpus(int32_t *out, int32_t cap);
+/* The per-frame calls (vsm_match, vsm_vo_stereo_process) split ONE triangulation - the final Matcher::removeOutliers,
+ * viso/matcher.cpp:1207-1377 - over up to eight fork-join threads that all sit in one L3 domain of that node (they take turns
+ * on one mesh; VSM_FJ_DOMAIN=k: domain k, -1: dealt over the domains).  The caller's thread takes part in that work: this
+ * returns the domain's CPUs, and a caller that confines the thread calling vsm_match to them (sched_setaffinity) saves the
+ * transfers between core complexes - 0.55 -> 0.50-0.52 ms per 1242 x 375 stereo pair; bench.py does for its per-frame legs.
+ * Same conventions as vsm_local_cpus; 0 = no such domain (no node found, affinity off, VSM_FJ_DOMAIN=-1). */
+int32_t vsm_forkjoin_cpus(int32_t *out, int32_t cap);
 /* Host-resident input at the link's rate.  Matcher::pushBack takes pageable host pointers (viso/matcher.cpp:95-181) and so do
  * vsm_push_back / vsm_sequence_run(on_device = 0): pageable memory is gathered into a pinned buffer by the host pool before it
  * can cross PCIe by DMA.  A caller whose images live in a buffer it reuses can page-lock that buffer ONCE

@@ -530,6 +530,7 @@ struct VsmSwitches {
   int match_heads = 0;       // the second matching pass takes a bin's start and its first 15 candidates' coordinates from one 64-byte head record (k_feat_heads) instead of bin starts + coordinate runs: measured slower, off; read when a context is made
   int fused_features = 1;    // filters + suppression of the matching resolution out of one LDS tile (k_feat_dense / k_feat_sparse; default radii) or the separate kernels (0)
   int feat_order = 1;        // feature records + bin-sorted copy by k_feat_scan / k_feat_order (tiles of whole search bins) or by k_scan_cells / k_emit / k_bin_* (0)
+  int frame_early_xy = 1;    // per-frame path: the pass-2 list's pixels cross in front of the list, the host triangulates while the refinement and the export run (vsm_match)
   int filter_planes = 0;     // vsm_push_back keeps f1 / f2 in HBM for vsm_get_filter_responses (the fused tiles write them on the side)
   static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
@@ -573,6 +574,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "fused_features")) fused_features = v != 0;
     else if (!strcmp(name, "filter_planes")) filter_planes = v != 0;
     else if (!strcmp(name, "feat_order")) feat_order = v != 0;
+    else if (!strcmp(name, "frame_early_xy")) frame_early_xy = v != 0;
     else return false;
     return true;
   }
@@ -617,6 +619,10 @@ struct vsm_handle {
   std::vector<float> ranges;
   std::vector<int32_t> pf;
   int capture_stage2 = 0;
+  bool stage3_in_hm = false;     // stage 3 is the ring's host-mapped pass-2 list as exported (vsm_stage_get)
+  uint32_t *xy_host = nullptr, *xy_dev = nullptr;  // the pass-2 list's pixels, x | y << 16, host-mapped (vsm_match: early_xy)
+  size_t xy_cap = 0;
+  hipEvent_t xy_ev = nullptr;
   VsmHostWork work;
   int64_t counters[5] = {0, 0, 0, 0, 0};
   double timings[5] = {0, 0, 0, 0, 0};
@@ -732,6 +738,11 @@ vsm_handle *vsm_create(const vsm_params *p) {
 }
 
 static void reset_ring_state(vsm_handle *h) {
+  if (h->stage3_in_hm && h->ring.hm_lcount && !h->ring.hm_list2.empty()) {  // the ring's host-mapped block is about to go: stage 3 moves out of it
+    const int32_t n = std::max(h->ring.hm_lcount[1], 0);
+    h->stage[3].assign(h->ring.hm_list2[0], h->ring.hm_list2[0] + n);
+  }
+  h->stage3_in_hm = false;
   h->have[0] = h->have[1] = h->right[0] = h->right[1] = false;
   h->f_valid = false;
   h->counts_pending = false;
@@ -749,6 +760,8 @@ void vsm_destroy(vsm_handle *h) {
   ctx_destroy(h->ring);
   ctx_destroy(h->seq);
   if (h->stage_host) (void)hipHostFree(h->stage_host);
+  if (h->xy_host) (void)hipHostFree(h->xy_host);
+  if (h->xy_ev) (void)hipEventDestroy(h->xy_ev);
   for (int k = 0; k < 2; k++) {
     if (h->seq_stage_h[k]) (void)hipHostFree(h->seq_stage_h[k]);
     if (h->seq_stage_d[k]) vsm_dev_free(h->seq_stage_d[k]);
@@ -983,6 +996,27 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
   const int nq2 = job.nq[1];
   vsm_launch_match(h->stream, h->prof, c.d_imgs, c.d_pairs, nullptr, job, 1, c.dims, cfg, nq2);
   h->counters[0] += (int64_t)nq2 * stages;
+  // The final removeOutliers' triangulation only needs the list's pixels (u1c, v1c), and those are final once the list is
+  // compacted (the refinement moves the other three points, viso/matcher.cpp:1544-1577): they cross first, 4 bytes per
+  // match, and the host triangulates while the refinement, the list's export and its 350 KB over PCIe are under way; the
+  // support test then reads flow and disparity from the refined list.  (Not with refinement = 2, whose fits drop matches,
+  // nor when the unrefined list is wanted as a stage view.)
+  const bool early_xy = h->sw.frame_early_xy && p.refinement != 2 && !h->capture_stage2 && nq2 > 0;
+  h->stage3_in_hm = false;
+  if (early_xy) {
+    if (h->xy_cap < (size_t)nq2) {
+      if (h->xy_host) (void)hipHostFree(h->xy_host);
+      h->xy_host = nullptr;
+      h->xy_cap = 0;
+      const size_t cap = ((size_t)nq2 + 4095) / 4096 * 4096;
+      HIPCHK(hipHostMalloc((void **)&h->xy_host, cap * sizeof(uint32_t), hipHostMallocMapped));
+      HIPCHK(hipHostGetDevicePointer((void **)&h->xy_dev, h->xy_host, 0));
+      h->xy_cap = cap;
+    }
+    if (!h->xy_ev) HIPCHK(hipEventCreateWithFlags(&h->xy_ev, hipEventDisableTiming));
+    vsm_launch_export_xy(h->stream, c.d_pairs, h->xy_dev, nq2);
+    HIPCHK(hipEventRecord(h->xy_ev, h->stream));
+  }
   // The list size is still on the device: the refinement / export grids are sized for the worst
   // case (every query matched) and surplus threads exit at once.
   if (h->capture_stage2 && p.refinement == 1)  // debug view: keep the unrefined list (raw is free again)
@@ -995,6 +1029,36 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
   const bool fits_on_device = p.refinement == 2 && !h->capture_stage2 && nq2 <= VSM_PARA_MAX_LIST;
   if (fits_on_device) vsm_launch_parabolic_apply(h->stream, c.d_pairs, 1);
   vsm_launch_export(h->stream, h->prof, c.d_pairs, 1, 1, nq2);
+  if (early_xy) {
+    HIPCHK(hipEventSynchronize(h->xy_ev));
+    const int32_t n2 = c.hm_lcount[1];  // (written by the compaction, in front of the pixels)
+    const double tk = now_us();
+    if (n2 > 3) {
+      vsm_host_outliers_begin_xy(h->work, h->xy_host, n2);
+      h->work.del.run(h->work.x.data(), h->work.y.data(), n2, h->work.pool, h->work.async);
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    h->prof.resolve();
+    const vsm_p_match *in = c.hm_list2[0];  // stage 3 is read where the device left it (vsm_stage_get)
+    h->stage3_in_hm = true;
+    h->counters[3] = n2;
+    if (n2 > 3) {
+      vsm_host_outliers_begin_flows(h->work, in, n2, method);
+      vsm_host_outliers_end(h->work, p, in, n2, method, h->stage[4]);
+    } else {
+      h->stage[4].assign(in, in + std::max(n2, 0));  // the reference leaves short lists alone (:1210)
+    }
+    h->matched = h->stage[4];
+    h->counters[4] = (int64_t)h->matched.size();
+    const double t4 = now_us();
+    h->timings[0] = t1 - t0;
+    h->timings[1] = t2 - t1;
+    h->timings[2] = tk - t2;  // until the pixels are on the host
+    h->timings[3] = t4 - tk;
+    h->timings[4] = t4 - t0;
+    return VSM_OK;
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
   const int32_t n2 = c.hm_lcount[1];
@@ -2034,6 +2098,9 @@ int32_t vsm_sequence_get_matches(vsm_handle *h, int32_t frame, vsm_p_match *out,
 void vsm_sequence_get_timings(vsm_handle *h, double *out4) { memcpy(out4, h->seq_timings, sizeof(h->seq_timings)); }
 int32_t vsm_sequence_path(vsm_handle *h) { return h->seq_v2_frames > 0 ? 2 : 1; }
 int32_t vsm_local_cpus(int32_t *out, int32_t cap) { return vsm_affinity_cpus(out, out ? cap : 0); }
+int32_t vsm_forkjoin_cpus(int32_t *out, int32_t cap) {
+  return vsm_forkjoin_domain() < 0 ? 0 : vsm_affinity_domain_cpus(nullptr, vsm_forkjoin_domain(), out, out ? cap : 0);
+}
 
 int vsm_host_register(const void *p, uint64_t bytes) {
   if (!p || bytes == 0) return VSM_EARG;
@@ -2079,13 +2146,19 @@ int32_t vsm_get_features(vsm_handle *h, int32_t which, int32_t *out, int32_t cap
 
 void vsm_set_stage_capture(vsm_handle *h, int on) { h->capture_stage2 = on ? 1 : 0; }
 
-int32_t vsm_stage_size(vsm_handle *h, int32_t s) { return (s >= 0 && s < 5) ? (int32_t)h->stage[s].size() : 0; }
+// (stage 3 of the per-frame path - the refined list in front of the final removeOutliers - stays where the device exported
+// it, in the ring's host-mapped block, until the next vsm_match: no copy of it inside the call)
+int32_t vsm_stage_size(vsm_handle *h, int32_t s) {
+  if (s == 3 && h->stage3_in_hm) return std::max(h->ring.hm_lcount[1], 0);
+  return (s >= 0 && s < 5) ? (int32_t)h->stage[s].size() : 0;
+}
 
 int32_t vsm_stage_get(vsm_handle *h, int32_t s, vsm_p_match *out, int32_t cap) {
   if (s < 0 || s >= 5) return 0;
-  int32_t n = (int32_t)h->stage[s].size();
+  const bool hm = s == 3 && h->stage3_in_hm;
+  int32_t n = hm ? std::max(h->ring.hm_lcount[1], 0) : (int32_t)h->stage[s].size();
   if (n > cap) n = cap;
-  if (n > 0) memcpy(out, h->stage[s].data(), (size_t)n * sizeof(vsm_p_match));
+  if (n > 0) memcpy(out, hm ? h->ring.hm_list2[0] : h->stage[s].data(), (size_t)n * sizeof(vsm_p_match));
   return n;
 }
 

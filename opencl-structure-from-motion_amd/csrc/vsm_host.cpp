@@ -134,7 +134,32 @@ void vsm_affinity_from_device(const char *pci_bus_id) {
     g_aff_last.store(A);
   }
 }
+// One triangulation is split over these threads and its upper merges read what the others have just built: in one L3
+// domain that is a shared-cache hit, across domains a transfer between core complexes.  VSM_FJ_DOMAIN: -1 deals the workers
+// over the domains like the pool's threads (the form up to round 5), k >= 0 (default 0) puts all of them into domain k.
+static int fj_domain() {
+  static const int d = [] {
+    const char *e = getenv("VSM_FJ_DOMAIN");
+    return e ? atoi(e) : 0;
+  }();
+  return d;
+}
+
 void *vsm_affinity_current() { return t_aff; }
+// the CPUs of L3 domain `domain` of the record (where vsm_pin_this_thread_together puts its callers)
+int vsm_affinity_domain_cpus(void *aff, int domain, int *out, int cap) {
+  VsmAffinity *A = aff ? (VsmAffinity *)aff : g_aff_last.load();
+  if (!A || !A->any || A->order.empty()) return 0;
+  const cpu_set_t &dom = A->order[(size_t)domain % A->order.size()];
+  int n = 0;
+  for (int c = 0; c < CPU_SETSIZE; c++)
+    if (CPU_ISSET(c, &dom)) {
+      if (n < cap) out[n] = c;
+      n++;
+    }
+  return n;
+}
+int vsm_forkjoin_domain() { return fj_domain(); }
 static thread_local int t_domain = -1;
 void vsm_pin_this_thread(void *aff) {
   VsmAffinity *A = aff ? (VsmAffinity *)aff : t_aff;
@@ -145,6 +170,14 @@ void vsm_pin_this_thread(void *aff) {
   t_domain = (int)at;
 }
 int vsm_thread_domain() { return t_domain; }
+// every thread that asks lands in ONE L3 domain of the device's node (the fork-join workers: they take turns on one mesh)
+void vsm_pin_this_thread_together(void *aff, int domain) {
+  VsmAffinity *A = aff ? (VsmAffinity *)aff : t_aff;
+  if (!A || !A->any || A->order.empty()) return;
+  const cpu_set_t &dom = A->order[(size_t)domain % A->order.size()];
+  (void)pthread_setaffinity_np(pthread_self(), sizeof(dom), &dom);
+  t_domain = (int)((size_t)domain % A->order.size());
+}
 int vsm_affinity_cpus(int *out, int cap) {  // the CPUs the threads of the device looked up last are confined to (their union)
   VsmAffinity *A = g_aff_last.load();
   if (!A || !A->any) return 0;
@@ -270,6 +303,9 @@ void VsmPool::run(int ntasks, const std::function<void(int)> &fn) {
 // VsmForkJoin: lock-free fork-join for the fine-grained phases inside one Delaunay
 // ---------------------------------------------------------------------------------------
 VsmForkJoin::VsmForkJoin(int threads) : nthreads_(threads < 1 ? 1 : threads), aff_(vsm_affinity_current()) {
+  // (Measured, per-frame matchFeatures(2) at 1242 x 375, tools/frame_timing.py: 578 us with the workers dealt over the
+  // domains, 548 together, 500-520 with the caller's thread inside the domain as well - vsm_forkjoin_cpus() says where that
+  // is.  A caller that only posts and waits while one more worker takes its share: 539 against 539, not kept.)
   for (int i = 1; i < nthreads_; i++) threads_.emplace_back([this] { worker(); });
 }
 
@@ -297,7 +333,10 @@ bool VsmForkJoin::claim(uint64_t g, int n, int &idx) {
 }
 
 void VsmForkJoin::worker() {
-  vsm_pin_this_thread(aff_);
+  if (fj_domain() < 0)
+    vsm_pin_this_thread(aff_);
+  else
+    vsm_pin_this_thread_together(aff_, fj_domain());
   uint64_t seen = 0;
   for (;;) {
     // wait for a new generation: spin first, then block
@@ -1116,6 +1155,27 @@ void vsm_host_outliers_begin(VsmHostWork &w, const vsm_p_match *in, int32_t n, i
     const vsm_p_match &a = in[i];
     w.x[i] = (int32_t)a.u1c;
     w.y[i] = (int32_t)a.v1c;
+    w.fu[i] = a.u1c - a.u1p;
+    w.fv[i] = a.v1c - a.v1p;
+    w.dp[i] = method == 1 ? a.u1c - a.u2c : a.u1p - a.u2p;
+  }
+}
+
+void vsm_host_outliers_begin_xy(VsmHostWork &w, const uint32_t *xy, int32_t n) {
+  w.x.resize(n);
+  w.y.resize(n);
+  for (int32_t i = 0; i < n; i++) {
+    w.x[i] = (int32_t)(xy[i] & 0xffffu);
+    w.y[i] = (int32_t)(xy[i] >> 16);
+  }
+}
+
+void vsm_host_outliers_begin_flows(VsmHostWork &w, const vsm_p_match *in, int32_t n, int method) {
+  w.fu.resize(n);
+  w.fv.resize(n);
+  w.dp.resize(n);
+  for (int32_t i = 0; i < n; i++) {
+    const vsm_p_match &a = in[i];
     w.fu[i] = a.u1c - a.u1p;
     w.fv[i] = a.v1c - a.v1p;
     w.dp[i] = method == 1 ? a.u1c - a.u2c : a.u1p - a.u2p;

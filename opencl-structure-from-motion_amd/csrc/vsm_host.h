@@ -30,8 +30,11 @@
 // entry [GE | LE << n] = eight 3-bit source positions, left << 24, (right + 1) << 28; returns the number of entries (21824)
 int vsm_host_tiny_table(uint32_t *out, int cap);
 void vsm_affinity_from_device(const char *pci_bus_id);  // "0000:0d:00.0" (hipDeviceGetPCIBusId); makes that device's record the calling thread's current one
+int vsm_affinity_domain_cpus(void *affinity, int domain, int *out, int cap);  // CPUs of one L3 domain of the record (nullptr: the device looked up last); returns how many
+int vsm_forkjoin_domain();                               // the L3 domain the fork-join workers share (VSM_FJ_DOMAIN; -1: they are dealt over all)
 void *vsm_affinity_current();                           // the calling thread's current record (what pools created now will pin their workers by)
 void vsm_pin_this_thread(void *affinity = nullptr);     // nullptr: the calling thread's current record
+void vsm_pin_this_thread_together(void *affinity, int domain);  // ... into L3 domain `domain` of the record, whoever asks
 int vsm_thread_domain();                                // the L3 domain (index in the pin sequence) this thread was pinned to, or -1
 int vsm_affinity_cpus(int *out, int cap);  // the CPUs the threads of the device looked up last may use (for the caller who wants its own threads there too); returns how many
 
@@ -269,6 +272,10 @@ void vsm_host_remove_outliers(VsmHostWork &w, const vsm_params &p, std::vector<v
 // the two ends of it, for callers that run the triangulation (w.del) themselves: the per-match
 // arrays (coordinates, flow, disparity), then support counting + survivors
 void vsm_host_outliers_begin(VsmHostWork &w, const vsm_p_match *in, int32_t n, int method);
+// ... in two steps, for a caller that has the list's pixels (x | y << 16 per match) before the list itself: the triangulation
+// (w.del.run on w.x / w.y) can start from the first, the support test waits for the second
+void vsm_host_outliers_begin_xy(VsmHostWork &w, const uint32_t *xy, int32_t n);
+void vsm_host_outliers_begin_flows(VsmHostWork &w, const vsm_p_match *in, int32_t n, int method);
 void vsm_host_count_support(VsmHostWork &w, const vsm_params &p, int32_t n, int method);  // -> w.support, from w.del
 void vsm_host_keep_supported(const vsm_p_match *in, const int32_t *support, int32_t n, std::vector<vsm_p_match> &out);
 void vsm_host_keep_supported(std::vector<vsm_p_match> &list, const int32_t *support);  // in place

@@ -179,6 +179,7 @@ int vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int 
 void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
                       const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq);
 void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair *d_pairs, int npairs, int pass, int n_upper);
+void vsm_launch_export_xy(hipStream_t s, const VsmPair *d_pairs, uint32_t *dst_host_mapped, int n_upper);  // pair 0's pass-2 pixels, x | y << 16
 #define VSM_PARA_MAX_LIST 16384  // matches per pair the batched tail of refinement==2 takes
 void vsm_launch_parabolic_apply(hipStream_t s, const VsmPair *d_pairs, int npairs);
 void vsm_launch_refine(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,

@@ -2201,6 +2201,17 @@ __global__ void __launch_bounds__(256)
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
 
+// the pixel of every match of the compacted pass-2 list as x | y << 16, into host-mapped memory: all the final
+// removeOutliers' triangulation needs of the list ((u1c, v1c), which the refinement leaves alone, viso/matcher.cpp:1544-1577) -
+// the per-frame path's host starts on it while the refinement and the list's export still run
+__global__ void __launch_bounds__(256) k_export_xy(const VsmPair *__restrict__ pairs, uint32_t *__restrict__ dst) {
+  const VsmPair &pair = pairs[0];
+  const int n = pair.count[1];
+  const vsm_p_match *__restrict__ src = pair.list2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    dst[i] = (uint32_t)(int32_t)src[i].u1c | ((uint32_t)(int32_t)src[i].v1c << 16);
+}
+
 // ---------------------------------------------------------------------------------------
 // R1 refinement, viso/matcher.cpp:1498-1585.  One thread per (match, relocation step) evaluates
 // the 25 candidate positions with the 16-byte ELAS descriptor (computeSmallDescriptor, :479-506)
@@ -2901,6 +2912,10 @@ void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair *d_pairs, int n
   hipLaunchKernelGGL(k_export_list, dim3(max(min(cdiv(n_upper * 3, 256), 256), 1), npairs), dim3(256), 0, s, d_pairs,
                      pass);
   pf.end(s);
+}
+
+void vsm_launch_export_xy(hipStream_t s, const VsmPair *d_pairs, uint32_t *dst_host_mapped, int n_upper) {
+  hipLaunchKernelGGL(k_export_xy, dim3(max(min(cdiv(n_upper, 256), 64), 1)), dim3(256), 0, s, d_pairs, dst_host_mapped);
 }
 
 // the batched tail of refinement==2 (behind vsm_launch_refine): fits, dropped matches, the lists closed up again

@@ -34,7 +34,7 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_num_features", "vsm_get_features", "vsm_set_stage_capture", "vsm_stage_size", "vsm_stage_get",
            "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
            "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
-           "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_host_outliers_and_prior", "vsm_debug_dc2", "vsm_debug_dc2_band_factor", "vsm_local_cpus", "vsm_device_pool_stats", "vsm_device_pool_trim", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
+           "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_host_outliers_and_prior", "vsm_debug_dc2", "vsm_debug_dc2_band_factor", "vsm_local_cpus", "vsm_forkjoin_cpus", "vsm_device_pool_stats", "vsm_device_pool_trim", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
            "vsm_sequence_get_timings", "vsm_sequence_path", "vsm_set_option", "vsm_version", "vsm_host_register", "vsm_host_unregister",
            "vsm_multi_create", "vsm_multi_destroy", "vsm_multi_process", "vsm_multi_num_sequences", "vsm_multi_get_motion",
            "vsm_multi_motion_valid", "vsm_multi_num_matches", "vsm_multi_get_matches", "vsm_multi_num_inliers", "vsm_multi_get_inliers",
@@ -156,6 +156,7 @@ def lib():
         L.vsm_debug_dc2.argtypes = [C.POINTER(VsmParams), vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, vp]
         L.vsm_debug_dc2_band_factor.argtypes = [i32]
         L.vsm_local_cpus.argtypes = [vp, i32]
+        L.vsm_forkjoin_cpus.argtypes = [vp, i32]
         L.vsm_debug_dc2_band_factor.restype = None
         L.vsm_sequence_run.argtypes = [vp, vp, vp, C.c_int64, C.c_int, i32, i32, i32, i32, i32, vp, vp]
         L.vsm_sequence_num_matches.argtypes = [vp, i32]
@@ -383,6 +384,14 @@ def local_cpus():
     restriction.  os.sched_setaffinity(0, local_cpus()) puts the calling thread there too."""
     buf = (C.c_int32 * 1024)()
     n = lib().vsm_local_cpus(C.cast(buf, C.c_void_p), 1024)
+    return [int(buf[i]) for i in range(min(n, 1024))]
+
+
+def forkjoin_cpus():
+    """the CPUs of the L3 domain the per-frame path's fork-join threads share (after the first Matcher exists); [] = none.
+    os.sched_setaffinity(0, forkjoin_cpus()) puts the thread that calls match_features / process beside them."""
+    buf = (C.c_int32 * 1024)()
+    n = lib().vsm_forkjoin_cpus(C.cast(buf, C.c_void_p), 1024)
     return [int(buf[i]) for i in range(min(n, 1024))]
 
 

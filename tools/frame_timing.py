@@ -20,6 +20,11 @@ g = np.load(os.path.join(ROOT, "tests", "golden", "cfg4_seq200_tr_8seeds.npz"))
 tr_in, tr_valid = g["s1234_tr_in"], g["s1234_tr_valid"]
 m = vm.Matcher()
 m.set_intrinsics(*[float(x) for x in g["intr"]])
+if os.environ.get("VSM_TOOL_PIN_CALLER"):  # the calling thread into the L3 domain of the fork-join workers
+    dom = vm.forkjoin_cpus()
+    if dom:
+        os.sched_setaffinity(0, dom)
+        print("caller pinned to", dom)
 for rep in range(2):
     T, push, match = [], [], []
     for f in range(nf):
