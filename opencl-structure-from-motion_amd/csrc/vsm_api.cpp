@@ -530,6 +530,7 @@ struct VsmSwitches {
   int match_heads = 0;       // the second matching pass takes a bin's start and its first 15 candidates' coordinates from one 64-byte head record (k_feat_heads) instead of bin starts + coordinate runs: measured slower, off; read when a context is made
   int fused_features = 1;    // filters + suppression of the matching resolution out of one LDS tile (k_feat_dense / k_feat_sparse; default radii) or the separate kernels (0)
   int feat_order = 1;        // feature records + bin-sorted copy by k_feat_scan / k_feat_order (tiles of whole search bins) or by k_scan_cells / k_emit / k_bin_* (0)
+  int multi_host_pass1 = -1; // vsm_multi_process: the first-pass lists' removeOutliers + prior boxes on the host pool (1) or by the device chain (0); -1: host for K <= pool threads
   int frame_early_xy = 1;    // per-frame path: the pass-2 list's pixels cross in front of the list, the host triangulates while the refinement and the export run (vsm_match)
   int filter_planes = 0;     // vsm_push_back keeps f1 / f2 in HBM for vsm_get_filter_responses (the fused tiles write them on the side)
   static int env_int(const char *name, int dflt) {
@@ -575,6 +576,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "filter_planes")) filter_planes = v != 0;
     else if (!strcmp(name, "feat_order")) feat_order = v != 0;
     else if (!strcmp(name, "frame_early_xy")) frame_early_xy = v != 0;
+    else if (!strcmp(name, "multi_host_pass1")) multi_host_pass1 = v;
     else return false;
     return true;
   }
