@@ -531,6 +531,7 @@ struct VsmSwitches {
   int fused_features = 1;    // filters + suppression of the matching resolution out of one LDS tile (k_feat_dense / k_feat_sparse; default radii) or the separate kernels (0)
   int feat_order = 1;        // feature records + bin-sorted copy by k_feat_scan / k_feat_order (tiles of whole search bins) or by k_scan_cells / k_emit / k_bin_* (0)
   int multi_host_pass1 = -1; // vsm_multi_process: the first-pass lists' removeOutliers + prior boxes on the host pool (1) or by the device chain (0); -1: host for K <= pool threads
+  int multi_shared_ego = 0;  // vsm_multi_process: idle pool threads take RANSAC hypotheses of the sequences' egomotion (1: measured, no gain), every sequence on one thread (0)
   int frame_early_xy = 1;    // per-frame path: the pass-2 list's pixels cross in front of the list, the host triangulates while the refinement and the export run (vsm_match)
   int filter_planes = 0;     // vsm_push_back keeps f1 / f2 in HBM for vsm_get_filter_responses (the fused tiles write them on the side)
   static int env_int(const char *name, int dflt) {
@@ -544,6 +545,8 @@ struct VsmSwitches {
     seq_serial = env_int("VSM_SEQ_SERIAL", 0) != 0;
     seq_gpu_sorts = env_int("VSM_SEQ_GPU_SORTS", -1);
     seq_early_export = env_int("VSM_SEQ_EARLY_EXPORT", -1);
+    multi_host_pass1 = env_int("VSM_MULTI_HOST_PASS1", -1);    // (measurements: vsm_multi_create takes no options)
+    multi_shared_ego = env_int("VSM_MULTI_SHARED_EGO", 0);
   }
   bool set(const char *name, int v) {
     if (!strcmp(name, "seq_v2")) seq_v2 = v != 0;
@@ -577,6 +580,7 @@ struct VsmSwitches {
     else if (!strcmp(name, "feat_order")) feat_order = v != 0;
     else if (!strcmp(name, "frame_early_xy")) frame_early_xy = v != 0;
     else if (!strcmp(name, "multi_host_pass1")) multi_host_pass1 = v;
+    else if (!strcmp(name, "multi_shared_ego")) multi_shared_ego = v;
     else return false;
     return true;
   }

@@ -441,10 +441,11 @@ VsmEgoSeq *vsm_ego_seq_create(const vsm_vo_stereo_params *p) {
   return e;
 }
 void vsm_ego_seq_destroy(VsmEgoSeq *e) { delete e; }
-int vsm_ego_seq_step(VsmEgoSeq *e, std::vector<vsm_p_match> &matches, double *T16, bool *valid, std::vector<int32_t> &inliers) {
+int vsm_ego_seq_step(VsmEgoSeq *e, std::vector<vsm_p_match> &matches, double *T16, bool *valid, std::vector<int32_t> &inliers, VsmPool *shared) {
   vsm_host_bucket_with(matches, e->ego.par.bucket_max_features, (float)e->ego.par.bucket_width, (float)e->ego.par.bucket_height, e->rnd);
   double tr[6];
-  const int rc = e->ego.estimate(matches.data(), (int)matches.size(), (VsmForkJoin *)nullptr, tr, inliers);
+  const int rc = shared ? e->ego.estimate(matches.data(), (int)matches.size(), shared, tr, inliers)
+                        : e->ego.estimate(matches.data(), (int)matches.size(), (VsmForkJoin *)nullptr, tr, inliers);
   if (rc != 1) return 0;
   pose_matrix(tr, T16);
   *valid = true;

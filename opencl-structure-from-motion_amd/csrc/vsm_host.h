@@ -323,7 +323,9 @@ void vsm_ego_seq_destroy(VsmEgoSeq *e);
 // VisualOdometryStereo::process behind the matcher (viso/viso_stereo.cpp:37-39, viso/viso.cpp:42-58): bucketFeatures on
 // `matches` (in: getMatches() after matchFeatures, out: the bucketed list), estimateMotion on one thread; on success T16
 // gets the new Tr_delta and *valid becomes true.  Returns 1 / 0 like process().
-int vsm_ego_seq_step(VsmEgoSeq *e, std::vector<vsm_p_match> &matches, double *T16, bool *valid, std::vector<int32_t> &inliers);
+// (shared: the host pool whose idle threads may take a share of this sequence's RANSAC hypotheses - the call itself runs on one
+// of its threads -, or nullptr)
+int vsm_ego_seq_step(VsmEgoSeq *e, std::vector<vsm_p_match> &matches, double *T16, bool *valid, std::vector<int32_t> &inliers, VsmPool *shared = nullptr);
 
 // Matcher::getGain, viso/matcher.cpp:286-324
 float vsm_host_gain(const uint8_t *I1p, const uint8_t *I1c, const int32_t *dims_p, const int32_t *dims_c,
