@@ -628,7 +628,8 @@ struct vsm_handle {
   bool stage3_in_hm = false;     // stage 3 is the ring's host-mapped pass-2 list as exported (vsm_stage_get)
   uint32_t *xy_host = nullptr, *xy_dev = nullptr;  // the pass-2 list's pixels, x | y << 16, host-mapped (vsm_match: early_xy)
   size_t xy_cap = 0;
-  hipEvent_t xy_ev = nullptr;
+  hipEvent_t xy_ev = nullptr, done_ev = nullptr, push_ev = nullptr;
+  bool push_ev_set = false;      // push_ev is recorded behind the pending push (settle)
   VsmHostWork work;
   int64_t counters[5] = {0, 0, 0, 0, 0};
   double timings[5] = {0, 0, 0, 0, 0};
@@ -752,6 +753,7 @@ static void reset_ring_state(vsm_handle *h) {
   h->have[0] = h->have[1] = h->right[0] = h->right[1] = false;
   h->f_valid = false;
   h->counts_pending = false;
+  h->push_ev_set = false;
   memset(h->n_feat, 0, sizeof(h->n_feat));
 }
 
@@ -768,6 +770,8 @@ void vsm_destroy(vsm_handle *h) {
   if (h->stage_host) (void)hipHostFree(h->stage_host);
   if (h->xy_host) (void)hipHostFree(h->xy_host);
   if (h->xy_ev) (void)hipEventDestroy(h->xy_ev);
+  if (h->done_ev) (void)hipEventDestroy(h->done_ev);
+  if (h->push_ev) (void)hipEventDestroy(h->push_ev);
   for (int k = 0; k < 2; k++) {
     if (h->seq_stage_h[k]) (void)hipHostFree(h->seq_stage_h[k]);
     if (h->seq_stage_d[k]) vsm_dev_free(h->seq_stage_d[k]);
@@ -807,7 +811,11 @@ void vsm_set_intrinsics(vsm_handle *h, double f, double cu, double cv, double ba
 // kernels wrote into host-mapped memory
 static int settle(vsm_handle *h) {
   if (!h->counts_pending) return VSM_OK;
-  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->push_ev_set)
+    HIPCHK(hipEventSynchronize(h->push_ev));  // (recorded behind the push's last kernel: cheaper to wait for than the stream)
+  else
+    HIPCHK(hipStreamSynchronize(h->stream));
+  h->push_ev_set = false;
   HIPCHK(hipGetLastError());
   h->prof.resolve();
   const int slot = h->pending_slot;
@@ -880,6 +888,9 @@ static int push_common(vsm_handle *h, const uint8_t *I1, const uint8_t *I2, int3
                                            h->param.multi_stage, h->param.half_resolution, h->param.match_binsize, c.h_imgs.data(),
                                            fused_front ? 1 : 0, (h->sw.fused_features ? 1 : 0) | (h->sw.filter_planes ? 2 : 0) | (h->sw.feat_order ? 0 : 4));
   HIPCHK(hipGetLastError());
+  if (!h->push_ev) HIPCHK(hipEventCreateWithFlags(&h->push_ev, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(h->push_ev, h->stream));
+  h->push_ev_set = true;
   h->have[slot] = true;
   h->right[slot] = (I2 != nullptr);
   h->pending_slot = slot;
@@ -986,16 +997,30 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
     cfg.use_prior = 0;
     vsm_launch_match(h->stream, h->prof, c.d_imgs, c.d_pairs, nullptr, job, 1, c.dims, cfg, job.nq[0]);
     vsm_launch_export(h->stream, h->prof, c.d_pairs, 1, 0, job.nq[0]);
-    HIPCHK(hipStreamSynchronize(h->stream));  // the list was written into host-mapped memory
+    if (!h->done_ev) HIPCHK(hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->done_ev, h->stream));
+    HIPCHK(hipEventSynchronize(h->done_ev));  // the list was written into host-mapped memory
     h->stage[0].assign(c.hm_list1[0], c.hm_list1[0] + c.hm_lcount[0]);
     h->counters[0] += (int64_t)job.nq[0] * stages;
     t1 = now_us();
     h->stage[1] = h->stage[0];
     vsm_host_remove_outliers(h->work, p, h->stage[1], method);
+    const double ta = now_us();
     vsm_host_prior_statistics(p, h->dims_c, h->stage[1], method, h->ranges);
+    const double tb = now_us();
     ranges_to_device_layout(c.h_ranges, h->ranges.data(), h->ranges.size());
     HIPCHK(vsm_upload(h->stream, c.d_ranges, c.h_ranges, h->ranges.size() * sizeof(float)));
     t2 = now_us();
+    if (vsm_debug_timing()) {
+      static double acc[3] = {0, 0, 0};
+      static long calls = 0;
+      acc[0] += ta - t1;
+      acc[1] += tb - ta;
+      acc[2] += t2 - tb;
+      if (++calls % 100 == 0)
+        fprintf(stderr, "  vsm_match pass-1 host stage, mean us: removeOutliers %.1f, prior statistics %.1f, boxes' upload %.1f (lists of %zu)\n",
+                acc[0] / calls, acc[1] / calls, acc[2] / calls, h->stage[0].size());
+    }
   }
   cfg.sparse = 0;
   cfg.use_prior = p.multi_stage ? 1 : 0;
@@ -1036,6 +1061,9 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
   if (fits_on_device) vsm_launch_parabolic_apply(h->stream, c.d_pairs, 1);
   vsm_launch_export(h->stream, h->prof, c.d_pairs, 1, 1, nq2);
   if (early_xy) {
+    // (an event behind the export: waiting for it when it has long fired costs 2 us, hipStreamSynchronize on the idle stream 18)
+    if (!h->done_ev) HIPCHK(hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->done_ev, h->stream));
     HIPCHK(hipEventSynchronize(h->xy_ev));
     const int32_t n2 = c.hm_lcount[1];  // (written by the compaction, in front of the pixels)
     const double tk = now_us();
@@ -1043,21 +1071,38 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
       vsm_host_outliers_begin_xy(h->work, h->xy_host, n2);
       h->work.del.run(h->work.x.data(), h->work.y.data(), n2, h->work.pool, h->work.async);
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    const double td = now_us();
+    HIPCHK(hipEventSynchronize(h->done_ev));
     HIPCHK(hipGetLastError());
     h->prof.resolve();
+    const double ts = now_us();
     const vsm_p_match *in = c.hm_list2[0];  // stage 3 is read where the device left it (vsm_stage_get)
     h->stage3_in_hm = true;
     h->counters[3] = n2;
+    double tf = ts;
     if (n2 > 3) {
       vsm_host_outliers_begin_flows(h->work, in, n2, method);
+      tf = now_us();
       vsm_host_outliers_end(h->work, p, in, n2, method, h->stage[4]);
     } else {
       h->stage[4].assign(in, in + std::max(n2, 0));  // the reference leaves short lists alone (:1210)
     }
+    const double te = now_us();
     h->matched = h->stage[4];
     h->counters[4] = (int64_t)h->matched.size();
     const double t4 = now_us();
+    if (vsm_debug_timing()) {
+      static double acc[5] = {0, 0, 0, 0, 0};
+      static long calls = 0;
+      acc[0] += td - tk;
+      acc[1] += ts - td;
+      acc[2] += tf - ts;
+      acc[3] += te - tf;
+      acc[4] += t4 - te;
+      if (++calls % 100 == 0)
+        fprintf(stderr, "  vsm_match final host stage, mean us: triangulation %.1f, wait for the list %.1f, flows %.1f, support + survivors %.1f, copy %.1f\n",
+                acc[0] / calls, acc[1] / calls, acc[2] / calls, acc[3] / calls, acc[4] / calls);
+    }
     h->timings[0] = t1 - t0;
     h->timings[1] = t2 - t1;
     h->timings[2] = tk - t2;  // until the pixels are on the host

@@ -1342,11 +1342,18 @@ void vsm_host_prior_statistics(const vsm_params &p, const int32_t *dims_c, const
   const float bs = (float)p.match_binsize;
   const int ub = (int)ceilf((float)dims_c[0] / bs), vb = (int)ceilf((float)dims_c[1] / bs);
   const int nb = ub * vb, ns = method == 2 ? 4 : 2;
-  std::vector<float> lo((size_t)nb * 8, +1000000.f), hi((size_t)nb * 8, -1000000.f);
-  std::vector<int32_t> cnt(nb, 0);
-  for (const vsm_p_match &it : m) {
-    float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float ur = it.u1c, vr = it.v1c;
+  // The reference adds every match to the nine bins around its own (:789-812).  Minimum, maximum and count do not care about
+  // the order: here a match goes into its OWN bin only and the bins are then widened over their 3 x 3 neighbourhoods - the
+  // same values with a ninth of the updates (18 -> 5 us for a first-pass list of 870 matches).
+  static thread_local std::vector<float> lo0, hi0, lo, hi;
+  static thread_local std::vector<int32_t> cnt0, cnt;
+  lo0.assign((size_t)nb * 8, +1000000.f);
+  hi0.assign((size_t)nb * 8, -1000000.f);
+  cnt0.assign(nb, 0);
+  auto flows_of = [&](const vsm_p_match &it, float *d, float &ur, float &vr) {
+    for (int i = 0; i < 8; i++) d[i] = 0;
+    ur = it.u1c;
+    vr = it.v1c;
     if (method == 0) {
       d[0] = it.u1p - it.u1c;
       d[1] = it.v1p - it.v1c;
@@ -1365,19 +1372,58 @@ void vsm_host_prior_statistics(const vsm_params &p, const int32_t *dims_c, const
       ur = it.u1p;
       vr = it.v1p;
     }
+  };
+  bool strays = false;  // matches whose own bin lies outside the grid (the reference clamps the neighbourhood's ends, not its middle)
+  for (const vsm_p_match &it : m) {
+    float d[8], ur, vr;
+    flows_of(it, d, ur, vr);
     const int ubin = (int)floorf(ur / bs), vbin = (int)floorf(vr / bs);
-    const int u0 = std::min(std::max(ubin - 1, 0), ub - 1), u1 = std::min(std::max(ubin + 1, 0), ub - 1);
-    const int v0 = std::min(std::max(vbin - 1, 0), vb - 1), v1 = std::min(std::max(vbin + 1, 0), vb - 1);
-    for (int v = v0; v <= v1; v++)
-      for (int u = u0; u <= u1; u++) {
-        const int b = v * ub + u;
-        cnt[b]++;
-        for (int i = 0; i < ns * 2; i++) {
-          lo[b * 8 + i] = std::min(lo[b * 8 + i], d[i]);
-          hi[b * 8 + i] = std::max(hi[b * 8 + i], d[i]);
-        }
-      }
+    if (ubin < 0 || ubin >= ub || vbin < 0 || vbin >= vb) {
+      strays = true;
+      continue;
+    }
+    const int b = vbin * ub + ubin;
+    cnt0[b]++;
+    for (int i = 0; i < ns * 2; i++) {
+      lo0[b * 8 + i] = std::min(lo0[b * 8 + i], d[i]);
+      hi0[b * 8 + i] = std::max(hi0[b * 8 + i], d[i]);
+    }
   }
+  lo.assign((size_t)nb * 8, +1000000.f);
+  hi.assign((size_t)nb * 8, -1000000.f);
+  cnt.assign(nb, 0);
+  for (int v = 0; v < vb; v++)
+    for (int u = 0; u < ub; u++) {
+      const int b = v * ub + u;
+      for (int v2 = std::max(v - 1, 0); v2 <= std::min(v + 1, vb - 1); v2++)
+        for (int u2 = std::max(u - 1, 0); u2 <= std::min(u + 1, ub - 1); u2++) {
+          const int s2 = v2 * ub + u2;
+          if (!cnt0[s2]) continue;
+          cnt[b] += cnt0[s2];
+          for (int i = 0; i < ns * 2; i++) {
+            lo[b * 8 + i] = std::min(lo[b * 8 + i], lo0[s2 * 8 + i]);
+            hi[b * 8 + i] = std::max(hi[b * 8 + i], hi0[s2 * 8 + i]);
+          }
+        }
+    }
+  if (strays)
+    for (const vsm_p_match &it : m) {
+      float d[8], ur, vr;
+      flows_of(it, d, ur, vr);
+      const int ubin = (int)floorf(ur / bs), vbin = (int)floorf(vr / bs);
+      if (!(ubin < 0 || ubin >= ub || vbin < 0 || vbin >= vb)) continue;
+      const int u0 = std::min(std::max(ubin - 1, 0), ub - 1), u1 = std::min(std::max(ubin + 1, 0), ub - 1);
+      const int v0 = std::min(std::max(vbin - 1, 0), vb - 1), v1 = std::min(std::max(vbin + 1, 0), vb - 1);
+      for (int v = v0; v <= v1; v++)
+        for (int u = u0; u <= u1; u++) {
+          const int b = v * ub + u;
+          cnt[b]++;
+          for (int i = 0; i < ns * 2; i++) {
+            lo[b * 8 + i] = std::min(lo[b * 8 + i], d[i]);
+            hi[b * 8 + i] = std::max(hi[b * 8 + i], d[i]);
+          }
+        }
+    }
   ranges.assign((size_t)nb * 16, 0.f);
   for (int b = 0; b < nb; b++) {
     float *r = &ranges[(size_t)b * 16];
