@@ -21,6 +21,7 @@ library's own stream, vs 8 TB/s) and "cpu_baseline" (the reference -- oracle/_re
 reference's own sources -- or, if that build is absent, the scalar oracle port, on one host core).
 """
 import argparse
+import gc
 import hashlib
 import importlib
 import json
@@ -235,6 +236,14 @@ def main():
 
     dmod = dist if world > 1 else None
 
+    # The interpreter's cyclic garbage collector stays off while the legs below are timed (as timeit does): with torch and numpy
+    # loaded a full collection is a 55-65 ms pause of THIS harness, not of the library - it fell on frame 74 of the live VO leg's
+    # second pass in every run (tools/vo_timing.py: 0.95 ms per frame with it, 0.62-0.71 without), and a collection of the young
+    # generations is the 2 ms call the per-frame legs showed now and then.  Collections run between the legs instead.
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+
     # (rounds 3-4 let 30 calls pass here: once per process one call took 10-13 ms.  Its cause - the runtime creating a hardware
     # queue in the middle of a run for a table upload whose DMA engine was busy - is gone (k_upload), and so are
     # the hidden calls; --startup N still runs N untimed calls and the line reports them)
@@ -270,6 +279,7 @@ def main():
     ranks_info = [{"rank": int(r[0]), "host_threads": int(r[1]), "cpus_allowed": int(r[2]), "chunk_frames": int(r[3]), "median_step_ms": round(r[4], 3),
                    "slowest_step_ms": round(r[5], 3), "lookahead_form": int(r[6])} for r in rank_rows]
 
+    gc.collect()
     # ---- the same sequence through the per-frame (drop-in) entry points ---------------------
     per_frame_value = None
     caller_cpus = None
@@ -306,6 +316,7 @@ def main():
             return dt, np.array(trail)
         with beside_forkjoin():
             run_vo()
+            gc.collect()
             shard.barrier(dmod, comm_dev)
             vo_dt, trail = run_vo()
         vo_pairs, vo_dt, _ = shard.aggregate(dmod, torch, nf, vo_dt, comm_dev)
@@ -314,6 +325,7 @@ def main():
             ge = np.load(os.path.join(ROOT, "tests", "golden", "cfg2_seq200_ego.npz"))
             vo_ok = bool(trail.tobytes() == ge["tr_out"][:nf].tobytes())
 
+    gc.collect()
     # ---- K sequences in lock-step with live feedback (row f-3, multi-sequence per GPU) -----------------
     multi = None
     if rank == 0 and world == 1 and not args.no_per_frame:
@@ -551,6 +563,7 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         # untimed calls in front of the W warm-up steps (process start-up) and the slowest call among start-up + warm-up
+        "python_gc": "off inside the timed legs (as timeit does), collections between them: a full collection is a 55-65 ms pause of the harness",
         "startup_calls": args.startup, "startup_worst_ms": max(startup_ms) if startup_ms else None,
         "config": {"workload": f"KITTI-shaped synthetic stereo sequence 1242x375, {nf} frames per GPU, quad matching, "
                                "default parameters, replayed Tr_delta feedback, look-ahead C-ABI entry point "
@@ -636,11 +649,14 @@ def multi_sequence_leg(vm, synth, torch, dev, W, H):
         left, right = frames[:, :, 0].contiguous(), frames[:, :, 1].contiguous()
         best, exact = None, True
         for rep in range(2):
+            gc.collect()
             vo = vm.MultiVisualOdometryStereo(K, *[float(x) for x in g["intr"]])
             torch.cuda.synchronize()
             t = time.perf_counter()
+            stamps = []
             for f in range(nf):
                 vo.process(left[f], right[f])
+                stamps.append(time.perf_counter())
                 if rep == 0 and f < nfix:               # (rep 0 is the checked warm-up pass, rep 1 the timed one)
                     for k in range(K):
                         exact = exact and vo.get_motion(k).tobytes() == g[f"s{seeds[k % len(seeds)]}_tr_out"][f].tobytes()
@@ -649,7 +665,9 @@ def multi_sequence_leg(vm, synth, torch, dev, W, H):
             vo.close()
             if rep == 1:
                 best = dt
+                steady = (nf - 8) / (stamps[-1] - stamps[7])   # steps per second behind the new object's first eight
         out[f"K{K}"] = {"value": round(K * nf / best, 1), "unit": "frames/s (all sequences)", "ms_per_step": round(best / nf * 1e3, 3),
+                        "after_the_first_frames": {"value": round(K * steady, 1), "ms_per_step": round(1e3 / steady, 3), "skipped": 8},
                         "tr_delta_trails_bit_exact_vs_reference": bool(exact), "last_step_us": {k: round(v, 1) for k, v in tm.items()}}
     out["what"] = ("vsm_multi_process: pushBack + matchFeatures(2, live Tr_delta) + bucketFeatures + egomotion of K sequences per call, "
                    "one launch per kernel over all K pairs; 48 frames per sequence, images resident in HBM")

@@ -2150,7 +2150,12 @@ void vsm_sequence_get_timings(vsm_handle *h, double *out4) { memcpy(out4, h->seq
 int32_t vsm_sequence_path(vsm_handle *h) { return h->seq_v2_frames > 0 ? 2 : 1; }
 int32_t vsm_local_cpus(int32_t *out, int32_t cap) { return vsm_affinity_cpus(out, out ? cap : 0); }
 int32_t vsm_forkjoin_cpus(int32_t *out, int32_t cap) {
-  return vsm_forkjoin_domain() < 0 ? 0 : vsm_affinity_domain_cpus(nullptr, vsm_forkjoin_domain(), out, out ? cap : 0);
+  if (vsm_forkjoin_domain() < 0) return 0;
+  if (vsm_forkjoin_per_core()) {  // the workers have a core each: the caller's is core 0 of their domain
+    const int32_t n = vsm_affinity_core_cpus(nullptr, vsm_forkjoin_domain(), 0, out, out ? cap : 0);
+    if (n > 0) return n;
+  }
+  return vsm_affinity_domain_cpus(nullptr, vsm_forkjoin_domain(), out, out ? cap : 0);
 }
 
 int vsm_host_register(const void *p, uint64_t bytes) {

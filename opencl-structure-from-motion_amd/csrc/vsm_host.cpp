@@ -178,6 +178,60 @@ void vsm_pin_this_thread_together(void *aff, int domain) {
   (void)pthread_setaffinity_np(pthread_self(), sizeof(dom), &dom);
   t_domain = (int)((size_t)domain % A->order.size());
 }
+// The physical cores of an L3 domain (hardware threads that share a core, within the domain's allowed CPUs).  The fork-join
+// threads of one triangulation spin between its phases: two of them on the two hardware threads of ONE core halve each
+// other, and the caller's serial stretches (flows, bucketing, egomotion) beside a spinning sibling run 10-15 % slower - left
+// to the scheduler a process came up in either mode (live VO 0.62 or 0.70 ms per frame, tools/vo_timing.py).  A core each:
+// worker i on core i of the domain, core 0 for the caller (vsm_forkjoin_cpus names it).
+static std::vector<cpu_set_t> domain_cores(const cpu_set_t &dom) {
+  std::vector<cpu_set_t> cores;
+  cpu_set_t left = dom;
+  for (int c = 0; c < CPU_SETSIZE; c++) {
+    if (!CPU_ISSET(c, &left)) continue;
+    cpu_set_t core;
+    CPU_ZERO(&core);
+    char p[160], l[512] = {0};
+    snprintf(p, sizeof(p), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+    FILE *f = fopen(p, "r");
+    if (f && fgets(l, sizeof(l), f)) parse_cpulist(l, &core, &dom);
+    if (f) fclose(f);
+    if (!CPU_ISSET(c, &core)) CPU_SET(c, &core);
+    for (int k = 0; k < CPU_SETSIZE; k++)
+      if (CPU_ISSET(k, &core)) CPU_CLR(k, &left);
+    cores.push_back(core);
+  }
+  return cores;
+}
+bool vsm_forkjoin_per_core() {
+  static const bool on = [] {
+    const char *e = getenv("VSM_FJ_CORES");
+    return !(e && atoi(e) == 0);
+  }();
+  return on && fj_domain() >= 0;
+}
+int vsm_affinity_core_cpus(void *aff, int domain, int core, int *out, int cap) {
+  VsmAffinity *A = aff ? (VsmAffinity *)aff : g_aff_last.load();
+  if (!A || !A->any || A->order.empty()) return 0;
+  const std::vector<cpu_set_t> cores = domain_cores(A->order[(size_t)domain % A->order.size()]);
+  if (cores.empty()) return 0;
+  const cpu_set_t &cs = cores[(size_t)core % cores.size()];
+  int n = 0;
+  for (int c = 0; c < CPU_SETSIZE; c++)
+    if (CPU_ISSET(c, &cs)) {
+      if (n < cap) out[n] = c;
+      n++;
+    }
+  return n;
+}
+void vsm_pin_this_thread_core(void *aff, int domain, int core) {
+  VsmAffinity *A = aff ? (VsmAffinity *)aff : t_aff;
+  if (!A || !A->any || A->order.empty()) return;
+  const std::vector<cpu_set_t> cores = domain_cores(A->order[(size_t)domain % A->order.size()]);
+  if (cores.empty()) return;
+  const cpu_set_t &cs = cores[(size_t)core % cores.size()];
+  (void)pthread_setaffinity_np(pthread_self(), sizeof(cs), &cs);
+  t_domain = (int)((size_t)domain % A->order.size());
+}
 int vsm_affinity_cpus(int *out, int cap) {  // the CPUs the threads of the device looked up last are confined to (their union)
   VsmAffinity *A = g_aff_last.load();
   if (!A || !A->any) return 0;
@@ -306,7 +360,7 @@ VsmForkJoin::VsmForkJoin(int threads) : nthreads_(threads < 1 ? 1 : threads), af
   // (Measured, per-frame matchFeatures(2) at 1242 x 375, tools/frame_timing.py: 578 us with the workers dealt over the
   // domains, 548 together, 500-520 with the caller's thread inside the domain as well - vsm_forkjoin_cpus() says where that
   // is.  A caller that only posts and waits while one more worker takes its share: 539 against 539, not kept.)
-  for (int i = 1; i < nthreads_; i++) threads_.emplace_back([this] { worker(); });
+  for (int i = 1; i < nthreads_; i++) threads_.emplace_back([this, i] { worker(i); });
 }
 
 VsmForkJoin::~VsmForkJoin() {
@@ -332,9 +386,11 @@ bool VsmForkJoin::claim(uint64_t g, int n, int &idx) {
   }
 }
 
-void VsmForkJoin::worker() {
+void VsmForkJoin::worker(int index) {
   if (fj_domain() < 0)
     vsm_pin_this_thread(aff_);
+  else if (vsm_forkjoin_per_core())
+    vsm_pin_this_thread_core(aff_, fj_domain(), index);  // (core 0 is the caller's: vsm_forkjoin_cpus)
   else
     vsm_pin_this_thread_together(aff_, fj_domain());
   uint64_t seen = 0;

@@ -35,6 +35,10 @@ int vsm_forkjoin_domain();                               // the L3 domain the fo
 void *vsm_affinity_current();                           // the calling thread's current record (what pools created now will pin their workers by)
 void vsm_pin_this_thread(void *affinity = nullptr);     // nullptr: the calling thread's current record
 void vsm_pin_this_thread_together(void *affinity, int domain);  // ... into L3 domain `domain` of the record, whoever asks
+// ... onto physical core `core` (mod the domain's cores) of that domain: both hardware threads of the core, nobody else's
+void vsm_pin_this_thread_core(void *affinity, int domain, int core);
+int vsm_affinity_core_cpus(void *affinity, int domain, int core, int *out, int cap);  // that core's CPUs; returns how many (0: unknown)
+bool vsm_forkjoin_per_core();  // the fork-join workers sit on a core each (VSM_FJ_CORES=0: anywhere in their domain)
 int vsm_thread_domain();                                // the L3 domain (index in the pin sequence) this thread was pinned to, or -1
 int vsm_affinity_cpus(int *out, int cap);  // the CPUs the threads of the device looked up last may use (for the caller who wants its own threads there too); returns how many
 
@@ -105,7 +109,7 @@ class VsmForkJoin {
   void run(int ntasks, const std::function<void(int)> &fn);
 
  private:
-  void worker();
+  void worker(int index);
   bool claim(uint64_t g, int n, int &idx);
   int nthreads_;
   void *aff_ = nullptr;

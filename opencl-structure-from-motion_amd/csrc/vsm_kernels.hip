@@ -260,12 +260,15 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------------------
 #define FRONT_TW 128
 #define FRONT_TH 64
-#define FRONT_LW (FRONT_TW + 8)  // bytes per LDS row
+#ifndef FRONT_LPAD
+#define FRONT_LPAD 16  // (8 is all the patches read; with 16 a row is nine WHOLE 16-byte items and an interior tile never takes the dword path)
+#endif
+#define FRONT_LW (FRONT_TW + FRONT_LPAD)  // bytes per LDS row
 #define FRONT_LH (FRONT_TH + 4)
 __global__ void __launch_bounds__(256)
     k_front(const VsmImage *__restrict__ imgs, int first, const uint8_t *__restrict__ src0, const uint8_t *__restrict__ src1,
             size_t frame_stride, int src_bpl, int sides, VsmDims d, int write_img, int nbx, int nby, int n_img) {
-  __shared__ uint32_t s_in[FRONT_LH][FRONT_LW / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t s_in[FRONT_LH][FRONT_LW / 4];
   // (XCD-aware placement: neighbouring tiles share the 128-byte lines their unaligned rows straddle and two halo rows; dealt
   // round-robin over the eight L2s every such line was fetched from HBM twice: 1.41 x the kernel's bytes)
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(256)
   const int x0 = bx * FRONT_TW, y0 = by * FRONT_TH;
   const int t = threadIdx.x;
   // ---- tile of the padded stream into LDS ----
-  // Items of four LDS dwords (16 stream bytes; the last item of a row has two).  An item that lies inside one image row
+  // Items of four LDS dwords (16 stream bytes; FRONT_LPAD = 8: the last item of a row has two).  An item that lies inside one image row
   // takes ONE aligned 16-byte load plus one dword and four byte-aligns; the others (row ends, tile edges, rows outside the
   // image) go dword by dword: two aligned dwords + an align each, bytes beyond the row's w and positions outside the
   // image 0.  (Every 4-byte piece used to cost two loads: the kernel was bound by the texture addresser's lane rate.)
@@ -332,10 +335,21 @@ __global__ void __launch_bounds__(256)
     const int nd = min(4, FRONT_LW / 4 - 4 * g);
     if (nd == 4 && y >= 0 && y < h && x >= 0 && x + 20 <= w) {
       const uint32_t sh = (uint32_t)((uintptr_t)(src + (size_t)y * src_bpl + x) & 3);
-      s_in[r][4 * g] = __builtin_amdgcn_alignbyte(q[i].y, q[i].x, sh);
-      s_in[r][4 * g + 1] = __builtin_amdgcn_alignbyte(q[i].z, q[i].y, sh);
-      s_in[r][4 * g + 2] = __builtin_amdgcn_alignbyte(q[i].w, q[i].z, sh);
-      s_in[r][4 * g + 3] = __builtin_amdgcn_alignbyte(q4[i], q[i].w, sh);
+      uint4 v;
+      v.x = __builtin_amdgcn_alignbyte(q[i].y, q[i].x, sh);
+      v.y = __builtin_amdgcn_alignbyte(q[i].z, q[i].y, sh);
+      v.z = __builtin_amdgcn_alignbyte(q[i].w, q[i].z, sh);
+      v.w = __builtin_amdgcn_alignbyte(q4[i], q[i].w, sh);
+      if ((FRONT_LW & 15) == 0) {
+        *(uint4 *)&s_in[r][4 * g] = v;  // (rows of whole items are 16-byte aligned)
+      } else {
+        s_in[r][4 * g] = v.x;
+        s_in[r][4 * g + 1] = v.y;
+        s_in[r][4 * g + 2] = v.z;
+        s_in[r][4 * g + 3] = v.w;
+      }
+    } else if ((y < 0 || y >= h) && x >= 0 && x + 16 <= bpl) {  // a row outside the image whose item does not wrap into one inside
+      for (int k = 0; k < nd; k++) s_in[r][4 * g + k] = 0u;
     } else {
       for (int k = 0; k < nd; k++) s_in[r][4 * g + k] = load_dword(y, x + 4 * k);
     }
@@ -377,6 +391,60 @@ __global__ void __launch_bounds__(256)
   static_assert(FRONT_TW == 128 && FRONT_TH == 64, "16 x 16 patches of 8 x 4 pixels");
   const int tx = t & 15, ty = t >> 4;
   const int x8 = x0 + 8 * tx, yb = y0 + 4 * ty;
+#ifndef FRONT_LINE_STORES
+#define FRONT_LINE_STORES 0
+#endif
+#if FRONT_LINE_STORES
+  // (Measured, off: 106.3 against 107.1 us per 200 images in the pipeline - the kernel is bound by its vector instructions,
+  // not by the shape of its stores - for 9 registers and 16 KB of LDS more.)
+  // The patch rows leave through LDS so that every store instruction writes WHOLE 128-byte lines of the tiled plane (a
+  // line = 8 rows of one 8-pixel column = the patches of two threads): a wave's 32 lines are staged in 4 KB of its own
+  // (pieces XOR-swizzled by the line so that the 16 lanes of a patch column do not share banks), then lane L of store k
+  // takes piece L & 7 of line 8 k + (L >> 3) - 1 KB of contiguous bytes per instruction instead of 16-byte pieces of 32 lines.
+  __shared__ __attribute__((aligned(16))) vsm_u4 s_out[4][256];
+  vsm_u4 o[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) o[rr].x = o[rr].y = o[rr].z = o[rr].w = 0u;
+  if (x8 < bpl && yb < h) {
+    VfWindow<4> W;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) W.w[r][q] = s_in[4 * ty + r][2 * tx + q];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int y = yb + rr;
+      if (y >= h) break;
+      vf_s2 S[6], D[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) vf_columns_sobel<4>(W, rr, j, S[j], D[j]);
+      if (y < 3 || y > h - 4) vf_sobel_zero_outside(S, D, y * bpl + x8, 2 * bpl, (h - 2) * bpl);
+      uint32_t du[2], dv[2];
+      vf_sobel_row(S, D, du, dv);
+      o[rr].x = du[0];
+      o[rr].y = dv[0];
+      o[rr].z = du[1];
+      o[rr].w = dv[1];
+    }
+  }
+  {
+    const int wv = t >> 6, lane = t & 63, tyl = ty & 3;
+    const int lw = (tyl >> 1) * 16 + tx;  // the thread's line among its wave's 32
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) s_out[wv][lw * 8 + (((tyl & 1) * 4 + rr) ^ (lw & 7))] = o[rr];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int l = k * 8 + (lane >> 3), pc = lane & 7;
+      const vsm_u4 v = s_out[wv][l * 8 + (pc ^ (l & 7))];
+      const int xx = x0 + 8 * (l & 15), yy = y0 + 16 * wv + 8 * (l >> 4) + pc;
+      if (xx < bpl && yy < h) *(VSM_AS1 vsm_u4 *)(im.duv_tiled + vsm_tiled_at(bpl, xx, yy)) = v;
+    }
+  }
+#else
   if (x8 >= bpl || yb >= h) return;
   VfWindow<4> W;
 #pragma unroll
@@ -401,6 +469,7 @@ __global__ void __launch_bounds__(256)
     o.w = dv[1];
     *(VSM_AS1 vsm_u4 *)(im.duv_tiled + vsm_tiled_at(bpl, x8, y)) = o;
   }
+#endif
   FT_STAMP;
   FT_FLUSH(4);
 }
