@@ -995,8 +995,8 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
   if (p.multi_stage) {
     cfg.sparse = 1;
     cfg.use_prior = 0;
-    vsm_launch_match(h->stream, h->prof, c.d_imgs, c.d_pairs, nullptr, job, 1, c.dims, cfg, job.nq[0]);
-    vsm_launch_export(h->stream, h->prof, c.d_pairs, 1, 0, job.nq[0]);
+    if (!vsm_launch_match(h->stream, h->prof, c.d_imgs, c.d_pairs, nullptr, job, 1, c.dims, cfg, job.nq[0], 1))
+      vsm_launch_export(h->stream, h->prof, c.d_pairs, 1, 0, job.nq[0]);
     if (!h->done_ev) HIPCHK(hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming));
     HIPCHK(hipEventRecord(h->done_ev, h->stream));
     HIPCHK(hipEventSynchronize(h->done_ev));  // the list was written into host-mapped memory
@@ -1025,7 +1025,6 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
   cfg.sparse = 0;
   cfg.use_prior = p.multi_stage ? 1 : 0;
   const int nq2 = job.nq[1];
-  vsm_launch_match(h->stream, h->prof, c.d_imgs, c.d_pairs, nullptr, job, 1, c.dims, cfg, nq2);
   h->counters[0] += (int64_t)nq2 * stages;
   // The final removeOutliers' triangulation only needs the list's pixels (u1c, v1c), and those are final once the list is
   // compacted (the refinement moves the other three points, viso/matcher.cpp:1544-1577): they cross first, 4 bytes per
@@ -1045,8 +1044,11 @@ int vsm_match(vsm_handle *h, int32_t method, const double *Tr) {
       h->xy_cap = cap;
     }
     if (!h->xy_ev) HIPCHK(hipEventCreateWithFlags(&h->xy_ev, hipEventDisableTiming));
-    vsm_launch_export_xy(h->stream, c.d_pairs, h->xy_dev, nq2);
+    if (!vsm_launch_match(h->stream, h->prof, c.d_imgs, c.d_pairs, nullptr, job, 1, c.dims, cfg, nq2, 2, h->xy_dev))
+      vsm_launch_export_xy(h->stream, c.d_pairs, h->xy_dev, nq2);
     HIPCHK(hipEventRecord(h->xy_ev, h->stream));
+  } else {
+    vsm_launch_match(h->stream, h->prof, c.d_imgs, c.d_pairs, nullptr, job, 1, c.dims, cfg, nq2);
   }
   // The list size is still on the device: the refinement / export grids are sized for the worst
   // case (every query matched) and surplus threads exit at once.

@@ -926,13 +926,18 @@ void ExactDelaunay::kd_order(int32_t m, VsmForkJoin *pool) {
     subtree(Nd{0, m, 0});
   } else {
     std::vector<Nd> level{Nd{0, m, 0}};
-    while ((int)level.size() < nthreads) {  // top levels, sequential
-      std::vector<Nd> next;
-      for (const Nd &nd : level) {
+    while ((int)level.size() < nthreads) {  // top levels: the root alone, then a thread per node (their slices are disjoint)
+      std::vector<Nd> next(level.size() * 2);
+      auto one = [&](int t) {
+        const Nd nd = level[t];
         const int32_t div = split(nd, tmp_.data() + nd.off);
-        next.push_back(Nd{nd.off, div, 1 - nd.axis});
-        next.push_back(Nd{nd.off + div, nd.n - div, 1 - nd.axis});
-      }
+        next[2 * t] = Nd{nd.off, div, 1 - nd.axis};
+        next[2 * t + 1] = Nd{nd.off + div, nd.n - div, 1 - nd.axis};
+      };
+      if (level.size() > 1)
+        pool->run((int)level.size(), one);
+      else
+        one(0);
       level.swap(next);
     }
     pool->run((int)level.size(), [&](int t) { subtree(level[t]); });
@@ -1242,6 +1247,44 @@ void vsm_host_outliers_begin_flows(VsmHostWork &w, const vsm_p_match *in, int32_
 void vsm_host_outliers_end(VsmHostWork &w, const vsm_params &p, const vsm_p_match *in, int32_t n, int method,
                            std::vector<vsm_p_match> &out) {
   vsm_host_count_support(w, p, n, method);
+  const int T = w.pool ? w.pool->size() : 1;
+  if (T > 1 && n >= 2048) {
+    // the per-frame path's final list (350 KB where the device exported it): every fork-join thread counts the survivors of
+    // its range, then copies them to their place behind those of the ranges in front
+    const int32_t *support = w.support.data();
+    int32_t cnt[64];
+    const int Tn = std::min(T, 64);
+    w.pool->run(Tn, [&](int k) {
+      const int32_t i0 = (int32_t)((int64_t)n * k / Tn), i1 = (int32_t)((int64_t)n * (k + 1) / Tn);
+      int32_t c = 0;
+      for (int32_t i = i0; i < i1; i++) c += support[i] >= 4;
+      cnt[k] = c;
+    });
+    int32_t total = 0;
+    for (int k = 0; k < Tn; k++) {
+      const int32_t c = cnt[k];
+      cnt[k] = total;
+      total += c;
+    }
+    out.resize((size_t)total);  // (about the previous frame's size: little to initialise)
+    vsm_p_match *dst = out.data();
+    w.pool->run(Tn, [&](int k) {
+      const int32_t i0 = (int32_t)((int64_t)n * k / Tn), i1 = (int32_t)((int64_t)n * (k + 1) / Tn);
+      vsm_p_match *d = dst + cnt[k];
+      int32_t i = i0;
+      while (i < i1) {
+        while (i < i1 && support[i] < 4) i++;
+        int32_t j = i;
+        while (j < i1 && support[j] >= 4) j++;
+        if (j > i) {
+          memcpy((void *)d, (const void *)(in + i), (size_t)(j - i) * sizeof(vsm_p_match));
+          d += j - i;
+        }
+        i = j;
+      }
+    });
+    return;
+  }
   vsm_host_keep_supported(in, w.support.data(), n, out);
 }
 

@@ -176,8 +176,10 @@ void vsm_launch_front(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int fi
 int vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int first, int n_img, const VsmDims &d,
                         int16_t *f1, int16_t *f2, size_t f_stride, int nms_tau, int multi_stage, int half_res,
                         int binsize, const VsmImage *h_imgs, int front_done = 0, int fused = 1);
-void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
-                      const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq);
+// fuse_export (quad matching only; the return value says whether it happened): 1 - the compacted list also goes to its host-mapped
+// copy (what vsm_launch_export does), 2 - pair 0's pixels go to xy_dst (what vsm_launch_export_xy does)
+bool vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
+                      const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq, int fuse_export = 0, uint32_t *xy_dst = nullptr);
 void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair *d_pairs, int npairs, int pass, int n_upper);
 void vsm_launch_export_xy(hipStream_t s, const VsmPair *d_pairs, uint32_t *dst_host_mapped, int n_upper);  // pair 0's pass-2 pixels, x | y << 16
 #define VSM_PARA_MAX_LIST 16384  // matches per pair the batched tail of refinement==2 takes

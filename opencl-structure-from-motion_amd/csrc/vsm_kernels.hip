@@ -2174,9 +2174,13 @@ __global__ void __launch_bounds__(256)
 // 1024 threads and 16 KB of LDS per pair - took 35 us per 67 pairs with the GPU to itself and 100-170 us in the pipeline,
 // whatever was in it: a 16-wave workgroup needs four free wave slots on every SIMD of one compute unit plus its LDS at the
 // same moment, and beside the Delaunay chains it waits for that.  Four waves and 4 KB find a place at once.
+// EXPORT (the per-frame path, where a launch of its own for the copy is 8 us of a 0.5 ms frame): 1 - every piece goes to the
+// list's host-mapped copy as well (k_export_list's work), 2 - the pixel (u1c, v1c) of every match as x | y << 16 to xy_dst
+// (k_export_xy's).
 #define QUAD_SPAN 1024
+template <int EXPORT>
 __global__ void __launch_bounds__(256)
-    k_compact_quad(const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs, VsmJob job0, int pass) {
+    k_compact_quad(const VsmPair *__restrict__ pairs, const VsmJob *__restrict__ jobs, VsmJob job0, int pass, uint32_t *__restrict__ xy_dst) {
   __shared__ int s_w[5];
   __shared__ int s_base[4];
   __shared__ int s_dst[QUAD_SPAN];  // place of every query of the span in the list, -1 = not accepted
@@ -2236,6 +2240,7 @@ __global__ void __launch_bounds__(256)
   {
     const uint4 *src = (const uint4 *)(pair.raw + q0);
     uint4 *dst = (uint4 *)list;
+    uint4 *hdst = EXPORT == 1 ? (uint4 *)(pass ? pair.hlist2 : pair.hlist1) : nullptr;
     const int pieces = 3 * (q1 - q0);
     for (int p0 = t; p0 < pieces; p0 += 4 * 256) {
       uint4 v[4];
@@ -2250,7 +2255,12 @@ __global__ void __launch_bounds__(256)
       }
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        if (d[k] >= 0) dst[3 * (size_t)d[k] + part[k]] = v[k];
+        if (d[k] >= 0) {
+          dst[3 * (size_t)d[k] + part[k]] = v[k];
+          if (EXPORT == 1) hdst[3 * (size_t)d[k] + part[k]] = v[k];
+          if (EXPORT == 2 && part[k] == 1)  // (piece 1 of a record: v2p, i2p, u1c, v1c)
+            xy_dst[d[k]] = (uint32_t)(int32_t)__uint_as_float(v[k].z) | ((uint32_t)(int32_t)__uint_as_float(v[k].w) << 16);
+        }
     }
   }
   if (q1 == n_query && t == 255) {  // the span that holds the last query
@@ -2929,8 +2939,8 @@ int vsm_launch_features(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, int 
 
 // One launch serves `npairs` frame pairs (blockIdx.y); jobs == nullptr: the single pair job0.
 // pass: 0 = sparse lists (list1/hlist1/count[0]), 1 = dense lists.  max_nq bounds nq[pass].
-void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
-                      const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq) {
+bool vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const VsmPair *d_pairs, const VsmJob *d_jobs,
+                      const VsmJob &job0, int npairs, const VsmDims &d, const VsmMatchCfg &cfg, int max_nq, int fuse_export, uint32_t *xy_dst) {
   // lanes per query: the chain is latency-bound per wavefront, so big batches want many
   // queries per wave (G = 2..4) and a lone frame pair wants more lanes per query (G = 8).
   const long total_q = (long)npairs * max_nq;
@@ -2967,13 +2977,22 @@ void vsm_launch_match(hipStream_t s, VsmProf &pf, const VsmImage *d_imgs, const 
   }
   const int nblk = max(cdiv(max_nq, 256), 1);
   pf.begin(cfg.sparse ? VSM_K_COMPACT1 : VSM_K_COMPACT2, s);
+  bool fused = false;
   if (cfg.method == 2) {
-    hipLaunchKernelGGL(k_compact_quad, dim3(std::max(1, cdiv(max_nq, QUAD_SPAN)), npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, pass);
+    const dim3 grid(std::max(1, cdiv(max_nq, QUAD_SPAN)), npairs);
+    if (fuse_export == 1)
+      hipLaunchKernelGGL(k_compact_quad<1>, grid, dim3(256), 0, s, d_pairs, d_jobs, job0, pass, nullptr);
+    else if (fuse_export == 2 && xy_dst && npairs == 1)
+      hipLaunchKernelGGL(k_compact_quad<2>, grid, dim3(256), 0, s, d_pairs, d_jobs, job0, pass, xy_dst);
+    else
+      hipLaunchKernelGGL(k_compact_quad<0>, grid, dim3(256), 0, s, d_pairs, d_jobs, job0, pass, nullptr);
+    fused = fuse_export == 1 || (fuse_export == 2 && xy_dst && npairs == 1);
   } else {
     hipLaunchKernelGGL(k_compact_count, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);
     hipLaunchKernelGGL(k_compact_write, dim3(nblk, npairs), dim3(256), 0, s, d_pairs, d_jobs, job0, cfg.method, pass);
   }
   pf.end(s);
+  return fused;  // the export asked for went along with the compaction (quad matching): no launch of its own
 }
 
 void vsm_launch_export(hipStream_t s, VsmProf &pf, const VsmPair *d_pairs, int npairs, int pass, int n_upper) {
