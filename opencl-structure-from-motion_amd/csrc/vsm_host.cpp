@@ -1177,7 +1177,10 @@ void ExactDelaunay::run(const int32_t *x, const int32_t *y, int32_t n, VsmForkJo
     max_task = std::max(63, (n >> depth) + 1);
   }
   // with somebody to take it, the emulated vertex sort runs next to the triangulation instead of in front of it
-  const bool apart = async != nullptr && async->size() > 1 && n >= 1024;
+#ifndef VSM_TIES_APART_MIN
+#define VSM_TIES_APART_MIN 1024
+#endif
+  const bool apart = async != nullptr && async->size() > 1 && n >= VSM_TIES_APART_MIN;
   if (!prepare(x, y, n, max_task, pool, 0, false, apart)) return;
   VsmPool::Ticket ties;
   if (has_ties_) ties = async->submit(1, [this](int) { resolve_ties(); }, true);
@@ -1235,12 +1238,20 @@ void vsm_host_outliers_begin_flows(VsmHostWork &w, const vsm_p_match *in, int32_
   w.fu.resize(n);
   w.fv.resize(n);
   w.dp.resize(n);
-  for (int32_t i = 0; i < n; i++) {
-    const vsm_p_match &a = in[i];
-    w.fu[i] = a.u1c - a.u1p;
-    w.fv[i] = a.v1c - a.v1p;
-    w.dp[i] = method == 1 ? a.u1c - a.u2c : a.u1p - a.u2p;
-  }
+  float *fu = w.fu.data(), *fv = w.fv.data(), *dp = w.dp.data();
+  auto part = [&](int32_t i0, int32_t i1) {
+    for (int32_t i = i0; i < i1; i++) {
+      const vsm_p_match &a = in[i];
+      fu[i] = a.u1c - a.u1p;
+      fv[i] = a.v1c - a.v1p;
+      dp[i] = method == 1 ? a.u1c - a.u2c : a.u1p - a.u2p;
+    }
+  };
+  const int T = w.pool ? w.pool->size() : 1;
+  if (T > 1 && n >= 2048)  // (the per-frame path's final list, 350 KB where the device exported it: 13 -> 4 us)
+    w.pool->run(T, [&](int k) { part((int32_t)((int64_t)n * k / T), (int32_t)((int64_t)n * (k + 1) / T)); });
+  else
+    part(0, n);
 }
 
 // support of every match from the triangulation in w.del, survivors (support >= 4) to `out`
