@@ -365,7 +365,7 @@ def main():
             verified = None
 
     # ---- the same look-ahead call fed from host memory (PCIe inclusive: the reference's pushBack takes host images) ----
-    host_in_value, host_in_verified = None, None
+    host_in_value, host_in_verified, host_in_calls = None, None, None
     host_pin_value, host_pin_verified = None, None
     if not args.no_per_frame:
         hl, hr = np.ascontiguousarray(host[:, 0]), np.ascontiguousarray(host[:, 1])
@@ -376,8 +376,11 @@ def main():
         shard.barrier(dmod, comm_dev)
         m.run_sequence(hl, hr, 2, tr12, trv, fetch=False)
         th = time.perf_counter()
+        host_in_calls = []
         for _ in range(6):
+            tc = time.perf_counter()
             m.run_sequence(hl, hr, 2, tr12, trv, fetch=False)
+            host_in_calls.append(round((time.perf_counter() - tc) * 1e3, 2))
         hdt = time.perf_counter() - th
         hp, hdt, _ = shard.aggregate(dmod, torch, 6 * nf, hdt, comm_dev)
         host_in_value = hp / hdt
@@ -604,6 +607,7 @@ def main():
         "lookahead_host_inputs": {"value": round(host_in_value, 3) if host_in_value else None, "unit": "frame-pairs/s",
                                   "of_resident": round(host_in_value / value, 3) if host_in_value else None,
                                   "bit_exact_vs_reference_hashes": host_in_verified if host_in_value else None,
+                                  "calls_ms_rank0": host_in_calls if host_in_value else None,
                                   "what": "the same look-ahead call fed from pageable host memory (on_device = 0): PCIe inclusive; the frames cross "
                                           "in pieces of 20 (pool gathers into pinned memory, DMA on a stream of its own) beside the GPU's work; 6 calls",
                                   "page_locked_by_the_caller": {"value": round(host_pin_value, 3) if host_pin_value else None,

@@ -160,9 +160,13 @@ int vsm_set_option(vsm_handle *h, const char *name, int32_t value);
 int32_t vsm_local_cpus(int32_t *out, int32_t cap);
 /* The per-frame calls (vsm_match, vsm_vo_stereo_process) split ONE triangulation - the final Matcher::removeOutliers,
  * viso/matcher.cpp:1207-1377 - over up to eight fork-join threads that all sit in one L3 domain of that node (they take turns
- * on one mesh; VSM_FJ_DOMAIN=k: domain k, -1: dealt over the domains).  The caller's thread takes part in that work: this
- * returns the domain's CPUs, and a caller that confines the thread calling vsm_match to them (sched_setaffinity) saves the
- * transfers between core complexes - 0.55 -> 0.50-0.52 ms per 1242 x 375 stereo pair; bench.py does for its per-frame legs.
+ * on one mesh; VSM_FJ_DOMAIN=k: domain k, -1: dealt over the domains), each worker on a physical core of its own (cores
+ * 1, 2, ... of the domain; VSM_FJ_CORES=0: anywhere in the domain - then two of them may share a core's hardware threads and
+ * halve each other between the phases they spin through).  The caller's thread takes part in that work: this returns the
+ * CPUs of the domain's core 0, which is left to it (the whole domain with VSM_FJ_CORES=0), and a caller that confines the
+ * thread calling vsm_match / vsm_vo_stereo_process to them (sched_setaffinity) saves the transfers between core complexes
+ * and never shares a core with a worker - 0.55 -> 0.47-0.50 ms per 1242 x 375 stereo pair, live VO 0.70 -> 0.62 ms per
+ * frame; bench.py does for its per-frame legs.
  * Same conventions as vsm_local_cpus; 0 = no such domain (no node found, affinity off, VSM_FJ_DOMAIN=-1). */
 int32_t vsm_forkjoin_cpus(int32_t *out, int32_t cap);
 /* Host-resident input at the link's rate.  Matcher::pushBack takes pageable host pointers (viso/matcher.cpp:95-181) and so do

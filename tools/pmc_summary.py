@@ -18,7 +18,7 @@ import sys
 NAMES = {"k_match<2, false>": "k_match<16>:pass2", "k_match<4, false>": "k_match<16>:pass2", "k_match<8, false>": "k_match<16>:pass2",
          "k_match<2, true>": "k_match<16>:pass1", "k_match<4, true>": "k_match<16>:pass1", "k_match<8, true>": "k_match<16>:pass1", "k_nms_tile": "k_nms:dense",
          "k_nms_tile8": "k_nms:sparse", "k_nms_fixed<3, 16, 8, 1>": "k_nms:dense", "k_nms_fixed<9, 4, 4, 8>": "k_nms:sparse",
-         "k_compact_write": "k_compact_matches", "k_compact_quad": "k_compact_matches", "k_refine<true>": "k_refine", "k_refine<false>": "k_refine",
+         "k_compact_write": "k_compact_matches", "k_compact_quad": "k_compact_matches", "k_compact_quad<0>": "k_compact_matches", "k_compact_quad<1>": "k_compact_matches", "k_compact_quad<2>": "k_compact_matches", "k_refine<true>": "k_refine", "k_refine<false>": "k_refine",
          "k_dc2_block": "k_dc_block", "k_dc2_merge": "k_dc_merge", "k_dc2_prepare": "k_dc_prepare_kd_order", "k_dc2_keys": "k_dc_keys",
          "k_dc2_ties": "k_dc_vertex_sort", "k_dc2_support": "k_dc_support", "k_dc2_support_lds": "k_dc_support", "k_dc2_export": "k_export_list", "k_dc2_compact": "k_dc_compact", "k_dc2_prior": "k_dc_prior"}
 
