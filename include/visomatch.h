@@ -266,6 +266,11 @@ int32_t vsm_debug_ties_gpu(const int32_t *x, const int32_t *y, int32_t n, int32_
  * the device chain for all copies. */
 int32_t vsm_host_outliers_and_prior(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, vsm_p_match *out,
                                     int32_t cap, float *ranges, int32_t w, int32_t h);
+/* The same host code the way vsm_match runs it on a frame's final list: `threads` fork-join threads (the caller's among
+ * them), the triangulation started from the packed pixels (x | y << 16) alone, flows, votes and the survivors' copy split
+ * over the threads.  threads <= 1 is vsm_host_outliers_and_prior.  No GPU needed: the CPU suite compares it with the oracle. */
+int32_t vsm_host_outliers_and_prior_threads(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, vsm_p_match *out,
+                                            int32_t cap, float *ranges, int32_t w, int32_t h, int32_t threads);
 int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, int32_t gpu_ties, int32_t copies,
                       vsm_p_match *out, int32_t cap, float *ranges, int32_t w, int32_t h, double *kernel_us);
 /* Test hook of the device chain's merge levels: a node's band (the records near its cut) is cached in 256 + f * sqrt(points)

@@ -2534,6 +2534,33 @@ int32_t vsm_host_outliers_and_prior(const vsm_params *p, const vsm_p_match *list
   return (int32_t)m.size();
 }
 
+int32_t vsm_host_outliers_and_prior_threads(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, vsm_p_match *out,
+                                            int32_t cap, float *ranges, int32_t w, int32_t hh, int32_t threads) {
+  if (threads <= 1) return vsm_host_outliers_and_prior(p, list, n, method, out, cap, ranges, w, hh);
+  VsmForkJoin fj(std::min(threads, 64));
+  VsmHostWork wk;
+  wk.pool = &fj;
+  std::vector<vsm_p_match> m;
+  if (n > 3) {  // vsm_match's final stage (early_xy): pixels first, then flows, votes, survivors
+    std::vector<uint32_t> xy((size_t)n);
+    for (int32_t i = 0; i < n; i++) xy[i] = (uint32_t)(int32_t)list[i].u1c | ((uint32_t)(int32_t)list[i].v1c << 16);
+    vsm_host_outliers_begin_xy(wk, xy.data(), n);
+    wk.del.run(wk.x.data(), wk.y.data(), n, wk.pool, wk.async);
+    vsm_host_outliers_begin_flows(wk, list, n, method);
+    vsm_host_outliers_end(wk, *p, list, n, method, m);
+  } else {
+    m.assign(list, list + std::max(n, 0));  // the reference leaves short lists alone (viso/matcher.cpp:1210)
+  }
+  if (ranges) {
+    const int32_t dims[3] = {w, hh, w};
+    std::vector<float> rg;
+    vsm_host_prior_statistics(*p, dims, m, method, rg);
+    ranges_to_device_layout(ranges, rg.data(), rg.size());
+  }
+  for (size_t i = 0; i < m.size() && (int32_t)i < cap; i++) out[i] = m[i];
+  return (int32_t)m.size();
+}
+
 int32_t vsm_debug_dc2(const vsm_params *p, const vsm_p_match *list, int32_t n, int32_t method, int32_t gpu_ties, int32_t copies,
                       vsm_p_match *out, int32_t cap, float *ranges, int32_t w, int32_t hh, double *kernel_us) {
   if (copies < 1) copies = 1;

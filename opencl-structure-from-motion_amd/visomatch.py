@@ -34,7 +34,7 @@ EXPORTS = ["vsm_default_params", "vsm_create", "vsm_destroy", "vsm_set_intrinsic
            "vsm_num_features", "vsm_get_features", "vsm_set_stage_capture", "vsm_stage_size", "vsm_stage_get",
            "vsm_num_ranges", "vsm_get_ranges", "vsm_get_gradients", "vsm_get_filter_responses", "vsm_get_counters",
            "vsm_get_timings", "vsm_set_profiling", "vsm_num_kernels", "vsm_kernel_name", "vsm_get_kernel_stats",
-           "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_host_outliers_and_prior", "vsm_debug_dc2", "vsm_debug_dc2_band_factor", "vsm_local_cpus", "vsm_forkjoin_cpus", "vsm_device_pool_stats", "vsm_device_pool_trim", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
+           "vsm_host_delaunay", "vsm_host_delaunay_split", "vsm_debug_delaunay_gpu", "vsm_debug_dc_bench", "vsm_host_ties", "vsm_debug_ties_gpu", "vsm_host_outliers_and_prior", "vsm_host_outliers_and_prior_threads", "vsm_debug_dc2", "vsm_debug_dc2_band_factor", "vsm_local_cpus", "vsm_forkjoin_cpus", "vsm_device_pool_stats", "vsm_device_pool_trim", "vsm_sequence_run", "vsm_sequence_num_matches", "vsm_sequence_get_matches",
            "vsm_sequence_get_timings", "vsm_sequence_path", "vsm_set_option", "vsm_version", "vsm_host_register", "vsm_host_unregister",
            "vsm_multi_create", "vsm_multi_destroy", "vsm_multi_process", "vsm_multi_num_sequences", "vsm_multi_get_motion",
            "vsm_multi_motion_valid", "vsm_multi_num_matches", "vsm_multi_get_matches", "vsm_multi_num_inliers", "vsm_multi_get_inliers",
@@ -153,6 +153,7 @@ def lib():
         L.vsm_host_ties.argtypes = [vp, vp, i32, vp, i32]
         L.vsm_debug_ties_gpu.argtypes = [vp, vp, i32, vp, i32, vp]
         L.vsm_host_outliers_and_prior.argtypes = [C.POINTER(VsmParams), vp, i32, i32, vp, i32, vp, i32, i32]
+        L.vsm_host_outliers_and_prior_threads.argtypes = [C.POINTER(VsmParams), vp, i32, i32, vp, i32, vp, i32, i32, i32]
         L.vsm_debug_dc2.argtypes = [C.POINTER(VsmParams), vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, vp]
         L.vsm_debug_dc2_band_factor.argtypes = [i32]
         L.vsm_local_cpus.argtypes = [vp, i32]
@@ -356,9 +357,10 @@ def ties(pts, gpu=False):
     return o[np.lexsort(o.T[::-1])], us.value
 
 
-def remove_outliers(matches, method, w, h, gpu=False, gpu_ties=False, copies=1, **params):
-    """Matcher::removeOutliers + computePriorStatistics on a match list: host code of the per-frame path (gpu=False) or
-    the GPU-resident chain of the look-ahead path; returns (survivors, ranges in device layout, kernel microseconds)"""
+def remove_outliers(matches, method, w, h, gpu=False, gpu_ties=False, copies=1, threads=1, **params):
+    """Matcher::removeOutliers + computePriorStatistics on a match list: host code of the per-frame path (gpu=False; threads > 1:
+    split over fork-join threads the way vsm_match runs a frame's final list) or the GPU-resident chain of the look-ahead path;
+    returns (survivors, ranges in device layout, kernel microseconds)"""
     p = default_params()
     for k, v in params.items():
         setattr(p, k, v)
@@ -371,6 +373,9 @@ def remove_outliers(matches, method, w, h, gpu=False, gpu_ties=False, copies=1, 
     if gpu:
         k = lib().vsm_debug_dc2(C.byref(p), m.ctypes.data_as(C.c_void_p), n, method, int(gpu_ties), copies, out.ctypes.data_as(C.c_void_p),
                                 len(out), rg.ctypes.data_as(C.c_void_p), w, h, C.cast(C.byref(us), C.c_void_p))
+    elif threads > 1:
+        k = lib().vsm_host_outliers_and_prior_threads(C.byref(p), m.ctypes.data_as(C.c_void_p), n, method, out.ctypes.data_as(C.c_void_p), len(out),
+                                                      rg.ctypes.data_as(C.c_void_p), w, h, threads)
     else:
         k = lib().vsm_host_outliers_and_prior(C.byref(p), m.ctypes.data_as(C.c_void_p), n, method, out.ctypes.data_as(C.c_void_p), len(out),
                                               rg.ctypes.data_as(C.c_void_p), w, h)
