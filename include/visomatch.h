@@ -160,7 +160,8 @@ int vsm_set_option(vsm_handle *h, const char *name, int32_t value);
 int32_t vsm_local_cpus(int32_t *out, int32_t cap);
 /* The per-frame calls (vsm_match, vsm_vo_stereo_process) split ONE triangulation - the final Matcher::removeOutliers,
  * viso/matcher.cpp:1207-1377 - over up to eight fork-join threads that all sit in one L3 domain of that node (they take turns
- * on one mesh; VSM_FJ_DOMAIN=k: domain k, -1: dealt over the domains), each worker on a physical core of its own (cores
+ * on one mesh; domain = the device ordinal mod the domains, so the ranks of one socket take one each; VSM_FJ_DOMAIN=k: domain k,
+ * -1: dealt over the domains), each worker on a physical core of its own (cores
  * 1, 2, ... of the domain; VSM_FJ_CORES=0: anywhere in the domain - then two of them may share a core's hardware threads and
  * halve each other between the phases they spin through).  The caller's thread takes part in that work: this returns the
  * CPUs of the domain's core 0, which is left to it (the whole domain with VSM_FJ_CORES=0), and a caller that confines the

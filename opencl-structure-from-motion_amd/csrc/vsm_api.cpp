@@ -722,6 +722,7 @@ vsm_handle *vsm_create(const vsm_params *p) {
     h->pool = new VsmPool(nt + 1);
     int fjt = nt < 8 ? nt : 8;
     if (const char *e = getenv("VSM_FJ_THREADS")) fjt = std::max(1, std::min(atoi(e), nt));  // (measurements: the fork-join pool of the per-frame path's Delaunay)
+    vsm_forkjoin_domain_hint(h->device);
     h->fj = new VsmForkJoin(fjt);
     h->work.pool = h->fj;
     h->work.async = h->pool;
@@ -2538,8 +2539,10 @@ int32_t vsm_host_outliers_and_prior_threads(const vsm_params *p, const vsm_p_mat
                                             int32_t cap, float *ranges, int32_t w, int32_t hh, int32_t threads) {
   if (threads <= 1) return vsm_host_outliers_and_prior(p, list, n, method, out, cap, ranges, w, hh);
   VsmForkJoin fj(std::min(threads, 64));
+  VsmPool apart(2);  // (as in a handle: Triangle's emulated vertex sort runs beside the triangulation of lists from 1024 matches)
   VsmHostWork wk;
   wk.pool = &fj;
+  wk.async = &apart;
   std::vector<vsm_p_match> m;
   if (n > 3) {  // vsm_match's final stage (early_xy): pixels first, then flows, votes, survivors
     std::vector<uint32_t> xy((size_t)n);

@@ -137,12 +137,16 @@ void vsm_affinity_from_device(const char *pci_bus_id) {
 // One triangulation is split over these threads and its upper merges read what the others have just built: in one L3
 // domain that is a shared-cache hit, across domains a transfer between core complexes.  VSM_FJ_DOMAIN: -1 deals the workers
 // over the domains like the pool's threads (the form up to round 5), k >= 0 (default 0) puts all of them into domain k.
+// Default: the device's ordinal (vsm_forkjoin_domain_hint, from vsm_create) - the ranks of a node's four GPUs per socket, a
+// process each, then take a domain each instead of all sitting on the socket's first.
+static std::atomic<int> g_fj_hint{0};
+void vsm_forkjoin_domain_hint(int device) { g_fj_hint.store(device < 0 ? 0 : device, std::memory_order_relaxed); }
 static int fj_domain() {
-  static const int d = [] {
+  static const int env = [] {
     const char *e = getenv("VSM_FJ_DOMAIN");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : INT32_MIN;
   }();
-  return d;
+  return env != INT32_MIN ? env : g_fj_hint.load(std::memory_order_relaxed);
 }
 
 void *vsm_affinity_current() { return t_aff; }

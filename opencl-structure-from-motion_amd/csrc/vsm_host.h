@@ -31,6 +31,7 @@
 int vsm_host_tiny_table(uint32_t *out, int cap);
 void vsm_affinity_from_device(const char *pci_bus_id);  // "0000:0d:00.0" (hipDeviceGetPCIBusId); makes that device's record the calling thread's current one
 int vsm_affinity_domain_cpus(void *affinity, int domain, int *out, int cap);  // CPUs of one L3 domain of the record (nullptr: the device looked up last); returns how many
+void vsm_forkjoin_domain_hint(int device);               // (vsm_create) without VSM_FJ_DOMAIN the workers' domain is the device's ordinal mod the domains
 int vsm_forkjoin_domain();                               // the L3 domain the fork-join workers share (VSM_FJ_DOMAIN; -1: they are dealt over all)
 void *vsm_affinity_current();                           // the calling thread's current record (what pools created now will pin their workers by)
 void vsm_pin_this_thread(void *affinity = nullptr);     // nullptr: the calling thread's current record
