@@ -710,6 +710,7 @@ vsm_handle *vsm_create(const vsm_params *p) {
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), dev) == hipSuccess)
       vsm_affinity_from_device(bdf);  // (before the pools start their threads)
     h->aff = vsm_affinity_current();
+    vsm_forkjoin_domain_hint(dev);  // (the fork-join workers' L3 domain: a domain per device of the socket)
   }
   {
     // host threads (the caller's thread included): VSM_HOST_THREADS frame-parallel workers for
@@ -722,7 +723,6 @@ vsm_handle *vsm_create(const vsm_params *p) {
     h->pool = new VsmPool(nt + 1);
     int fjt = nt < 8 ? nt : 8;
     if (const char *e = getenv("VSM_FJ_THREADS")) fjt = std::max(1, std::min(atoi(e), nt));  // (measurements: the fork-join pool of the per-frame path's Delaunay)
-    vsm_forkjoin_domain_hint(h->device);
     h->fj = new VsmForkJoin(fjt);
     h->work.pool = h->fj;
     h->work.async = h->pool;
