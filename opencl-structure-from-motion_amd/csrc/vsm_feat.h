@@ -163,6 +163,26 @@ VF_HD void vf_columns_sobel(const VfWindow<ROWS> &W, int rr, int j, vf_s2 &S, vf
   S = (a + e) + (b + dd) * (short)4 + c * (short)6;
   D = (a - e) + (b - dd) * (short)2;
 }
+// The same sums for ALL rows of a patch at once: [1 4 6 4 1] = four cascaded pair adds down the window's rows, [1 2 0 -2 -1]
+// = the second stage ([1 2 1]) two rows up minus two rows down - the stages are shared between the patch's rows: 4 ROWS + 10
+// packed operations per column pair where the row-by-row form takes 10 per row (same 16-bit lanes, no value beyond 16 * 255)
+template <int ROWS>
+VF_HD void vf_columns_sobel_all(const VfWindow<ROWS> &W, int j, vf_s2 (&S)[ROWS], vf_s2 (&D)[ROWS]) {
+  vf_s2 r[ROWS + 4], p1[ROWS + 3], p2[ROWS + 2], p3[ROWS + 1];
+#pragma unroll
+  for (int i = 0; i < ROWS + 4; i++) r[i] = W.pair(i, j);
+#pragma unroll
+  for (int i = 0; i < ROWS + 3; i++) p1[i] = r[i] + r[i + 1];
+#pragma unroll
+  for (int i = 0; i < ROWS + 2; i++) p2[i] = p1[i] + p1[i + 1];
+#pragma unroll
+  for (int i = 0; i < ROWS + 1; i++) p3[i] = p2[i] + p2[i + 1];
+#pragma unroll
+  for (int rr = 0; rr < ROWS; rr++) {
+    S[rr] = p3[rr] + p3[rr + 1];
+    D[rr] = p2[rr] - p2[rr + 2];
+  }
+}
 template <int ROWS>
 VF_HD void vf_columns_blob(const VfWindow<ROWS> &W, int rr, int j, vf_s2 &C3, vf_s2 &C5, vf_s2 &Cc) {
   const vf_s2 a = W.pair(rr, j), b = W.pair(rr + 1, j), c = W.pair(rr + 2, j), dd = W.pair(rr + 3, j), e = W.pair(rr + 4, j);

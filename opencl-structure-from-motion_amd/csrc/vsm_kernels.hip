@@ -452,13 +452,30 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int q = 0; q < 4; q++) W.w[r][q] = s_in[4 * ty + r][2 * tx + q];
   }
+#ifndef FRONT_CASCADE
+#define FRONT_CASCADE 1  // the column sums of the patch's four rows share their stages (vf_columns_sobel_all)
+#endif
+#if FRONT_CASCADE
+  vf_s2 Sa[4][6], Da[4][6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    vf_s2 sj[4], dj[4];
+    vf_columns_sobel_all<4>(W, j, sj, dj);
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) Sa[rr][j] = sj[rr], Da[rr][j] = dj[rr];
+  }
+#endif
 #pragma unroll
   for (int rr = 0; rr < 4; rr++) {
     const int y = yb + rr;
     if (y >= h) break;
+#if FRONT_CASCADE
+    vf_s2 (&S)[6] = Sa[rr], (&D)[6] = Da[rr];
+#else
     vf_s2 S[6], D[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) vf_columns_sobel<4>(W, rr, j, S[j], D[j]);
+#endif
     if (y < 3 || y > h - 4) vf_sobel_zero_outside(S, D, y * bpl + x8, 2 * bpl, (h - 2) * bpl);
     uint32_t du[2], dv[2];
     vf_sobel_row(S, D, du, dv);
